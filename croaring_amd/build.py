@@ -1,0 +1,60 @@
+"""Build libroaring_hip.so (gfx950) in-tree with hipcc.  `python -m croaring_amd.build`"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+OUT = os.path.join(PKG, "libroaring_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+SOURCES = ["rhip_prims.hip", "rhip_engine.hip", "roaring_compat.cpp"]
+DEPS = ["rhip_kernels.h", "rhip_many.h", "rhip_many_host.inc", "rhip_prims.h", "roaring_compat_types.h",
+        os.path.join("..", "..", "include", "roaring_hip.h"), os.path.join("..", "..", "include", "roaring_hip_compat.h")]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libroaring_hip.so can only be built with the ROCm toolchain")
+
+
+def _stale(obj: str, src: str) -> bool:
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    paths = [src] + [os.path.join(CSRC, d) for d in DEPS]
+    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in paths)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = _hipcc()
+    objdir = os.path.join(PKG, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs, rebuilt = [], False
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        if force or _stale(obj, sp):
+            cmd = [hipcc, *FLAGS, "-x", "hip", "-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            rebuilt = True
+        objs.append(obj)
+    if rebuilt or not os.path.exists(OUT):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", OUT]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

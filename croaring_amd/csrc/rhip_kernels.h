@@ -1,0 +1,783 @@
+// rhip_kernels.h -- CDNA4 (gfx950, wave64) kernels of the Roaring set-operation engine.
+//
+// Data layout in HBM: a pool is a structure-of-arrays container DIRECTORY
+// (key, type, card, nruns, byte offset; containers sorted by (bitmap, key)) plus one payload
+// ARENA.  Every payload starts 16-byte aligned and is padded to a multiple of 16 bytes, so
+// every kernel moves payload as 16 B/lane (1 KiB per wave instruction, fully coalesced).
+// A bitset container is 1024 contiguous u64 words = 8 wave-wide 16-byte loads.
+//
+// Kernel inventory (one per SURVEY §2.2 row it replaces):
+//   k_count / k_emit   two-pointer key merge of roaring.c:742-768 as lane-per-key binary
+//                      search + wave ballot/mbcnt ranking -> work items in 3 class queues
+//   k_bb               K1-K3: bitset (x) bitset {and,or,xor,andnot} fused with popcount,
+//                      one wave per container pair, 16 x 16-byte loads in flight per lane
+//   k_copy             pass-through containers (roaring.c:914-941 clone paths)
+//   k_gen              K5-K15: every other type pair -- both operands rasterised into LDS
+//                      bitsets (arrays: ds_or scatter; runs: toggle bits + wave prefix-xor),
+//                      op + popcount + run counting in LDS, result re-typed by the
+//                      reference's rules (Appendix A) and extracted with ballot/prefix sums
+//   k_many_*           group-by-key OR/XOR accumulation for or_many / xor_many
+//   k_compact          drops empty results, builds the result directory
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+
+enum { T_BITSET = 1, T_ARRAY = 2, T_RUN = 3 };
+enum { OP_AND = 0, OP_OR = 1, OP_XOR = 2, OP_ANDNOT = 3 };
+enum { CLS_BB = 0, CLS_GEN = 1, CLS_COPY = 2, CLS_RETRY = 3, N_CLS = 4 };
+#define NONE32 0xFFFFFFFFu
+
+struct PoolView {
+    const u64* bm_start;  // [n_bitmaps+1] first container of each bitmap
+    const u64* key;       // [n_cont] 16-bit (or 48-bit) container key
+    const uint8_t* type;  // [n_cont]
+    const uint32_t* card; // [n_cont] cardinality
+    const uint32_t* nruns;// [n_cont] run count (runs only)
+    const u64* off;       // [n_cont] byte offset of the payload in arena
+    const uint8_t* arena;
+};
+
+struct OutView {  // candidate (pre-compaction) result directory + the result arena
+    u64* key;
+    uint8_t* type;
+    uint32_t* card;
+    uint32_t* nruns;
+    const u64* off;  // exclusive scan of slot[]
+    uint8_t* arena;
+    uint32_t* slot;  // upper-bound payload bytes of each candidate (multiple of 16)
+};
+
+struct Item {
+    uint32_t a;    // container index in pool A (NONE32: pass-through from B)
+    uint32_t b;    // container index in pool B (NONE32: pass-through from A)
+    uint32_t out;  // candidate index (cardinality mode: pair index)
+};
+
+struct Stats {  // device-side counters, see rhip_stats_t
+    u64 matched_pairs, passthrough, bytes_in, bytes_out, n_bb, result_containers;
+};
+
+// ------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint32_t mbcnt(u64 m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ u64 wave_sum64(u64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o);
+        if (lane_id() >= (uint32_t)o) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t payload_bytes(uint8_t type, uint32_t card, uint32_t nruns) {
+    return type == T_BITSET ? 8192u : (type == T_ARRAY ? 2u * card : 4u * nruns);
+}
+__device__ __forceinline__ uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
+
+// first index in [lo,hi) with key[idx] >= k
+__device__ __forceinline__ u64 lower_bound(const u64* __restrict__ key, u64 lo, u64 hi, u64 k) {
+    while (lo < hi) {
+        u64 mid = (lo + hi) >> 1;
+        if (key[mid] < k) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// upper bound on the result cardinality of op over a matched pair
+__device__ __forceinline__ uint32_t ub_card(int op, uint32_t ca, uint32_t cb) {
+    if (op == OP_AND) return ca < cb ? ca : cb;
+    if (op == OP_ANDNOT) return ca;
+    uint32_t s = ca + cb;
+    return s > 65536u ? 65536u : s;
+}
+// Upper bound on the result payload: whatever type the reference's rules pick, the payload is
+// <= min(8192, 2*ub_card) (bitset 8192 needs card > 4096; array = 2*card; a run survives
+// convert_run_to_efficient_container only if 2+4*n_runs <= min(8192, 2*card), convert.c:154-170).
+__device__ __forceinline__ uint32_t matched_slot(int op, uint32_t ca, uint32_t cb) {
+    uint32_t ub = 2u * ub_card(op, ca, cb);
+    if (ub > 8192u) ub = 8192u;
+    ub = align16(ub);
+    return ub < 16u ? 16u : ub;
+}
+
+// ------------------------------------------------------------------ planning
+// One wave per bitmap pair.  cand[p] = number of candidate result containers.
+__global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uint32_t* __restrict__ lhs,
+                                               const uint32_t* __restrict__ rhs, uint32_t npairs, int op,
+                                               int cardmode, uint32_t* __restrict__ cand) {
+    uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (p >= npairs) return;
+    const uint32_t lane = lane_id();
+    u64 a0 = A.bm_start[lhs[p]], a1 = A.bm_start[lhs[p] + 1];
+    u64 b0 = B.bm_start[rhs[p]], b1 = B.bm_start[rhs[p] + 1];
+    u64 nA = a1 - a0, nB = b1 - b0;
+    // search the shorter directory slice in the longer one
+    const u64 *ks = A.key, *kl = B.key;
+    u64 s0 = a0, s1 = a1, l0 = b0, l1 = b1;
+    if (nA > nB) { ks = B.key; kl = A.key; s0 = b0; s1 = b1; l0 = a0; l1 = a1; }
+    uint32_t matched = 0;
+    for (u64 i = s0; i < s1; i += 64) {
+        bool found = false;
+        if (i + lane < s1) {
+            u64 k = ks[i + lane];
+            u64 j = lower_bound(kl, l0, l1, k);
+            found = (j < l1) && (kl[j] == k);
+        }
+        matched += (uint32_t)__popcll(__ballot(found));
+    }
+    if (lane == 0) {
+        uint32_t c;
+        if (cardmode || op == OP_AND) c = matched;
+        else if (op == OP_ANDNOT) c = (uint32_t)nA;
+        else c = (uint32_t)(nA + nB) - matched;
+        cand[p] = c;
+    }
+}
+
+__device__ __forceinline__ void push_items(int cls, bool valid, Item it, Item* const* q, uint32_t* qcount) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        u64 m = __ballot(valid && cls == c);
+        if (m) {
+            uint32_t base = 0;
+            int leader = __ffsll((long long)m) - 1;
+            if ((int)lane_id() == leader) base = atomicAdd(&qcount[c], (uint32_t)__popcll(m));
+            base = __shfl(base, leader);
+            if (valid && cls == c) q[c][base + mbcnt(m)] = it;
+        }
+    }
+}
+
+// One wave per bitmap pair: emit candidates in merged key order (roaring.c:742-768, 895-951).
+// Position of a candidate inside its result bitmap is computed by ranking, not by a serial merge:
+//   matched / A-only element i (key k):  i + |{B keys < k}| - |{matched keys < k}|
+//   B-only element j (key k)          :  j + |{A keys < k}| - |{matched keys < k}|
+struct EmitQueues { Item* q[3]; };
+__global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint32_t* __restrict__ lhs,
+                                              const uint32_t* __restrict__ rhs, uint32_t npairs, int op,
+                                              int cardmode, const u64* __restrict__ cand_start, OutView O,
+                                              EmitQueues Q, uint32_t* qcount, Stats* stats) {
+    uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (p >= npairs) return;
+    const uint32_t lane = lane_id();
+    u64 a0 = A.bm_start[lhs[p]], a1 = A.bm_start[lhs[p] + 1];
+    u64 b0 = B.bm_start[rhs[p]], b1 = B.bm_start[rhs[p] + 1];
+    const u64 base = cand_start[p];
+    u64 bytes_in = 0;
+    uint32_t n_matched = 0, n_pass = 0, n_bb = 0;
+
+    uint32_t mbefore = 0;  // matched keys among A elements already visited
+    for (u64 i = a0; i < a1; i += 64) {
+        bool act = (i + lane) < a1;
+        u64 ai = i + lane;
+        u64 k = 0, j = b0;
+        bool found = false;
+        if (act) {
+            k = A.key[ai];
+            j = lower_bound(B.key, b0, b1, k);
+            found = (j < b1) && (B.key[j] == k);
+        }
+        u64 fm = __ballot(found);
+        uint32_t mb = mbefore + mbcnt(fm);
+        mbefore += (uint32_t)__popcll(fm);
+        bool emit = act && (found || (!cardmode && op != OP_AND));
+        Item it;
+        int cls = CLS_GEN;
+        if (emit) {
+            uint32_t ilocal = (uint32_t)(ai - a0), lbcount = (uint32_t)(j - b0);
+            uint32_t pos;
+            if (op == OP_AND || cardmode) pos = mb;
+            else if (op == OP_ANDNOT) pos = ilocal;
+            else pos = ilocal + lbcount - mb;
+            uint8_t ta = A.type[ai];
+            uint32_t ca = A.card[ai];
+            uint32_t pa = payload_bytes(ta, ca, A.nruns[ai]);
+            it.a = (uint32_t)ai;
+            if (found) {
+                uint8_t tb = B.type[j];
+                uint32_t cb = B.card[j];
+                it.b = (uint32_t)j;
+                cls = (ta == T_BITSET && tb == T_BITSET) ? CLS_BB : CLS_GEN;
+                bytes_in += pa + payload_bytes(tb, cb, B.nruns[j]);
+                n_matched++;
+                n_bb += (cls == CLS_BB);
+                if (!cardmode) O.slot[base + pos] = matched_slot(op, ca, cb);
+            } else {
+                it.b = NONE32;
+                cls = CLS_COPY;
+                bytes_in += pa;
+                n_pass++;
+                O.slot[base + pos] = align16(pa) < 16u ? 16u : align16(pa);
+            }
+            if (cardmode) it.out = p;
+            else {
+                it.out = (uint32_t)(base + pos);
+                O.key[base + pos] = k;
+            }
+        }
+        push_items(cls, emit, it, Q.q, qcount);
+    }
+    if (!cardmode && (op == OP_OR || op == OP_XOR)) {
+        mbefore = 0;
+        for (u64 i = b0; i < b1; i += 64) {
+            bool act = (i + lane) < b1;
+            u64 bi = i + lane;
+            u64 k = 0, j = a0;
+            bool found = false;
+            if (act) {
+                k = B.key[bi];
+                j = lower_bound(A.key, a0, a1, k);
+                found = (j < a1) && (A.key[j] == k);
+            }
+            u64 fm = __ballot(found);
+            uint32_t mb = mbefore + mbcnt(fm);
+            mbefore += (uint32_t)__popcll(fm);
+            bool emit = act && !found;
+            Item it;
+            if (emit) {
+                uint32_t pos = (uint32_t)(bi - b0) + (uint32_t)(j - a0) - mb;
+                uint32_t pb = payload_bytes(B.type[bi], B.card[bi], B.nruns[bi]);
+                it.a = NONE32;
+                it.b = (uint32_t)bi;
+                it.out = (uint32_t)(base + pos);
+                O.key[base + pos] = k;
+                O.slot[base + pos] = align16(pb) < 16u ? 16u : align16(pb);
+                bytes_in += pb;
+                n_pass++;
+            }
+            push_items(CLS_COPY, emit, it, Q.q, qcount);
+        }
+    }
+    bytes_in = wave_sum64(bytes_in);
+    n_matched = wave_sum(n_matched);
+    n_pass = wave_sum(n_pass);
+    n_bb = wave_sum(n_bb);
+    if (lane == 0) {
+        if (bytes_in) atomicAdd(&stats->bytes_in, bytes_in);
+        if (n_matched) atomicAdd(&stats->matched_pairs, (u64)n_matched);
+        if (n_pass) atomicAdd(&stats->passthrough, (u64)n_pass);
+        if (n_bb) atomicAdd(&stats->n_bb, (u64)n_bb);
+    }
+}
+
+// ------------------------------------------------------------------ bitset x bitset (K1-K3)
+// One wave per container pair, persistent waves striding over the queue.  Each lane issues
+// 16 independent 16-byte loads (8 per operand) before the first use: 16 KiB in flight per
+// wave.  Result words stay in registers; popcount is fused; the typed result is written once.
+// Replaces bitset_container_{and,or,xor,andnot}{,_nocard,_justcard} (src/containers/bitset.c:
+// 343-942) and the two-pass justcard->nocard structure of mixed_intersection.c:305-325.
+__device__ __forceinline__ uint4 op4(int op, uint4 a, uint4 b) {
+    uint4 r;
+    switch (op) {
+        case OP_AND: r.x = a.x & b.x; r.y = a.y & b.y; r.z = a.z & b.z; r.w = a.w & b.w; break;
+        case OP_OR: r.x = a.x | b.x; r.y = a.y | b.y; r.z = a.z | b.z; r.w = a.w | b.w; break;
+        case OP_XOR: r.x = a.x ^ b.x; r.y = a.y ^ b.y; r.z = a.z ^ b.z; r.w = a.w ^ b.w; break;
+        default: r.x = a.x & ~b.x; r.y = a.y & ~b.y; r.z = a.z & ~b.z; r.w = a.w & ~b.w; break;
+    }
+    return r;
+}
+__device__ __forceinline__ uint32_t popc4(uint4 v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+
+// native 128-bit vector for the streaming kernel (the nontemporal builtins need a native vector type)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int OP>
+__device__ __forceinline__ u32x4 vop(u32x4 a, u32x4 b) {
+    if (OP == OP_AND) return a & b;
+    if (OP == OP_OR) return a | b;
+    if (OP == OP_XOR) return a ^ b;
+    return a & ~b;
+}
+__device__ __forceinline__ uint32_t vpopc(u32x4 v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_bb(PoolView A, PoolView B, OutView O, const Item* __restrict__ q,
+                                            const uint32_t* __restrict__ qcount, int cardmode, u64* pair_acc,
+                                            Item* retry_q, uint32_t* retry_count) {
+    const uint32_t lane = lane_id();
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n = *qcount;
+    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
+        Item t = q[w];
+        const u32x4* __restrict__ pa = (const u32x4*)(A.arena + A.off[t.a]);
+        const u32x4* __restrict__ pb = (const u32x4*)(B.arena + B.off[t.b]);
+        u32x4 va[8], vb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) va[i] = __builtin_nontemporal_load(pa + i * 64 + lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vb[i] = __builtin_nontemporal_load(pb + i * 64 + lane);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            va[i] = vop<OP>(va[i], vb[i]);
+            cnt += vpopc(va[i]);
+        }
+        const uint32_t card = wave_sum(cnt);
+        if (cardmode) {
+            if (lane == 0 && card) atomicAdd(&pair_acc[t.out], (u64)card);
+            continue;
+        }
+        // result typing: OR is always a bitset (containers.h:1015-1020); and/xor/andnot are a
+        // bitset iff card > 4096 (mixed_intersection.c:305-325, mixed_xor.c:260-273,
+        // mixed_andnot.c:482-497)
+        if (OP == OP_OR || card > 4096u) {
+            u32x4* __restrict__ po = (u32x4*)(O.arena + O.off[t.out]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) __builtin_nontemporal_store(va[i], po + i * 64 + lane);
+            if (lane == 0) {
+                O.type[t.out] = T_BITSET;
+                O.card[t.out] = card;
+                O.nruns[t.out] = 0;
+            }
+        } else if (card == 0) {
+            if (lane == 0) {
+                O.type[t.out] = T_ARRAY;
+                O.card[t.out] = 0;
+                O.nruns[t.out] = 0;
+            }
+        } else {
+            // rare: result becomes an array -> re-queue for the LDS extraction kernel
+            if (lane == 0) retry_q[atomicAdd(retry_count, 1u)] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ pass-through copy
+__global__ __launch_bounds__(256) void k_copy(PoolView A, PoolView B, OutView O, const Item* __restrict__ q,
+                                              const uint32_t* __restrict__ qcount) {
+    const uint32_t lane = lane_id();
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n = *qcount;
+    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
+        Item t = q[w];
+        const PoolView& S = (t.b == NONE32) ? A : B;
+        const uint32_t c = (t.b == NONE32) ? t.a : t.b;
+        const uint8_t ty = S.type[c];
+        const uint32_t card = S.card[c], nr = S.nruns[c];
+        const uint32_t n16 = (payload_bytes(ty, card, nr) + 15u) >> 4;
+        const uint4* __restrict__ ps = (const uint4*)(S.arena + S.off[c]);
+        uint4* __restrict__ po = (uint4*)(O.arena + O.off[t.out]);
+        for (uint32_t i = lane; i < n16; i += 64) po[i] = ps[i];
+        if (lane == 0) {
+            O.type[t.out] = ty;
+            O.card[t.out] = card;
+            O.nruns[t.out] = nr;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ LDS bitset machinery
+// A 65536-bit container image in LDS is uint32_t[2048]; thread t of a 256-thread workgroup
+// owns words [8t, 8t+8) (two ds_read_b128 / ds_write_b128).
+struct BlockScratch {
+    uint32_t wsum[8];   // per-wave partials
+    uint32_t wsum2[8];
+};
+
+__device__ __forceinline__ void lds_zero(uint32_t* dst) {
+    uint4 z = make_uint4(0, 0, 0, 0);
+    ((uint4*)dst)[2 * threadIdx.x] = z;
+    ((uint4*)dst)[2 * threadIdx.x + 1] = z;
+}
+
+// exclusive prefix sum over the 256 threads of the block; *total gets the block total
+__device__ __forceinline__ uint32_t blk_exscan(uint32_t v, uint32_t* wsum, uint32_t* total) {
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan(v);
+    __syncthreads();
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; ++w) {
+        uint32_t s = wsum[w];
+        if (w < wave) off += s;
+        tot += s;
+    }
+    *total = tot;
+    return off + inc - v;
+}
+__device__ __forceinline__ uint32_t blk_sum(uint32_t v, uint32_t* wsum) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane_id() == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// Rasterise container c of pool V into the LDS image dst (K6 / K7 of SURVEY §2.2):
+//   bitset: straight 16-byte copy;
+//   array : zero + ds_or_b32 scatter (bitset_set_list, bitset_util.c:978-1141);
+//   run   : zero + toggle bits at every run start and end+1, then an inclusive prefix-XOR over
+//           the 65536 bits (in-word shifts + a cross-word parity carry obtained from one
+//           ballot per wave) -- O(1) work per word regardless of run lengths
+//           (replaces the serial bitset_set_lenrange loop, bitset_util.h:41-161).
+__device__ void lds_load(uint32_t* dst, const PoolView& V, uint32_t c, BlockScratch* sc) {
+    const uint32_t tid = threadIdx.x;
+    const uint8_t ty = V.type[c];
+    const uint8_t* p = V.arena + V.off[c];
+    if (ty == T_BITSET) {
+        const uint4* __restrict__ g = (const uint4*)p;
+        uint4 x0 = g[2 * tid], x1 = g[2 * tid + 1];
+        ((uint4*)dst)[2 * tid] = x0;
+        ((uint4*)dst)[2 * tid + 1] = x1;
+        __syncthreads();
+        return;
+    }
+    lds_zero(dst);
+    __syncthreads();
+    if (ty == T_ARRAY) {
+        const uint32_t n = V.card[c];
+        const uint32_t* __restrict__ a2 = (const uint32_t*)p;  // two values per dword, slot is 16-byte padded
+        for (uint32_t i = tid; 2 * i < n; i += 256) {
+            uint32_t v2 = a2[i];
+            uint32_t v = v2 & 0xFFFFu;
+            atomicOr(&dst[v >> 5], 1u << (v & 31));
+            if (2 * i + 1 < n) {
+                v = v2 >> 16;
+                atomicOr(&dst[v >> 5], 1u << (v & 31));
+            }
+        }
+        __syncthreads();
+        return;
+    }
+    {
+        const uint32_t n = V.nruns[c];
+        const uint32_t* __restrict__ r = (const uint32_t*)p;  // {u16 value, u16 length} little-endian
+        for (uint32_t i = tid; i < n; i += 256) {
+            uint32_t rl = r[i];
+            uint32_t s = rl & 0xFFFFu, e1 = s + (rl >> 16) + 1u;
+            atomicXor(&dst[s >> 5], 1u << (s & 31));
+            if (e1 < 65536u) atomicXor(&dst[e1 >> 5], 1u << (e1 & 31));
+        }
+        __syncthreads();
+        uint4 x0 = ((uint4*)dst)[2 * tid], x1 = ((uint4*)dst)[2 * tid + 1];
+        uint32_t w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        uint32_t par = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) par ^= __popc(w[k]) & 1u;
+        const u64 m = __ballot(par != 0);
+        uint32_t carry = mbcnt(m) & 1u;
+        if (lane_id() == 0) sc->wsum[tid >> 6] = (uint32_t)__popcll(m) & 1u;
+        __syncthreads();
+        for (uint32_t wv = 0; wv < (tid >> 6); ++wv) carry ^= sc->wsum[wv];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t x = w[k], y = x;
+            y ^= y << 1; y ^= y << 2; y ^= y << 4; y ^= y << 8; y ^= y << 16;
+            w[k] = carry ? ~y : y;
+            carry ^= __popc(x) & 1u;
+        }
+        ((uint4*)dst)[2 * tid] = make_uint4(w[0], w[1], w[2], w[3]);
+        ((uint4*)dst)[2 * tid + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ int type_eff(uint32_t rc, uint32_t rn) {
+    // convert_run_to_efficient_container, convert.c:154-200
+    uint32_t size_run = 2u + 4u * rn, size_arr = 2u * rc;
+    uint32_t mn = size_arr < 8192u ? size_arr : 8192u;
+    if (size_run <= mn) return T_RUN;
+    return rc <= 4096u ? T_ARRAY : T_BITSET;
+}
+__device__ __forceinline__ int type_ba(uint32_t rc) { return rc <= 4096u ? T_ARRAY : T_BITSET; }
+
+// The reference's result-type rules, as a pure function of the operand
+// types/cardinalities and the result's cardinality / canonical run count.
+__device__ int decide_type(int op, int ta, int tb, uint32_t ca, uint32_t cb, bool fulla, bool fullb, uint32_t rc,
+                           uint32_t rn) {
+    const bool aA = ta == T_ARRAY, aB = ta == T_BITSET, aR = ta == T_RUN;
+    const bool bA = tb == T_ARRAY, bB = tb == T_BITSET, bR = tb == T_RUN;
+    switch (op) {
+        case OP_AND:  // containers.h:726-806
+            if (aA || bA) return T_ARRAY;
+            if (aB && bB) return type_ba(rc);
+            if (aR && bR) return type_eff(rc, rn);
+            {   // bitset x run, mixed_intersection.c:117-202
+                const bool full = aR ? fulla : fullb;
+                const uint32_t crun = aR ? ca : cb;
+                if (full) return T_BITSET;
+                if (crun <= 4096u) return T_ARRAY;
+                return type_ba(rc);
+            }
+        case OP_OR:  // containers.h:1008-1103
+            if (aB && bB) return T_BITSET;
+            if (aA && bA) return (ca + cb <= 4096u) ? T_ARRAY : type_ba(rc);  // mixed_union.c:162-191
+            if (aR && bR) return type_eff(rc, rn);
+            if ((aB && bA) || (aA && bB)) return T_BITSET;
+            if (aB || bB) return (aR ? fulla : fullb) ? T_RUN : T_BITSET;
+            return type_eff(rc, rn);  // array x run, mixed_union.c:66-108
+        case OP_XOR:  // containers.h:1449-1524
+            if (aA && bA) return (ca + cb <= 4096u) ? T_ARRAY : type_ba(rc);  // mixed_xor.c:196-219
+            if (aR && bR) return type_eff(rc, rn);
+            if (aB || bB) return type_ba(rc);
+            {   // array x run, mixed_xor.c:104-138
+                const uint32_t carr = aA ? ca : cb, crun = aA ? cb : ca;
+                if (carr < 32u) return type_eff(rc, rn);
+                if (crun <= 4096u) return (carr + crun <= 4096u) ? T_ARRAY : type_ba(rc);
+                return type_ba(rc);
+            }
+        default:  // OP_ANDNOT, containers.h:1783-1876
+            if (aA) return T_ARRAY;
+            if (aB) return type_ba(rc);
+            // a is a run
+            if (bR) return type_eff(rc, rn);                       // mixed_andnot.c:430-438
+            if (bB) return ca <= 4096u ? T_ARRAY : type_ba(rc);    // mixed_andnot.c:104-150
+            if (ca <= 32u) return type_eff(rc, rn);                // mixed_andnot.c:277-361
+            return ca <= 4096u ? T_ARRAY : type_ba(rc);
+    }
+}
+
+// Emit the LDS image `img` (result words also in r[8]) as a container of type ty into the
+// candidate slot.  stage is an 8 KiB LDS buffer for coalesced output of arrays / runs
+// (K5: bitset -> sorted u16 list by per-thread popcount + block prefix sum).
+__device__ void lds_emit(const uint32_t* img, const uint32_t r[8], int ty, uint32_t rc, uint32_t rn,
+                         uint16_t* stage, uint8_t* out, BlockScratch* sc) {
+    const uint32_t tid = threadIdx.x;
+    if (ty == T_BITSET) {
+        uint4* __restrict__ po = (uint4*)out;
+        po[2 * tid] = make_uint4(r[0], r[1], r[2], r[3]);
+        po[2 * tid + 1] = make_uint4(r[4], r[5], r[6], r[7]);
+        return;
+    }
+    uint32_t nbytes;
+    if (ty == T_ARRAY) {
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cnt += __popc(r[k]);
+        uint32_t tot;
+        uint32_t base = blk_exscan(cnt, sc->wsum, &tot);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t x = r[k];
+            const uint32_t vbase = (8u * tid + k) * 32u;
+            while (x) {
+                stage[base++] = (uint16_t)(vbase + (__ffs((int)x) - 1));
+                x &= x - 1;
+            }
+        }
+        nbytes = 2u * rc;
+    } else {
+        // run extraction: starts = set bits whose predecessor is clear, ends = set bits whose
+        // successor is clear; the k-th start pairs with the k-th end.
+        const uint32_t prev_msb = tid ? (img[8 * tid - 1] >> 31) : 0u;
+        const uint32_t next_lsb = tid < 255 ? (img[8 * tid + 8] & 1u) : 0u;
+        uint32_t S[8], E[8], ns = 0, ne = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t pm = k ? (r[k - 1] >> 31) : prev_msb;
+            uint32_t nl = k < 7 ? (r[k + 1] & 1u) : next_lsb;
+            S[k] = r[k] & ~((r[k] << 1) | pm);
+            E[k] = r[k] & ~((r[k] >> 1) | (nl << 31));
+            ns += __popc(S[k]);
+            ne += __popc(E[k]);
+        }
+        uint32_t tot;
+        uint32_t bs = blk_exscan(ns, sc->wsum, &tot);
+        uint32_t be = blk_exscan(ne, sc->wsum2, &tot);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t x = S[k];
+            const uint32_t vbase = (8u * tid + k) * 32u;
+            while (x) {
+                stage[2 * bs] = (uint16_t)(vbase + (__ffs((int)x) - 1));
+                bs++;
+                x &= x - 1;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t x = E[k];
+            const uint32_t vbase = (8u * tid + k) * 32u;
+            while (x) {
+                uint32_t e = vbase + (__ffs((int)x) - 1);
+                stage[2 * be + 1] = (uint16_t)(e - stage[2 * be]);
+                be++;
+                x &= x - 1;
+            }
+        }
+        nbytes = 4u * rn;
+    }
+    __syncthreads();
+    const uint32_t n16 = (nbytes + 15u) >> 4;
+    uint4* __restrict__ po = (uint4*)out;
+    for (uint32_t i = tid; i < n16; i += 256) po[i] = ((const uint4*)stage)[i];
+}
+
+// ------------------------------------------------------------------ universal pair kernel
+// One 256-thread workgroup per container pair (persistent, striding over the queue).
+__global__ __launch_bounds__(256) void k_gen(PoolView A, PoolView B, OutView O, const Item* __restrict__ q,
+                                             const uint32_t* __restrict__ qcount, int op, int cardmode,
+                                             u64* pair_acc) {
+    __shared__ __attribute__((aligned(16))) uint32_t sA[2048];
+    __shared__ __attribute__((aligned(16))) uint32_t sB[2048];
+    __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];
+    __shared__ BlockScratch sc;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n = *qcount;
+    for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
+        const Item t = q[it];
+        __syncthreads();  // previous iteration's LDS reads are done
+        lds_load(sA, A, t.a, &sc);
+        lds_load(sB, B, t.b, &sc);
+        uint4 a0 = ((uint4*)sA)[2 * tid], a1 = ((uint4*)sA)[2 * tid + 1];
+        uint4 b0 = ((uint4*)sB)[2 * tid], b1 = ((uint4*)sB)[2 * tid + 1];
+        uint4 r0 = op4(op, a0, b0), r1 = op4(op, a1, b1);
+        uint32_t r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        const uint32_t rc = blk_sum(popc4(r0) + popc4(r1), sc.wsum);
+        if (cardmode) {
+            if (tid == 0 && rc) atomicAdd(&pair_acc[t.out], (u64)rc);
+            continue;
+        }
+        ((uint4*)sA)[2 * tid] = r0;
+        ((uint4*)sA)[2 * tid + 1] = r1;
+        __syncthreads();
+        // canonical run count of the result
+        uint32_t ns = 0;
+        {
+            uint32_t pm = tid ? (sA[8 * tid - 1] >> 31) : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                ns += __popc(r[k] & ~((r[k] << 1) | pm));
+                pm = r[k] >> 31;
+            }
+        }
+        const uint32_t rn = blk_sum(ns, sc.wsum2);
+        const uint8_t ta = A.type[t.a], tb = B.type[t.b];
+        const uint32_t ca = A.card[t.a], cb = B.card[t.b];
+        const bool fulla = ta == T_RUN && ca == 65536u, fullb = tb == T_RUN && cb == 65536u;
+        int ty = T_ARRAY;
+        if (rc) {
+            ty = decide_type(op, ta, tb, ca, cb, fulla, fullb, rc, rn);
+            lds_emit(sA, r, ty, rc, rn, stage, O.arena + O.off[t.out], &sc);
+        }
+        if (tid == 0) {
+            O.type[t.out] = (uint8_t)ty;
+            O.card[t.out] = rc;
+            O.nruns[t.out] = (ty == T_RUN) ? rn : 0u;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ directory compaction
+__global__ void k_flags(const uint32_t* __restrict__ card, u64 n, uint32_t* __restrict__ flag) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = card[i] ? 1u : 0u;
+}
+struct DirOut {
+    u64* bm_start;
+    u64* key;
+    uint8_t* type;
+    uint32_t* card;
+    uint32_t* nruns;
+    u64* off;
+};
+__global__ void k_compact(OutView O, u64 n, const u64* __restrict__ newidx, DirOut R, Stats* stats) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 bytes = 0;
+    uint32_t keep = 0;
+    if (i < n && O.card[i]) {
+        u64 d = newidx[i];
+        uint8_t ty = O.type[i];
+        R.key[d] = O.key[i];
+        R.type[d] = ty;
+        R.card[d] = O.card[i];
+        R.nruns[d] = O.nruns[i];
+        R.off[d] = O.off[i];
+        bytes = payload_bytes(ty, O.card[i], O.nruns[i]);
+        keep = 1;
+    }
+    bytes = wave_sum64(bytes);
+    keep = wave_sum(keep);
+    if (lane_id() == 0 && keep) {
+        atomicAdd(&stats->bytes_out, bytes);
+        atomicAdd(&stats->result_containers, (u64)keep);
+    }
+}
+__global__ void k_bm_start(const u64* __restrict__ cand_start, uint32_t npairs, const u64* __restrict__ newidx,
+                           u64* __restrict__ bm_start) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p <= npairs) bm_start[p] = newidx[cand_start[p]];
+}
+
+// per-bitmap cardinality = sum of container cardinalities (roaring.c:1436-1443); wave per bitmap
+__global__ __launch_bounds__(256) void k_bitmap_cards(PoolView P, uint32_t nbm, u64* __restrict__ out) {
+    uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (b >= nbm) return;
+    u64 s = 0;
+    for (u64 i = P.bm_start[b] + lane_id(); i < P.bm_start[b + 1]; i += 64) s += P.card[i];
+    s = wave_sum64(s);
+    if (lane_id() == 0) out[b] = s;
+}
+__global__ __launch_bounds__(256) void k_payload_stats(const uint8_t* type, const uint32_t* card,
+                                                       const uint32_t* nruns, u64 n, u64* out /*[4]*/) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 bytes = 0;
+    uint32_t nb = 0, na = 0, nr = 0;
+    if (i < n) {
+        uint8_t t = type[i];
+        bytes = payload_bytes(t, card[i], nruns[i]);
+        nb = t == T_BITSET; na = t == T_ARRAY; nr = t == T_RUN;
+    }
+    bytes = wave_sum64(bytes); nb = wave_sum(nb); na = wave_sum(na); nr = wave_sum(nr);
+    if (lane_id() == 0) {
+        if (bytes) atomicAdd(&out[0], bytes);
+        if (nb) atomicAdd(&out[1], (u64)nb);
+        if (na) atomicAdd(&out[2], (u64)na);
+        if (nr) atomicAdd(&out[3], (u64)nr);
+    }
+}
+
+// ------------------------------------------------------------------ synthetic C2 pool
+__device__ __forceinline__ u64 splitmix64_at(u64 seed, u64 idx) {  // idx-th output (1-based) of splitmix64(seed)
+    u64 z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void k_synth_fill(u64* words, uint32_t n_bitmaps, uint32_t n_containers, u64 seed) {
+    const u64 per_bm = (u64)n_containers * 1024ull;
+    const u64 total = per_bm * n_bitmaps;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x) {
+        u64 b = i / per_bm, w = i % per_bm;
+        words[i] = splitmix64_at(seed + b, w + 1);
+    }
+}
+__global__ __launch_bounds__(256) void k_synth_dir(const u64* words, uint32_t n_bitmaps, uint32_t n_containers,
+                                                   u64* bm_start, u64* key, uint8_t* type, uint32_t* card,
+                                                   uint32_t* nruns, u64* off) {
+    // one wave per container: popcount its 1024 words
+    u64 c = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const u64 total = (u64)n_bitmaps * n_containers;
+    if (c >= total) return;
+    const uint4* p = (const uint4*)(words + c * 1024ull);
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cnt += popc4(p[i * 64 + lane_id()]);
+    cnt = wave_sum(cnt);
+    if (lane_id() == 0) {
+        key[c] = c % n_containers;
+        type[c] = T_BITSET;
+        card[c] = cnt;
+        nruns[c] = 0;
+        off[c] = c * 8192ull;
+        if (c % n_containers == 0) bm_start[c / n_containers] = c;
+        if (c == total - 1) bm_start[n_bitmaps] = total;
+    }
+}

@@ -1,0 +1,293 @@
+// rhip_many.h -- many-way OR / XOR aggregation kernels (roaring_bitmap_or_many /
+// roaring_bitmap_xor_many, src/roaring.c:775-809).
+//
+// The reference folds bitmap after bitmap into a growing answer ("for every key, OR all
+// containers with that key into one 8 KiB accumulator, then canonicalise",
+// roaring.c:2600-2682 + 2845-2856).  Here the same computation is a group-by-key:
+//   1. gather (key, container) members of the selected bitmaps, stable radix sort by key;
+//   2. split each key group into units of <= CH members;
+//   3. k_many_l1: one workgroup per unit accumulates its members into an LDS bitset
+//      (arrays: ds_or/ds_xor scatter by all four waves; bitsets: owner-thread word OR;
+//      runs: toggle + prefix-xor rasterisation into a second LDS image, then word OR);
+//   4. groups with one unit are canonicalised straight from LDS; groups with several units
+//      write 8 KiB partial chunks that k_many_l2 combines (same shape as the multi-GPU
+//      exchange: partial chunks -> owner -> combine -> canonicalise).
+#pragma once
+#include "rhip_kernels.h"
+
+struct ManyView {
+    const u64* skey;        // [M] sorted member keys
+    const uint32_t* sval;   // [M] member container index (into the pool directory)
+    const u64* gstart;      // [G+1] first member of each group
+    const u64* ustart;      // [G+1] first unit of each group
+    const uint32_t* n_groups;  // device scalar
+    uint32_t ch;            // members per unit
+};
+
+// wave per selected bitmap: append its (key, container index) members
+__global__ __launch_bounds__(256) void k_many_gather(PoolView P, const uint32_t* __restrict__ ids,
+                                                     const u64* __restrict__ sel_start, uint32_t nsel,
+                                                     u64* __restrict__ mkey, uint32_t* __restrict__ mval) {
+    uint32_t s = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (s >= nsel) return;
+    const uint32_t b = ids[s];
+    const u64 c0 = P.bm_start[b], c1 = P.bm_start[b + 1], d0 = sel_start[s];
+    for (u64 i = c0 + lane_id(); i < c1; i += 64) {
+        mkey[d0 + (i - c0)] = P.key[i];
+        mval[d0 + (i - c0)] = (uint32_t)i;
+    }
+}
+
+__global__ void k_many_heads(const u64* __restrict__ skey, u64 M, uint32_t* __restrict__ flag) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) flag[i] = (i == 0 || skey[i] != skey[i - 1]) ? 1u : 0u;
+    if (i == M) flag[i] = 0;
+}
+// gid = exclusive scan of flag (so head i belongs to group gid[i]); gid[M] = number of groups
+__global__ void k_many_gstart(const uint32_t* __restrict__ flag, const u64* __restrict__ gid, u64 M,
+                              u64* __restrict__ gstart, uint32_t* __restrict__ n_groups) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M && flag[i]) gstart[gid[i]] = i;
+    if (i == M) {
+        gstart[gid[M]] = M;
+        *n_groups = (uint32_t)gid[M];
+    }
+}
+// per group: number of units; also the group's key
+__global__ void k_many_units(const u64* __restrict__ gstart, const u64* __restrict__ skey,
+                             const uint32_t* __restrict__ n_groups, uint32_t ch, uint32_t* __restrict__ nunits,
+                             u64* __restrict__ gkey, u64 maxg) {
+    u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 G = *n_groups;
+    if (g < G) {
+        u64 cnt = gstart[g + 1] - gstart[g];
+        nunits[g] = (uint32_t)((cnt + ch - 1) / ch);
+        gkey[g] = skey[gstart[g]];
+    } else if (g <= maxg) {
+        nunits[g] = 0;
+    }
+}
+
+// unit -> group lookup: largest g with ustart[g] <= u
+__device__ __forceinline__ uint32_t unit_group(const u64* __restrict__ ustart, uint32_t G, u64 u) {
+    u64 lo = 0, hi = G;  // ustart[G] = total units
+    while (lo + 1 < hi) {
+        u64 mid = (lo + hi) >> 1;
+        if (ustart[mid] <= u) lo = mid;
+        else hi = mid;
+    }
+    return (uint32_t)lo;
+}
+
+// wave per unit: sum of member cardinalities -> gcard[group]; single-member groups also
+// record their payload size (pass-through slot)
+__global__ __launch_bounds__(256) void k_many_cardsum(PoolView P, ManyView V, const u64* __restrict__ n_units,
+                                                      u64* __restrict__ gcard) {
+    const u64 u = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (u >= *n_units) return;
+    const uint32_t G = *V.n_groups;
+    const uint32_t g = unit_group(V.ustart, G, u);
+    const u64 m0 = V.gstart[g] + (u - V.ustart[g]) * V.ch;
+    const u64 m1 = (m0 + V.ch < V.gstart[g + 1]) ? m0 + V.ch : V.gstart[g + 1];
+    u64 s = 0;
+    for (u64 m = m0 + lane_id(); m < m1; m += 64) s += P.card[V.sval[m]];
+    s = wave_sum64(s);
+    if (lane_id() == 0) atomicAdd(&gcard[g], s);
+}
+
+// slot size of every group (upper bound on the canonical result payload)
+__global__ void k_many_slots(PoolView P, ManyView V, const u64* __restrict__ gcard, int force_typed,
+                             uint32_t* __restrict__ slot, u64 maxg) {
+    u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 G = *V.n_groups;
+    if (g < G) {
+        u64 cnt = V.gstart[g + 1] - V.gstart[g];
+        uint32_t sz;
+        if (cnt == 1 && !force_typed) {
+            uint32_t c = V.sval[V.gstart[g]];
+            sz = align16(payload_bytes(P.type[c], P.card[c], P.nruns[c]));
+        } else {
+            u64 ub = gcard[g] > 65536ull ? 65536ull : gcard[g];
+            sz = align16((uint32_t)(2 * ub > 8192 ? 8192 : 2 * ub));
+        }
+        slot[g] = sz < 16u ? 16u : sz;
+    } else if (g <= maxg) {
+        slot[g] = 0;
+    }
+}
+
+// Accumulate the members [m0, m1) into the LDS image acc (zeroed by the caller).
+__device__ void many_accumulate(uint32_t* acc, uint32_t* tmp, const PoolView& P, const ManyView& V, u64 m0, u64 m1,
+                                int op, BlockScratch* sc) {
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    // phase A: array members, one wave per member, LDS atomics (commutative: no ordering needed)
+    for (u64 m = m0 + wave; m < m1; m += 4) {
+        const uint32_t c = V.sval[m];
+        if (P.type[c] != T_ARRAY) continue;
+        const uint32_t n = P.card[c];
+        const uint32_t* __restrict__ a2 = (const uint32_t*)(P.arena + P.off[c]);
+        for (uint32_t i = lane; 2 * i < n; i += 64) {
+            uint32_t v2 = a2[i];
+            uint32_t v = v2 & 0xFFFFu;
+            if (op == OP_OR) atomicOr(&acc[v >> 5], 1u << (v & 31));
+            else atomicXor(&acc[v >> 5], 1u << (v & 31));
+            if (2 * i + 1 < n) {
+                v = v2 >> 16;
+                if (op == OP_OR) atomicOr(&acc[v >> 5], 1u << (v & 31));
+                else atomicXor(&acc[v >> 5], 1u << (v & 31));
+            }
+        }
+    }
+    __syncthreads();
+    // phase B: bitset members, thread-owned words
+    {
+        uint4 r0 = ((uint4*)acc)[2 * tid], r1 = ((uint4*)acc)[2 * tid + 1];
+        bool any = false;
+        for (u64 m = m0; m < m1; ++m) {
+            const uint32_t c = V.sval[m];
+            if (P.type[c] != T_BITSET) continue;
+            const uint4* __restrict__ g = (const uint4*)(P.arena + P.off[c]);
+            uint4 x0 = g[2 * tid], x1 = g[2 * tid + 1];
+            r0 = op4(op, r0, x0);
+            r1 = op4(op, r1, x1);
+            any = true;
+        }
+        if (any) {
+            ((uint4*)acc)[2 * tid] = r0;
+            ((uint4*)acc)[2 * tid + 1] = r1;
+        }
+    }
+    __syncthreads();
+    // phase C: run members, rasterised one at a time into tmp
+    for (u64 m = m0; m < m1; ++m) {
+        const uint32_t c = V.sval[m];
+        if (P.type[c] != T_RUN) continue;  // uniform across the block
+        lds_load(tmp, P, c, sc);
+        uint4 r0 = ((uint4*)acc)[2 * tid], r1 = ((uint4*)acc)[2 * tid + 1];
+        uint4 x0 = ((uint4*)tmp)[2 * tid], x1 = ((uint4*)tmp)[2 * tid + 1];
+        ((uint4*)acc)[2 * tid] = op4(op, r0, x0);
+        ((uint4*)acc)[2 * tid + 1] = op4(op, r1, x1);
+        __syncthreads();
+    }
+}
+
+struct ManyOut {
+    OutView O;          // candidate directory indexed by group
+    u64* partial;       // [n_units][1024] scratch chunks (multi-unit groups)
+    u64* chunk_out;     // partial_mode: [G][1024] final uncompressed chunks
+    int partial_mode;   // 1: write uncompressed chunks instead of canonical containers
+    int force_typed;    // 1: single-member groups are typed by cardinality too
+};
+
+// canonicalise the LDS image of a finished group: card <= 4096 -> array, else bitset
+// (container_repair_after_lazy, containers.h:344-371); empty -> dropped by compaction
+__device__ void many_finalize(uint32_t* acc, uint16_t* stage, const ManyOut& MO, uint32_t g, BlockScratch* sc) {
+    const uint32_t tid = threadIdx.x;
+    uint4 r0 = ((uint4*)acc)[2 * tid], r1 = ((uint4*)acc)[2 * tid + 1];
+    if (MO.partial_mode) {
+        uint4* po = (uint4*)(MO.chunk_out + (u64)g * 1024ull);
+        po[2 * tid] = r0;
+        po[2 * tid + 1] = r1;
+        return;
+    }
+    uint32_t r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    const uint32_t rc = blk_sum(popc4(r0) + popc4(r1), sc->wsum);
+    int ty = T_ARRAY;
+    if (rc) {
+        ty = type_ba(rc);
+        lds_emit(acc, r, ty, rc, 0, stage, MO.O.arena + MO.O.off[g], sc);
+    }
+    if (tid == 0) {
+        MO.O.type[g] = (uint8_t)ty;
+        MO.O.card[g] = rc;
+        MO.O.nruns[g] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_many_l1(PoolView P, ManyView V, ManyOut MO, const u64* __restrict__ n_units,
+                                                 int op) {
+    __shared__ __attribute__((aligned(16))) uint32_t acc[2048];
+    __shared__ __attribute__((aligned(16))) uint32_t tmp[2048];
+    __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];
+    __shared__ BlockScratch sc;
+    const uint32_t G = *V.n_groups;
+    const u64 U = *n_units;
+    for (u64 u = blockIdx.x; u < U; u += gridDim.x) {
+        const uint32_t g = unit_group(V.ustart, G, u);
+        const u64 gs = V.gstart[g], ge = V.gstart[g + 1];
+        const u64 nu = V.ustart[g + 1] - V.ustart[g];
+        if (nu == 1 && (ge - gs) == 1 && !MO.force_typed && !MO.partial_mode) continue;  // pass-through copy path
+        const u64 m0 = gs + (u - V.ustart[g]) * V.ch;
+        const u64 m1 = (m0 + V.ch < ge) ? m0 + V.ch : ge;
+        __syncthreads();
+        lds_zero(acc);
+        __syncthreads();
+        many_accumulate(acc, tmp, P, V, m0, m1, op, &sc);
+        if (nu == 1) {
+            many_finalize(acc, stage, MO, g, &sc);
+        } else {
+            uint4* po = (uint4*)(MO.partial + u * 1024ull);
+            po[2 * threadIdx.x] = ((uint4*)acc)[2 * threadIdx.x];
+            po[2 * threadIdx.x + 1] = ((uint4*)acc)[2 * threadIdx.x + 1];
+        }
+    }
+}
+
+// combine the partial chunks of multi-unit groups
+__global__ __launch_bounds__(256) void k_many_l2(ManyView V, ManyOut MO, int op) {
+    __shared__ __attribute__((aligned(16))) uint32_t acc[2048];
+    __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];
+    __shared__ BlockScratch sc;
+    const uint32_t G = *V.n_groups;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t g = blockIdx.x; g < G; g += gridDim.x) {
+        const u64 u0 = V.ustart[g], u1 = V.ustart[g + 1];
+        if (u1 - u0 < 2) continue;
+        uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
+        for (u64 u = u0; u < u1; ++u) {
+            const uint4* __restrict__ p = (const uint4*)(MO.partial + u * 1024ull);
+            r0 = op4(op, r0, p[2 * tid]);
+            r1 = op4(op, r1, p[2 * tid + 1]);
+        }
+        __syncthreads();
+        ((uint4*)acc)[2 * tid] = r0;
+        ((uint4*)acc)[2 * tid + 1] = r1;
+        __syncthreads();
+        many_finalize(acc, stage, MO, g, &sc);
+    }
+}
+
+// single-member groups keep their container unchanged (type included): roaring.c:2660-2676
+__global__ __launch_bounds__(256) void k_many_copy(PoolView P, ManyView V, ManyOut MO) {
+    const uint32_t G = *V.n_groups;
+    const uint32_t lane = lane_id();
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; g < G; g += nwaves) {
+        if (V.gstart[g + 1] - V.gstart[g] != 1) continue;
+        const uint32_t c = V.sval[V.gstart[g]];
+        const uint8_t ty = P.type[c];
+        const uint32_t card = P.card[c], nr = P.nruns[c];
+        const uint32_t n16 = (payload_bytes(ty, card, nr) + 15u) >> 4;
+        const uint4* __restrict__ ps = (const uint4*)(P.arena + P.off[c]);
+        uint4* __restrict__ po = (uint4*)(MO.O.arena + MO.O.off[g]);
+        for (uint32_t i = lane; i < n16; i += 64) po[i] = ps[i];
+        if (lane == 0) {
+            MO.O.type[g] = ty;
+            MO.O.card[g] = card;
+            MO.O.nruns[g] = nr;
+        }
+    }
+}
+
+__global__ void k_iota64(u64* p, u64 n, u64 mul) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i * mul;
+}
+__global__ void k_fill8(uint8_t* p, u64 n, uint8_t v) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void k_fill32(uint32_t* p, u64 n, uint32_t v) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}

@@ -1,0 +1,226 @@
+"""Host-side mirror of the CRoaring hot-path API over device-resident bitmaps.
+
+Vocabulary follows the reference (include/roaring/roaring.h): bitmaps, containers, portable
+serialization, and / or / xor / andnot, *_cardinality, or_many / xor_many.  A `Pool` is an
+immutable set of bitmaps living in HBM; operations take index arrays into pools and return new
+pools, so chained expressions never leave the device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import RoaringHipError, Stats, Partials
+
+OPS = {"and": 0, "or": 1, "xor": 2, "andnot": 3}
+
+
+def _u32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+class Engine:
+    """One per process and device (rhip_ctx_t): owns the HIP stream and scratch buffers."""
+
+    def __init__(self, device: int = -1):
+        self.lib = _lib.load()
+        self.h = self.lib.rhip_ctx_create(device)
+        if not self.h:
+            raise RoaringHipError("rhip_ctx_create failed: " + _lib.last_error())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rhip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self) -> int:
+        return self.lib.rhip_ctx_stream(self.h)
+
+    def synchronize(self):
+        if self.lib.rhip_ctx_synchronize(self.h) != 0:
+            raise RoaringHipError(_lib.last_error())
+
+    def set_timing(self, on: bool):
+        self.lib.rhip_ctx_set_timing(self.h, 1 if on else 0)
+
+    def last_stats(self) -> dict:
+        s = Stats()
+        self.lib.rhip_last_stats(self.h, C.byref(s))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    # ---- loading -------------------------------------------------------
+    def _from_bufs(self, fn, bufs: Sequence[bytes]) -> "Pool":
+        n = len(bufs)
+        arr = (C.c_char_p * max(n, 1))(*bufs)
+        lens = (C.c_size_t * max(n, 1))(*[len(b) for b in bufs])
+        h = fn(self.h, n, arr, lens)
+        if not h:
+            raise RoaringHipError("deserialize failed: " + _lib.last_error())
+        return Pool(self, h)
+
+    def pool_from_serialized(self, bufs: Sequence[bytes]) -> "Pool":
+        """roaring_bitmap_portable_deserialize_safe for every buffer, into one HBM pool."""
+        return self._from_bufs(self.lib.rhip_pool_from_portable, bufs)
+
+    def pool_from_serialized64(self, bufs: Sequence[bytes]) -> "Pool":
+        """roaring64_bitmap_portable_deserialize_safe for every buffer."""
+        return self._from_bufs(self.lib.rhip_pool_from_portable64, bufs)
+
+    def pool_synth_bitset(self, n_bitmaps: int, n_containers: int, seed: int) -> "Pool":
+        h = self.lib.rhip_pool_synth_bitset(self.h, n_bitmaps, n_containers, seed & (2**64 - 1))
+        if not h:
+            raise RoaringHipError("synth failed: " + _lib.last_error())
+        return Pool(self, h)
+
+    # ---- pairwise ------------------------------------------------------
+    def pairwise(self, op: str, A: "Pool", lhs, B: Optional["Pool"] = None, rhs=None,
+                 reuse: Optional["Pool"] = None) -> "Pool":
+        """result[k] = op(A[lhs[k]], B[rhs[k]]) -- roaring_bitmap_{and,or,xor,andnot} batched."""
+        B = A if B is None else B
+        lhs, rhs = _u32(lhs), _u32(rhs)
+        if lhs.shape != rhs.shape:
+            raise ValueError("lhs/rhs length mismatch")
+        rh = None
+        if reuse is not None:
+            rh, reuse.h = reuse.h, None  # consumed
+        h = self.lib.rhip_pairwise(self.h, OPS[op], A.h, B.h, lhs.size, lhs.ctypes.data, rhs.ctypes.data, rh)
+        if not h:
+            raise RoaringHipError(f"pairwise {op} failed: " + _lib.last_error())
+        return Pool(self, h)
+
+    def pairwise_cardinality(self, op: str, A: "Pool", lhs, B: Optional["Pool"] = None, rhs=None) -> np.ndarray:
+        """roaring_bitmap_{and,or,xor,andnot}_cardinality batched."""
+        B = A if B is None else B
+        lhs, rhs = _u32(lhs), _u32(rhs)
+        out = np.zeros(lhs.size, dtype=np.uint64)
+        rc = self.lib.rhip_pairwise_cardinality(self.h, OPS[op], A.h, B.h, lhs.size, lhs.ctypes.data,
+                                                rhs.ctypes.data, out.ctypes.data)
+        if rc != 0:
+            raise RoaringHipError(f"pairwise_cardinality {op} failed: " + _lib.last_error())
+        return out
+
+    # ---- many-way ------------------------------------------------------
+    def _many(self, fn, P: "Pool", ids) -> "Pool":
+        if ids is None:
+            h = fn(self.h, P.h, 0, None)
+        else:
+            ids = _u32(ids)
+            h = fn(self.h, P.h, ids.size, ids.ctypes.data)
+        if not h:
+            raise RoaringHipError("many-way aggregation failed: " + _lib.last_error())
+        return Pool(self, h)
+
+    def or_many(self, P: "Pool", ids=None) -> "Pool":
+        """roaring_bitmap_or_many over P[ids] (whole pool if ids is None); one-bitmap pool."""
+        return self._many(self.lib.rhip_or_many, P, ids)
+
+    def xor_many(self, P: "Pool", ids=None) -> "Pool":
+        return self._many(self.lib.rhip_xor_many, P, ids)
+
+    def many_partials(self, op: str, P: "Pool", ids=None) -> "PartialChunks":
+        """Stage 1 of the sharded or_many/xor_many: one uncompressed 1024-word chunk per key."""
+        out = Partials()
+        if ids is None:
+            rc = self.lib.rhip_many_partials(self.h, OPS[op], P.h, 0, None, C.byref(out))
+        else:
+            ids = _u32(ids)
+            rc = self.lib.rhip_many_partials(self.h, OPS[op], P.h, ids.size, ids.ctypes.data, C.byref(out))
+        if rc != 0:
+            raise RoaringHipError("many_partials failed: " + _lib.last_error())
+        return PartialChunks(self, out)
+
+    def many_finalize(self, op: str, is64: bool, n_chunks: int, d_keys: int, d_words: int) -> "Pool":
+        """Stage 2: combine (key, chunk) records by key and canonicalise; device pointers in."""
+        h = self.lib.rhip_many_finalize(self.h, OPS[op], 1 if is64 else 0, n_chunks, d_keys, d_words)
+        if not h:
+            raise RoaringHipError("many_finalize failed: " + _lib.last_error())
+        return Pool(self, h)
+
+
+class PartialChunks:
+    def __init__(self, eng: Engine, p: Partials):
+        self.eng, self.p = eng, p
+
+    n_keys = property(lambda self: int(self.p.n_keys))
+    d_keys = property(lambda self: int(self.p.d_keys or 0))
+    d_words = property(lambda self: int(self.p.d_words or 0))
+
+    def free(self):
+        if self.p is not None:
+            self.eng.lib.rhip_partials_free(self.eng.h, C.byref(self.p))
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Pool:
+    """A device-resident set of bitmaps (rhip_pool_t)."""
+
+    def __init__(self, eng: Engine, h):
+        self.eng, self.h = eng, h
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.eng.lib.rhip_pool_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        return self.eng.lib.rhip_pool_size(self.h)
+
+    @property
+    def n_containers(self) -> int:
+        return self.eng.lib.rhip_pool_containers(self.h)
+
+    @property
+    def is64(self) -> bool:
+        return bool(self.eng.lib.rhip_pool_is64(self.h))
+
+    def payload_bytes(self) -> int:
+        return self.eng.lib.rhip_pool_payload_bytes(self.h)
+
+    def type_counts(self) -> tuple:
+        out = (C.c_uint64 * 3)()
+        if self.eng.lib.rhip_pool_type_counts(self.h, out) != 0:
+            raise RoaringHipError(_lib.last_error())
+        return tuple(int(x) for x in out)  # (bitset, array, run)
+
+    def cardinalities(self) -> np.ndarray:
+        """roaring_bitmap_get_cardinality of every bitmap."""
+        out = np.zeros(len(self), dtype=np.uint64)
+        if self.eng.lib.rhip_pool_cardinalities(self.h, out.ctypes.data) != 0:
+            raise RoaringHipError(_lib.last_error())
+        return out
+
+    def serialize(self, i: int) -> bytes:
+        """roaring_bitmap_portable_serialize of bitmap i."""
+        n = self.eng.lib.rhip_pool_portable_size(self.h, i)
+        if n == 0:
+            raise RoaringHipError("portable_size failed: " + _lib.last_error())
+        buf = C.create_string_buffer(n)
+        w = self.eng.lib.rhip_pool_portable_serialize(self.h, i, buf)
+        if w != n:
+            raise RoaringHipError(f"serialize wrote {w} of {n} bytes: " + _lib.last_error())
+        return buf.raw
+
+    def serialize_all(self) -> list:
+        return [self.serialize(i) for i in range(len(self))]

@@ -1,0 +1,157 @@
+/*
+ * roaring_hip.h -- C ABI of libroaring_hip.so, the MI355X (gfx950) Roaring
+ * set-operation engine.
+ *
+ * Boundary: CRoaring has no plug-in registry; its boundary is
+ * the C ABI of libroaring.  Per-call offload of a sub-microsecond CPU op can
+ * never win, so the engine's native unit of work is a BATCH of
+ * bitmap pairs over DEVICE-RESIDENT bitmaps.  Each entry point below names the
+ * reference entry point (file:line under the reference tree) whose semantics --
+ * result set, result container types, empty-container dropping, error
+ * convention -- it reproduces for every element of the batch.  The
+ * CRoaring-named per-call drop-ins (roaring_bitmap_and, ...) built on top of
+ * this API are declared in roaring_hip_compat.h.
+ *
+ * Conventions
+ *  - plain C types only; device buffers are opaque inside rhip_pool_t.
+ *  - pointer-returning functions return NULL on error (CRoaring convention,
+ *    include/roaring/roaring.h:216-226); int-returning functions return 0 on
+ *    success, a negative rhip_status otherwise.  rhip_last_error() gives text.
+ *  - there is NO CPU fallback: every entry point fails if no HIP device is
+ *    usable.
+ *  - wire format = portable RoaringFormatSpec (src/roaring_array.c:469-813);
+ *    64-bit pools use the portable 64-bit format (src/roaring64.c:2323-2393).
+ */
+#ifndef ROARING_HIP_H
+#define ROARING_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rhip_ctx_s rhip_ctx_t;   /* one per process+device: stream, scratch */
+typedef struct rhip_pool_s rhip_pool_t; /* a device-resident, immutable set of bitmaps */
+
+typedef enum { RHIP_AND = 0, RHIP_OR = 1, RHIP_XOR = 2, RHIP_ANDNOT = 3 } rhip_op;
+typedef enum {
+    RHIP_OK = 0,
+    RHIP_ERR_DEVICE = -1,   /* no device / HIP runtime error */
+    RHIP_ERR_ALLOC = -2,    /* device or host allocation failed */
+    RHIP_ERR_FORMAT = -3,   /* malformed portable buffer */
+    RHIP_ERR_ARG = -4       /* bad argument (index out of range, ...) */
+} rhip_status;
+
+/* container type codes, identical to include/roaring/containers/containers.h:48-53 */
+enum { RHIP_BITSET = 1, RHIP_ARRAY = 2, RHIP_RUN = 3 };
+
+/* ---- context ---------------------------------------------------------- */
+/* device < 0 selects the current HIP device.  NULL if no device. */
+rhip_ctx_t *rhip_ctx_create(int device);
+void rhip_ctx_destroy(rhip_ctx_t *ctx);
+/* the hipStream_t every kernel of this context is launched on */
+void *rhip_ctx_stream(rhip_ctx_t *ctx);
+int rhip_ctx_synchronize(rhip_ctx_t *ctx);
+const char *rhip_last_error(void);
+const char *rhip_version(void);
+
+/* ---- pools: loading / storing ------------------------------------------ */
+/* roaring_bitmap_portable_deserialize_safe (include/roaring/roaring.h:746,
+ * src/roaring.c:1631-1651) for n buffers at once: headers are parsed on the
+ * host, payloads land in one HBM arena (bitset words 16-byte aligned and
+ * contiguous).  Container invariants are those of
+ * roaring_bitmap_internal_validate (src/roaring.c:454-523); buffers violating
+ * them are rejected with RHIP_ERR_FORMAT. */
+rhip_pool_t *rhip_pool_from_portable(rhip_ctx_t *ctx, size_t n, const char *const *bufs, const size_t *lens);
+/* same for the 64-bit portable format: roaring64_bitmap_portable_deserialize_safe
+ * (include/roaring/roaring64.h:652, src/roaring64.c:2442-2535).  Keys are the
+ * high 48 bits. */
+rhip_pool_t *rhip_pool_from_portable64(rhip_ctx_t *ctx, size_t n, const char *const *bufs, const size_t *lens);
+/* SURVEY §8d C2 generator: n_bitmaps bitmaps with keys 0..n_containers-1, all
+ * bitset containers, word w of bitmap b = splitmix64 stream seeded
+ * seed + b (generated on the device). */
+rhip_pool_t *rhip_pool_synth_bitset(rhip_ctx_t *ctx, uint32_t n_bitmaps, uint32_t n_containers, uint64_t seed);
+void rhip_pool_free(rhip_pool_t *pool); /* roaring_bitmap_free, roaring.h:365 */
+
+uint32_t rhip_pool_size(const rhip_pool_t *pool);          /* number of bitmaps */
+uint64_t rhip_pool_containers(const rhip_pool_t *pool);    /* total containers */
+int rhip_pool_is64(const rhip_pool_t *pool);
+/* payload bytes (bitset 8192, array 2*card, run 4*n_runs) of all containers */
+uint64_t rhip_pool_payload_bytes(rhip_pool_t *pool);
+/* per-type container counts out[0]=bitset out[1]=array out[2]=run */
+int rhip_pool_type_counts(rhip_pool_t *pool, uint64_t out[3]);
+
+/* roaring_bitmap_portable_size_in_bytes (roaring.h:791) of bitmap i (64-bit
+ * pools: roaring64_bitmap_portable_size_in_bytes, roaring64.h:595). 0 on error. */
+size_t rhip_pool_portable_size(rhip_pool_t *pool, uint32_t i);
+/* roaring_bitmap_portable_serialize (roaring.h:807): writes bitmap i, returns bytes written */
+size_t rhip_pool_portable_serialize(rhip_pool_t *pool, uint32_t i, char *buf);
+/* roaring_bitmap_get_cardinality (roaring.h:537, src/roaring.c:1436-1443) of every bitmap */
+int rhip_pool_cardinalities(rhip_pool_t *pool, uint64_t *out /* [rhip_pool_size] */);
+
+/* ---- pairwise set operations ------------------------------------------- */
+/* For k in [0,npairs): result k = op(A[lhs[k]], B[rhs[k]]) with the exact
+ * semantics of roaring_bitmap_and (roaring.h:225, src/roaring.c:731-770),
+ * _or (:288, :877-953), _xor (:320, :1121-1196), _andnot (:342, :1275-1338),
+ * including the per-container result types of container_and/or/xor/andnot
+ * (include/roaring/containers/containers.h:726-806, 1008-1103, 1449-1524,
+ * 1783-1876).  A and B may be the same pool.  `reuse` (may be NULL) is a result
+ * pool from an earlier call whose device buffers are recycled (it is consumed:
+ * the returned pool replaces it). */
+rhip_pool_t *rhip_pairwise(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *A, rhip_pool_t *B, size_t npairs,
+                           const uint32_t *lhs, const uint32_t *rhs, rhip_pool_t *reuse);
+/* roaring_bitmap_{and,or,xor,andnot}_cardinality (roaring.h:231,258,270,264;
+ * src/roaring.c:3048-3107): nothing is materialised. */
+int rhip_pairwise_cardinality(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *A, rhip_pool_t *B, size_t npairs,
+                              const uint32_t *lhs, const uint32_t *rhs, uint64_t *out);
+
+/* ---- many-way aggregation ------------------------------------------------ */
+/* roaring_bitmap_or_many (roaring.h:304, src/roaring.c:775-790) /
+ * roaring_bitmap_xor_many (roaring.h:334, src/roaring.c:795-809) over
+ * pool[ids[0..n)] (ids == NULL: the whole pool, in order).  Returns a pool
+ * holding ONE bitmap.  n == 0 gives an empty bitmap, n == 1 a copy. */
+rhip_pool_t *rhip_or_many(rhip_ctx_t *ctx, rhip_pool_t *pool, size_t n, const uint32_t *ids);
+rhip_pool_t *rhip_xor_many(rhip_ctx_t *ctx, rhip_pool_t *pool, size_t n, const uint32_t *ids);
+
+/* Multi-GPU or_many / xor_many building blocks.  Stage 1 on each
+ * rank: reduce the local shard to one UNCOMPRESSED 1024-word chunk per distinct
+ * key (no cardinality, no typing).  The caller exchanges chunks between ranks
+ * (RCCL all-to-all to the key-range owner) and calls stage 2 on the owner. */
+typedef struct rhip_partials_s {
+    uint64_t n_keys;       /* distinct keys in this shard */
+    uint64_t *d_keys;      /* device: [n_keys] ascending */
+    uint64_t *d_words;     /* device: [n_keys][1024] */
+} rhip_partials_t;
+int rhip_many_partials(rhip_ctx_t *ctx, rhip_op op /* RHIP_OR | RHIP_XOR */, rhip_pool_t *pool, size_t n,
+                       const uint32_t *ids, rhip_partials_t *out);
+void rhip_partials_free(rhip_ctx_t *ctx, rhip_partials_t *p);
+/* Stage 2: n_chunks (key, 1024-word chunk) records in device memory, any order,
+ * duplicates allowed: chunks with equal keys are combined with op, then every
+ * key is canonicalised (card <= 4096 -> array, else bitset; empty dropped) into
+ * a pool holding ONE bitmap. */
+rhip_pool_t *rhip_many_finalize(rhip_ctx_t *ctx, rhip_op op, int is64, uint64_t n_chunks, const uint64_t *d_keys,
+                                const uint64_t *d_words);
+
+/* ---- measurement hooks (bench.py) --------------------------------------- */
+/* algorithmic bytes and matched container pairs of the last
+ * rhip_pairwise / rhip_pairwise_cardinality / rhip_or_many call on ctx */
+typedef struct rhip_stats_s {
+    uint64_t matched_pairs;     /* container pairs sent to a set-op kernel */
+    uint64_t passthrough;       /* containers copied unchanged */
+    uint64_t bytes_in;          /* payload bytes read (matched + pass-through) */
+    uint64_t bytes_out;         /* payload bytes of result containers */
+    uint64_t n_bitset_pairs;    /* matched pairs handled by the bitset x bitset kernel */
+    uint64_t result_containers; /* non-empty result containers */
+    float ms_bitset_kernel;     /* HIP-event time of the bitset x bitset kernel launch, ms */
+    float ms_total;             /* HIP-event time of the whole call on the stream, ms */
+} rhip_stats_t;
+int rhip_last_stats(rhip_ctx_t *ctx, rhip_stats_t *out);
+/* enable/disable HIP-event timing of kernel launches (adds two event records per call) */
+void rhip_ctx_set_timing(rhip_ctx_t *ctx, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROARING_HIP_H */

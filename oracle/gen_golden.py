@@ -1,0 +1,160 @@
+"""Generate tests/golden/* with the REAL reference (oracle/_ref, built from /root/reference).
+
+Run in the build container only (needs /root/reference for the realdata text files):
+    python oracle/gen_golden.py
+
+Outputs (committed; the GPU box cannot see /root/reference):
+  tests/golden/<dataset>.rbnd.xz    portable-serialized input bitmaps, built exactly as the
+                                    reference benchmark does (benchmarks/benchmark.cpp:1938-1942:
+                                    roaring_bitmap_of_ptr + run_optimize + shrink_to_fit), files in
+                                    alphasort order (benchmarks/numbersfromtextfiles.h:113-118).
+  tests/golden/<dataset>_pairs.npz  for ALL unordered pairs i<j and each op in (and, or, xor, andnot):
+                                    result cardinality, portable size and crc32 of the reference's
+                                    portable serialization; plus or_many / or_many_heap / xor_many
+                                    results (serialized) over the whole dataset.
+  tests/golden/bitmapwith{,out}runs.bin   Java-produced format fixtures, verbatim copies of
+                                    tests/testdata/* (format_portability_unit.c:51-90).
+  tests/golden/synth_mixed.npz      crc32/size/cardinality of the reference's results on seeded synthetic
+                                    bitmaps hitting every container-type pair and result-typing branch
+                                    (inputs are regenerated from the seed; their crc32 is pinned too).
+"""
+import lzma
+import os
+import shutil
+import struct
+import sys
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle.pyoracle import Ref  # noqa: E402
+from gen_inputs import random_bitmap, PROFILES, chunk_values  # noqa: E402
+
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+OPS = ("and", "or", "xor", "andnot")
+
+
+def write_bundle(path, blobs):
+    raw = b"RBND" + struct.pack("<I", len(blobs)) + b"".join(struct.pack("<I", len(b)) + b for b in blobs)
+    with lzma.open(path, "wb", preset=9) as f:
+        f.write(raw)
+
+
+def load_text_dataset(R, name):
+    d = os.path.join(REF, "benchmarks", "realdata", name)
+    files = sorted(f for f in os.listdir(d) if f.endswith(".txt"))  # alphasort == byte order
+    hs = []
+    for f in files:
+        txt = open(os.path.join(d, f)).read().strip()
+        vals = np.array(sorted(set(int(x) for x in txt.split(",") if x.strip())), dtype=np.uint32)
+        hs.append(R.from_sorted(vals))
+    return hs
+
+
+def pairs_golden(R, hs, name):
+    n = len(hs)
+    idx = [(i, j) for i in range(n) for j in range(i + 1, n)]
+    out = {}
+    for op in OPS:
+        card = np.zeros(len(idx), np.uint32)
+        size = np.zeros(len(idx), np.uint32)
+        crc = np.zeros(len(idx), np.uint32)
+        for k, (i, j) in enumerate(idx):
+            r = R.op(op, hs[i], hs[j])
+            s = R.serialize(r)
+            card[k] = R.cardinality(r)
+            size[k] = len(s)
+            crc[k] = zlib.crc32(s)
+            assert R.op_cardinality(op, hs[i], hs[j]) == card[k]
+            R.free(r)
+        out[f"{op}_card"], out[f"{op}_size"], out[f"{op}_crc"] = card, size, crc
+        print(f"  {name} {op}: sum card = {int(card.astype(np.uint64).sum())}")
+    for nm, fn in (("or_many", R.or_many), ("or_many_heap", R.or_many_heap), ("xor_many", R.xor_many)):
+        r = fn(hs)
+        out[nm] = np.frombuffer(R.serialize(r), dtype=np.uint8)
+        print(f"  {name} {nm}: card = {R.cardinality(r)}")
+        R.free(r)
+    out["pairs"] = np.array(idx, dtype=np.uint16)
+    np.savez_compressed(os.path.join(GOLD, f"{name}_pairs.npz"), **out)
+
+
+def synth_inputs():
+    """Seeded synthetic inputs (sorted uint32 arrays).  Shared with tests/test_golden_*.py,
+    which regenerate them and check their crc32 against the fixture before using them."""
+    rng = np.random.default_rng(20260923)
+    singles = []
+    for pa in PROFILES:
+        for pb in PROFILES:
+            a = (np.uint32(5) << np.uint32(16)) | chunk_values(rng, pa).astype(np.uint32)
+            b = (np.uint32(5) << np.uint32(16)) | chunk_values(rng, pb).astype(np.uint32)
+            singles.append((a, b))
+    for _ in range(120):
+        singles.append((random_bitmap(rng), random_bitmap(rng)))
+    many = []
+    for _ in range(40):
+        k = int(rng.integers(0, 10))
+        many.append([random_bitmap(rng, max_keys=6, key_space=8) for _ in range(k)])
+    return singles, many
+
+
+def synth_golden(R):
+    """Every (profile_a, profile_b) container pair under one key + random multi-key bitmaps.
+    Only crc32/size/cardinality are stored: inputs are regenerated from the seed by the tests."""
+    singles, many = synth_inputs()
+    out = {"in_crc": [], "in_size": []}
+    for op in OPS:
+        out[f"{op}_crc"], out[f"{op}_size"], out[f"{op}_card"] = [], [], []
+    for a, b in singles:
+        ha, hb = R.from_sorted(a), R.from_sorted(b)
+        for h in (ha, hb):
+            s = R.serialize(h)
+            out["in_crc"].append(zlib.crc32(s)); out["in_size"].append(len(s))
+        for op in OPS:
+            r = R.op(op, ha, hb)
+            s = R.serialize(r)
+            out[f"{op}_crc"].append(zlib.crc32(s)); out[f"{op}_size"].append(len(s))
+            out[f"{op}_card"].append(R.cardinality(r))
+            R.free(r)
+        R.free(ha); R.free(hb)
+    for nm in ("or_many", "xor_many", "or_many_heap"):
+        out[f"{nm}_crc"], out[f"{nm}_size"], out[f"{nm}_card"] = [], [], []
+    out["many_in_crc"] = []
+    for vs in many:
+        hs = [R.from_sorted(v) for v in vs]
+        out["many_in_crc"].append(zlib.crc32(b"".join(R.serialize(h) for h in hs)))
+        for nm, fn in (("or_many", R.or_many), ("xor_many", R.xor_many), ("or_many_heap", R.or_many_heap)):
+            r = fn(hs)
+            s = R.serialize(r)
+            out[f"{nm}_crc"].append(zlib.crc32(s)); out[f"{nm}_size"].append(len(s))
+            out[f"{nm}_card"].append(R.cardinality(r))
+            R.free(r)
+        for h in hs:
+            R.free(h)
+    np.savez_compressed(os.path.join(GOLD, "synth_mixed.npz"),
+                        **{k: np.array(v, dtype=np.uint32) for k, v in out.items()})
+    print(f"  synth: {len(singles)} pairs, {len(many)} many-way groups")
+
+
+def main():
+    R = Ref()
+    os.makedirs(GOLD, exist_ok=True)
+    for f in ("bitmapwithruns.bin", "bitmapwithoutruns.bin"):
+        shutil.copy(os.path.join(REF, "tests", "testdata", f), os.path.join(GOLD, f))
+    for f in ("64map32bitvals.bin", "64mapspreadvals.bin", "64maphighvals.bin", "64mapempty.bin"):
+        shutil.copy(os.path.join(REF, "tests", "testdata", f), os.path.join(GOLD, f))
+    synth_golden(R)
+    for name in sys.argv[1:] or ["census1881", "weather_sept_85", "wikileaks-noquotes", "census-income"]:
+        print(name)
+        hs = load_text_dataset(R, name)
+        write_bundle(os.path.join(GOLD, f"{name}.rbnd.xz"), [R.serialize(h) for h in hs])
+        pairs_golden(R, hs, name)
+        for h in hs:
+            R.free(h)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,173 @@
+"""GPU parity tests: the HIP engine (through the C ABI) vs the reference's golden results
+(tests/golden/*, produced by the real CRoaring) and vs the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from util import DATASETS, OPS, all_pairs, crc, load_bundle, load_pairs, synth_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def synth(oracle):
+    singles, many = synth_inputs()
+    gold = np.load(__import__("os").path.join(__import__("util").GOLD, "synth_mixed.npz"))
+    bufs = []
+    for a, b in singles:
+        for v in (a, b):
+            h = oracle.from_sorted(v)
+            bufs.append(oracle.serialize(h))
+            oracle.free(h)
+    assert [crc(b) for b in bufs] == list(gold["in_crc"]), "synthetic inputs drifted from the fixture"
+    return bufs, many, gold
+
+
+@pytest.mark.parametrize("op", OPS)
+def test_synth_every_type_pair(engine, oracle, synth, op):
+    """All 14x14 container-profile pairs + 120 random multi-key pairs: byte-identical portable
+    serialization vs the reference (crc/size/card fixture) and vs the oracle (full bytes)."""
+    bufs, _, gold = synth
+    pool = engine.pool_from_serialized(bufs)
+    n = len(bufs) // 2
+    lhs, rhs = np.arange(n, dtype=np.uint32) * 2, np.arange(n, dtype=np.uint32) * 2 + 1
+    res = engine.pairwise(op, pool, lhs, pool, rhs)
+    cards = res.cardinalities()
+    bad = []
+    for k in range(n):
+        got = res.serialize(k)
+        oa, ob = oracle.deserialize(bufs[2 * k]), oracle.deserialize(bufs[2 * k + 1])
+        oo = oracle.op(op, oa, ob)
+        want = oracle.serialize(oo)
+        for h in (oa, ob, oo):
+            oracle.free(h)
+        if got != want or crc(got) != gold[f"{op}_crc"][k] or len(got) != gold[f"{op}_size"][k] \
+                or cards[k] != gold[f"{op}_card"][k]:
+            bad.append(k)
+    assert not bad, f"{op}: {len(bad)} mismatching pairs, first {bad[:10]}"
+    c2 = engine.pairwise_cardinality(op, pool, lhs, pool, rhs)
+    assert np.array_equal(c2, gold[f"{op}_card"].astype(np.uint64))
+
+
+@pytest.mark.parametrize("name", DATASETS)
+@pytest.mark.parametrize("op", OPS)
+def test_realdata_all_pairs(engine, name, op):
+    """Every unordered pair of a realdata set: cardinality, portable size and crc32 of the
+    serialized result equal the reference's (SURVEY §8d C1/C3 checksums included)."""
+    bufs = load_bundle(name)
+    gold = load_pairs(name)
+    pool = engine.pool_from_serialized(bufs)
+    lhs, rhs = all_pairs(len(bufs))
+    assert np.array_equal(np.stack([lhs, rhs], 1), gold["pairs"].astype(np.uint32))
+    res = engine.pairwise(op, pool, lhs, pool, rhs)
+    cards = res.cardinalities()
+    assert int(cards.sum()) == int(gold[f"{op}_card"].astype(np.uint64).sum())
+    assert np.array_equal(cards, gold[f"{op}_card"].astype(np.uint64))
+    cc = engine.pairwise_cardinality(op, pool, lhs, pool, rhs)
+    assert np.array_equal(cc, cards)
+    bad = 0
+    for k in range(len(lhs)):
+        s = res.serialize(k)
+        if len(s) != gold[f"{op}_size"][k] or crc(s) != gold[f"{op}_crc"][k]:
+            bad += 1
+    assert bad == 0, f"{name} {op}: {bad} of {len(lhs)} results differ from the reference"
+
+
+@pytest.mark.parametrize("name", DATASETS)
+def test_realdata_many(engine, oracle, name):
+    """or_many / xor_many over a whole dataset: set-equal to the reference's result (L1) and, for
+    or_many, byte-identical wherever the reference's own two algorithms agree."""
+    bufs = load_bundle(name)
+    gold = load_pairs(name)
+    pool = engine.pool_from_serialized(bufs)
+    for nm, fn in (("or_many", engine.or_many), ("xor_many", engine.xor_many)):
+        got = fn(pool).serialize(0)
+        want = bytes(gold[nm])
+        hg, hw = oracle.deserialize(got), oracle.deserialize(want)
+        assert oracle.validate(hg)
+        assert np.array_equal(oracle.to_array(hg), oracle.to_array(hw)), f"{name} {nm}: set mismatch"
+        if nm == "or_many" and got != want:
+            # L2 (byte identity) is best-effort for *_many; L1 is asserted above
+            import warnings
+            warnings.warn(f"{name} or_many: set-equal but container types differ from roaring_bitmap_or_many")
+        oracle.free(hg)
+        oracle.free(hw)
+
+
+def test_synth_many(engine, oracle, synth):
+    _, many, gold = synth
+    for k, vs in enumerate(many):
+        hs = [oracle.from_sorted(v) for v in vs]
+        bufs = [oracle.serialize(h) for h in hs]
+        pool = engine.pool_from_serialized(bufs)
+        for nm, fn in (("or_many", engine.or_many), ("xor_many", engine.xor_many)):
+            got = fn(pool).serialize(0)
+            hg = oracle.deserialize(got)
+            ow = (oracle.or_many if nm == "or_many" else oracle.xor_many)(hs)
+            assert oracle.validate(hg)
+            assert np.array_equal(oracle.to_array(hg), oracle.to_array(ow)), f"group {k} {nm}"
+            assert oracle.cardinality(hg) == gold[f"{nm}_card"][k]
+            oracle.free(hg)
+            oracle.free(ow)
+        for h in hs:
+            oracle.free(h)
+
+
+def test_bitset_only_synthetic_pool(engine, oracle):
+    """SURVEY §8d C2 at test size: device-generated splitmix64 pool == host restatement, and
+    pairwise results on it are byte-identical to the oracle."""
+    from gen_inputs import splitmix64
+    nb, nc, seed = 6, 40, 0x9E3779B97F4A7C15
+    pool = engine.pool_synth_bitset(nb, nc, seed)
+    assert pool.type_counts() == (nb * nc, 0, 0)
+    hs = []
+    for b in range(nb):
+        words = splitmix64((seed + b) & (2**64 - 1), nc * 1024)
+        bits = np.unpackbits(words.view(np.uint8), bitorder="little")
+        vals = np.flatnonzero(bits).astype(np.uint32)
+        h = oracle.from_sorted(vals, run_optimize=False)
+        assert oracle.serialize(h) == pool.serialize(b)
+        hs.append(h)
+    lhs = np.array([0, 1, 2, 3, 4, 5, 0], np.uint32)
+    rhs = np.array([1, 2, 3, 4, 5, 0, 0], np.uint32)
+    for op in OPS:
+        res = engine.pairwise(op, pool, lhs, pool, rhs)
+        st = engine.last_stats()
+        assert st["n_bitset_pairs"] == 7 * nc
+        for k in range(len(lhs)):
+            oo = oracle.op(op, hs[lhs[k]], hs[rhs[k]])
+            assert res.serialize(k) == oracle.serialize(oo), (op, k)
+            oracle.free(oo)
+    for h in hs:
+        oracle.free(h)
+
+
+def test_edge_cases(engine, oracle):
+    """Empty bitmaps, empty batches, self-pairs, disjoint keys."""
+    e = oracle.from_sorted(np.zeros(0, np.uint32))
+    a = oracle.from_sorted(np.arange(0, 200000, 3, dtype=np.uint32))
+    b = oracle.from_sorted(np.arange(1 << 20, (1 << 20) + 5000, dtype=np.uint32))
+    hs = [e, a, b]
+    bufs = [oracle.serialize(h) for h in hs]
+    pool = engine.pool_from_serialized(bufs)
+    assert len(engine.pairwise("and", pool, [], pool, [])) == 0
+    idx = [(i, j) for i in range(3) for j in range(3)]
+    lhs = np.array([i for i, _ in idx], np.uint32)
+    rhs = np.array([j for _, j in idx], np.uint32)
+    for op in OPS:
+        res = engine.pairwise(op, pool, lhs, pool, rhs)
+        for k, (i, j) in enumerate(idx):
+            oo = oracle.op(op, hs[i], hs[j])
+            assert res.serialize(k) == oracle.serialize(oo), (op, i, j)
+            oracle.free(oo)
+    assert engine.or_many(pool, []).serialize(0) == bufs[0]
+    assert engine.or_many(pool, [1]).serialize(0) == bufs[1]
+    # chained: (a | b) & a == a   -- results are pools and feed the next op without leaving HBM
+    u = engine.pairwise("or", pool, [1], pool, [2])
+    back = engine.pairwise("and", u, [0], pool, [1])
+    assert back.serialize(0) == bufs[1]
+    for h in hs:
+        oracle.free(h)
+    with pytest.raises(Exception):
+        engine.pool_from_serialized([b"\x00\x01\x02\x03garbage"])
+    with pytest.raises(Exception):
+        engine.pairwise("and", pool, [7], pool, [0])
