@@ -69,8 +69,7 @@ struct rhip_ctx_s {
     int device = 0;
     hipStream_t stream = nullptr;
     // scratch (grow-only): candidate directory + queues + scan temporaries
-    DBuf lhs, rhs, cand, cand_start, o_key, o_type, o_card, o_nruns, o_slot, o_off, flag, newidx, q[N_CLS], misc,
-        prim_tmp, pair_acc;
+    DBuf lhs, rhs, cand, cand_start, o_key, o_meta, o_slot, o_off, flag, newidx, q[N_CLS], misc, prim_tmp, pair_acc;
     DBuf many[16];
     void* h_pinned = nullptr;  // small pinned readback area
     rhip_stats_t stats{};
@@ -143,7 +142,7 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
 extern "C" void rhip_ctx_destroy(rhip_ctx_t* c) {
     if (!c) return;
     (void)hipStreamSynchronize(c->stream);
-    DBuf* all[] = {&c->lhs, &c->rhs, &c->cand, &c->cand_start, &c->o_key, &c->o_type, &c->o_card, &c->o_nruns,
+    DBuf* all[] = {&c->lhs, &c->rhs, &c->cand, &c->cand_start, &c->o_key, &c->o_meta,
                    &c->o_slot, &c->o_off, &c->flag, &c->newidx, &c->misc, &c->prim_tmp, &c->pair_acc};
     for (auto* b : all) b->release();
     for (auto& b : c->q) b.release();
@@ -366,8 +365,7 @@ extern "C" rhip_pool_t* rhip_pool_from_portable64(rhip_ctx_t* ctx, size_t n, con
 
 extern "C" void rhip_pool_free(rhip_pool_t* P) {
     if (!P) return;
-    if (P->ctx) (void)hipStreamSynchronize(P->ctx->stream);
-    P->release();
+    P->release();  // hipFree synchronises with the device; the context may already be gone
     delete P;
 }
 extern "C" uint32_t rhip_pool_size(const rhip_pool_t* P) { return P->n_bitmaps; }
@@ -595,26 +593,37 @@ extern "C" int rhip_pool_cardinalities(rhip_pool_t* P, uint64_t* out) {
 
 // ------------------------------------------------------------------ pairwise pipeline
 namespace {
-template <int OP>
-void launch_bb(rhip_ctx_t* c, unsigned grid, const PoolView& A, const PoolView& B, const OutView& O, int cardmode) {
-    hipLaunchKernelGGL(k_bb<OP>, dim3(grid), dim3(256), 0, c->stream, A, B, O, c->q[CLS_BB].as<Item>(),
-                       c->misc.as<uint32_t>() + CLS_BB, cardmode, c->pair_acc.as<u64>(), c->q[CLS_RETRY].as<Item>(),
-                       c->misc.as<uint32_t>() + CLS_RETRY);
-}
-
 struct PlanResult {
     uint64_t total_cand = 0;
     uint64_t total_bytes = 0;
-    uint32_t qn[N_CLS] = {0, 0, 0, 0};
+    uint64_t n_bb = 0, n_gen = 0, n_copy = 0;
 };
 
-// misc layout: [0..4) u32 queue counters, [8 bytes aligned] Stats at +32
-constexpr size_t MISC_STATS_OFF = 32;
+// misc layout (device): [0, 64) four {begin,end} u64 section ranges; [64, 72) retry counter;
+// [128, ...) Stats
+constexpr size_t MISC_RANGES_OFF = 0;
+constexpr size_t MISC_RETRY_OFF = 64;
+constexpr size_t MISC_STATS_OFF = 128;
+
+__global__ void k_plan_totals(const u64* __restrict__ starts, u64 S, u64* __restrict__ ranges) {
+    const uint32_t k = threadIdx.x;
+    if (k < 4) {
+        ranges[2 * k] = starts[k * S];
+        ranges[2 * k + 1] = starts[k * S + (S - 1)];
+    }
+}
+
+template <int OP>
+void launch_bb(rhip_ctx_t* c, unsigned grid, const PoolView& A, const PoolView& B, const OutView& O, int cardmode) {
+    hipLaunchKernelGGL(k_bb<OP>, dim3(grid), dim3(256), 0, c->stream, A.arena, B.arena, O, c->q[CLS_BB].as<BBItem>(),
+                       (const u64*)((char*)c->misc.p + MISC_RANGES_OFF) + 2 * SEC_BB, cardmode, c->pair_acc.as<u64>(),
+                       c->q[CLS_RETRY].as<Item>(), (uint32_t*)((char*)c->misc.p + MISC_RETRY_OFF));
+}
 
 void check_pair_args(rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs, const uint32_t* rhs) {
     if (!A || !B) { set_err("null pool"); throw (int)RHIP_ERR_ARG; }
     if (A->is64 != B->is64) { set_err("mixing 32-bit and 64-bit pools"); throw (int)RHIP_ERR_ARG; }
-    if (npairs >= 0xFFFFFFF0ull) { set_err("too many pairs"); throw (int)RHIP_ERR_ARG; }
+    if (npairs >= 0x3FFFFFF0ull) { set_err("too many pairs"); throw (int)RHIP_ERR_ARG; }
     for (size_t i = 0; i < npairs; ++i)
         if (lhs[i] >= A->n_bitmaps || rhs[i] >= B->n_bitmaps) {
             set_err("pair %zu: bitmap index out of range", i);
@@ -622,72 +631,77 @@ void check_pair_args(rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32
         }
 }
 
-// Runs count -> scan -> emit (-> slot scan).  On return the class queues are filled and the
-// host knows the candidate/byte totals (one small readback).
+// count -> one scan -> emit -> slot scan.  On return the class queues are filled (at
+// deterministic positions) and the host knows the totals (ONE small readback).
 PlanResult plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs,
                 const uint32_t* rhs, int cardmode, OutView& O) {
     hipStream_t s = c->stream;
     PlanResult R;
-    c->lhs.ensure(4 * (npairs + 1));
-    c->rhs.ensure(4 * (npairs + 1));
-    c->cand.ensure(4 * (npairs + 2));
-    c->cand_start.ensure(8 * (npairs + 2));
-    c->misc.ensure(256);
+    const size_t S = npairs + 1;
+    c->lhs.ensure(4 * S);
+    c->rhs.ensure(4 * S);
+    c->cand.ensure(4 * (4 * S + 1));
+    c->cand_start.ensure(8 * (4 * S + 1));
+    c->misc.ensure(512);
     HIPCHK(hipMemcpyAsync(c->lhs.p, lhs, 4 * npairs, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->rhs.p, rhs, 4 * npairs, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(c->misc.p, 0, 256, s));
+    HIPCHK(hipMemsetAsync(c->misc.p, 0, 512, s));
+    HIPCHK(hipMemsetAsync(c->cand.p, 0, 4 * (4 * S + 1), s));
     PoolView VA = A->view(), VB = B->view();
-    unsigned gp = (unsigned)((npairs * 64 + 255) / 256);
+    unsigned gp = (unsigned)std::max<size_t>(1, (npairs * 64 + 255) / 256);
     hipLaunchKernelGGL(k_count, dim3(gp), dim3(256), 0, s, VA, VB, c->lhs.as<uint32_t>(), c->rhs.as<uint32_t>(),
                        (uint32_t)npairs, op, cardmode, c->cand.as<uint32_t>());
-    exscan(c, c->cand.as<uint32_t>(), c->cand_start.as<u64>(), npairs);
-    // upper bound on candidates known on the host without a sync
-    uint64_t ub = 0;
-    {
-        // host mirrors of bm_start exist for uploaded pools; result pools fetch theirs lazily
-        if (!A->host_dir) fetch_dir(A);
-        if (!B->host_dir) fetch_dir(B);
-        for (size_t i = 0; i < npairs; ++i) {
-            uint64_t nA = A->h_bm_start[lhs[i] + 1] - A->h_bm_start[lhs[i]];
-            uint64_t nB = B->h_bm_start[rhs[i] + 1] - B->h_bm_start[rhs[i]];
-            if (cardmode || op == OP_AND) ub += std::min(nA, nB);
-            else if (op == OP_ANDNOT) ub += nA;
-            else ub += nA + nB;
-        }
+    exscan(c, c->cand.as<uint32_t>(), c->cand_start.as<u64>(), 4 * S - 1);
+    u64* ranges = (u64*)((char*)c->misc.p + MISC_RANGES_OFF);
+    hipLaunchKernelGGL(k_plan_totals, dim3(1), dim3(64), 0, s, c->cand_start.as<u64>(), (u64)S, ranges);
+    // upper bounds known on the host without a sync (directory mirrors)
+    uint64_t ub_match = 0, ub = 0;
+    if (!A->host_dir) fetch_dir(A);
+    if (!B->host_dir) fetch_dir(B);
+    for (size_t i = 0; i < npairs; ++i) {
+        uint64_t nA = A->h_bm_start[lhs[i] + 1] - A->h_bm_start[lhs[i]];
+        uint64_t nB = B->h_bm_start[rhs[i] + 1] - B->h_bm_start[rhs[i]];
+        ub_match += std::min(nA, nB);
+        if (cardmode || op == OP_AND) ub += std::min(nA, nB);
+        else if (op == OP_ANDNOT) ub += nA;
+        else ub += nA + nB;
     }
     if (ub >= 0xFFFFFFF0ull) { set_err("batch too large: %llu candidate containers", (unsigned long long)ub); throw (int)RHIP_ERR_ARG; }
-    for (int k = 0; k < 3; ++k) c->q[k].ensure(sizeof(Item) * (ub + 1));
+    c->q[CLS_BB].ensure(sizeof(BBItem) * (ub_match + 1));
+    c->q[CLS_GEN].ensure(sizeof(Item) * (ub_match + 1));
+    c->q[CLS_COPY].ensure(sizeof(Item) * (ub + 1));
     if (!cardmode) {
-        c->o_key.ensure(8 * (ub + 1)); c->o_type.ensure(ub + 16); c->o_card.ensure(4 * (ub + 1));
-        c->o_nruns.ensure(4 * (ub + 1)); c->o_slot.ensure(4 * (ub + 2)); c->o_off.ensure(8 * (ub + 2));
+        c->o_key.ensure(8 * (ub + 1)); c->o_meta.ensure(8 * (ub + 1));
+        c->o_slot.ensure(4 * (ub + 2)); c->o_off.ensure(8 * (ub + 2));
         HIPCHK(hipMemsetAsync(c->o_slot.p, 0, 4 * (ub + 2), s));
     }
-    O.key = c->o_key.as<u64>(); O.type = c->o_type.as<uint8_t>(); O.card = c->o_card.as<uint32_t>();
-    O.nruns = c->o_nruns.as<uint32_t>(); O.slot = c->o_slot.as<uint32_t>(); O.off = c->o_off.as<u64>();
+    O.key = c->o_key.as<u64>(); O.meta = c->o_meta.as<u64>();
+    O.slot = c->o_slot.as<uint32_t>(); O.off = c->o_off.as<u64>();
     O.arena = nullptr;
-    EmitQueues Q;
-    for (int k = 0; k < 3; ++k) Q.q[k] = c->q[k].as<Item>();
+    EmitQueues Q{c->q[CLS_BB].as<BBItem>(), c->q[CLS_GEN].as<Item>(), c->q[CLS_COPY].as<Item>()};
     hipLaunchKernelGGL(k_emit, dim3(gp), dim3(256), 0, s, VA, VB, c->lhs.as<uint32_t>(), c->rhs.as<uint32_t>(),
-                       (uint32_t)npairs, op, cardmode, c->cand_start.as<u64>(), O, Q, c->misc.as<uint32_t>(),
+                       (uint32_t)npairs, op, cardmode, c->cand_start.as<u64>(), O, Q,
                        (Stats*)((char*)c->misc.p + MISC_STATS_OFF));
-    // one small readback: total candidates, queue counts, total slot bytes
     char* hp = (char*)c->h_pinned;
     if (!cardmode) {
         // slots beyond the exact candidate count were zeroed, so scanning the upper bound is exact
         exscan(c, O.slot, c->o_off.as<u64>(), ub);
-        HIPCHK(hipMemcpyAsync(hp + 8, c->o_off.as<u64>() + ub, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hp + 64, c->o_off.as<u64>() + ub, 8, hipMemcpyDeviceToHost, s));
     }
-    HIPCHK(hipMemcpyAsync(hp, c->cand_start.as<u64>() + npairs, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hp + 16, c->misc.p, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hp, ranges, 64, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    memcpy(&R.total_cand, hp, 8);
-    memcpy(R.qn, hp + 16, 16);
-    if (!cardmode) memcpy(&R.total_bytes, hp + 8, 8);
+    uint64_t r[8];
+    memcpy(r, hp, 64);
+    R.total_cand = r[1] - r[0];
+    R.n_bb = r[3] - r[2];
+    R.n_gen = r[5] - r[4];
+    R.n_copy = r[7] - r[6];
+    if (!cardmode) memcpy(&R.total_bytes, hp + 64, 8);
     return R;
 }
 
-unsigned persistent_grid(uint32_t n_items, unsigned items_per_block, unsigned max_blocks) {
-    uint64_t need = ((uint64_t)n_items + items_per_block - 1) / items_per_block;
+unsigned persistent_grid(uint64_t n_items, unsigned items_per_block, unsigned max_blocks) {
+    uint64_t need = (n_items + items_per_block - 1) / items_per_block;
     if (need < 1) need = 1;
     return (unsigned)std::min<uint64_t>(need, max_blocks);
 }
@@ -695,10 +709,11 @@ unsigned persistent_grid(uint32_t n_items, unsigned items_per_block, unsigned ma
 void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, const OutView& O,
                  const PlanResult& R, int cardmode) {
     hipStream_t s = c->stream;
-    uint32_t* qc = c->misc.as<uint32_t>();
-    if (R.qn[CLS_BB]) {
-        c->q[CLS_RETRY].ensure(sizeof(Item) * ((size_t)R.qn[CLS_BB] + 1));
-        unsigned grid = persistent_grid(R.qn[CLS_BB], 4, 256 * 8);
+    const u64* ranges = (const u64*)((char*)c->misc.p + MISC_RANGES_OFF);
+    uint32_t* retry_count = (uint32_t*)((char*)c->misc.p + MISC_RETRY_OFF);
+    if (R.n_bb) {
+        c->q[CLS_RETRY].ensure(sizeof(Item) * (R.n_bb + 1));
+        unsigned grid = persistent_grid(R.n_bb, 4, 256 * 16);
         if (c->timing) HIPCHK(hipEventRecord(c->ev[2], s));
         switch (op) {
             case OP_AND: launch_bb<OP_AND>(c, grid, VA, VB, O, cardmode); break;
@@ -709,40 +724,41 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
         if (c->timing) HIPCHK(hipEventRecord(c->ev[3], s));
         if (!cardmode && op != OP_OR) {
             // bitset x bitset results that must become arrays (card <= 4096): LDS extraction
-            unsigned g2 = persistent_grid(R.qn[CLS_BB], 1, 256 * 6);
+            unsigned g2 = persistent_grid(R.n_bb, 1, 256 * 6);
             hipLaunchKernelGGL(k_gen, dim3(g2), dim3(256), 0, s, VA, VB, O, c->q[CLS_RETRY].as<Item>(),
-                               qc + CLS_RETRY, op, 0, c->pair_acc.as<u64>());
+                               (const u64*)nullptr, retry_count, op, 0, c->pair_acc.as<u64>());
         }
     }
-    if (R.qn[CLS_GEN]) {
-        unsigned grid = persistent_grid(R.qn[CLS_GEN], 1, 256 * 6);
-        hipLaunchKernelGGL(k_gen, dim3(grid), dim3(256), 0, s, VA, VB, O, c->q[CLS_GEN].as<Item>(), qc + CLS_GEN, op,
-                           cardmode, c->pair_acc.as<u64>());
+    if (R.n_gen) {
+        unsigned grid = persistent_grid(R.n_gen, 1, 256 * 6);
+        hipLaunchKernelGGL(k_gen, dim3(grid), dim3(256), 0, s, VA, VB, O, c->q[CLS_GEN].as<Item>(),
+                           ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, cardmode, c->pair_acc.as<u64>());
     }
-    if (R.qn[CLS_COPY] && !cardmode) {
-        unsigned grid = persistent_grid(R.qn[CLS_COPY], 4, 256 * 8);
-        hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, s, VA, VB, O, c->q[CLS_COPY].as<Item>(), qc + CLS_COPY);
+    if (R.n_copy && !cardmode) {
+        unsigned grid = persistent_grid(R.n_copy, 4, 256 * 8);
+        hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, s, VA, VB, O, c->q[CLS_COPY].as<Item>(),
+                           ranges + 2 * SEC_COPY);
     }
 }
 
-void finish_stats(rhip_ctx_t* c, bool had_bb) {
+void finish_stats(rhip_ctx_t* c, const PlanResult* R) {
     hipStream_t s = c->stream;
     Stats st;
     HIPCHK(hipMemcpyAsync(c->h_pinned, (char*)c->misc.p + MISC_STATS_OFF, sizeof(Stats), hipMemcpyDeviceToHost, s));
     if (c->timing) HIPCHK(hipEventRecord(c->ev[1], s));
     HIPCHK(hipStreamSynchronize(s));
     memcpy(&st, c->h_pinned, sizeof(Stats));
-    c->stats.matched_pairs = st.matched_pairs;
-    c->stats.passthrough = st.passthrough;
+    c->stats.matched_pairs = R ? R->n_bb + R->n_gen : 0;
+    c->stats.passthrough = R ? R->n_copy : 0;
     c->stats.bytes_in = st.bytes_in;
     c->stats.bytes_out = st.bytes_out;
-    c->stats.n_bitset_pairs = st.n_bb;
+    c->stats.n_bitset_pairs = R ? R->n_bb : 0;
     c->stats.result_containers = st.result_containers;
     c->stats.ms_bitset_kernel = 0.f;
     c->stats.ms_total = 0.f;
     if (c->timing) {
         (void)hipEventElapsedTime(&c->stats.ms_total, c->ev[0], c->ev[1]);
-        if (had_bb) (void)hipEventElapsedTime(&c->stats.ms_bitset_kernel, c->ev[2], c->ev[3]);
+        if (R && R->n_bb) (void)hipEventElapsedTime(&c->stats.ms_bitset_kernel, c->ev[2], c->ev[3]);
     }
 }
 }  // namespace
@@ -776,18 +792,18 @@ extern "C" rhip_pool_t* rhip_pairwise(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A
         uint64_t n = P.total_cand;
         c->flag.ensure(4 * (n + 2));
         c->newidx.ensure(8 * (n + 2));
-        if (n) hipLaunchKernelGGL(k_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, O.card, (u64)n,
+        if (n) hipLaunchKernelGGL(k_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, O.meta, (u64)n,
                                   c->flag.as<uint32_t>());
         exscan(c, c->flag.as<uint32_t>(), c->newidx.as<u64>(), n);
         DirOut D{R->bm_start.as<u64>(), R->key.as<u64>(), R->type.as<uint8_t>(), R->card.as<uint32_t>(),
                  R->nruns.as<uint32_t>(), R->off.as<u64>()};
         Stats* st = (Stats*)((char*)c->misc.p + MISC_STATS_OFF);
-        if (n) hipLaunchKernelGGL(k_compact, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, O, (u64)n,
-                                  c->newidx.as<u64>(), D, st);
+        if (n) hipLaunchKernelGGL(k_compact, dim3((unsigned)std::min<uint64_t>((n + 4095) / 4096, 1024)), dim3(1024), 0, s,
+                                  O, (u64)n, c->newidx.as<u64>(), D, st);
         hipLaunchKernelGGL(k_bm_start, dim3((unsigned)((npairs + 1 + 255) / 256)), dim3(256), 0, s,
                            c->cand_start.as<u64>(), (uint32_t)npairs, c->newidx.as<u64>(), R->bm_start.as<u64>());
         HIPCHK(hipMemcpyAsync((char*)c->h_pinned + 512, c->newidx.as<u64>() + n, 8, hipMemcpyDeviceToHost, s));
-        finish_stats(c, P.qn[CLS_BB] != 0);
+        finish_stats(c, &P);
         memcpy(&R->n_cont, (char*)c->h_pinned + 512, 8);
         return R;
     } catch (int) {
@@ -820,7 +836,7 @@ extern "C" int rhip_pairwise_cardinality(rhip_ctx_t* c, rhip_op op_, rhip_pool_t
         PoolView VA = A->view(), VB = B->view();
         run_kernels(c, OP_AND, VA, VB, O, P, 1);
         HIPCHK(hipMemcpyAsync(out, c->pair_acc.p, 8 * npairs, hipMemcpyDeviceToHost, s));
-        finish_stats(c, P.qn[CLS_BB] != 0);
+        finish_stats(c, &P);
         for (size_t i = 0; i < npairs; ++i) {
             uint64_t in = out[i];
             switch (op) {

@@ -41,18 +41,26 @@ struct PoolView {
 
 struct OutView {  // candidate (pre-compaction) result directory + the result arena
     u64* key;
-    uint8_t* type;
-    uint32_t* card;
-    uint32_t* nruns;
+    u64* meta;       // card | nruns << 32 | type << 56 : one 8-byte store per result container
     const u64* off;  // exclusive scan of slot[]
     uint8_t* arena;
     uint32_t* slot;  // upper-bound payload bytes of each candidate (multiple of 16)
 };
+__device__ __forceinline__ u64 pack_meta(uint32_t type, uint32_t card, uint32_t nruns) {
+    return (u64)card | ((u64)nruns << 32) | ((u64)type << 56);
+}
+__device__ __forceinline__ uint32_t meta_card(u64 m) { return (uint32_t)m; }
+__device__ __forceinline__ uint32_t meta_nruns(u64 m) { return (uint32_t)(m >> 32) & 0xFFFFFFu; }
+__device__ __forceinline__ uint32_t meta_type(u64 m) { return (uint32_t)(m >> 56); }
 
 struct Item {
     uint32_t a;    // container index in pool A (NONE32: pass-through from B)
     uint32_t b;    // container index in pool B (NONE32: pass-through from A)
     uint32_t out;  // candidate index (cardinality mode: pair index)
+};
+struct __attribute__((aligned(16))) BBItem {  // bitset x bitset work item: payload offsets resolved at plan time
+    u64 offa, offb;
+    uint32_t a, b, out, pad;
 };
 
 struct Stats {  // device-side counters, see rhip_stats_t
@@ -116,163 +124,193 @@ __device__ __forceinline__ uint32_t matched_slot(int op, uint32_t ca, uint32_t c
 }
 
 // ------------------------------------------------------------------ planning
-// One wave per bitmap pair.  cand[p] = number of candidate result containers.
+// Four lower_bound searches per lane issued together (independent dependent-load chains).
+__device__ __forceinline__ void lower_bound4(const u64* __restrict__ key, u64 lo0, u64 hi0, const u64 k[4],
+                                             const bool act[4], u64 out[4]) {
+    u64 lo[4], hi[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { lo[t] = lo0; hi[t] = act[t] ? hi0 : lo0; }
+    bool more = true;
+    while (more) {
+        more = false;
+        u64 mid[4], kv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { mid[t] = (lo[t] + hi[t]) >> 1; kv[t] = (lo[t] < hi[t]) ? key[mid[t]] : 0; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (lo[t] < hi[t]) {
+                if (kv[t] < k[t]) lo[t] = mid[t] + 1;
+                else hi[t] = mid[t];
+                more |= lo[t] < hi[t];
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) out[t] = lo[t];
+}
+
+// Layout of the per-pair count arrays (and of their exclusive scan): 4 sections of npairs+1
+// entries: [candidates | bitset-pair items | general items | copy items].
+enum { SEC_CAND = 0, SEC_BB = 1, SEC_GEN = 2, SEC_COPY = 3 };
+
+// One wave per bitmap pair: counts of candidate result containers and of work items per class.
 __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uint32_t* __restrict__ lhs,
                                                const uint32_t* __restrict__ rhs, uint32_t npairs, int op,
-                                               int cardmode, uint32_t* __restrict__ cand) {
+                                               int cardmode, uint32_t* __restrict__ counts) {
     uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (p >= npairs) return;
     const uint32_t lane = lane_id();
-    u64 a0 = A.bm_start[lhs[p]], a1 = A.bm_start[lhs[p] + 1];
-    u64 b0 = B.bm_start[rhs[p]], b1 = B.bm_start[rhs[p] + 1];
-    u64 nA = a1 - a0, nB = b1 - b0;
-    // search the shorter directory slice in the longer one
-    const u64 *ks = A.key, *kl = B.key;
-    u64 s0 = a0, s1 = a1, l0 = b0, l1 = b1;
-    if (nA > nB) { ks = B.key; kl = A.key; s0 = b0; s1 = b1; l0 = a0; l1 = a1; }
-    uint32_t matched = 0;
-    for (u64 i = s0; i < s1; i += 64) {
-        bool found = false;
-        if (i + lane < s1) {
-            u64 k = ks[i + lane];
-            u64 j = lower_bound(kl, l0, l1, k);
-            found = (j < l1) && (kl[j] == k);
+    const u64 a0 = A.bm_start[lhs[p]], a1 = A.bm_start[lhs[p] + 1];
+    const u64 b0 = B.bm_start[rhs[p]], b1 = B.bm_start[rhs[p] + 1];
+    const u64 nA = a1 - a0, nB = b1 - b0;
+    uint32_t matched = 0, nbb = 0;
+    for (u64 i = a0; i < a1; i += 256) {
+        u64 k[4], j[4];
+        bool act[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            act[t] = i + 64 * t + lane < a1;
+            k[t] = act[t] ? A.key[i + 64 * t + lane] : 0;
         }
-        matched += (uint32_t)__popcll(__ballot(found));
+        lower_bound4(B.key, b0, b1, k, act, j);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            bool found = act[t] && j[t] < b1 && B.key[j[t]] == k[t];
+            bool bb = found && A.type[i + 64 * t + lane] == T_BITSET && B.type[j[t]] == T_BITSET;
+            matched += (uint32_t)__popcll(__ballot(found));
+            nbb += (uint32_t)__popcll(__ballot(bb));
+        }
     }
     if (lane == 0) {
-        uint32_t c;
-        if (cardmode || op == OP_AND) c = matched;
-        else if (op == OP_ANDNOT) c = (uint32_t)nA;
-        else c = (uint32_t)(nA + nB) - matched;
-        cand[p] = c;
+        uint32_t ncopy;
+        if (cardmode || op == OP_AND) ncopy = 0;
+        else if (op == OP_ANDNOT) ncopy = (uint32_t)nA - matched;
+        else ncopy = (uint32_t)(nA + nB) - 2u * matched;
+        const size_t S = (size_t)npairs + 1;
+        counts[SEC_CAND * S + p] = matched + ncopy;
+        counts[SEC_BB * S + p] = nbb;
+        counts[SEC_GEN * S + p] = matched - nbb;
+        counts[SEC_COPY * S + p] = ncopy;
     }
 }
 
-__device__ __forceinline__ void push_items(int cls, bool valid, Item it, Item* const* q, uint32_t* qcount) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        u64 m = __ballot(valid && cls == c);
-        if (m) {
-            uint32_t base = 0;
-            int leader = __ffsll((long long)m) - 1;
-            if ((int)lane_id() == leader) base = atomicAdd(&qcount[c], (uint32_t)__popcll(m));
-            base = __shfl(base, leader);
-            if (valid && cls == c) q[c][base + mbcnt(m)] = it;
-        }
-    }
-}
-
-// One wave per bitmap pair: emit candidates in merged key order (roaring.c:742-768, 895-951).
+// One wave per bitmap pair: emit candidates in merged key order (roaring.c:742-768, 895-951)
+// and the work items of each class at deterministic queue positions (no atomics).
 // Position of a candidate inside its result bitmap is computed by ranking, not by a serial merge:
 //   matched / A-only element i (key k):  i + |{B keys < k}| - |{matched keys < k}|
 //   B-only element j (key k)          :  j + |{A keys < k}| - |{matched keys < k}|
-struct EmitQueues { Item* q[3]; };
+struct EmitQueues {
+    BBItem* bb;   // section SEC_BB
+    Item* gen;    // section SEC_GEN
+    Item* copy;   // section SEC_COPY
+};
 __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint32_t* __restrict__ lhs,
                                               const uint32_t* __restrict__ rhs, uint32_t npairs, int op,
-                                              int cardmode, const u64* __restrict__ cand_start, OutView O,
-                                              EmitQueues Q, uint32_t* qcount, Stats* stats) {
+                                              int cardmode, const u64* __restrict__ starts, OutView O,
+                                              EmitQueues Q, Stats* stats) {
     uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (p >= npairs) return;
     const uint32_t lane = lane_id();
-    u64 a0 = A.bm_start[lhs[p]], a1 = A.bm_start[lhs[p] + 1];
-    u64 b0 = B.bm_start[rhs[p]], b1 = B.bm_start[rhs[p] + 1];
-    const u64 base = cand_start[p];
+    const size_t S = (size_t)npairs + 1;
+    const u64 a0 = A.bm_start[lhs[p]], a1 = A.bm_start[lhs[p] + 1];
+    const u64 b0 = B.bm_start[rhs[p]], b1 = B.bm_start[rhs[p] + 1];
+    const u64 base = starts[SEC_CAND * S + p];
+    // queue cursors of this pair, relative to the beginning of each section
+    u64 qbb = starts[SEC_BB * S + p] - starts[SEC_BB * S];
+    u64 qgen = starts[SEC_GEN * S + p] - starts[SEC_GEN * S];
+    u64 qcopy = starts[SEC_COPY * S + p] - starts[SEC_COPY * S];
     u64 bytes_in = 0;
-    uint32_t n_matched = 0, n_pass = 0, n_bb = 0;
 
     uint32_t mbefore = 0;  // matched keys among A elements already visited
-    for (u64 i = a0; i < a1; i += 64) {
-        bool act = (i + lane) < a1;
-        u64 ai = i + lane;
-        u64 k = 0, j = b0;
-        bool found = false;
-        if (act) {
-            k = A.key[ai];
-            j = lower_bound(B.key, b0, b1, k);
-            found = (j < b1) && (B.key[j] == k);
+    for (u64 i = a0; i < a1; i += 256) {
+        u64 k[4], j[4];
+        bool act[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            act[t] = i + 64 * t + lane < a1;
+            k[t] = act[t] ? A.key[i + 64 * t + lane] : 0;
         }
-        u64 fm = __ballot(found);
-        uint32_t mb = mbefore + mbcnt(fm);
-        mbefore += (uint32_t)__popcll(fm);
-        bool emit = act && (found || (!cardmode && op != OP_AND));
-        Item it;
-        int cls = CLS_GEN;
-        if (emit) {
-            uint32_t ilocal = (uint32_t)(ai - a0), lbcount = (uint32_t)(j - b0);
-            uint32_t pos;
-            if (op == OP_AND || cardmode) pos = mb;
-            else if (op == OP_ANDNOT) pos = ilocal;
-            else pos = ilocal + lbcount - mb;
-            uint8_t ta = A.type[ai];
-            uint32_t ca = A.card[ai];
-            uint32_t pa = payload_bytes(ta, ca, A.nruns[ai]);
-            it.a = (uint32_t)ai;
-            if (found) {
-                uint8_t tb = B.type[j];
-                uint32_t cb = B.card[j];
-                it.b = (uint32_t)j;
-                cls = (ta == T_BITSET && tb == T_BITSET) ? CLS_BB : CLS_GEN;
-                bytes_in += pa + payload_bytes(tb, cb, B.nruns[j]);
-                n_matched++;
-                n_bb += (cls == CLS_BB);
-                if (!cardmode) O.slot[base + pos] = matched_slot(op, ca, cb);
-            } else {
-                it.b = NONE32;
-                cls = CLS_COPY;
+        lower_bound4(B.key, b0, b1, k, act, j);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const u64 ai = i + 64 * t + lane;
+            const bool found = act[t] && j[t] < b1 && B.key[j[t]] == k[t];
+            const u64 fm = __ballot(found);
+            const uint32_t mb = mbefore + mbcnt(fm);
+            mbefore += (uint32_t)__popcll(fm);
+            const bool emit = act[t] && (found || (!cardmode && op != OP_AND));
+            uint8_t ta = 0, tb = 0;
+            uint32_t ca = 0, cb = 0, pa = 0, pos = 0;
+            if (emit) {
+                const uint32_t ilocal = (uint32_t)(ai - a0), lbcount = (uint32_t)(j[t] - b0);
+                if (op == OP_AND || cardmode) pos = mb;
+                else if (op == OP_ANDNOT) pos = ilocal;
+                else pos = ilocal + lbcount - mb;
+                ta = A.type[ai];
+                ca = A.card[ai];
+                pa = payload_bytes(ta, ca, A.nruns[ai]);
                 bytes_in += pa;
-                n_pass++;
-                O.slot[base + pos] = align16(pa) < 16u ? 16u : align16(pa);
+                if (found) {
+                    tb = B.type[j[t]];
+                    cb = B.card[j[t]];
+                    bytes_in += payload_bytes(tb, cb, B.nruns[j[t]]);
+                }
+                if (!cardmode) {
+                    O.key[base + pos] = k[t];
+                    uint32_t sl = found ? matched_slot(op, ca, cb) : align16(pa);
+                    O.slot[base + pos] = sl < 16u ? 16u : sl;
+                }
             }
-            if (cardmode) it.out = p;
-            else {
-                it.out = (uint32_t)(base + pos);
-                O.key[base + pos] = k;
+            const uint32_t outidx = cardmode ? p : (uint32_t)(base + pos);
+            const bool isbb = emit && found && ta == T_BITSET && tb == T_BITSET;
+            const bool isgen = emit && found && !isbb;
+            const bool iscopy = emit && !found;
+            const u64 mbb = __ballot(isbb), mgen = __ballot(isgen), mcp = __ballot(iscopy);
+            if (isbb) {
+                BBItem it;
+                it.offa = A.off[ai]; it.offb = B.off[j[t]];
+                it.a = (uint32_t)ai; it.b = (uint32_t)j[t]; it.out = outidx; it.pad = 0;
+                Q.bb[qbb + mbcnt(mbb)] = it;
             }
+            if (isgen) Q.gen[qgen + mbcnt(mgen)] = Item{(uint32_t)ai, (uint32_t)j[t], outidx};
+            if (iscopy) Q.copy[qcopy + mbcnt(mcp)] = Item{(uint32_t)ai, NONE32, outidx};
+            qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp);
         }
-        push_items(cls, emit, it, Q.q, qcount);
     }
     if (!cardmode && (op == OP_OR || op == OP_XOR)) {
         mbefore = 0;
-        for (u64 i = b0; i < b1; i += 64) {
-            bool act = (i + lane) < b1;
-            u64 bi = i + lane;
-            u64 k = 0, j = a0;
-            bool found = false;
-            if (act) {
-                k = B.key[bi];
-                j = lower_bound(A.key, a0, a1, k);
-                found = (j < a1) && (A.key[j] == k);
+        for (u64 i = b0; i < b1; i += 256) {
+            u64 k[4], j[4];
+            bool act[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                act[t] = i + 64 * t + lane < b1;
+                k[t] = act[t] ? B.key[i + 64 * t + lane] : 0;
             }
-            u64 fm = __ballot(found);
-            uint32_t mb = mbefore + mbcnt(fm);
-            mbefore += (uint32_t)__popcll(fm);
-            bool emit = act && !found;
-            Item it;
-            if (emit) {
-                uint32_t pos = (uint32_t)(bi - b0) + (uint32_t)(j - a0) - mb;
-                uint32_t pb = payload_bytes(B.type[bi], B.card[bi], B.nruns[bi]);
-                it.a = NONE32;
-                it.b = (uint32_t)bi;
-                it.out = (uint32_t)(base + pos);
-                O.key[base + pos] = k;
-                O.slot[base + pos] = align16(pb) < 16u ? 16u : align16(pb);
-                bytes_in += pb;
-                n_pass++;
+            lower_bound4(A.key, a0, a1, k, act, j);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const u64 bi = i + 64 * t + lane;
+                const bool found = act[t] && j[t] < a1 && A.key[j[t]] == k[t];
+                const u64 fm = __ballot(found);
+                const uint32_t mb = mbefore + mbcnt(fm);
+                mbefore += (uint32_t)__popcll(fm);
+                const bool emit = act[t] && !found;
+                const u64 mcp = __ballot(emit);
+                if (emit) {
+                    const uint32_t pos = (uint32_t)(bi - b0) + (uint32_t)(j[t] - a0) - mb;
+                    const uint32_t pb = payload_bytes(B.type[bi], B.card[bi], B.nruns[bi]);
+                    O.key[base + pos] = k[t];
+                    O.slot[base + pos] = align16(pb) < 16u ? 16u : align16(pb);
+                    bytes_in += pb;
+                    Q.copy[qcopy + mbcnt(mcp)] = Item{NONE32, (uint32_t)bi, (uint32_t)(base + pos)};
+                }
+                qcopy += __popcll(mcp);
             }
-            push_items(CLS_COPY, emit, it, Q.q, qcount);
         }
     }
     bytes_in = wave_sum64(bytes_in);
-    n_matched = wave_sum(n_matched);
-    n_pass = wave_sum(n_pass);
-    n_bb = wave_sum(n_bb);
-    if (lane == 0) {
-        if (bytes_in) atomicAdd(&stats->bytes_in, bytes_in);
-        if (n_matched) atomicAdd(&stats->matched_pairs, (u64)n_matched);
-        if (n_pass) atomicAdd(&stats->passthrough, (u64)n_pass);
-        if (n_bb) atomicAdd(&stats->n_bb, (u64)n_bb);
-    }
+    if (lane == 0 && bytes_in) atomicAdd(&stats->bytes_in, bytes_in);
 }
 
 // ------------------------------------------------------------------ bitset x bitset (K1-K3)
@@ -305,16 +343,16 @@ __device__ __forceinline__ u32x4 vop(u32x4 a, u32x4 b) {
 __device__ __forceinline__ uint32_t vpopc(u32x4 v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
 
 template <int OP>
-__global__ __launch_bounds__(256) void k_bb(PoolView A, PoolView B, OutView O, const Item* __restrict__ q,
-                                            const uint32_t* __restrict__ qcount, int cardmode, u64* pair_acc,
-                                            Item* retry_q, uint32_t* retry_count) {
+__global__ __launch_bounds__(256) void k_bb(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                            OutView O, const BBItem* __restrict__ q, const u64* __restrict__ qrange,
+                                            int cardmode, u64* pair_acc, Item* retry_q, uint32_t* retry_count) {
     const uint32_t lane = lane_id();
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t n = *qcount;
+    const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
     for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
-        Item t = q[w];
-        const u32x4* __restrict__ pa = (const u32x4*)(A.arena + A.off[t.a]);
-        const u32x4* __restrict__ pb = (const u32x4*)(B.arena + B.off[t.b]);
+        const BBItem t = q[w];
+        const u32x4* __restrict__ pa = (const u32x4*)(arenaA + t.offa);
+        const u32x4* __restrict__ pb = (const u32x4*)(arenaB + t.offb);
         u32x4 va[8], vb[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) va[i] = __builtin_nontemporal_load(pa + i * 64 + lane);
@@ -338,30 +376,22 @@ __global__ __launch_bounds__(256) void k_bb(PoolView A, PoolView B, OutView O, c
             u32x4* __restrict__ po = (u32x4*)(O.arena + O.off[t.out]);
 #pragma unroll
             for (int i = 0; i < 8; ++i) __builtin_nontemporal_store(va[i], po + i * 64 + lane);
-            if (lane == 0) {
-                O.type[t.out] = T_BITSET;
-                O.card[t.out] = card;
-                O.nruns[t.out] = 0;
-            }
+            if (lane == 0) O.meta[t.out] = pack_meta(T_BITSET, card, 0);
         } else if (card == 0) {
-            if (lane == 0) {
-                O.type[t.out] = T_ARRAY;
-                O.card[t.out] = 0;
-                O.nruns[t.out] = 0;
-            }
+            if (lane == 0) O.meta[t.out] = pack_meta(T_ARRAY, 0, 0);
         } else {
             // rare: result becomes an array -> re-queue for the LDS extraction kernel
-            if (lane == 0) retry_q[atomicAdd(retry_count, 1u)] = t;
+            if (lane == 0) retry_q[atomicAdd(retry_count, 1u)] = Item{t.a, t.b, t.out};
         }
     }
 }
 
 // ------------------------------------------------------------------ pass-through copy
 __global__ __launch_bounds__(256) void k_copy(PoolView A, PoolView B, OutView O, const Item* __restrict__ q,
-                                              const uint32_t* __restrict__ qcount) {
+                                              const u64* __restrict__ qrange) {
     const uint32_t lane = lane_id();
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t n = *qcount;
+    const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
     for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
         Item t = q[w];
         const PoolView& S = (t.b == NONE32) ? A : B;
@@ -372,11 +402,7 @@ __global__ __launch_bounds__(256) void k_copy(PoolView A, PoolView B, OutView O,
         const uint4* __restrict__ ps = (const uint4*)(S.arena + S.off[c]);
         uint4* __restrict__ po = (uint4*)(O.arena + O.off[t.out]);
         for (uint32_t i = lane; i < n16; i += 64) po[i] = ps[i];
-        if (lane == 0) {
-            O.type[t.out] = ty;
-            O.card[t.out] = card;
-            O.nruns[t.out] = nr;
-        }
+        if (lane == 0) O.meta[t.out] = pack_meta(ty, card, nr);
     }
 }
 
@@ -623,14 +649,14 @@ __device__ void lds_emit(const uint32_t* img, const uint32_t r[8], int ty, uint3
 // ------------------------------------------------------------------ universal pair kernel
 // One 256-thread workgroup per container pair (persistent, striding over the queue).
 __global__ __launch_bounds__(256) void k_gen(PoolView A, PoolView B, OutView O, const Item* __restrict__ q,
-                                             const uint32_t* __restrict__ qcount, int op, int cardmode,
-                                             u64* pair_acc) {
+                                             const u64* __restrict__ qrange, const uint32_t* __restrict__ qcount,
+                                             int op, int cardmode, u64* pair_acc) {
     __shared__ __attribute__((aligned(16))) uint32_t sA[2048];
     __shared__ __attribute__((aligned(16))) uint32_t sB[2048];
     __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];
     __shared__ BlockScratch sc;
     const uint32_t tid = threadIdx.x;
-    const uint32_t n = *qcount;
+    const uint32_t n = qrange ? (uint32_t)(qrange[1] - qrange[0]) : *qcount;
     for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
         const Item t = q[it];
         __syncthreads();  // previous iteration's LDS reads are done
@@ -667,18 +693,14 @@ __global__ __launch_bounds__(256) void k_gen(PoolView A, PoolView B, OutView O, 
             ty = decide_type(op, ta, tb, ca, cb, fulla, fullb, rc, rn);
             lds_emit(sA, r, ty, rc, rn, stage, O.arena + O.off[t.out], &sc);
         }
-        if (tid == 0) {
-            O.type[t.out] = (uint8_t)ty;
-            O.card[t.out] = rc;
-            O.nruns[t.out] = (ty == T_RUN) ? rn : 0u;
-        }
+        if (tid == 0) O.meta[t.out] = pack_meta(ty, rc, (ty == T_RUN) ? rn : 0u);
     }
 }
 
 // ------------------------------------------------------------------ directory compaction
-__global__ void k_flags(const uint32_t* __restrict__ card, u64 n, uint32_t* __restrict__ flag) {
+__global__ void k_flags(const u64* __restrict__ meta, u64 n, uint32_t* __restrict__ flag) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = card[i] ? 1u : 0u;
+    if (i < n) flag[i] = meta_card(meta[i]) ? 1u : 0u;
 }
 struct DirOut {
     u64* bm_start;
@@ -688,26 +710,35 @@ struct DirOut {
     uint32_t* nruns;
     u64* off;
 };
-__global__ void k_compact(OutView O, u64 n, const u64* __restrict__ newidx, DirOut R, Stats* stats) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+// grid-stride, 1024 threads per block: one pair of atomics per block for the statistics
+__global__ __launch_bounds__(1024) void k_compact(OutView O, u64 n, const u64* __restrict__ newidx, DirOut R,
+                                                  Stats* stats) {
+    __shared__ u64 sb[16];
+    __shared__ uint32_t sk[16];
     u64 bytes = 0;
     uint32_t keep = 0;
-    if (i < n && O.card[i]) {
-        u64 d = newidx[i];
-        uint8_t ty = O.type[i];
-        R.key[d] = O.key[i];
-        R.type[d] = ty;
-        R.card[d] = O.card[i];
-        R.nruns[d] = O.nruns[i];
-        R.off[d] = O.off[i];
-        bytes = payload_bytes(ty, O.card[i], O.nruns[i]);
-        keep = 1;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 m = O.meta[i];
+        if (meta_card(m)) {
+            const u64 d = newidx[i];
+            const uint32_t ty = meta_type(m);
+            R.key[d] = O.key[i];
+            R.type[d] = (uint8_t)ty;
+            R.card[d] = meta_card(m);
+            R.nruns[d] = meta_nruns(m);
+            R.off[d] = O.off[i];
+            bytes += payload_bytes((uint8_t)ty, meta_card(m), meta_nruns(m));
+            keep++;
+        }
     }
     bytes = wave_sum64(bytes);
     keep = wave_sum(keep);
-    if (lane_id() == 0 && keep) {
-        atomicAdd(&stats->bytes_out, bytes);
-        atomicAdd(&stats->result_containers, (u64)keep);
+    if (lane_id() == 0) { sb[threadIdx.x >> 6] = bytes; sk[threadIdx.x >> 6] = keep; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 b = 0; uint32_t k = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) { b += sb[w]; k += sk[w]; }
+        if (k) { atomicAdd(&stats->bytes_out, b); atomicAdd(&stats->result_containers, (u64)k); }
     }
 }
 __global__ void k_bm_start(const u64* __restrict__ cand_start, uint32_t npairs, const u64* __restrict__ newidx,

@@ -197,11 +197,7 @@ __device__ void many_finalize(uint32_t* acc, uint16_t* stage, const ManyOut& MO,
         ty = type_ba(rc);
         lds_emit(acc, r, ty, rc, 0, stage, MO.O.arena + MO.O.off[g], sc);
     }
-    if (tid == 0) {
-        MO.O.type[g] = (uint8_t)ty;
-        MO.O.card[g] = rc;
-        MO.O.nruns[g] = 0;
-    }
+    if (tid == 0) MO.O.meta[g] = pack_meta(ty, rc, 0);
 }
 
 __global__ __launch_bounds__(256) void k_many_l1(PoolView P, ManyView V, ManyOut MO, const u64* __restrict__ n_units,
@@ -271,11 +267,7 @@ __global__ __launch_bounds__(256) void k_many_copy(PoolView P, ManyView V, ManyO
         const uint4* __restrict__ ps = (const uint4*)(P.arena + P.off[c]);
         uint4* __restrict__ po = (uint4*)(MO.O.arena + MO.O.off[g]);
         for (uint32_t i = lane; i < n16; i += 64) po[i] = ps[i];
-        if (lane == 0) {
-            MO.O.type[g] = ty;
-            MO.O.card[g] = card;
-            MO.O.nruns[g] = nr;
-        }
+        if (lane == 0) MO.O.meta[g] = pack_meta(ty, card, nr);
     }
 }
 
