@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <unistd.h>
 #include "../croaring_amd/csrc/rhip_kernels.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("ERR %s line %d: %s\n", #x, __LINE__, hipGetErrorString(e)); exit(1);} } while (0)
 
@@ -95,6 +96,28 @@ int main() {
             rep("abl2 no meta store", timeit([&] { hipLaunchKernelGGL((k_abl<2>), dim3(4096), dim3(256), 0, 0, A, A, O, q, n); }));
             rep("abl3 computed off + no meta", timeit([&] { hipLaunchKernelGGL((k_abl<3>), dim3(4096), dim3(256), 0, 0, A, A, O, q, n); }));
             rep("abl4 plain loads", timeit([&] { hipLaunchKernelGGL((k_abl<4>), dim3(4096), dim3(256), 0, 0, A, A, O, q, n); }));
+        }
+    }
+    {
+        // DVFS / idle-gap hypothesis: same kernel, timed individually, with different things in front of it
+        OutView O; O.key = nullptr; O.meta = meta; O.off = off; O.arena = Oa; O.slot = nullptr;
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        auto one = [&](hipStream_t s) { float ms; CK(hipEventRecord(e0, s));
+            hipLaunchKernelGGL((k_bb<OP_AND>), dim3(4096), dim3(256), 0, s, A, A, O, q, qr, 0, acc, rq, rc);
+            CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); return ms; };
+        for (int mode = 0; mode < 5; ++mode) {
+            float sum = 0; int n = 0;
+            for (int r = 0; r < 10; ++r) {
+                hipStream_t s = (mode == 4) ? st : 0;
+                if (mode == 1) { CK(hipDeviceSynchronize()); usleep(500); }
+                if (mode == 2) { CK(hipDeviceSynchronize()); usleep(5000); }
+                if (mode == 3) { hipLaunchKernelGGL(k_fill, dim3(1), dim3(64), 0, s, (u64*)Oa, (u64)200000); CK(hipDeviceSynchronize()); }
+                float ms = one(s);
+                if (r >= 2) { sum += ms; ++n; }
+            }
+            const char* nm[] = {"back-to-back", "sync + 0.5 ms idle before", "sync + 5 ms idle before", "1-wave 64-lane kernel + sync before", "non-blocking stream back-to-back"};
+            printf("gap test: %-40s %8.3f ms  %8.1f GB/s\n", nm[mode], sum / n, (double)nitems * 24576.0 / (sum / n) / 1e6); fflush(stdout);
         }
     }
     return 0;

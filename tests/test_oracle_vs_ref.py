@@ -1,0 +1,71 @@
+"""Randomised differential test: oracle restatement vs the REAL CRoaring (oracle/_ref), byte level.
+Skipped where the reference library was not prebuilt (it cannot be built without /root/reference)."""
+import numpy as np
+import pytest
+
+from gen_inputs import random_bitmap
+from util import OPS
+
+
+def test_pairwise_bytes(oracle, ref):
+    rng = np.random.default_rng(42)
+    for it in range(150):
+        va, vb = random_bitmap(rng), random_bitmap(rng)
+        ra, rb = ref.from_sorted(va), ref.from_sorted(vb)
+        sa, sb = ref.serialize(ra), ref.serialize(rb)
+        oa, ob = oracle.deserialize(sa), oracle.deserialize(sb)
+        oa2 = oracle.from_sorted(va)
+        assert oracle.serialize(oa2) == sa, "run_optimize parity"
+        for op in OPS:
+            rr, oo = ref.op(op, ra, rb), oracle.op(op, oa, ob)
+            assert ref.serialize(rr) == oracle.serialize(oo), (it, op)
+            assert ref.op_cardinality(op, ra, rb) == oracle.op_cardinality(op, oa, ob) == ref.cardinality(rr)
+            assert oracle.validate(oo) and ref.validate(rr)
+            ref.free(rr)
+            oracle.free(oo)
+        for h in (ra, rb):
+            ref.free(h)
+        for h in (oa, ob, oa2):
+            oracle.free(h)
+
+
+def test_many_way(oracle, ref):
+    rng = np.random.default_rng(43)
+    for it in range(60):
+        n = int(rng.integers(0, 9))
+        vs = [random_bitmap(rng, max_keys=6, key_space=8) for _ in range(n)]
+        rs = [ref.from_sorted(v) for v in vs]
+        os_ = [oracle.deserialize(ref.serialize(r)) for r in rs]
+        rr, oo = ref.or_many(rs), oracle.or_many(os_)
+        assert ref.serialize(rr) == oracle.serialize(oo), f"or_many {it}"
+        rx, ox = ref.xor_many(rs), oracle.xor_many(os_)
+        assert np.array_equal(ref.to_array(rx), oracle.to_array(ox))
+        rh = ref.or_many_heap(rs)
+        assert np.array_equal(ref.to_array(rh), oracle.to_array(oo))
+        for h in rs + [rr, rx, rh]:
+            ref.free(h)
+        for h in os_ + [oo, ox]:
+            oracle.free(h)
+
+
+def test_64bit(oracle, ref):
+    rng = np.random.default_rng(44)
+    for it in range(40):
+        def mk():
+            parts = [(np.uint64(int(hi)) << np.uint64(32)) | random_bitmap(rng, max_keys=4, key_space=6).astype(np.uint64)
+                     for hi in rng.choice(5, int(rng.integers(0, 4)), replace=False)]
+            return np.sort(np.concatenate(parts)) if parts else np.zeros(0, np.uint64)
+        va, vb = mk(), mk()
+        ra, rb = ref.from_sorted64(va), ref.from_sorted64(vb)
+        oa, ob = oracle.deserialize64(ref.serialize64(ra)), oracle.deserialize64(ref.serialize64(rb))
+        assert oracle.serialize64(oa) == ref.serialize64(ra)
+        for op in OPS:
+            rr, oo = ref.op64(op, ra, rb), oracle.op64(op, oa, ob)
+            assert ref.serialize64(rr) == oracle.serialize64(oo), (it, op)
+            assert ref.cardinality64(rr) == oracle.cardinality64(oo)
+            ref.free64(rr)
+            oracle.free64(oo)
+        for h in (ra, rb):
+            ref.free64(h)
+        for h in (oa, ob):
+            oracle.free64(h)
