@@ -74,7 +74,7 @@ def load() -> C.CDLL:
         raise RoaringHipError(
             f"{LIB_PATH} is missing: build it with `python -m croaring_amd.build` (hipcc, gfx950). "
             "croaring_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(LIB_PATH)  # RTLD_LOCAL: the CRoaring-named drop-ins must not interpose on a co-loaded libroaring
     for name, res, args in SYMBOLS:
         f = getattr(lib, name)  # AttributeError if the ABI drifted
         f.restype = res

@@ -851,3 +851,4 @@ extern "C" int rhip_pairwise_cardinality(rhip_ctx_t* c, rhip_op op_, rhip_pool_t
 }
 
 #include "rhip_many_host.inc"
+#include "roaring_compat.inc"

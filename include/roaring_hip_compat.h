@@ -1,0 +1,69 @@
+/*
+ * roaring_hip_compat.h -- the CRoaring-named, per-call drop-in entry points of libroaring_hip.so.
+ *
+ * These are the exact C symbols (names, signatures, ownership and error conventions) of the
+ * reference's hot path, include/roaring/roaring.h in CRoaring 5.1.0:
+ *
+ *   roaring_bitmap_and            roaring.h:225    roaring_bitmap_and_inplace       roaring.h:280
+ *   roaring_bitmap_or             roaring.h:288    roaring_bitmap_or_inplace        roaring.h:295
+ *   roaring_bitmap_xor            roaring.h:320    roaring_bitmap_xor_inplace       roaring.h:326
+ *   roaring_bitmap_andnot         roaring.h:342    roaring_bitmap_andnot_inplace    roaring.h:348
+ *   roaring_bitmap_and_cardinality roaring.h:231   roaring_bitmap_or_cardinality    roaring.h:258
+ *   roaring_bitmap_andnot_cardinality roaring.h:264  roaring_bitmap_xor_cardinality roaring.h:270
+ *   roaring_bitmap_or_many        roaring.h:304    roaring_bitmap_or_many_heap      roaring.h:312
+ *   roaring_bitmap_xor_many       roaring.h:334
+ *
+ * They operate on the reference's own host structs (roaring_bitmap_t / roaring_array_t and the three
+ * container structs are part of CRoaring's ABI, include/roaring/roaring_types.h:61-68,
+ * containers/bitset.h:40-48, array.h:46-50, run.h:69-73): operands are read in place, every result
+ * is a fresh caller-owned roaring_bitmap_t allocated with malloc / posix_memalign exactly as the
+ * reference allocates, so the reference's roaring_bitmap_free (and every other reference function)
+ * works on it.  Results carry COW = cow(x1) || cow(x2) (src/roaring.c:738); shared containers in the
+ * operands are read through (containers.h:71-152) and never mutated.
+ *
+ * Each call uploads its operands, runs the batched device pipeline with a batch of one, and
+ * downloads the result: correct, but latency-bound.  Throughput users bind the batched
+ * API in roaring_hip.h instead.  A process-wide context on the current HIP device is created on
+ * first use; without a device pointer-returning functions return NULL (roaring.h:216-226), the
+ * *_cardinality functions return UINT64_MAX and the in-place functions leave x1 untouched.
+ *
+ * How a program uses it: keep including <roaring/roaring.h>, link libroaring_hip.so BEFORE libroaring
+ * (or build libroaring with these symbols renamed): these symbols then resolve here,
+ * everything else (add, contains, iterators, serialization, free ...) stays the reference's.
+ */
+#ifndef ROARING_HIP_COMPAT_H
+#define ROARING_HIP_COMPAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* opaque here; the layout is the reference's (a program normally sees it through roaring.h) */
+typedef struct roaring_bitmap_s roaring_bitmap_t;
+
+roaring_bitmap_t *roaring_bitmap_and(const roaring_bitmap_t *r1, const roaring_bitmap_t *r2);
+roaring_bitmap_t *roaring_bitmap_or(const roaring_bitmap_t *r1, const roaring_bitmap_t *r2);
+roaring_bitmap_t *roaring_bitmap_xor(const roaring_bitmap_t *r1, const roaring_bitmap_t *r2);
+roaring_bitmap_t *roaring_bitmap_andnot(const roaring_bitmap_t *r1, const roaring_bitmap_t *r2);
+
+void roaring_bitmap_and_inplace(roaring_bitmap_t *r1, const roaring_bitmap_t *r2);
+void roaring_bitmap_or_inplace(roaring_bitmap_t *r1, const roaring_bitmap_t *r2);
+void roaring_bitmap_xor_inplace(roaring_bitmap_t *r1, const roaring_bitmap_t *r2);
+void roaring_bitmap_andnot_inplace(roaring_bitmap_t *r1, const roaring_bitmap_t *r2);
+
+uint64_t roaring_bitmap_and_cardinality(const roaring_bitmap_t *r1, const roaring_bitmap_t *r2);
+uint64_t roaring_bitmap_or_cardinality(const roaring_bitmap_t *r1, const roaring_bitmap_t *r2);
+uint64_t roaring_bitmap_andnot_cardinality(const roaring_bitmap_t *r1, const roaring_bitmap_t *r2);
+uint64_t roaring_bitmap_xor_cardinality(const roaring_bitmap_t *r1, const roaring_bitmap_t *r2);
+
+roaring_bitmap_t *roaring_bitmap_or_many(size_t number, const roaring_bitmap_t **rs);
+roaring_bitmap_t *roaring_bitmap_or_many_heap(uint32_t number, const roaring_bitmap_t **rs);
+roaring_bitmap_t *roaring_bitmap_xor_many(size_t number, const roaring_bitmap_t **rs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROARING_HIP_COMPAT_H */

@@ -31,6 +31,7 @@ def ref():
 @pytest.fixture(scope="session")
 def engine():
     # No skip: on the GPU box a missing library or device must fail loudly.
+    import torch  # noqa: F401  (first, so the engine binds to the HIP runtime torch loads)
     import croaring_amd
     eng = croaring_amd.Engine()
     yield eng

@@ -1,0 +1,90 @@
+"""GPU test of the CRoaring-named drop-in entry points (include/roaring_hip_compat.h): operands are
+REAL reference structs (built by oracle/_ref), results come back as reference-layout structs that the
+reference's own serialize / validate / free accept -- struct-layout compatibility in both directions."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gen_inputs import random_bitmap
+from util import OPS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import croaring_amd
+    lib = croaring_amd.load()
+    vp = C.c_void_p
+    for op in OPS:
+        f = getattr(lib, f"roaring_bitmap_{op}"); f.restype = vp; f.argtypes = [vp, vp]
+        f = getattr(lib, f"roaring_bitmap_{op}_inplace"); f.restype = None; f.argtypes = [vp, vp]
+        f = getattr(lib, f"roaring_bitmap_{op}_cardinality"); f.restype = C.c_uint64; f.argtypes = [vp, vp]
+    lib.roaring_bitmap_or_many.restype = vp; lib.roaring_bitmap_or_many.argtypes = [C.c_size_t, C.POINTER(vp)]
+    lib.roaring_bitmap_xor_many.restype = vp; lib.roaring_bitmap_xor_many.argtypes = [C.c_size_t, C.POINTER(vp)]
+    lib.roaring_bitmap_or_many_heap.restype = vp
+    lib.roaring_bitmap_or_many_heap.argtypes = [C.c_uint32, C.POINTER(vp)]
+    return lib
+
+
+def set_cow(handle, on=True):
+    # roaring_array_t: int32 size, int32 allocation_size, 3 pointers, uint8 flags (roaring_types.h:61-68)
+    flags = C.cast(handle + 32, C.POINTER(C.c_uint8))
+    flags[0] = (flags[0] | 1) if on else (flags[0] & ~1)
+
+
+def get_flags(handle):
+    return C.cast(handle + 32, C.POINTER(C.c_uint8))[0]
+
+
+def test_dropin_pairwise(hip, ref):
+    rng = np.random.default_rng(5)
+    ref.L.roaring_bitmap_copy.restype = C.c_void_p
+    ref.L.roaring_bitmap_copy.argtypes = [C.c_void_p]
+    for it in range(25):
+        a, b = ref.from_sorted(random_bitmap(rng)), ref.from_sorted(random_bitmap(rng))
+        cow = it % 3 == 0
+        keep = None
+        if cow:
+            set_cow(a); set_cow(b)
+            keep = ref.L.roaring_bitmap_copy(a)  # a's containers become shared (refcounted) wrappers
+        for op in OPS:
+            want = ref.op(op, a, b)
+            got = getattr(hip, f"roaring_bitmap_{op}")(a, b)
+            assert got, "drop-in returned NULL"
+            assert ref.validate(got)
+            assert ref.serialize(got) == ref.serialize(want), (it, op)
+            assert (get_flags(got) & 1) == (1 if cow else 0)
+            assert getattr(hip, f"roaring_bitmap_{op}_cardinality")(a, b) == ref.cardinality(want)
+            # in-place form on a copy of a
+            a2 = ref.L.roaring_bitmap_copy(a)
+            getattr(hip, f"roaring_bitmap_{op}_inplace")(a2, b)
+            assert ref.validate(a2)
+            assert np.array_equal(ref.to_array(a2), ref.to_array(want)), (it, op, "inplace")
+            assert ref.serialize(a2) == ref.serialize(want)
+            for h in (want, got, a2):
+                ref.free(h)  # the REFERENCE's roaring_bitmap_free releases our allocations
+        if keep:
+            ref.free(keep)
+        ref.free(a)
+        ref.free(b)
+
+
+def test_dropin_many(hip, ref):
+    rng = np.random.default_rng(6)
+    for it in range(10):
+        n = int(rng.integers(0, 8))
+        hs = [ref.from_sorted(random_bitmap(rng, max_keys=6, key_space=8)) for _ in range(n)]
+        arr = (C.c_void_p * max(n, 1))(*hs)
+        for nm, fn, rf in (("or_many", hip.roaring_bitmap_or_many, ref.or_many),
+                           ("or_many_heap", hip.roaring_bitmap_or_many_heap, ref.or_many),
+                           ("xor_many", hip.roaring_bitmap_xor_many, ref.xor_many)):
+            got = fn(n, arr)
+            want = rf(hs)
+            assert got and ref.validate(got)
+            assert np.array_equal(ref.to_array(got), ref.to_array(want)), (it, nm)
+            ref.free(got)
+            ref.free(want)
+        for h in hs:
+            ref.free(h)

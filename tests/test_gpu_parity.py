@@ -171,3 +171,43 @@ def test_edge_cases(engine, oracle):
         engine.pool_from_serialized([b"\x00\x01\x02\x03garbage"])
     with pytest.raises(Exception):
         engine.pairwise("and", pool, [7], pool, [0])
+
+
+@pytest.mark.parametrize("op", ["or", "xor"])
+@pytest.mark.parametrize("shards", [2, 4, 8])
+def test_sharded_many_logical_shards(engine, oracle, op, shards):
+    """SURVEY §8e on ONE device: G logical shards -> per-shard partial chunks (rhip_many_partials) ->
+    chunks routed to key owners -> owner combine + canonicalise (rhip_many_finalize).  The union of the
+    owners' results must equal or_many / xor_many over the whole set."""
+    import torch
+    from croaring_amd.distributed import _DevArray, shard_ids
+    bufs = load_bundle("census-income")[:64] + load_bundle("wikileaks-noquotes")[:32]
+    hs = [oracle.deserialize(b) for b in bufs]
+    pool = engine.pool_from_serialized(bufs)
+    parts = [engine.many_partials(op, pool, shard_ids(len(bufs), s, shards)) for s in range(shards)]
+    engine.synchronize()
+    keys = [torch.as_tensor(_DevArray(p.d_keys, (p.n_keys,)), device="cuda") for p in parts if p.n_keys]
+    words = [torch.as_tensor(_DevArray(p.d_words, (p.n_keys, 1024)), device="cuda") for p in parts if p.n_keys]
+    K, W = torch.cat(keys), torch.cat(words)
+    got_vals = []
+    for owner in range(shards):
+        sel = (K % shards) == owner
+        k, w = K[sel].contiguous(), W[sel].contiguous()
+        torch.cuda.synchronize()
+        res = engine.many_finalize(op, False, k.numel(), k.data_ptr() if k.numel() else 0,
+                                   w.data_ptr() if k.numel() else 0)
+        h = oracle.deserialize(res.serialize(0))
+        assert oracle.validate(h)
+        v = oracle.to_array(h)
+        assert np.all((v >> 16) % shards == owner)
+        got_vals.append(v)
+        oracle.free(h)
+    want = (oracle.or_many if op == "or" else oracle.xor_many)(hs)
+    assert np.array_equal(np.sort(np.concatenate(got_vals)), oracle.to_array(want))
+    single = (engine.or_many if op == "or" else engine.xor_many)(pool)
+    hsingle = oracle.deserialize(single.serialize(0))
+    assert np.array_equal(oracle.to_array(hsingle), oracle.to_array(want))
+    for h in hs + [want, hsingle]:
+        oracle.free(h)
+    for p in parts:
+        p.free()
