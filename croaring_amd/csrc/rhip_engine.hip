@@ -69,7 +69,7 @@ struct rhip_ctx_s {
     int device = 0;
     hipStream_t stream = nullptr;
     // scratch (grow-only): candidate directory + queues + scan temporaries
-    DBuf lhs, rhs, cand, cand_start, o_key, o_meta, o_slot, o_off, flag, newidx, q[N_CLS], misc, prim_tmp, pair_acc;
+    DBuf lhs, rhs, u_pair, u_tile, u_pair0, cand, cand_start, o_key, o_meta, o_slot, o_off, flag, newidx, q[N_CLS], misc, prim_tmp, pair_acc;
     DBuf many[16];
     void* h_pinned = nullptr;  // small pinned readback area
     rhip_stats_t stats{};
@@ -142,7 +142,7 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
 extern "C" void rhip_ctx_destroy(rhip_ctx_t* c) {
     if (!c) return;
     (void)hipStreamSynchronize(c->stream);
-    DBuf* all[] = {&c->lhs, &c->rhs, &c->cand, &c->cand_start, &c->o_key, &c->o_meta,
+    DBuf* all[] = {&c->lhs, &c->rhs, &c->u_pair, &c->u_tile, &c->u_pair0, &c->cand, &c->cand_start, &c->o_key, &c->o_meta,
                    &c->o_slot, &c->o_off, &c->flag, &c->newidx, &c->misc, &c->prim_tmp, &c->pair_acc};
     for (auto* b : all) b->release();
     for (auto& b : c->q) b.release();
@@ -599,15 +599,15 @@ struct PlanResult {
     uint64_t n_bb = 0, n_gen = 0, n_copy = 0;
 };
 
-// misc layout (device): [0, 64) four {begin,end} u64 section ranges; [64, 72) retry counter;
+// misc layout (device): [0, 80) five {begin,end} u64 section ranges; [96, 100) retry counter;
 // [128, ...) Stats
 constexpr size_t MISC_RANGES_OFF = 0;
-constexpr size_t MISC_RETRY_OFF = 64;
+constexpr size_t MISC_RETRY_OFF = 96;
 constexpr size_t MISC_STATS_OFF = 128;
 
 __global__ void k_plan_totals(const u64* __restrict__ starts, u64 S, u64* __restrict__ ranges) {
     const uint32_t k = threadIdx.x;
-    if (k < 4) {
+    if (k < N_SEC) {
         ranges[2 * k] = starts[k * S];
         ranges[2 * k + 1] = starts[k * S + (S - 1)];
     }
@@ -637,36 +637,52 @@ PlanResult plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t np
                 const uint32_t* rhs, int cardmode, OutView& O) {
     hipStream_t s = c->stream;
     PlanResult R;
-    const size_t S = npairs + 1;
-    c->lhs.ensure(4 * S);
-    c->rhs.ensure(4 * S);
-    c->cand.ensure(4 * (4 * S + 1));
-    c->cand_start.ensure(8 * (4 * S + 1));
-    c->misc.ensure(512);
-    HIPCHK(hipMemcpyAsync(c->lhs.p, lhs, 4 * npairs, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->rhs.p, rhs, 4 * npairs, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(c->misc.p, 0, 512, s));
-    HIPCHK(hipMemsetAsync(c->cand.p, 0, 4 * (4 * S + 1), s));
-    PoolView VA = A->view(), VB = B->view();
-    unsigned gp = (unsigned)std::max<size_t>(1, (npairs * 64 + 255) / 256);
-    hipLaunchKernelGGL(k_count, dim3(gp), dim3(256), 0, s, VA, VB, c->lhs.as<uint32_t>(), c->rhs.as<uint32_t>(),
-                       (uint32_t)npairs, op, cardmode, c->cand.as<uint32_t>());
-    exscan(c, c->cand.as<uint32_t>(), c->cand_start.as<u64>(), 4 * S - 1);
-    u64* ranges = (u64*)((char*)c->misc.p + MISC_RANGES_OFF);
-    hipLaunchKernelGGL(k_plan_totals, dim3(1), dim3(64), 0, s, c->cand_start.as<u64>(), (u64)S, ranges);
-    // upper bounds known on the host without a sync (directory mirrors)
-    uint64_t ub_match = 0, ub = 0;
+    // ---- units (host: directory mirrors) + upper bounds, no sync needed
     if (!A->host_dir) fetch_dir(A);
     if (!B->host_dir) fetch_dir(B);
+    const bool btiles = !cardmode && (op == OP_OR || op == OP_XOR);
+    std::vector<uint32_t> upair, utile;
+    std::vector<uint64_t> pair0(npairs + 1);
+    uint64_t ub_match = 0, ub = 0;
     for (size_t i = 0; i < npairs; ++i) {
-        uint64_t nA = A->h_bm_start[lhs[i] + 1] - A->h_bm_start[lhs[i]];
-        uint64_t nB = B->h_bm_start[rhs[i] + 1] - B->h_bm_start[rhs[i]];
+        const uint64_t nA = A->h_bm_start[lhs[i] + 1] - A->h_bm_start[lhs[i]];
+        const uint64_t nB = B->h_bm_start[rhs[i] + 1] - B->h_bm_start[rhs[i]];
+        pair0[i] = upair.size();
+        for (uint64_t t = 0; t < (nA + 255) / 256; ++t) { upair.push_back((uint32_t)i); utile.push_back((uint32_t)t); }
+        if (btiles)
+            for (uint64_t t = 0; t < (nB + 255) / 256; ++t) { upair.push_back((uint32_t)i); utile.push_back((uint32_t)t | UNIT_B); }
         ub_match += std::min(nA, nB);
         if (cardmode || op == OP_AND) ub += std::min(nA, nB);
         else if (op == OP_ANDNOT) ub += nA;
         else ub += nA + nB;
     }
-    if (ub >= 0xFFFFFFF0ull) { set_err("batch too large: %llu candidate containers", (unsigned long long)ub); throw (int)RHIP_ERR_ARG; }
+    const size_t NU = upair.size();
+    pair0[npairs] = NU;
+    if (ub >= 0xFFFFFFF0ull || NU >= 0x7FFFFFF0ull) { set_err("batch too large: %llu candidate containers", (unsigned long long)ub); throw (int)RHIP_ERR_ARG; }
+    const size_t S = NU + 1;
+    c->lhs.ensure(4 * (npairs + 1));
+    c->rhs.ensure(4 * (npairs + 1));
+    c->u_pair.ensure(4 * S); c->u_tile.ensure(4 * S); c->u_pair0.ensure(8 * (npairs + 1));
+    c->cand.ensure(4 * (N_SEC * S + 1));
+    c->cand_start.ensure(8 * (N_SEC * S + 1));
+    c->misc.ensure(512);
+    HIPCHK(hipMemcpyAsync(c->lhs.p, lhs, 4 * npairs, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->rhs.p, rhs, 4 * npairs, hipMemcpyHostToDevice, s));
+    if (NU) {
+        HIPCHK(hipMemcpyAsync(c->u_pair.p, upair.data(), 4 * NU, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(c->u_tile.p, utile.data(), 4 * NU, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(hipMemcpyAsync(c->u_pair0.p, pair0.data(), 8 * (npairs + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(c->misc.p, 0, 512, s));
+    HIPCHK(hipMemsetAsync(c->cand.p, 0, 4 * (N_SEC * S + 1), s));
+    PoolView VA = A->view(), VB = B->view();
+    UnitView UV{c->u_pair.as<uint32_t>(), c->u_tile.as<uint32_t>(), c->u_pair0.as<u64>(), (uint32_t)NU};
+    unsigned gp = (unsigned)std::max<size_t>(1, (NU * 64 + 255) / 256);
+    hipLaunchKernelGGL(k_count, dim3(gp), dim3(256), 0, s, VA, VB, c->lhs.as<uint32_t>(), c->rhs.as<uint32_t>(), UV, op,
+                       cardmode, c->cand.as<uint32_t>());
+    exscan(c, c->cand.as<uint32_t>(), c->cand_start.as<u64>(), N_SEC * S - 1);
+    u64* ranges = (u64*)((char*)c->misc.p + MISC_RANGES_OFF);
+    hipLaunchKernelGGL(k_plan_totals, dim3(1), dim3(64), 0, s, c->cand_start.as<u64>(), (u64)S, ranges);
     c->q[CLS_BB].ensure(sizeof(BBItem) * (ub_match + 1));
     c->q[CLS_GEN].ensure(sizeof(Item) * (ub_match + 1));
     c->q[CLS_COPY].ensure(sizeof(Item) * (ub + 1));
@@ -679,24 +695,23 @@ PlanResult plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t np
     O.slot = c->o_slot.as<uint32_t>(); O.off = c->o_off.as<u64>();
     O.arena = nullptr;
     EmitQueues Q{c->q[CLS_BB].as<BBItem>(), c->q[CLS_GEN].as<Item>(), c->q[CLS_COPY].as<Item>()};
-    hipLaunchKernelGGL(k_emit, dim3(gp), dim3(256), 0, s, VA, VB, c->lhs.as<uint32_t>(), c->rhs.as<uint32_t>(),
-                       (uint32_t)npairs, op, cardmode, c->cand_start.as<u64>(), O, Q,
-                       (Stats*)((char*)c->misc.p + MISC_STATS_OFF));
+    hipLaunchKernelGGL(k_emit, dim3(gp), dim3(256), 0, s, VA, VB, c->lhs.as<uint32_t>(), c->rhs.as<uint32_t>(), UV, op,
+                       cardmode, c->cand_start.as<u64>(), O, Q, (Stats*)((char*)c->misc.p + MISC_STATS_OFF));
     char* hp = (char*)c->h_pinned;
     if (!cardmode) {
         // slots beyond the exact candidate count were zeroed, so scanning the upper bound is exact
         exscan(c, O.slot, c->o_off.as<u64>(), ub);
-        HIPCHK(hipMemcpyAsync(hp + 64, c->o_off.as<u64>() + ub, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hp + 96, c->o_off.as<u64>() + ub, 8, hipMemcpyDeviceToHost, s));
     }
-    HIPCHK(hipMemcpyAsync(hp, ranges, 64, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hp, ranges, 80, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    uint64_t r[8];
-    memcpy(r, hp, 64);
-    R.total_cand = r[1] - r[0];
-    R.n_bb = r[3] - r[2];
-    R.n_gen = r[5] - r[4];
-    R.n_copy = r[7] - r[6];
-    if (!cardmode) memcpy(&R.total_bytes, hp + 64, 8);
+    uint64_t r[10];
+    memcpy(r, hp, 80);
+    R.total_cand = r[2 * SEC_CAND + 1] - r[2 * SEC_CAND];
+    R.n_bb = r[2 * SEC_BB + 1] - r[2 * SEC_BB];
+    R.n_gen = r[2 * SEC_GEN + 1] - r[2 * SEC_GEN];
+    R.n_copy = r[2 * SEC_COPY + 1] - r[2 * SEC_COPY];
+    if (!cardmode) memcpy(&R.total_bytes, hp + 96, 8);
     return R;
 }
 
@@ -801,7 +816,8 @@ extern "C" rhip_pool_t* rhip_pairwise(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A
         if (n) hipLaunchKernelGGL(k_compact, dim3((unsigned)std::min<uint64_t>((n + 4095) / 4096, 1024)), dim3(1024), 0, s,
                                   O, (u64)n, c->newidx.as<u64>(), D, st);
         hipLaunchKernelGGL(k_bm_start, dim3((unsigned)((npairs + 1 + 255) / 256)), dim3(256), 0, s,
-                           c->cand_start.as<u64>(), (uint32_t)npairs, c->newidx.as<u64>(), R->bm_start.as<u64>());
+                           c->cand_start.as<u64>(), c->u_pair0.as<u64>(), (uint32_t)npairs, c->newidx.as<u64>(),
+                           R->bm_start.as<u64>());
         HIPCHK(hipMemcpyAsync((char*)c->h_pinned + 512, c->newidx.as<u64>() + n, 8, hipMemcpyDeviceToHost, s));
         finish_stats(c, &P);
         memcpy(&R->n_cont, (char*)c->h_pinned + 512, 8);

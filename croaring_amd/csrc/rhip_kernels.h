@@ -149,91 +149,113 @@ __device__ __forceinline__ void lower_bound4(const u64* __restrict__ key, u64 lo
     for (int t = 0; t < 4; ++t) out[t] = lo[t];
 }
 
-// Layout of the per-pair count arrays (and of their exclusive scan): 4 sections of npairs+1
-// entries: [candidates | bitset-pair items | general items | copy items].
-enum { SEC_CAND = 0, SEC_BB = 1, SEC_GEN = 2, SEC_COPY = 3 };
+// Planning works on UNITS: one unit = one tile of up to 256 consecutive directory entries of the
+// left bitmap of a pair ("A-tile"), or -- for OR/XOR, whose result also carries the right bitmap's
+// unmatched containers -- of the right bitmap ("B-tile").  One wave per unit, so a batch of 250 pairs
+// of 4096-container bitmaps plans on 4000 waves instead of 250.
+// Count arrays (and their exclusive scan) have 5 sections of n_units+1 entries:
+enum { SEC_CAND = 0, SEC_M = 1, SEC_BB = 2, SEC_GEN = 3, SEC_COPY = 4, N_SEC = 5 };
+#define UNIT_B 0x80000000u
 
-// One wave per bitmap pair: counts of candidate result containers and of work items per class.
+struct UnitView {
+    const uint32_t* pair;   // [U] pair index of the unit
+    const uint32_t* tile;   // [U] tile index inside its side; UNIT_B flag marks a B-tile
+    const u64* pair_unit0;  // [npairs+1] first unit of each pair
+    uint32_t n_units;
+};
+
+// One wave per unit: contributions of the tile to every section.
 __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uint32_t* __restrict__ lhs,
-                                               const uint32_t* __restrict__ rhs, uint32_t npairs, int op,
-                                               int cardmode, uint32_t* __restrict__ counts) {
-    uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (p >= npairs) return;
+                                               const uint32_t* __restrict__ rhs, UnitView U, int op, int cardmode,
+                                               uint32_t* __restrict__ counts) {
+    const uint32_t u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (u >= U.n_units) return;
     const uint32_t lane = lane_id();
+    const uint32_t p = U.pair[u];
+    const bool bside = (U.tile[u] & UNIT_B) != 0;
+    const u64 tile = U.tile[u] & ~UNIT_B;
     const u64 a0 = A.bm_start[lhs[p]], a1 = A.bm_start[lhs[p] + 1];
     const u64 b0 = B.bm_start[rhs[p]], b1 = B.bm_start[rhs[p] + 1];
-    const u64 nA = a1 - a0, nB = b1 - b0;
+    // s* = the side this tile walks, l* = the side it searches
+    const PoolView& SV = bside ? B : A;
+    const PoolView& LV = bside ? A : B;
+    const u64 s0 = (bside ? b0 : a0) + tile * 256, sEnd = bside ? b1 : a1;
+    const u64 s1 = s0 + 256 < sEnd ? s0 + 256 : sEnd;
+    const u64 l0 = bside ? a0 : b0, l1 = bside ? a1 : b1;
+    u64 k[4], j[4];
+    bool act[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        act[t] = s0 + 64 * t + lane < s1;
+        k[t] = act[t] ? SV.key[s0 + 64 * t + lane] : 0;
+    }
+    lower_bound4(LV.key, l0, l1, k, act, j);
     uint32_t matched = 0, nbb = 0;
-    for (u64 i = a0; i < a1; i += 256) {
-        u64 k[4], j[4];
-        bool act[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            act[t] = i + 64 * t + lane < a1;
-            k[t] = act[t] ? A.key[i + 64 * t + lane] : 0;
-        }
-        lower_bound4(B.key, b0, b1, k, act, j);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            bool found = act[t] && j[t] < b1 && B.key[j[t]] == k[t];
-            bool bb = found && A.type[i + 64 * t + lane] == T_BITSET && B.type[j[t]] == T_BITSET;
-            matched += (uint32_t)__popcll(__ballot(found));
-            nbb += (uint32_t)__popcll(__ballot(bb));
-        }
+    for (int t = 0; t < 4; ++t) {
+        const bool found = act[t] && j[t] < l1 && LV.key[j[t]] == k[t];
+        const bool bb = found && !bside && SV.type[s0 + 64 * t + lane] == T_BITSET && LV.type[j[t]] == T_BITSET;
+        matched += (uint32_t)__popcll(__ballot(found));
+        nbb += (uint32_t)__popcll(__ballot(bb));
     }
     if (lane == 0) {
+        const uint32_t n = (uint32_t)(s1 - s0);
+        const size_t S = (size_t)U.n_units + 1;
         uint32_t ncopy;
-        if (cardmode || op == OP_AND) ncopy = 0;
-        else if (op == OP_ANDNOT) ncopy = (uint32_t)nA - matched;
-        else ncopy = (uint32_t)(nA + nB) - 2u * matched;
-        const size_t S = (size_t)npairs + 1;
-        counts[SEC_CAND * S + p] = matched + ncopy;
-        counts[SEC_BB * S + p] = nbb;
-        counts[SEC_GEN * S + p] = matched - nbb;
-        counts[SEC_COPY * S + p] = ncopy;
+        if (bside) ncopy = n - matched;                              // OR/XOR only
+        else ncopy = (cardmode || op == OP_AND) ? 0u : n - matched;  // A-only containers pass through
+        counts[SEC_CAND * S + u] = bside ? ncopy : matched + ncopy;
+        counts[SEC_M * S + u] = matched;
+        counts[SEC_BB * S + u] = nbb;
+        counts[SEC_GEN * S + u] = bside ? 0u : matched - nbb;
+        counts[SEC_COPY * S + u] = ncopy;
     }
 }
 
-// One wave per bitmap pair: emit candidates in merged key order (roaring.c:742-768, 895-951)
-// and the work items of each class at deterministic queue positions (no atomics).
-// Position of a candidate inside its result bitmap is computed by ranking, not by a serial merge:
+// One wave per unit: emit candidates in merged key order (roaring.c:742-768, 895-951) and the work
+// items of each class at deterministic queue positions (no atomics).  The position of a candidate
+// inside its result bitmap is computed by ranking, not by a serial merge:
 //   matched / A-only element i (key k):  i + |{B keys < k}| - |{matched keys < k}|
 //   B-only element j (key k)          :  j + |{A keys < k}| - |{matched keys < k}|
+// with |{matched keys < k}| = (matched count of the pair's earlier tiles, from the scan) + a ballot rank.
 struct EmitQueues {
     BBItem* bb;   // section SEC_BB
     Item* gen;    // section SEC_GEN
     Item* copy;   // section SEC_COPY
 };
 __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint32_t* __restrict__ lhs,
-                                              const uint32_t* __restrict__ rhs, uint32_t npairs, int op,
-                                              int cardmode, const u64* __restrict__ starts, OutView O,
-                                              EmitQueues Q, Stats* stats) {
-    uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (p >= npairs) return;
+                                              const uint32_t* __restrict__ rhs, UnitView U, int op, int cardmode,
+                                              const u64* __restrict__ starts, OutView O, EmitQueues Q,
+                                              Stats* stats) {
+    const uint32_t u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (u >= U.n_units) return;
     const uint32_t lane = lane_id();
-    const size_t S = (size_t)npairs + 1;
+    const size_t S = (size_t)U.n_units + 1;
+    const uint32_t p = U.pair[u];
+    const bool bside = (U.tile[u] & UNIT_B) != 0;
+    const u64 tile = U.tile[u] & ~UNIT_B;
     const u64 a0 = A.bm_start[lhs[p]], a1 = A.bm_start[lhs[p] + 1];
     const u64 b0 = B.bm_start[rhs[p]], b1 = B.bm_start[rhs[p] + 1];
-    const u64 base = starts[SEC_CAND * S + p];
-    // queue cursors of this pair, relative to the beginning of each section
-    u64 qbb = starts[SEC_BB * S + p] - starts[SEC_BB * S];
-    u64 qgen = starts[SEC_GEN * S + p] - starts[SEC_GEN * S];
-    u64 qcopy = starts[SEC_COPY * S + p] - starts[SEC_COPY * S];
+    const u64 u0 = U.pair_unit0[p];
+    const u64 base = starts[SEC_CAND * S + u0];
+    u64 qbb = starts[SEC_BB * S + u] - starts[SEC_BB * S];
+    u64 qgen = starts[SEC_GEN * S + u] - starts[SEC_GEN * S];
+    u64 qcopy = starts[SEC_COPY * S + u] - starts[SEC_COPY * S];
     u64 bytes_in = 0;
-
-    uint32_t mbefore = 0;  // matched keys among A elements already visited
-    for (u64 i = a0; i < a1; i += 256) {
-        u64 k[4], j[4];
-        bool act[4];
+    u64 k[4], j[4];
+    bool act[4];
+    if (!bside) {
+        const u64 s0 = a0 + tile * 256;
+        uint32_t mbefore = (uint32_t)(starts[SEC_M * S + u] - starts[SEC_M * S + u0]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            act[t] = i + 64 * t + lane < a1;
-            k[t] = act[t] ? A.key[i + 64 * t + lane] : 0;
+            act[t] = s0 + 64 * t + lane < a1 && 64 * t + lane < 256;
+            k[t] = act[t] ? A.key[s0 + 64 * t + lane] : 0;
         }
         lower_bound4(B.key, b0, b1, k, act, j);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const u64 ai = i + 64 * t + lane;
+            const u64 ai = s0 + 64 * t + lane;
             const bool found = act[t] && j[t] < b1 && B.key[j[t]] == k[t];
             const u64 fm = __ballot(found);
             const uint32_t mb = mbefore + mbcnt(fm);
@@ -276,37 +298,34 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
             if (iscopy) Q.copy[qcopy + mbcnt(mcp)] = Item{(uint32_t)ai, NONE32, outidx};
             qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp);
         }
-    }
-    if (!cardmode && (op == OP_OR || op == OP_XOR)) {
-        mbefore = 0;
-        for (u64 i = b0; i < b1; i += 256) {
-            u64 k[4], j[4];
-            bool act[4];
+    } else {
+        const u64 nAt = (a1 - a0 + 255) / 256;
+        const u64 s0 = b0 + tile * 256;
+        uint32_t mbefore = (uint32_t)(starts[SEC_M * S + u] - starts[SEC_M * S + u0 + nAt]);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                act[t] = i + 64 * t + lane < b1;
-                k[t] = act[t] ? B.key[i + 64 * t + lane] : 0;
-            }
-            lower_bound4(A.key, a0, a1, k, act, j);
+        for (int t = 0; t < 4; ++t) {
+            act[t] = s0 + 64 * t + lane < b1;
+            k[t] = act[t] ? B.key[s0 + 64 * t + lane] : 0;
+        }
+        lower_bound4(A.key, a0, a1, k, act, j);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const u64 bi = i + 64 * t + lane;
-                const bool found = act[t] && j[t] < a1 && A.key[j[t]] == k[t];
-                const u64 fm = __ballot(found);
-                const uint32_t mb = mbefore + mbcnt(fm);
-                mbefore += (uint32_t)__popcll(fm);
-                const bool emit = act[t] && !found;
-                const u64 mcp = __ballot(emit);
-                if (emit) {
-                    const uint32_t pos = (uint32_t)(bi - b0) + (uint32_t)(j[t] - a0) - mb;
-                    const uint32_t pb = payload_bytes(B.type[bi], B.card[bi], B.nruns[bi]);
-                    O.key[base + pos] = k[t];
-                    O.slot[base + pos] = align16(pb) < 16u ? 16u : align16(pb);
-                    bytes_in += pb;
-                    Q.copy[qcopy + mbcnt(mcp)] = Item{NONE32, (uint32_t)bi, (uint32_t)(base + pos)};
-                }
-                qcopy += __popcll(mcp);
+        for (int t = 0; t < 4; ++t) {
+            const u64 bi = s0 + 64 * t + lane;
+            const bool found = act[t] && j[t] < a1 && A.key[j[t]] == k[t];
+            const u64 fm = __ballot(found);
+            const uint32_t mb = mbefore + mbcnt(fm);
+            mbefore += (uint32_t)__popcll(fm);
+            const bool emit = act[t] && !found;
+            const u64 mcp = __ballot(emit);
+            if (emit) {
+                const uint32_t pos = (uint32_t)(bi - b0) + (uint32_t)(j[t] - a0) - mb;
+                const uint32_t pb = payload_bytes(B.type[bi], B.card[bi], B.nruns[bi]);
+                O.key[base + pos] = k[t];
+                O.slot[base + pos] = align16(pb) < 16u ? 16u : align16(pb);
+                bytes_in += pb;
+                Q.copy[qcopy + mbcnt(mcp)] = Item{NONE32, (uint32_t)bi, (uint32_t)(base + pos)};
             }
+            qcopy += __popcll(mcp);
         }
     }
     bytes_in = wave_sum64(bytes_in);
@@ -741,10 +760,10 @@ __global__ __launch_bounds__(1024) void k_compact(OutView O, u64 n, const u64* _
         if (k) { atomicAdd(&stats->bytes_out, b); atomicAdd(&stats->result_containers, (u64)k); }
     }
 }
-__global__ void k_bm_start(const u64* __restrict__ cand_start, uint32_t npairs, const u64* __restrict__ newidx,
-                           u64* __restrict__ bm_start) {
+__global__ void k_bm_start(const u64* __restrict__ cand_start, const u64* __restrict__ pair_unit0, uint32_t npairs,
+                           const u64* __restrict__ newidx, u64* __restrict__ bm_start) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p <= npairs) bm_start[p] = newidx[cand_start[p]];
+    if (p <= npairs) bm_start[p] = newidx[cand_start[pair_unit0[p]]];
 }
 
 // per-bitmap cardinality = sum of container cardinalities (roaring.c:1436-1443); wave per bitmap

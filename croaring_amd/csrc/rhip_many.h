@@ -177,11 +177,55 @@ struct ManyOut {
     u64* chunk_out;     // partial_mode: [G][1024] final uncompressed chunks
     int partial_mode;   // 1: write uncompressed chunks instead of canonical containers
     int force_typed;    // 1: single-member groups are typed by cardinality too
+    int exact_or_many;  // 1: reproduce roaring_bitmap_or_many's run-vs-bitset choice for FULL containers
+    u64 first_lo, first_hi, second_lo, second_hi;  // container index ranges of ids[0] and ids[1]
 };
+
+// A union that fills the whole chunk is the one place where roaring_bitmap_or_many's result type
+// depends on the fold order (SURVEY G11 / Appendix A "or_many"): the accumulator is a lazy bitset
+// whose cardinality is only computed by bitset x bitset steps (container_lazy_ior, containers.h:
+// 1343-1352, which turn a full result into a full RUN), a full run operand replaces it by a full run
+// (containers.h:1407-1412), and a known-full accumulator short-circuits later steps (roaring.c:2621).
+// Given that the final union IS full, the outcome follows from member metadata plus ONE question:
+// "is the union already full after the last bitset member?" -- answered by re-accumulating that prefix.
+// Returns true for a full run, false for a (full) bitset.
+__device__ bool full_union_is_run(uint32_t* acc2, uint32_t* tmp, const PoolView& P, const ManyView& V,
+                                  const ManyOut& MO, u64 gs, u64 ge, BlockScratch* sc) {
+    const uint32_t c0 = V.sval[gs], c1 = V.sval[gs + 1];
+    const bool first = c0 >= MO.first_lo && c0 < MO.first_hi && c1 >= MO.second_lo && c1 < MO.second_hi;
+    auto isB = [&](uint32_t c) { return P.type[c] == T_BITSET; };
+    auto isRF = [&](uint32_t c) { return P.type[c] == T_RUN && P.card[c] == 65536u; };
+    u64 start;  // first member handled by the generic lazy_or_inplace step
+    if (first) {  // roaring_bitmap_lazy_or(x0, x1), roaring.c:2529-2548
+        if (isB(c0) || isB(c1)) { if (isRF(c0) || isRF(c1)) return true; }
+        else if (isRF(c1)) return true;
+        start = gs + 2;
+    } else {
+        if (isRF(c0)) return true;                          // container_is_full -> every step skipped
+        if (isB(c0) && P.card[c0] == 65536u) return false;  // known-full bitset: skipped, repair keeps a bitset
+        start = gs + 1;
+    }
+    u64 last_b = 0;
+    bool any_b = false;
+    for (u64 m = start; m < ge; ++m) {
+        const uint32_t c = V.sval[m];
+        if (isRF(c)) return true;  // a full run operand always wins (not skipped: accumulator card unknown or < 65536)
+        if (isB(c)) { any_b = true; last_b = m; }
+    }
+    if (!any_b) return false;
+    // union of members [gs, last_b] full?
+    __syncthreads();
+    lds_zero(acc2);
+    __syncthreads();
+    many_accumulate(acc2, tmp, P, V, gs, last_b + 1, OP_OR, sc);
+    uint4 r0 = ((uint4*)acc2)[2 * threadIdx.x], r1 = ((uint4*)acc2)[2 * threadIdx.x + 1];
+    return blk_sum(popc4(r0) + popc4(r1), sc->wsum) == 65536u;
+}
 
 // canonicalise the LDS image of a finished group: card <= 4096 -> array, else bitset
 // (container_repair_after_lazy, containers.h:344-371); empty -> dropped by compaction
-__device__ void many_finalize(uint32_t* acc, uint16_t* stage, const ManyOut& MO, uint32_t g, BlockScratch* sc) {
+__device__ void many_finalize(uint32_t* acc, uint16_t* stage, const ManyOut& MO, uint32_t g, BlockScratch* sc,
+                              uint32_t* acc2, uint32_t* tmp, const PoolView& P, const ManyView& V, u64 gs, u64 ge) {
     const uint32_t tid = threadIdx.x;
     uint4 r0 = ((uint4*)acc)[2 * tid], r1 = ((uint4*)acc)[2 * tid + 1];
     if (MO.partial_mode) {
@@ -193,6 +237,13 @@ __device__ void many_finalize(uint32_t* acc, uint16_t* stage, const ManyOut& MO,
     uint32_t r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
     const uint32_t rc = blk_sum(popc4(r0) + popc4(r1), sc->wsum);
     int ty = T_ARRAY;
+    if (rc == 65536u && MO.exact_or_many && ge - gs >= 2 && full_union_is_run(acc2, tmp, P, V, MO, gs, ge, sc)) {
+        if (tid == 0) {
+            *(uint32_t*)(MO.O.arena + MO.O.off[g]) = 0xFFFF0000u;  // one run {value 0, length 0xFFFF}
+            MO.O.meta[g] = pack_meta(T_RUN, 65536u, 1u);
+        }
+        return;
+    }
     if (rc) {
         ty = type_ba(rc);
         lds_emit(acc, r, ty, rc, 0, stage, MO.O.arena + MO.O.off[g], sc);
@@ -204,7 +255,7 @@ __global__ __launch_bounds__(256) void k_many_l1(PoolView P, ManyView V, ManyOut
                                                  int op) {
     __shared__ __attribute__((aligned(16))) uint32_t acc[2048];
     __shared__ __attribute__((aligned(16))) uint32_t tmp[2048];
-    __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];
+    __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];  // doubles as the replay image (8 KiB)
     __shared__ BlockScratch sc;
     const uint32_t G = *V.n_groups;
     const u64 U = *n_units;
@@ -220,7 +271,7 @@ __global__ __launch_bounds__(256) void k_many_l1(PoolView P, ManyView V, ManyOut
         __syncthreads();
         many_accumulate(acc, tmp, P, V, m0, m1, op, &sc);
         if (nu == 1) {
-            many_finalize(acc, stage, MO, g, &sc);
+            many_finalize(acc, stage, MO, g, &sc, (uint32_t*)stage, tmp, P, V, gs, ge);
         } else {
             uint4* po = (uint4*)(MO.partial + u * 1024ull);
             po[2 * threadIdx.x] = ((uint4*)acc)[2 * threadIdx.x];
@@ -230,8 +281,9 @@ __global__ __launch_bounds__(256) void k_many_l1(PoolView P, ManyView V, ManyOut
 }
 
 // combine the partial chunks of multi-unit groups
-__global__ __launch_bounds__(256) void k_many_l2(ManyView V, ManyOut MO, int op) {
+__global__ __launch_bounds__(256) void k_many_l2(PoolView P, ManyView V, ManyOut MO, int op) {
     __shared__ __attribute__((aligned(16))) uint32_t acc[2048];
+    __shared__ __attribute__((aligned(16))) uint32_t tmp[2048];
     __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];
     __shared__ BlockScratch sc;
     const uint32_t G = *V.n_groups;
@@ -249,7 +301,7 @@ __global__ __launch_bounds__(256) void k_many_l2(ManyView V, ManyOut MO, int op)
         ((uint4*)acc)[2 * tid] = r0;
         ((uint4*)acc)[2 * tid + 1] = r1;
         __syncthreads();
-        many_finalize(acc, stage, MO, g, &sc);
+        many_finalize(acc, stage, MO, g, &sc, (uint32_t*)stage, tmp, P, V, V.gstart[g], V.gstart[g + 1]);
     }
 }
 

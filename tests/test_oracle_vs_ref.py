@@ -69,3 +69,25 @@ def test_64bit(oracle, ref):
             ref.free64(h)
         for h in (oa, ob):
             oracle.free64(h)
+
+
+def test_or_many_full_container_orderings(oracle, ref):
+    """Every ordering of an adversarial set whose union fills the chunk: the run-vs-bitset outcome of
+    roaring_bitmap_or_many depends on the fold order (roaring.c:2529-2548 vs 2619-2647)."""
+    import itertools
+    full = np.arange(65536, dtype=np.uint32)
+    sets = {"fullrun": (full, True), "fullbits": (full, False),
+            "evens": (np.arange(0, 65536, 2, dtype=np.uint32), False),
+            "odds": (np.arange(1, 65536, 2, dtype=np.uint32), False),
+            "lo": (np.arange(0, 40000, dtype=np.uint32), True), "hi": (np.arange(30000, 65536, dtype=np.uint32), True),
+            "few": (np.array([5, 77, 4000], dtype=np.uint32), True)}
+    names = list(sets)
+    rs = {n: ref.from_sorted(v, run_optimize=ro) for n, (v, ro) in sets.items()}
+    os_ = {n: oracle.deserialize(ref.serialize(rs[n])) for n in names}
+    for r in (2, 3, 4):
+        for combo in itertools.permutations(range(len(names)), r):
+            a = ref.or_many([rs[names[i]] for i in combo])
+            b = oracle.or_many([os_[names[i]] for i in combo])
+            assert ref.serialize(a) == oracle.serialize(b), [names[i] for i in combo]
+            ref.free(a)
+            oracle.free(b)
