@@ -69,7 +69,7 @@ struct rhip_ctx_s {
     int device = 0;
     hipStream_t stream = nullptr;
     // scratch (grow-only): candidate directory + queues + scan temporaries
-    DBuf lhs, rhs, u_pair, u_tile, u_pair0, cand, cand_start, o_key, o_meta, o_slot, o_off, flag, newidx, q[N_CLS], misc, prim_tmp, pair_acc;
+    DBuf lhs, rhs, u_pair, u_tile, u_pair0, unit_bytes, cand, cand_start, o_key, o_meta, o_slot, o_off, flag, newidx, q[N_CLS], misc, prim_tmp, pair_acc;
     DBuf many[16];
     void* h_pinned = nullptr;  // small pinned readback area
     rhip_stats_t stats{};
@@ -142,7 +142,7 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
 extern "C" void rhip_ctx_destroy(rhip_ctx_t* c) {
     if (!c) return;
     (void)hipStreamSynchronize(c->stream);
-    DBuf* all[] = {&c->lhs, &c->rhs, &c->u_pair, &c->u_tile, &c->u_pair0, &c->cand, &c->cand_start, &c->o_key, &c->o_meta,
+    DBuf* all[] = {&c->lhs, &c->rhs, &c->u_pair, &c->u_tile, &c->u_pair0, &c->unit_bytes, &c->cand, &c->cand_start, &c->o_key, &c->o_meta,
                    &c->o_slot, &c->o_off, &c->flag, &c->newidx, &c->misc, &c->prim_tmp, &c->pair_acc};
     for (auto* b : all) b->release();
     for (auto& b : c->q) b.release();
@@ -596,13 +596,13 @@ namespace {
 struct PlanResult {
     uint64_t total_cand = 0;
     uint64_t total_bytes = 0;
-    uint64_t n_bb = 0, n_gen = 0, n_copy = 0;
+    uint64_t n_bb = 0, n_gen = 0, n_copy = 0, n_filt = 0, n_wave = 0;
 };
 
-// misc layout (device): [0, 80) five {begin,end} u64 section ranges; [96, 100) retry counter;
+// misc layout (device): [0, 112) seven {begin,end} u64 section ranges; [120, 124) retry counter;
 // [128, ...) Stats
 constexpr size_t MISC_RANGES_OFF = 0;
-constexpr size_t MISC_RETRY_OFF = 96;
+constexpr size_t MISC_RETRY_OFF = 120;
 constexpr size_t MISC_STATS_OFF = 128;
 
 __global__ void k_plan_totals(const u64* __restrict__ starts, u64 S, u64* __restrict__ ranges) {
@@ -685,6 +685,9 @@ PlanResult plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t np
     hipLaunchKernelGGL(k_plan_totals, dim3(1), dim3(64), 0, s, c->cand_start.as<u64>(), (u64)S, ranges);
     c->q[CLS_BB].ensure(sizeof(BBItem) * (ub_match + 1));
     c->q[CLS_GEN].ensure(sizeof(Item) * (ub_match + 1));
+    c->q[CLS_FILT].ensure(sizeof(Item) * (ub_match + 1));
+    c->q[CLS_WAVE].ensure(sizeof(Item) * (ub_match + 1));
+    c->unit_bytes.ensure(8 * (NU + 1));
     c->q[CLS_COPY].ensure(sizeof(Item) * (ub + 1));
     if (!cardmode) {
         c->o_key.ensure(8 * (ub + 1)); c->o_meta.ensure(8 * (ub + 1));
@@ -694,24 +697,28 @@ PlanResult plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t np
     O.key = c->o_key.as<u64>(); O.meta = c->o_meta.as<u64>();
     O.slot = c->o_slot.as<uint32_t>(); O.off = c->o_off.as<u64>();
     O.arena = nullptr;
-    EmitQueues Q{c->q[CLS_BB].as<BBItem>(), c->q[CLS_GEN].as<Item>(), c->q[CLS_COPY].as<Item>()};
+    EmitQueues Q{c->q[CLS_BB].as<BBItem>(), c->q[CLS_GEN].as<Item>(), c->q[CLS_COPY].as<Item>(), c->q[CLS_FILT].as<Item>(), c->q[CLS_WAVE].as<Item>()};
     hipLaunchKernelGGL(k_emit, dim3(gp), dim3(256), 0, s, VA, VB, c->lhs.as<uint32_t>(), c->rhs.as<uint32_t>(), UV, op,
-                       cardmode, c->cand_start.as<u64>(), O, Q, (Stats*)((char*)c->misc.p + MISC_STATS_OFF));
+                       cardmode, c->cand_start.as<u64>(), O, Q, c->unit_bytes.as<u64>());
+    hipLaunchKernelGGL(k_sum_u64, dim3(1), dim3(1024), 0, s, c->unit_bytes.as<u64>(), (u64)NU,
+                       &((Stats*)((char*)c->misc.p + MISC_STATS_OFF))->bytes_in);
     char* hp = (char*)c->h_pinned;
     if (!cardmode) {
         // slots beyond the exact candidate count were zeroed, so scanning the upper bound is exact
         exscan(c, O.slot, c->o_off.as<u64>(), ub);
-        HIPCHK(hipMemcpyAsync(hp + 96, c->o_off.as<u64>() + ub, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hp + 128, c->o_off.as<u64>() + ub, 8, hipMemcpyDeviceToHost, s));
     }
-    HIPCHK(hipMemcpyAsync(hp, ranges, 80, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hp, ranges, 112, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    uint64_t r[10];
-    memcpy(r, hp, 80);
+    uint64_t r[14];
+    memcpy(r, hp, 112);
     R.total_cand = r[2 * SEC_CAND + 1] - r[2 * SEC_CAND];
     R.n_bb = r[2 * SEC_BB + 1] - r[2 * SEC_BB];
     R.n_gen = r[2 * SEC_GEN + 1] - r[2 * SEC_GEN];
     R.n_copy = r[2 * SEC_COPY + 1] - r[2 * SEC_COPY];
-    if (!cardmode) memcpy(&R.total_bytes, hp + 96, 8);
+    R.n_filt = r[2 * SEC_FILT + 1] - r[2 * SEC_FILT];
+    R.n_wave = r[2 * SEC_WAVE + 1] - r[2 * SEC_WAVE];
+    if (!cardmode) memcpy(&R.total_bytes, hp + 128, 8);
     return R;
 }
 
@@ -744,6 +751,16 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
                                (const u64*)nullptr, retry_count, op, 0, c->pair_acc.as<u64>());
         }
     }
+    if (R.n_filt) {
+        unsigned grid = persistent_grid(R.n_filt, 4, 256 * 4);
+        hipLaunchKernelGGL(k_filter, dim3(grid), dim3(256), 0, s, VA, VB, O, c->q[CLS_FILT].as<Item>(),
+                           ranges + 2 * SEC_FILT, op, cardmode, c->pair_acc.as<u64>());
+    }
+    if (R.n_wave && !cardmode) {
+        unsigned grid = persistent_grid(R.n_wave, 4, 256 * 5);
+        hipLaunchKernelGGL(k_wave, dim3(grid), dim3(256), 0, s, VA, VB, O, c->q[CLS_WAVE].as<Item>(),
+                           ranges + 2 * SEC_WAVE, op);
+    }
     if (R.n_gen) {
         unsigned grid = persistent_grid(R.n_gen, 1, 256 * 6);
         hipLaunchKernelGGL(k_gen, dim3(grid), dim3(256), 0, s, VA, VB, O, c->q[CLS_GEN].as<Item>(),
@@ -763,7 +780,7 @@ void finish_stats(rhip_ctx_t* c, const PlanResult* R) {
     if (c->timing) HIPCHK(hipEventRecord(c->ev[1], s));
     HIPCHK(hipStreamSynchronize(s));
     memcpy(&st, c->h_pinned, sizeof(Stats));
-    c->stats.matched_pairs = R ? R->n_bb + R->n_gen : 0;
+    c->stats.matched_pairs = R ? R->n_bb + R->n_gen + R->n_filt + R->n_wave : 0;
     c->stats.passthrough = R ? R->n_copy : 0;
     c->stats.bytes_in = st.bytes_in;
     c->stats.bytes_out = st.bytes_out;

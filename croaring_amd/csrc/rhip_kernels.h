@@ -26,7 +26,7 @@ typedef unsigned long long u64;
 
 enum { T_BITSET = 1, T_ARRAY = 2, T_RUN = 3 };
 enum { OP_AND = 0, OP_OR = 1, OP_XOR = 2, OP_ANDNOT = 3 };
-enum { CLS_BB = 0, CLS_GEN = 1, CLS_COPY = 2, CLS_RETRY = 3, N_CLS = 4 };
+enum { CLS_BB = 0, CLS_GEN = 1, CLS_COPY = 2, CLS_RETRY = 3, CLS_FILT = 4, CLS_WAVE = 5, N_CLS = 6 };
 #define NONE32 0xFFFFFFFFu
 
 struct PoolView {
@@ -154,7 +154,21 @@ __device__ __forceinline__ void lower_bound4(const u64* __restrict__ key, u64 lo
 // unmatched containers -- of the right bitmap ("B-tile").  One wave per unit, so a batch of 250 pairs
 // of 4096-container bitmaps plans on 4000 waves instead of 250.
 // Count arrays (and their exclusive scan) have 5 sections of n_units+1 entries:
-enum { SEC_CAND = 0, SEC_M = 1, SEC_BB = 2, SEC_GEN = 3, SEC_COPY = 4, N_SEC = 5 };
+enum { SEC_CAND = 0, SEC_M = 1, SEC_BB = 2, SEC_GEN = 3, SEC_COPY = 4, SEC_FILT = 5, SEC_WAVE = 6, N_SEC = 7 };
+// work class of a matched container pair
+__device__ __forceinline__ int classify(int op, int cardmode, uint8_t ta, uint8_t tb) {
+    if (ta == T_BITSET && tb == T_BITSET) return CLS_BB;
+    // array filtered by membership in an array / bitset: and (either order), array \ x
+    if (cardmode || op == OP_AND) {
+        if ((ta == T_ARRAY && tb != T_RUN) || (tb == T_ARRAY && ta != T_RUN)) return CLS_FILT;
+    } else if (op == OP_ANDNOT) {
+        if (ta == T_ARRAY && tb != T_RUN) return CLS_FILT;
+        if (ta == T_BITSET && tb == T_ARRAY) return CLS_WAVE;  // bitset \ array: clear-list in LDS
+    } else {
+        if (ta != T_RUN && tb != T_RUN) return CLS_WAVE;       // or / xor with an array operand
+    }
+    return CLS_GEN;
+}
 #define UNIT_B 0x80000000u
 
 struct UnitView {
@@ -190,13 +204,16 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         k[t] = act[t] ? SV.key[s0 + 64 * t + lane] : 0;
     }
     lower_bound4(LV.key, l0, l1, k, act, j);
-    uint32_t matched = 0, nbb = 0;
+    uint32_t matched = 0, nbb = 0, nfilt = 0, nwave = 0;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const bool found = act[t] && j[t] < l1 && LV.key[j[t]] == k[t];
-        const bool bb = found && !bside && SV.type[s0 + 64 * t + lane] == T_BITSET && LV.type[j[t]] == T_BITSET;
+        int cls = -1;
+        if (found && !bside) cls = classify(op, cardmode, SV.type[s0 + 64 * t + lane], LV.type[j[t]]);
         matched += (uint32_t)__popcll(__ballot(found));
-        nbb += (uint32_t)__popcll(__ballot(bb));
+        nbb += (uint32_t)__popcll(__ballot(cls == CLS_BB));
+        nfilt += (uint32_t)__popcll(__ballot(cls == CLS_FILT));
+        nwave += (uint32_t)__popcll(__ballot(cls == CLS_WAVE));
     }
     if (lane == 0) {
         const uint32_t n = (uint32_t)(s1 - s0);
@@ -207,7 +224,9 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         counts[SEC_CAND * S + u] = bside ? ncopy : matched + ncopy;
         counts[SEC_M * S + u] = matched;
         counts[SEC_BB * S + u] = nbb;
-        counts[SEC_GEN * S + u] = bside ? 0u : matched - nbb;
+        counts[SEC_GEN * S + u] = bside ? 0u : matched - nbb - nfilt - nwave;
+        counts[SEC_FILT * S + u] = nfilt;
+        counts[SEC_WAVE * S + u] = nwave;
         counts[SEC_COPY * S + u] = ncopy;
     }
 }
@@ -222,11 +241,13 @@ struct EmitQueues {
     BBItem* bb;   // section SEC_BB
     Item* gen;    // section SEC_GEN
     Item* copy;   // section SEC_COPY
+    Item* filt;   // section SEC_FILT
+    Item* wave;   // section SEC_WAVE
 };
 __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint32_t* __restrict__ lhs,
                                               const uint32_t* __restrict__ rhs, UnitView U, int op, int cardmode,
                                               const u64* __restrict__ starts, OutView O, EmitQueues Q,
-                                              Stats* stats) {
+                                              u64* __restrict__ unit_bytes) {
     const uint32_t u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (u >= U.n_units) return;
     const uint32_t lane = lane_id();
@@ -241,6 +262,8 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
     u64 qbb = starts[SEC_BB * S + u] - starts[SEC_BB * S];
     u64 qgen = starts[SEC_GEN * S + u] - starts[SEC_GEN * S];
     u64 qcopy = starts[SEC_COPY * S + u] - starts[SEC_COPY * S];
+    u64 qfilt = starts[SEC_FILT * S + u] - starts[SEC_FILT * S];
+    u64 qwave = starts[SEC_WAVE * S + u] - starts[SEC_WAVE * S];
     u64 bytes_in = 0;
     u64 k[4], j[4];
     bool act[4];
@@ -284,10 +307,14 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 }
             }
             const uint32_t outidx = cardmode ? p : (uint32_t)(base + pos);
-            const bool isbb = emit && found && ta == T_BITSET && tb == T_BITSET;
-            const bool isgen = emit && found && !isbb;
+            const int cls = (emit && found) ? classify(op, cardmode, ta, tb) : -1;
+            const bool isbb = cls == CLS_BB;
+            const bool isgen = cls == CLS_GEN;
+            const bool isfilt = cls == CLS_FILT;
+            const bool iswave = cls == CLS_WAVE;
             const bool iscopy = emit && !found;
-            const u64 mbb = __ballot(isbb), mgen = __ballot(isgen), mcp = __ballot(iscopy);
+            const u64 mbb = __ballot(isbb), mgen = __ballot(isgen), mcp = __ballot(iscopy), mfl = __ballot(isfilt);
+            const u64 mwv = __ballot(iswave);
             if (isbb) {
                 BBItem it;
                 it.offa = A.off[ai]; it.offb = B.off[j[t]];
@@ -295,8 +322,10 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 Q.bb[qbb + mbcnt(mbb)] = it;
             }
             if (isgen) Q.gen[qgen + mbcnt(mgen)] = Item{(uint32_t)ai, (uint32_t)j[t], outidx};
+            if (isfilt) Q.filt[qfilt + mbcnt(mfl)] = Item{(uint32_t)ai, (uint32_t)j[t], outidx};
+            if (iswave) Q.wave[qwave + mbcnt(mwv)] = Item{(uint32_t)ai, (uint32_t)j[t], outidx};
             if (iscopy) Q.copy[qcopy + mbcnt(mcp)] = Item{(uint32_t)ai, NONE32, outidx};
-            qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp);
+            qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv);
         }
     } else {
         const u64 nAt = (a1 - a0 + 255) / 256;
@@ -329,7 +358,21 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
         }
     }
     bytes_in = wave_sum64(bytes_in);
-    if (lane == 0 && bytes_in) atomicAdd(&stats->bytes_in, bytes_in);
+    if (lane == 0) unit_bytes[u] = bytes_in;  // summed by k_sum_u64 (no contended atomics)
+}
+
+__global__ __launch_bounds__(1024) void k_sum_u64(const u64* __restrict__ v, u64 n, u64* __restrict__ out) {
+    __shared__ u64 sb[16];
+    u64 s = 0;
+    for (u64 i = threadIdx.x; i < n; i += blockDim.x) s += v[i];
+    s = wave_sum64(s);
+    if (lane_id() == 0) sb[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 t = 0;
+        for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) t += sb[w];
+        *out = t;
+    }
 }
 
 // ------------------------------------------------------------------ bitset x bitset (K1-K3)
@@ -422,6 +465,213 @@ __global__ __launch_bounds__(256) void k_copy(PoolView A, PoolView B, OutView O,
         uint4* __restrict__ po = (uint4*)(O.arena + O.off[t.out]);
         for (uint32_t i = lane; i < n16; i += 64) po[i] = ps[i];
         if (lane == 0) O.meta[t.out] = pack_meta(ty, card, nr);
+    }
+}
+
+__device__ int decide_type(int op, int ta, int tb, uint32_t ca, uint32_t cb, bool fulla, bool fullb, uint32_t rc,
+                           uint32_t rn);
+
+// ------------------------------------------------------------------ array filter (K8, K9, K12)
+// One WAVE per container pair, no workgroup barriers: the array operand Y is streamed 64 values at
+// a time, each lane tests its value for membership in X and survivors are compacted with a ballot +
+// mbcnt prefix.  X = bitset: one gathered dword test per value (array_bitset_container_intersection
+// / _andnot, mixed_intersection.c:19-46, mixed_andnot.c:24-39).  X = array: X is first scattered into
+// a wave-private 8 KiB LDS bitset (ds_or_b32), replacing the SIMD merge / galloping intersections of
+// array_util.c:385-459, 801-906 (intersect_vector16, intersect_skewed_uint16) and difference_uint16.
+// The result is always an array (containers.h:741-746, 1799-1803).
+__global__ __launch_bounds__(256) void k_filter(PoolView A, PoolView B, OutView O, const Item* __restrict__ q,
+                                                const u64* __restrict__ qrange, int op, int cardmode,
+                                                u64* pair_acc) {
+    __shared__ __attribute__((aligned(16))) uint32_t img_all[4][2048];
+    const uint32_t lane = lane_id();
+    uint32_t* img = img_all[threadIdx.x >> 6];
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
+    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
+        const Item t = q[w];
+        const uint8_t ta = A.type[t.a], tb = B.type[t.b];
+        const uint32_t ca = A.card[t.a], cb = B.card[t.b];
+        // Y = the streamed array, X = the membership side
+        bool y_is_a = true;
+        if (op == OP_AND) y_is_a = (ta == T_ARRAY) && (tb != T_ARRAY || ca <= cb);
+        const uint8_t* yp = y_is_a ? A.arena + A.off[t.a] : B.arena + B.off[t.b];
+        const uint8_t* xp = y_is_a ? B.arena + B.off[t.b] : A.arena + A.off[t.a];
+        const uint32_t ny = y_is_a ? ca : cb, nx = y_is_a ? cb : ca;
+        const bool x_bitset = (y_is_a ? tb : ta) == T_BITSET;
+        const bool keep_present = op == OP_AND;
+        const uint32_t* __restrict__ xw = (const uint32_t*)xp;
+        if (!x_bitset) {
+            const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ((uint4*)img)[i * 64 + lane] = z;
+            const uint4* __restrict__ x4 = (const uint4*)xp;  // 8 values per lane per step (slots are 16-byte padded)
+            for (uint32_t i = lane; 8 * i < nx; i += 64) {
+                const uint4 q4 = x4[i];
+                const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    if (8 * i + h < nx) {
+                        const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                        atomicOr(&img[v >> 5], 1u << (v & 31));
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        const uint4* __restrict__ y4 = (const uint4*)yp;
+        uint16_t* __restrict__ out = cardmode ? nullptr : (uint16_t*)(O.arena + O.off[t.out]);
+        uint32_t run = 0;
+        for (uint32_t base = 0; base < ny; base += 512) {
+            const uint32_t i0 = base + 8 * lane;
+            uint4 q4 = make_uint4(0, 0, 0, 0);
+            if (i0 < ny) q4 = y4[(base >> 3) + lane];
+            const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
+            uint32_t vals[8];
+            uint32_t keepmask = 0;
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                vals[h] = v;
+                const uint32_t word = x_bitset ? xw[v >> 5] : img[v >> 5];
+                const bool present = (word >> (v & 31)) & 1u;
+                if (i0 + h < ny && present == keep_present) keepmask |= 1u << h;
+            }
+            const uint32_t cnt = __popc(keepmask);
+            const uint32_t inc = wave_incl_scan(cnt);
+            if (!cardmode) {
+                uint32_t pos = run + inc - cnt;
+#pragma unroll
+                for (int h = 0; h < 8; ++h)
+                    if ((keepmask >> h) & 1u) out[pos++] = (uint16_t)vals[h];
+            }
+            run += __shfl(inc, 63);
+        }
+        if (cardmode) {
+            if (lane == 0 && run) atomicAdd(&pair_acc[t.out], (u64)run);
+        } else if (lane == 0) {
+            O.meta[t.out] = pack_meta(T_ARRAY, run, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------ wave-private LDS image kernel (K6, K10, K11)
+// One WAVE per container pair for {array,bitset} x {array,bitset} pairs with at least one array under
+// or / xor, and bitset \ array.  The wave owns an 8 KiB LDS image: X is loaded into it (bitset: 8
+// coalesced 16-byte loads per lane; array: zero + ds_or scatter), then Y's values are applied with
+// returning LDS atomics (ds_or_rtn / ds_xor_rtn / ds_and_rtn) whose old values give the cardinality
+// delta -- bitset_set_list_withcard / bitset_flip_list_withcard / bitset_clear_list
+// (bitset_util.c:978-1141) without their serial dependence.  The result is typed by the reference's
+// rules and either streamed out as a bitset or extracted as a sorted array (lane owns 32 consecutive
+// words; wave prefix sum of popcounts).  No workgroup barrier anywhere.
+__global__ __launch_bounds__(256) void k_wave(PoolView A, PoolView B, OutView O, const Item* __restrict__ q,
+                                              const u64* __restrict__ qrange, int op) {
+    __shared__ __attribute__((aligned(16))) uint32_t img_all[4][2048];
+    const uint32_t lane = lane_id();
+    uint32_t* img = img_all[threadIdx.x >> 6];
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
+    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
+        const Item t = q[w];
+        const uint8_t ta = A.type[t.a], tb = B.type[t.b];
+        const uint32_t ca = A.card[t.a], cb = B.card[t.b];
+        // X = image side, Y = applied array.  andnot: X = a (bitset), Y = b.  or/xor are symmetric:
+        // take the bitset (or the larger array) as X.
+        bool x_is_a = true;
+        if (op != OP_ANDNOT) x_is_a = (ta == T_BITSET) || (tb != T_BITSET && ca >= cb);
+        const uint8_t tx = x_is_a ? ta : tb;
+        const uint32_t cx = x_is_a ? ca : cb, cy = x_is_a ? cb : ca;
+        const uint8_t* xp = x_is_a ? A.arena + A.off[t.a] : B.arena + B.off[t.b];
+        const uint32_t* __restrict__ y2 = (const uint32_t*)(x_is_a ? B.arena + B.off[t.b] : A.arena + A.off[t.a]);
+        if (tx == T_BITSET) {
+            const uint4* __restrict__ g = (const uint4*)xp;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ((uint4*)img)[i * 64 + lane] = g[i * 64 + lane];
+        } else {
+            const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ((uint4*)img)[i * 64 + lane] = z;
+            const uint4* __restrict__ x4 = (const uint4*)xp;
+            for (uint32_t i = lane; 8 * i < cx; i += 64) {
+                const uint4 q4 = x4[i];
+                const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    if (8 * i + h < cx) {
+                        const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                        atomicOr(&img[v >> 5], 1u << (v & 31));
+                    }
+                }
+            }
+        }
+        int delta = 0;
+        {
+            const uint4* __restrict__ y4 = (const uint4*)y2;
+            for (uint32_t i = lane; 8 * i < cy; i += 64) {
+                const uint4 q4 = y4[i];
+                const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
+                uint32_t old[8], bit[8];
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                    bit[h] = (8 * i + h < cy) ? (1u << (v & 31)) : 0u;
+                    if (op == OP_OR) old[h] = atomicOr(&img[v >> 5], bit[h]);
+                    else if (op == OP_XOR) old[h] = atomicXor(&img[v >> 5], bit[h]);
+                    else old[h] = atomicAnd(&img[v >> 5], ~bit[h]);
+                }
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    if (bit[h]) {
+                        const bool was = (old[h] & bit[h]) != 0;
+                        if (op == OP_OR) delta += was ? 0 : 1;
+                        else if (op == OP_XOR) delta += was ? -1 : 1;
+                        else delta -= was ? 1 : 0;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) delta += __shfl_xor(delta, o);
+        const uint32_t rc = (uint32_t)((int)cx + delta);
+        int ty = T_ARRAY;
+        if (rc) ty = decide_type(op, ta, tb, ca, cb, false, false, rc, 0);
+        uint8_t* outp = O.arena + O.off[t.out];
+        __builtin_amdgcn_wave_barrier();
+        if (rc && ty == T_BITSET) {
+            uint4* __restrict__ po = (uint4*)outp;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) po[i * 64 + lane] = ((const uint4*)img)[i * 64 + lane];
+        } else if (rc) {
+            // lane owns words [32*lane, 32*lane+32): values [1024*lane, 1024*lane+1024)
+            uint32_t wv[32];
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint4 x = ((const uint4*)img)[8 * lane + i];
+                wv[4 * i] = x.x; wv[4 * i + 1] = x.y; wv[4 * i + 2] = x.z; wv[4 * i + 3] = x.w;
+                cnt += popc4(x);
+            }
+            uint32_t pos = wave_incl_scan(cnt) - cnt;
+            // every lane holds its 32 words in registers now: the image is dead and is reused as the
+            // staging buffer of the compacted u16 list (<= 4096 values = 8 KiB), written out coalesced
+            __builtin_amdgcn_wave_barrier();
+            uint16_t* st16 = (uint16_t*)img;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                uint32_t x = wv[k];
+                const uint32_t vbase = (32u * lane + k) * 32u;
+                while (x) {
+                    st16[pos++] = (uint16_t)(vbase + (__ffs((int)x) - 1));
+                    x &= x - 1;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t n16 = (2u * rc + 15u) >> 4;
+            uint4* __restrict__ po = (uint4*)outp;
+            for (uint32_t i = lane; i < n16; i += 64) po[i] = ((const uint4*)img)[i];
+        }
+        if (lane == 0) O.meta[t.out] = pack_meta(ty, rc, 0);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

@@ -72,6 +72,19 @@ class Engine:
         """roaring_bitmap_portable_deserialize_safe for every buffer, into one HBM pool."""
         return self._from_bufs(self.lib.rhip_pool_from_portable, bufs)
 
+    def pool_from_packed(self, blob: np.ndarray, offsets, lens, is64: bool = False) -> "Pool":
+        """Same as pool_from_serialized, for n portable bitmaps packed back to back in one uint8 array
+        (no per-bitmap Python objects: used for 10^5-bitmap pools)."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint64)
+        ptrs = (offsets + np.uint64(blob.ctypes.data)).astype(np.uint64)
+        fn = self.lib.rhip_pool_from_portable64 if is64 else self.lib.rhip_pool_from_portable
+        h = fn(self.h, len(offsets), ptrs.ctypes.data, lens.ctypes.data)
+        if not h:
+            raise RoaringHipError("deserialize failed: " + _lib.last_error())
+        return Pool(self, h)
+
     def pool_from_serialized64(self, bufs: Sequence[bytes]) -> "Pool":
         """roaring64_bitmap_portable_deserialize_safe for every buffer."""
         return self._from_bufs(self.lib.rhip_pool_from_portable64, bufs)
