@@ -685,8 +685,8 @@ PlanResult plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t np
     hipLaunchKernelGGL(k_plan_totals, dim3(1), dim3(64), 0, s, c->cand_start.as<u64>(), (u64)S, ranges);
     c->q[CLS_BB].ensure(sizeof(BBItem) * (ub_match + 1));
     c->q[CLS_GEN].ensure(sizeof(Item) * (ub_match + 1));
-    c->q[CLS_FILT].ensure(sizeof(Item) * (ub_match + 1));
-    c->q[CLS_WAVE].ensure(sizeof(Item) * (ub_match + 1));
+    c->q[CLS_FILT].ensure(sizeof(FatItem) * (ub_match + 1));
+    c->q[CLS_WAVE].ensure(sizeof(FatItem) * (ub_match + 1));
     c->unit_bytes.ensure(8 * (NU + 1));
     c->q[CLS_COPY].ensure(sizeof(Item) * (ub + 1));
     if (!cardmode) {
@@ -697,7 +697,7 @@ PlanResult plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t np
     O.key = c->o_key.as<u64>(); O.meta = c->o_meta.as<u64>();
     O.slot = c->o_slot.as<uint32_t>(); O.off = c->o_off.as<u64>();
     O.arena = nullptr;
-    EmitQueues Q{c->q[CLS_BB].as<BBItem>(), c->q[CLS_GEN].as<Item>(), c->q[CLS_COPY].as<Item>(), c->q[CLS_FILT].as<Item>(), c->q[CLS_WAVE].as<Item>()};
+    EmitQueues Q{c->q[CLS_BB].as<BBItem>(), c->q[CLS_GEN].as<Item>(), c->q[CLS_COPY].as<Item>(), c->q[CLS_FILT].as<FatItem>(), c->q[CLS_WAVE].as<FatItem>()};
     hipLaunchKernelGGL(k_emit, dim3(gp), dim3(256), 0, s, VA, VB, c->lhs.as<uint32_t>(), c->rhs.as<uint32_t>(), UV, op,
                        cardmode, c->cand_start.as<u64>(), O, Q, c->unit_bytes.as<u64>());
     hipLaunchKernelGGL(k_sum_u64, dim3(1), dim3(1024), 0, s, c->unit_bytes.as<u64>(), (u64)NU,
@@ -753,12 +753,12 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
     }
     if (R.n_filt) {
         unsigned grid = persistent_grid(R.n_filt, 4, 256 * 4);
-        hipLaunchKernelGGL(k_filter, dim3(grid), dim3(256), 0, s, VA, VB, O, c->q[CLS_FILT].as<Item>(),
+        hipLaunchKernelGGL(k_filter, dim3(grid), dim3(256), 0, s, VA.arena, VB.arena, O, c->q[CLS_FILT].as<FatItem>(),
                            ranges + 2 * SEC_FILT, op, cardmode, c->pair_acc.as<u64>());
     }
     if (R.n_wave && !cardmode) {
-        unsigned grid = persistent_grid(R.n_wave, 4, 256 * 5);
-        hipLaunchKernelGGL(k_wave, dim3(grid), dim3(256), 0, s, VA, VB, O, c->q[CLS_WAVE].as<Item>(),
+        unsigned grid = persistent_grid(R.n_wave, 4, 256 * 4);
+        hipLaunchKernelGGL(k_wave, dim3(grid), dim3(256), 0, s, VA.arena, VB.arena, O, c->q[CLS_WAVE].as<FatItem>(),
                            ranges + 2 * SEC_WAVE, op);
     }
     if (R.n_gen) {

@@ -58,6 +58,12 @@ struct Item {
     uint32_t b;    // container index in pool B (NONE32: pass-through from A)
     uint32_t out;  // candidate index (cardinality mode: pair index)
 };
+struct __attribute__((aligned(16))) FatItem {  // array/bitset pair item: everything the kernel needs, resolved at plan time
+    u64 offa, offb;      // payload offsets in arena A / arena B
+    uint32_t out;        // candidate index (cardinality mode: pair index)
+    uint32_t ca, cb;     // cardinalities
+    uint32_t types;      // ta | tb << 8
+};
 struct __attribute__((aligned(16))) BBItem {  // bitset x bitset work item: payload offsets resolved at plan time
     u64 offa, offb;
     uint32_t a, b, out, pad;
@@ -241,8 +247,8 @@ struct EmitQueues {
     BBItem* bb;   // section SEC_BB
     Item* gen;    // section SEC_GEN
     Item* copy;   // section SEC_COPY
-    Item* filt;   // section SEC_FILT
-    Item* wave;   // section SEC_WAVE
+    FatItem* filt;  // section SEC_FILT
+    FatItem* wave;  // section SEC_WAVE
 };
 __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint32_t* __restrict__ lhs,
                                               const uint32_t* __restrict__ rhs, UnitView U, int op, int cardmode,
@@ -322,8 +328,13 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 Q.bb[qbb + mbcnt(mbb)] = it;
             }
             if (isgen) Q.gen[qgen + mbcnt(mgen)] = Item{(uint32_t)ai, (uint32_t)j[t], outidx};
-            if (isfilt) Q.filt[qfilt + mbcnt(mfl)] = Item{(uint32_t)ai, (uint32_t)j[t], outidx};
-            if (iswave) Q.wave[qwave + mbcnt(mwv)] = Item{(uint32_t)ai, (uint32_t)j[t], outidx};
+            if (isfilt || iswave) {
+                FatItem it;
+                it.offa = A.off[ai]; it.offb = B.off[j[t]];
+                it.out = outidx; it.ca = ca; it.cb = cb; it.types = (uint32_t)ta | ((uint32_t)tb << 8);
+                if (isfilt) Q.filt[qfilt + mbcnt(mfl)] = it;
+                else Q.wave[qwave + mbcnt(mwv)] = it;
+            }
             if (iscopy) Q.copy[qcopy + mbcnt(mcp)] = Item{(uint32_t)ai, NONE32, outidx};
             qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv);
         }
@@ -479,7 +490,8 @@ __device__ int decide_type(int op, int ta, int tb, uint32_t ca, uint32_t cb, boo
 // a wave-private 8 KiB LDS bitset (ds_or_b32), replacing the SIMD merge / galloping intersections of
 // array_util.c:385-459, 801-906 (intersect_vector16, intersect_skewed_uint16) and difference_uint16.
 // The result is always an array (containers.h:741-746, 1799-1803).
-__global__ __launch_bounds__(256) void k_filter(PoolView A, PoolView B, OutView O, const Item* __restrict__ q,
+__global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                                OutView O, const FatItem* __restrict__ q,
                                                 const u64* __restrict__ qrange, int op, int cardmode,
                                                 u64* pair_acc) {
     __shared__ __attribute__((aligned(16))) uint32_t img_all[4][2048];
@@ -488,14 +500,14 @@ __global__ __launch_bounds__(256) void k_filter(PoolView A, PoolView B, OutView 
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
     for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
-        const Item t = q[w];
-        const uint8_t ta = A.type[t.a], tb = B.type[t.b];
-        const uint32_t ca = A.card[t.a], cb = B.card[t.b];
+        const FatItem t = q[w];
+        const uint8_t ta = (uint8_t)(t.types & 0xFF), tb = (uint8_t)(t.types >> 8);
+        const uint32_t ca = t.ca, cb = t.cb;
         // Y = the streamed array, X = the membership side
         bool y_is_a = true;
         if (op == OP_AND) y_is_a = (ta == T_ARRAY) && (tb != T_ARRAY || ca <= cb);
-        const uint8_t* yp = y_is_a ? A.arena + A.off[t.a] : B.arena + B.off[t.b];
-        const uint8_t* xp = y_is_a ? B.arena + B.off[t.b] : A.arena + A.off[t.a];
+        const uint8_t* yp = y_is_a ? arenaA + t.offa : arenaB + t.offb;
+        const uint8_t* xp = y_is_a ? arenaB + t.offb : arenaA + t.offa;
         const uint32_t ny = y_is_a ? ca : cb, nx = y_is_a ? cb : ca;
         const bool x_bitset = (y_is_a ? tb : ta) == T_BITSET;
         const bool keep_present = op == OP_AND;
@@ -564,7 +576,8 @@ __global__ __launch_bounds__(256) void k_filter(PoolView A, PoolView B, OutView 
 // (bitset_util.c:978-1141) without their serial dependence.  The result is typed by the reference's
 // rules and either streamed out as a bitset or extracted as a sorted array (lane owns 32 consecutive
 // words; wave prefix sum of popcounts).  No workgroup barrier anywhere.
-__global__ __launch_bounds__(256) void k_wave(PoolView A, PoolView B, OutView O, const Item* __restrict__ q,
+__global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                              OutView O, const FatItem* __restrict__ q,
                                               const u64* __restrict__ qrange, int op) {
     __shared__ __attribute__((aligned(16))) uint32_t img_all[4][2048];
     const uint32_t lane = lane_id();
@@ -572,17 +585,17 @@ __global__ __launch_bounds__(256) void k_wave(PoolView A, PoolView B, OutView O,
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
     for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
-        const Item t = q[w];
-        const uint8_t ta = A.type[t.a], tb = B.type[t.b];
-        const uint32_t ca = A.card[t.a], cb = B.card[t.b];
+        const FatItem t = q[w];
+        const uint8_t ta = (uint8_t)(t.types & 0xFF), tb = (uint8_t)(t.types >> 8);
+        const uint32_t ca = t.ca, cb = t.cb;
         // X = image side, Y = applied array.  andnot: X = a (bitset), Y = b.  or/xor are symmetric:
         // take the bitset (or the larger array) as X.
         bool x_is_a = true;
         if (op != OP_ANDNOT) x_is_a = (ta == T_BITSET) || (tb != T_BITSET && ca >= cb);
         const uint8_t tx = x_is_a ? ta : tb;
         const uint32_t cx = x_is_a ? ca : cb, cy = x_is_a ? cb : ca;
-        const uint8_t* xp = x_is_a ? A.arena + A.off[t.a] : B.arena + B.off[t.b];
-        const uint32_t* __restrict__ y2 = (const uint32_t*)(x_is_a ? B.arena + B.off[t.b] : A.arena + A.off[t.a]);
+        const uint8_t* xp = x_is_a ? arenaA + t.offa : arenaB + t.offb;
+        const uint32_t* __restrict__ y2 = (const uint32_t*)(x_is_a ? arenaB + t.offb : arenaA + t.offa);
         if (tx == T_BITSET) {
             const uint4* __restrict__ g = (const uint4*)xp;
 #pragma unroll
@@ -642,33 +655,54 @@ __global__ __launch_bounds__(256) void k_wave(PoolView A, PoolView B, OutView O,
 #pragma unroll
             for (int i = 0; i < 8; ++i) po[i * 64 + lane] = ((const uint4*)img)[i * 64 + lane];
         } else if (rc) {
-            // lane owns words [32*lane, 32*lane+32): values [1024*lane, 1024*lane+1024)
+            // Balanced extraction.  Words are owned strided (lane l: words 64 r + l), so clustered values
+            // spread over all lanes; the output position of each word comes from a two-level prefix:
+            // per-word popcounts -> LDS, each lane prefix-sums 32 CONSECUTIVE counts, one wave scan of the
+            // lane totals, word bases back to LDS.  The image is dead once the words are in registers,
+            // so its first 4 KiB hold the u16 count/base table.
             uint32_t wv[32];
-            uint32_t cnt = 0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint4 x = ((const uint4*)img)[8 * lane + i];
-                wv[4 * i] = x.x; wv[4 * i + 1] = x.y; wv[4 * i + 2] = x.z; wv[4 * i + 3] = x.w;
-                cnt += popc4(x);
-            }
-            uint32_t pos = wave_incl_scan(cnt) - cnt;
-            // every lane holds its 32 words in registers now: the image is dead and is reused as the
-            // staging buffer of the compacted u16 list (<= 4096 values = 8 KiB), written out coalesced
+            for (int r = 0; r < 32; ++r) wv[r] = img[64 * r + lane];
             __builtin_amdgcn_wave_barrier();
-            uint16_t* st16 = (uint16_t*)img;
+            uint16_t* tab = (uint16_t*)img;
 #pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                uint32_t x = wv[k];
-                const uint32_t vbase = (32u * lane + k) * 32u;
+            for (int r = 0; r < 32; ++r) tab[64 * r + lane] = (uint16_t)__popc(wv[r]);
+            __builtin_amdgcn_wave_barrier();
+            {
+                uint4 c4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c4[i] = ((const uint4*)tab)[4 * lane + i];
+                const uint32_t cw[16] = {c4[0].x, c4[0].y, c4[0].z, c4[0].w, c4[1].x, c4[1].y, c4[1].z, c4[1].w,
+                                         c4[2].x, c4[2].y, c4[2].z, c4[2].w, c4[3].x, c4[3].y, c4[3].z, c4[3].w};
+                uint32_t tot = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tot += (cw[i] & 0xFFFFu) + (cw[i] >> 16);
+                uint32_t base = wave_incl_scan(tot) - tot;
+                uint32_t ow[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t lo = base;
+                    base += cw[i] & 0xFFFFu;
+                    const uint32_t hi = base;
+                    base += cw[i] >> 16;
+                    ow[i] = lo | (hi << 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    ((uint4*)tab)[4 * lane + i] = make_uint4(ow[4 * i], ow[4 * i + 1], ow[4 * i + 2], ow[4 * i + 3]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint16_t* __restrict__ o16 = (uint16_t*)outp;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                uint32_t x = wv[r];
+                uint32_t pos = tab[64 * r + lane];
+                const uint32_t vbase = (64u * r + lane) * 32u;
                 while (x) {
-                    st16[pos++] = (uint16_t)(vbase + (__ffs((int)x) - 1));
+                    o16[pos++] = (uint16_t)(vbase + (__ffs((int)x) - 1));
                     x &= x - 1;
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t n16 = (2u * rc + 15u) >> 4;
-            uint4* __restrict__ po = (uint4*)outp;
-            for (uint32_t i = lane; i < n16; i += 64) po[i] = ((const uint4*)img)[i];
         }
         if (lane == 0) O.meta[t.out] = pack_meta(ty, rc, 0);
         __builtin_amdgcn_wave_barrier();
