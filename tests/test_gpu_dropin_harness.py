@@ -1,0 +1,28 @@
+"""SURVEY G13 acceptance harness on the GPU: the reference's own UNMODIFIED tests/toplevel_unit.c
+(169 registered tests, prebuilt by `make -C oracle dropin` into oracle/_ref/toplevel_unit_dropin) with
+the 15 hot-path symbols resolved to libroaring_hip.so and everything else to the (symbol-renamed)
+reference library."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "oracle", "_ref", "toplevel_unit_dropin")
+
+
+def test_reference_toplevel_unit_against_dropin():
+    if not os.path.exists(BIN):
+        pytest.skip("oracle/_ref/toplevel_unit_dropin not prebuilt (needs /root/reference at build time)")
+    env = dict(os.environ, RHIP_COMPAT_STATS="1")
+    p = subprocess.run([BIN], capture_output=True, text=True, timeout=1200, env=env)
+    tail = (p.stdout + p.stderr)[-3000:]
+    m = re.search(r"(\d+) tests, (\d+) failed", p.stdout)
+    assert m, tail
+    assert int(m.group(1)) >= 160, tail
+    assert int(m.group(2)) == 0 and p.returncode == 0, tail
+    c = re.search(r"pairwise (\d+), in-place (\d+), cardinality (\d+), many-way (\d+)", p.stderr)
+    assert c, tail
+    assert int(c.group(1)) > 100 and int(c.group(2)) > 20 and int(c.group(4)) > 10, c.group(0)
