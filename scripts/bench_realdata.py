@@ -33,7 +33,7 @@ def cpu_rate(hs, lhs, rhs, op, budget=2.0):
 
 
 for name in sys.argv[1:] or ["census1881", "weather_sept_85", "wikileaks-noquotes", "census-income"]:
-    if name.startswith("c4"):
+    if name.startswith("c4") or name == "c5":
         continue
     bufs = load_bundle(name)
     pool = eng.pool_from_serialized(bufs)
@@ -59,6 +59,36 @@ for name in sys.argv[1:] or ["census1881", "weather_sept_85", "wikileaks-noquote
         t0 = time.perf_counter(); r = cf(hs); tc = time.perf_counter() - t0; chk.free(r)
         print(json.dumps({"dataset": name, "op": nm, "n": len(bufs), "gpu_ms": tmin * 1e3, "cpu1_ms": tc * 1e3}), flush=True)
     for h in hs: chk.free(h)
+
+if any(a == "c5" for a in sys.argv[1:]) or len(sys.argv) == 1:
+    # C5: 64-bit bitmaps = wikileaks-noquotes replicated into 10 high-32 buckets (v + (r << 32))
+    import struct
+    base = load_bundle("wikileaks-noquotes")
+    bufs64 = [struct.pack("<Q", 10) + b"".join(struct.pack("<I", r) + b for r in range(10)) for b in base]
+    pool = eng.pool_from_serialized64(bufs64)
+    lhs, rhs = all_pairs(len(bufs64))
+    hs = [chk.deserialize64(b) for b in bufs64]
+    for op in ("and", "or"):
+        res = [None]
+        def run():
+            res[0] = eng.pairwise(op, pool, lhs, pool, rhs, reuse=res[0])
+        tmin, _ = timed(run)
+        st = eng.last_stats()
+        n, t0 = 0, time.perf_counter()
+        for i, j in zip(lhs[:4000], rhs[:4000]):
+            r = chk.op64(op, hs[i], hs[j]); chk.cardinality64(r); chk.free64(r); n += 1
+        cpu = n / (time.perf_counter() - t0)
+        k = 777
+        ok = res[0].serialize(k) == chk.serialize64(chk.op64(op, hs[lhs[k]], hs[rhs[k]]))
+        print(json.dumps({"dataset": "C5 roaring64 wikileaks-noquotes x10 buckets", "op": op, "pairs": len(lhs),
+                          "gpu_ops_per_s": len(lhs) / tmin, "gpu_ms_batch": tmin * 1e3,
+                          "gpu_GBps": (st["bytes_in"] + st["bytes_out"]) / tmin / 1e9, "matched_pairs": st["matched_pairs"],
+                          "cpu1_ops_per_s": cpu, "cpu_kind": chk.name, "sample_equal": bool(ok)}), flush=True)
+    tmin, _ = timed(lambda: eng.or_many(pool))
+    t0 = time.perf_counter(); r = chk.or_many64(hs); tc = time.perf_counter() - t0
+    print(json.dumps({"dataset": "C5 roaring64 wikileaks-noquotes x10 buckets", "op": "or_many (200-way)",
+                      "gpu_ms": tmin * 1e3, "cpu1_ms_fold": tc * 1e3,
+                      "equal_card": bool(eng.or_many(pool).cardinalities()[0] == chk.cardinality64(r))}), flush=True)
 
 if any(a.startswith("c4") for a in sys.argv[1:]) or len(sys.argv) == 1:
     arg = [a for a in sys.argv[1:] if a.startswith("c4")]

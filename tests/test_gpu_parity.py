@@ -249,3 +249,35 @@ def test_or_many_full_container_typing(engine, oracle):
             oracle.free(want)
     for h in members.values():
         oracle.free(h)
+
+
+def test_many_sharded_nccl_world1(engine, oracle):
+    """croaring_amd.distributed.many_sharded end to end on the RCCL backend with a 1-rank group
+    (the only world size one GPU allows): partials -> exchange -> finalize -> gather."""
+    import torch
+    import torch.distributed as dist
+    from croaring_amd.distributed import gather_serialized, many_sharded
+    os_env = __import__("os").environ
+    os_env.setdefault("MASTER_ADDR", "127.0.0.1")
+    os_env.setdefault("MASTER_PORT", "29571")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        bufs = load_bundle("census1881")[:50]
+        hs = [oracle.deserialize(b) for b in bufs]
+        pool = engine.pool_from_serialized(bufs)
+        for op, fn in (("or", oracle.or_many), ("xor", oracle.xor_many)):
+            owned = many_sharded(engine, pool, op)
+            blob = gather_serialized(engine, owned)
+            hg, want = oracle.deserialize(blob), fn(hs)
+            assert oracle.validate(hg)
+            assert np.array_equal(oracle.to_array(hg), oracle.to_array(want)), op
+            oracle.free(hg)
+            oracle.free(want)
+        for h in hs:
+            oracle.free(h)
+    finally:
+        if created:
+            dist.destroy_process_group()
