@@ -617,7 +617,7 @@ template <int OP>
 void launch_bb(rhip_ctx_t* c, unsigned grid, const PoolView& A, const PoolView& B, const OutView& O, int cardmode) {
     hipLaunchKernelGGL(k_bb<OP>, dim3(grid), dim3(256), 0, c->stream, A.arena, B.arena, O, c->q[CLS_BB].as<BBItem>(),
                        (const u64*)((char*)c->misc.p + MISC_RANGES_OFF) + 2 * SEC_BB, cardmode, c->pair_acc.as<u64>(),
-                       c->q[CLS_RETRY].as<Item>(), (uint32_t*)((char*)c->misc.p + MISC_RETRY_OFF));
+                       c->q[CLS_RETRY].as<GenItem>(), (uint32_t*)((char*)c->misc.p + MISC_RETRY_OFF));
 }
 
 void check_pair_args(rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs, const uint32_t* rhs) {
@@ -684,7 +684,7 @@ PlanResult plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t np
     u64* ranges = (u64*)((char*)c->misc.p + MISC_RANGES_OFF);
     hipLaunchKernelGGL(k_plan_totals, dim3(1), dim3(64), 0, s, c->cand_start.as<u64>(), (u64)S, ranges);
     c->q[CLS_BB].ensure(sizeof(BBItem) * (ub_match + 1));
-    c->q[CLS_GEN].ensure(sizeof(Item) * (ub_match + 1));
+    c->q[CLS_GEN].ensure(sizeof(GenItem) * (ub_match + 1));
     c->q[CLS_FILT].ensure(sizeof(FatItem) * (ub_match + 1));
     c->q[CLS_WAVE].ensure(sizeof(FatItem) * (ub_match + 1));
     c->unit_bytes.ensure(8 * (NU + 1));
@@ -697,7 +697,7 @@ PlanResult plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t np
     O.key = c->o_key.as<u64>(); O.meta = c->o_meta.as<u64>();
     O.slot = c->o_slot.as<uint32_t>(); O.off = c->o_off.as<u64>();
     O.arena = nullptr;
-    EmitQueues Q{c->q[CLS_BB].as<BBItem>(), c->q[CLS_GEN].as<Item>(), c->q[CLS_COPY].as<Item>(), c->q[CLS_FILT].as<FatItem>(), c->q[CLS_WAVE].as<FatItem>()};
+    EmitQueues Q{c->q[CLS_BB].as<BBItem>(), c->q[CLS_GEN].as<GenItem>(), c->q[CLS_COPY].as<Item>(), c->q[CLS_FILT].as<FatItem>(), c->q[CLS_WAVE].as<FatItem>()};
     hipLaunchKernelGGL(k_emit, dim3(gp), dim3(256), 0, s, VA, VB, c->lhs.as<uint32_t>(), c->rhs.as<uint32_t>(), UV, op,
                        cardmode, c->cand_start.as<u64>(), O, Q, c->unit_bytes.as<u64>());
     hipLaunchKernelGGL(k_sum_u64, dim3(1), dim3(1024), 0, s, c->unit_bytes.as<u64>(), (u64)NU,
@@ -734,8 +734,8 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
     const u64* ranges = (const u64*)((char*)c->misc.p + MISC_RANGES_OFF);
     uint32_t* retry_count = (uint32_t*)((char*)c->misc.p + MISC_RETRY_OFF);
     if (R.n_bb) {
-        c->q[CLS_RETRY].ensure(sizeof(Item) * (R.n_bb + 1));
-        unsigned grid = persistent_grid(R.n_bb, 4, 256 * 16);
+        c->q[CLS_RETRY].ensure(sizeof(GenItem) * (R.n_bb + 1));
+        unsigned grid = persistent_grid(R.n_bb, 4, 256 * 32);
         if (c->timing) HIPCHK(hipEventRecord(c->ev[2], s));
         switch (op) {
             case OP_AND: launch_bb<OP_AND>(c, grid, VA, VB, O, cardmode); break;
@@ -746,8 +746,8 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
         if (c->timing) HIPCHK(hipEventRecord(c->ev[3], s));
         if (!cardmode && op != OP_OR) {
             // bitset x bitset results that must become arrays (card <= 4096): LDS extraction
-            unsigned g2 = persistent_grid(R.n_bb, 1, 256 * 6);
-            hipLaunchKernelGGL(k_gen, dim3(g2), dim3(256), 0, s, VA, VB, O, c->q[CLS_RETRY].as<Item>(),
+            unsigned g2 = persistent_grid(R.n_bb, 4, 256 * 4);
+            hipLaunchKernelGGL(k_genw, dim3(g2), dim3(256), 0, s, VA.arena, VB.arena, O, c->q[CLS_RETRY].as<GenItem>(),
                                (const u64*)nullptr, retry_count, op, 0, c->pair_acc.as<u64>());
         }
     }
@@ -762,8 +762,8 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
                            ranges + 2 * SEC_WAVE, op);
     }
     if (R.n_gen) {
-        unsigned grid = persistent_grid(R.n_gen, 1, 256 * 6);
-        hipLaunchKernelGGL(k_gen, dim3(grid), dim3(256), 0, s, VA, VB, O, c->q[CLS_GEN].as<Item>(),
+        unsigned grid = persistent_grid(R.n_gen, 4, 256 * 4);
+        hipLaunchKernelGGL(k_genw, dim3(grid), dim3(256), 0, s, VA.arena, VB.arena, O, c->q[CLS_GEN].as<GenItem>(),
                            ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, cardmode, c->pair_acc.as<u64>());
     }
     if (R.n_copy && !cardmode) {

@@ -12,10 +12,13 @@
 //   k_bb               K1-K3: bitset (x) bitset {and,or,xor,andnot} fused with popcount,
 //                      one wave per container pair, 16 x 16-byte loads in flight per lane
 //   k_copy             pass-through containers (roaring.c:914-941 clone paths)
-//   k_gen              K5-K15: every other type pair -- both operands rasterised into LDS
-//                      bitsets (arrays: ds_or scatter; runs: toggle bits + wave prefix-xor),
-//                      op + popcount + run counting in LDS, result re-typed by the
-//                      reference's rules (Appendix A) and extracted with ballot/prefix sums
+//   k_filter           K8/K9/K12: array filtered by membership (and / andnot), wave per pair
+//   k_wave             K6/K10/K11: or / xor / bitset\\array with an array operand, wave-private LDS
+//                      image + returning LDS atomics, wave per pair
+//   k_genw             K5/K7/K13-K16: every pair with a run container (and bitset x bitset results
+//                      that become arrays): two wave-private LDS images (runs: toggle bits +
+//                      prefix-xor), op + popcount + run counting, result re-typed by the
+//                      reference's rules (Appendix A) and extracted with prefix sums
 //   k_many_*           group-by-key OR/XOR accumulation for or_many / xor_many
 //   k_compact          drops empty results, builds the result directory
 #pragma once
@@ -63,6 +66,11 @@ struct __attribute__((aligned(16))) FatItem {  // array/bitset pair item: everyt
     uint32_t out;        // candidate index (cardinality mode: pair index)
     uint32_t ca, cb;     // cardinalities
     uint32_t types;      // ta | tb << 8
+};
+struct __attribute__((aligned(16))) GenItem {  // general pair item (any type pair, runs included)
+    u64 offa, offb;
+    uint32_t out, ca, cb, types;   // types = ta | tb << 8
+    uint32_t nra, nrb, pad0, pad1; // run counts
 };
 struct __attribute__((aligned(16))) BBItem {  // bitset x bitset work item: payload offsets resolved at plan time
     u64 offa, offb;
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
 // with |{matched keys < k}| = (matched count of the pair's earlier tiles, from the scan) + a ballot rank.
 struct EmitQueues {
     BBItem* bb;   // section SEC_BB
-    Item* gen;    // section SEC_GEN
+    GenItem* gen; // section SEC_GEN
     Item* copy;   // section SEC_COPY
     FatItem* filt;  // section SEC_FILT
     FatItem* wave;  // section SEC_WAVE
@@ -327,7 +335,13 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 it.a = (uint32_t)ai; it.b = (uint32_t)j[t]; it.out = outidx; it.pad = 0;
                 Q.bb[qbb + mbcnt(mbb)] = it;
             }
-            if (isgen) Q.gen[qgen + mbcnt(mgen)] = Item{(uint32_t)ai, (uint32_t)j[t], outidx};
+            if (isgen) {
+                GenItem it;
+                it.offa = A.off[ai]; it.offb = B.off[j[t]];
+                it.out = outidx; it.ca = ca; it.cb = cb; it.types = (uint32_t)ta | ((uint32_t)tb << 8);
+                it.nra = A.nruns[ai]; it.nrb = B.nruns[j[t]]; it.pad0 = 0; it.pad1 = 0;
+                Q.gen[qgen + mbcnt(mgen)] = it;
+            }
             if (isfilt || iswave) {
                 FatItem it;
                 it.offa = A.off[ai]; it.offb = B.off[j[t]];
@@ -418,7 +432,7 @@ __device__ __forceinline__ uint32_t vpopc(u32x4 v) { return __popc(v.x) + __popc
 template <int OP>
 __global__ __launch_bounds__(256) void k_bb(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                             OutView O, const BBItem* __restrict__ q, const u64* __restrict__ qrange,
-                                            int cardmode, u64* pair_acc, Item* retry_q, uint32_t* retry_count) {
+                                            int cardmode, u64* pair_acc, GenItem* retry_q, uint32_t* retry_count) {
     const uint32_t lane = lane_id();
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
@@ -454,7 +468,13 @@ __global__ __launch_bounds__(256) void k_bb(const uint8_t* __restrict__ arenaA, 
             if (lane == 0) O.meta[t.out] = pack_meta(T_ARRAY, 0, 0);
         } else {
             // rare: result becomes an array -> re-queue for the LDS extraction kernel
-            if (lane == 0) retry_q[atomicAdd(retry_count, 1u)] = Item{t.a, t.b, t.out};
+            if (lane == 0) {
+                GenItem g;
+                g.offa = t.offa; g.offb = t.offb; g.out = t.out; g.ca = 65536u; g.cb = 65536u;
+                g.types = (uint32_t)T_BITSET | ((uint32_t)T_BITSET << 8);
+                g.nra = 0; g.nrb = 0; g.pad0 = 0; g.pad1 = 0;
+                retry_q[atomicAdd(retry_count, 1u)] = g;
+            }
         }
     }
 }
@@ -709,6 +729,211 @@ __global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA
     }
 }
 
+// ------------------------------------------------------------------ wave-level general pair kernel (K5, K7, K13-K16)
+// Every type pair the specialised kernels do not take (all pairs with a run container, plus
+// bitset x bitset results that must become arrays): ONE WAVE per container pair, two wave-private
+// 8 KiB LDS images, no workgroup barrier.  Lane l owns the 32 consecutive logical words
+// [32 l, 32 l + 32) -- the ownership that prefix-XOR run rasterisation and run counting need -- and a
+// skewed transposed physical layout keeps both the per-lane accesses (k-th word of every lane) and
+// the coalesced global<->LDS copies conflict-free:
+__device__ __forceinline__ uint32_t wphys(uint32_t w) { return ((w & 31u) << 6) | (((w >> 5) + (w & 31u)) & 63u); }
+__device__ __forceinline__ uint32_t wown(uint32_t lane, uint32_t k) { return (k << 6) | ((lane + k) & 63u); }
+
+// Rasterise one container into a wave-private image (K6: array scatter; K7: runs as toggle bits at
+// start / end+1 followed by a 65536-bit inclusive prefix-XOR -- 5 shift-xors per word, a serial carry
+// over the lane's 32 words and ONE ballot for the carry across lanes).
+__device__ void wimg_build(uint32_t* img, const uint8_t* __restrict__ p, uint32_t type, uint32_t card,
+                           uint32_t nruns) {
+    const uint32_t lane = lane_id();
+    if (type == T_BITSET) {
+        const uint4* __restrict__ g = (const uint4*)p;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint4 x = g[i * 64 + lane];
+            const uint32_t w0 = 4u * (i * 64 + lane);
+            img[wphys(w0)] = x.x; img[wphys(w0 + 1)] = x.y; img[wphys(w0 + 2)] = x.z; img[wphys(w0 + 3)] = x.w;
+        }
+        return;
+    }
+    const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ((uint4*)img)[i * 64 + lane] = z;
+    const uint4* __restrict__ q4p = (const uint4*)p;
+    if (type == T_ARRAY) {
+        for (uint32_t i = lane; 8 * i < card; i += 64) {
+            const uint4 q4 = q4p[i];
+            const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                if (8 * i + h < card) {
+                    const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                    atomicOr(&img[wphys(v >> 5)], 1u << (v & 31));
+                }
+            }
+        }
+        return;
+    }
+    for (uint32_t i = lane; 4 * i < nruns; i += 64) {  // 4 runs {u16 value, u16 length} per 16-byte load
+        const uint4 q4 = q4p[i];
+        const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            if (4 * i + h < nruns) {
+                const uint32_t s0 = d[h] & 0xFFFFu, e1 = s0 + (d[h] >> 16) + 1u;
+                atomicXor(&img[wphys(s0 >> 5)], 1u << (s0 & 31));
+                if (e1 < 65536u) atomicXor(&img[wphys(e1 >> 5)], 1u << (e1 & 31));
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t w[32];
+    uint32_t par = 0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        w[k] = img[wown(lane, k)];
+        par ^= __popc(w[k]) & 1u;
+    }
+    uint32_t carry = mbcnt(__ballot(par != 0)) & 1u;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const uint32_t x = w[k];
+        uint32_t y = x;
+        y ^= y << 1; y ^= y << 2; y ^= y << 4; y ^= y << 8; y ^= y << 16;
+        img[wown(lane, k)] = carry ? ~y : y;
+        carry ^= __popc(x) & 1u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_genw(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                              OutView O, const GenItem* __restrict__ q,
+                                              const u64* __restrict__ qrange, const uint32_t* __restrict__ qcount,
+                                              int op, int cardmode, u64* pair_acc) {
+    // ONE 8 KiB image per wave: operand A is rasterised, pulled into registers, then the same image is
+    // reused for operand B and finally as the output staging buffer (16 waves per CU instead of 8)
+    __shared__ __attribute__((aligned(16))) uint32_t img_all[4][2048];
+    const uint32_t lane = lane_id();
+    uint32_t* ia = img_all[threadIdx.x >> 6];
+    uint32_t* ib = ia;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n = qrange ? (uint32_t)(qrange[1] - qrange[0]) : *qcount;
+    for (uint32_t wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wi < n; wi += nwaves) {
+        const GenItem t = q[wi];
+        const uint32_t ta = t.types & 0xFFu, tb = t.types >> 8;
+        wimg_build(ia, arenaA + t.offa, ta, t.ca, t.nra);
+        __builtin_amdgcn_wave_barrier();
+        uint32_t r[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) r[k] = ia[wown(lane, k)];
+        __builtin_amdgcn_wave_barrier();
+        wimg_build(ib, arenaB + t.offb, tb, t.cb, t.nrb);
+        __builtin_amdgcn_wave_barrier();
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const uint32_t a = r[k], b = ib[wown(lane, k)];
+            r[k] = op == OP_AND ? (a & b) : op == OP_OR ? (a | b) : op == OP_XOR ? (a ^ b) : (a & ~b);
+            cnt += __popc(r[k]);
+        }
+        const uint32_t rc = wave_sum(cnt);
+        if (cardmode) {
+            if (lane == 0 && rc) atomicAdd(&pair_acc[t.out], (u64)rc);
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
+        // canonical run count: set bits whose predecessor is clear (bitset_container_number_of_runs, bitset.c:1046-1062)
+        uint32_t prev_msb = __shfl_up(r[31] >> 31, 1);
+        if (lane == 0) prev_msb = 0;
+        uint32_t next_lsb = __shfl_down(r[0] & 1u, 1);
+        if (lane == 63) next_lsb = 0;
+        uint32_t ns = 0;
+        {
+            uint32_t pm = prev_msb;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                ns += __popc(r[k] & ~((r[k] << 1) | pm));
+                pm = r[k] >> 31;
+            }
+        }
+        const uint32_t rn = wave_sum(ns);
+        const bool fulla = ta == T_RUN && t.ca == 65536u, fullb = tb == T_RUN && t.cb == 65536u;
+        int ty = T_ARRAY;
+        if (rc) ty = decide_type(op, (int)ta, (int)tb, t.ca, t.cb, fulla, fullb, rc, rn);
+        uint8_t* outp = O.arena + O.off[t.out];
+        __builtin_amdgcn_wave_barrier();
+        if (rc && ty == T_BITSET) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) ia[wown(lane, k)] = r[k];
+            __builtin_amdgcn_wave_barrier();
+            uint4* __restrict__ po = (uint4*)outp;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t w0 = 4u * (i * 64 + lane);
+                po[i * 64 + lane] = make_uint4(ia[wphys(w0)], ia[wphys(w0 + 1)], ia[wphys(w0 + 2)], ia[wphys(w0 + 3)]);
+            }
+        } else if (rc && ty == T_ARRAY) {
+            uint16_t* st16 = (uint16_t*)ib;  // both images are dead: ib becomes the u16 staging buffer
+            uint32_t pos = wave_incl_scan(cnt) - cnt;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                uint32_t x = r[k];
+                const uint32_t vbase = (32u * lane + k) * 32u;
+                while (x) {
+                    st16[pos++] = (uint16_t)(vbase + (__ffs((int)x) - 1));
+                    x &= x - 1;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t n16 = (2u * rc + 15u) >> 4;
+            uint4* __restrict__ po = (uint4*)outp;
+            for (uint32_t i = lane; i < n16; i += 64) po[i] = ((const uint4*)ib)[i];
+        } else if (rc) {
+            // runs: k-th start pairs with k-th end (run_container layout {value, length}, run.h:48-73)
+            uint16_t* st16 = (uint16_t*)ib;
+            uint32_t ne = 0;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const uint32_t nl = k < 31 ? (r[k + 1] & 1u) : next_lsb;
+                ne += __popc(r[k] & ~((r[k] >> 1) | (nl << 31)));
+            }
+            uint32_t bs = wave_incl_scan(ns) - ns;
+            uint32_t be = wave_incl_scan(ne) - ne;
+            {
+                uint32_t pm = prev_msb;
+#pragma unroll
+                for (int k = 0; k < 32; ++k) {
+                    uint32_t x = r[k] & ~((r[k] << 1) | pm);
+                    pm = r[k] >> 31;
+                    const uint32_t vbase = (32u * lane + k) * 32u;
+                    while (x) {
+                        st16[2 * bs] = (uint16_t)(vbase + (__ffs((int)x) - 1));
+                        ++bs;
+                        x &= x - 1;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const uint32_t nl = k < 31 ? (r[k + 1] & 1u) : next_lsb;
+                uint32_t x = r[k] & ~((r[k] >> 1) | (nl << 31));
+                const uint32_t vbase = (32u * lane + k) * 32u;
+                while (x) {
+                    const uint32_t e = vbase + (__ffs((int)x) - 1);
+                    st16[2 * be + 1] = (uint16_t)(e - st16[2 * be]);
+                    ++be;
+                    x &= x - 1;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t n16 = (4u * rn + 15u) >> 4;
+            uint4* __restrict__ po = (uint4*)outp;
+            for (uint32_t i = lane; i < n16; i += 64) po[i] = ((const uint4*)ib)[i];
+        }
+        if (lane == 0) O.meta[t.out] = pack_meta(ty, rc, (ty == T_RUN) ? rn : 0u);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ------------------------------------------------------------------ LDS bitset machinery
 // A 65536-bit container image in LDS is uint32_t[2048]; thread t of a 256-thread workgroup
 // owns words [8t, 8t+8) (two ds_read_b128 / ds_write_b128).
@@ -947,57 +1172,6 @@ __device__ void lds_emit(const uint32_t* img, const uint32_t r[8], int ty, uint3
     const uint32_t n16 = (nbytes + 15u) >> 4;
     uint4* __restrict__ po = (uint4*)out;
     for (uint32_t i = tid; i < n16; i += 256) po[i] = ((const uint4*)stage)[i];
-}
-
-// ------------------------------------------------------------------ universal pair kernel
-// One 256-thread workgroup per container pair (persistent, striding over the queue).
-__global__ __launch_bounds__(256) void k_gen(PoolView A, PoolView B, OutView O, const Item* __restrict__ q,
-                                             const u64* __restrict__ qrange, const uint32_t* __restrict__ qcount,
-                                             int op, int cardmode, u64* pair_acc) {
-    __shared__ __attribute__((aligned(16))) uint32_t sA[2048];
-    __shared__ __attribute__((aligned(16))) uint32_t sB[2048];
-    __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];
-    __shared__ BlockScratch sc;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t n = qrange ? (uint32_t)(qrange[1] - qrange[0]) : *qcount;
-    for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
-        const Item t = q[it];
-        __syncthreads();  // previous iteration's LDS reads are done
-        lds_load(sA, A, t.a, &sc);
-        lds_load(sB, B, t.b, &sc);
-        uint4 a0 = ((uint4*)sA)[2 * tid], a1 = ((uint4*)sA)[2 * tid + 1];
-        uint4 b0 = ((uint4*)sB)[2 * tid], b1 = ((uint4*)sB)[2 * tid + 1];
-        uint4 r0 = op4(op, a0, b0), r1 = op4(op, a1, b1);
-        uint32_t r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-        const uint32_t rc = blk_sum(popc4(r0) + popc4(r1), sc.wsum);
-        if (cardmode) {
-            if (tid == 0 && rc) atomicAdd(&pair_acc[t.out], (u64)rc);
-            continue;
-        }
-        ((uint4*)sA)[2 * tid] = r0;
-        ((uint4*)sA)[2 * tid + 1] = r1;
-        __syncthreads();
-        // canonical run count of the result
-        uint32_t ns = 0;
-        {
-            uint32_t pm = tid ? (sA[8 * tid - 1] >> 31) : 0u;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                ns += __popc(r[k] & ~((r[k] << 1) | pm));
-                pm = r[k] >> 31;
-            }
-        }
-        const uint32_t rn = blk_sum(ns, sc.wsum2);
-        const uint8_t ta = A.type[t.a], tb = B.type[t.b];
-        const uint32_t ca = A.card[t.a], cb = B.card[t.b];
-        const bool fulla = ta == T_RUN && ca == 65536u, fullb = tb == T_RUN && cb == 65536u;
-        int ty = T_ARRAY;
-        if (rc) {
-            ty = decide_type(op, ta, tb, ca, cb, fulla, fullb, rc, rn);
-            lds_emit(sA, r, ty, rc, rn, stage, O.arena + O.off[t.out], &sc);
-        }
-        if (tid == 0) O.meta[t.out] = pack_meta(ty, rc, (ty == T_RUN) ? rn : 0u);
-    }
 }
 
 // ------------------------------------------------------------------ directory compaction

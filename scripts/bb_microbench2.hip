@@ -61,10 +61,10 @@ float timeit(F f, int reps = 4) {
 int main() {
     const uint32_t NBM = 256, NC = 4096, PAIRS = 250;
     const u64 ncont = (u64)NBM * NC, nitems = (u64)PAIRS * NC;
-    uint8_t *A, *Oa; u64 *meta, *off, *qr; BBItem* q; Item* rq; uint32_t* rc; u64* acc;
+    uint8_t *A, *Oa; u64 *meta, *off, *qr; BBItem* q; GenItem* rq; uint32_t* rc; u64* acc;
     CK(hipMalloc(&A, ncont * 8192)); CK(hipMalloc(&Oa, nitems * 8192));
     CK(hipMalloc(&meta, nitems * 8)); CK(hipMalloc(&off, nitems * 8)); CK(hipMalloc(&q, nitems * sizeof(BBItem)));
-    CK(hipMalloc(&rq, nitems * sizeof(Item))); CK(hipMalloc(&rc, 64)); CK(hipMalloc(&qr, 64)); CK(hipMalloc(&acc, 8 * 1024));
+    CK(hipMalloc(&rq, nitems * sizeof(GenItem))); CK(hipMalloc(&rc, 64)); CK(hipMalloc(&qr, 64)); CK(hipMalloc(&acc, 8 * 1024));
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (u64*)A, ncont * 1024);
     std::vector<BBItem> h(nitems); std::vector<u64> ho(nitems);
     for (int order = 0; order < 2; ++order) {

@@ -281,3 +281,36 @@ def test_many_sharded_nccl_world1(engine, oracle):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_full_size_properties(engine):
+    """BASELINE config C2 at FULL size (pool of 256 bitmaps x 4096 bitset containers = 8 GiB): properties
+    that need no oracle -- idempotence, self-inverse, inclusion-exclusion, commutativity checksums."""
+    from bench import SEED, schedule
+    pool = engine.pool_synth_bitset(256, 4096, SEED)
+    cards = pool.cardinalities()
+    assert pool.type_counts() == (256 * 4096, 0, 0)
+    assert abs(float(cards.mean()) / (4096 * 65536) - 0.5) < 1e-3       # density 0.5
+    ids = np.arange(0, 256, 8, dtype=np.uint32)                          # 32 bitmaps
+    # a & a == a, a | a == a, a ^ a == {}, a \ a == {}
+    for op, want in (("and", cards[ids]), ("or", cards[ids]), ("xor", 0 * cards[ids]), ("andnot", 0 * cards[ids])):
+        r = engine.pairwise(op, pool, ids, pool, ids)
+        assert np.array_equal(r.cardinalities(), want), op
+        if op in ("xor", "andnot"):
+            assert r.n_containers == 0                                   # empties are dropped
+        else:
+            assert r.serialize(3) == pool.serialize(int(ids[3]))         # byte-identical to the operand
+    lhs, rhs = schedule(0, 32, 256)
+    c_and = engine.pairwise("and", pool, lhs, pool, rhs).cardinalities()
+    c_or = engine.pairwise("or", pool, lhs, pool, rhs).cardinalities()
+    c_xor = engine.pairwise("xor", pool, lhs, pool, rhs).cardinalities()
+    c_andnot = engine.pairwise("andnot", pool, lhs, pool, rhs).cardinalities()
+    assert np.array_equal(c_and + c_or, cards[lhs] + cards[rhs])         # |A n B| + |A u B| = |A| + |B|
+    assert np.array_equal(c_xor, c_or - c_and)
+    assert np.array_equal(c_andnot, cards[lhs] - c_and)
+    for op, c in (("and", c_and), ("or", c_or), ("xor", c_xor), ("andnot", c_andnot)):
+        assert np.array_equal(engine.pairwise_cardinality(op, pool, lhs, pool, rhs), c), op
+    assert np.array_equal(engine.pairwise("and", pool, rhs, pool, lhs).cardinalities(), c_and)  # commutes
+    # or_many over 16 half-dense bitmaps: every chunk fills up (65536 * (1 - 2^-16) expected)
+    u = engine.or_many(pool, np.arange(16, dtype=np.uint32))
+    assert u.n_containers == 4096 and int(u.cardinalities()[0]) > 4096 * 65530
