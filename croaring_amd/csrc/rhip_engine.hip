@@ -596,14 +596,14 @@ namespace {
 struct PlanResult {
     uint64_t total_cand = 0;
     uint64_t total_bytes = 0;
-    uint64_t n_bb = 0, n_gen = 0, n_copy = 0, n_filt = 0, n_wave = 0;
+    uint64_t n_bb = 0, n_gen = 0, n_copy = 0, n_filt = 0, n_wave = 0, n_runs = 0;
 };
 
-// misc layout (device): [0, 112) seven {begin,end} u64 section ranges; [120, 124) retry counter;
-// [128, ...) Stats
+// misc layout (device): [0, 128) eight {begin,end} u64 section ranges; [128, 132) retry counter;
+// [192, ...) Stats
 constexpr size_t MISC_RANGES_OFF = 0;
-constexpr size_t MISC_RETRY_OFF = 120;
-constexpr size_t MISC_STATS_OFF = 128;
+constexpr size_t MISC_RETRY_OFF = 128;
+constexpr size_t MISC_STATS_OFF = 192;
 
 __global__ void k_plan_totals(const u64* __restrict__ starts, u64 S, u64* __restrict__ ranges) {
     const uint32_t k = threadIdx.x;
@@ -687,6 +687,7 @@ PlanResult plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t np
     c->q[CLS_GEN].ensure(sizeof(GenItem) * (ub_match + 1));
     c->q[CLS_FILT].ensure(sizeof(FatItem) * (ub_match + 1));
     c->q[CLS_WAVE].ensure(sizeof(FatItem) * (ub_match + 1));
+    c->q[CLS_RUNS].ensure(sizeof(GenItem) * (ub_match + 1));
     c->unit_bytes.ensure(8 * (NU + 1));
     c->q[CLS_COPY].ensure(sizeof(Item) * (ub + 1));
     if (!cardmode) {
@@ -697,7 +698,7 @@ PlanResult plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t np
     O.key = c->o_key.as<u64>(); O.meta = c->o_meta.as<u64>();
     O.slot = c->o_slot.as<uint32_t>(); O.off = c->o_off.as<u64>();
     O.arena = nullptr;
-    EmitQueues Q{c->q[CLS_BB].as<BBItem>(), c->q[CLS_GEN].as<GenItem>(), c->q[CLS_COPY].as<Item>(), c->q[CLS_FILT].as<FatItem>(), c->q[CLS_WAVE].as<FatItem>()};
+    EmitQueues Q{c->q[CLS_BB].as<BBItem>(), c->q[CLS_GEN].as<GenItem>(), c->q[CLS_COPY].as<Item>(), c->q[CLS_FILT].as<FatItem>(), c->q[CLS_WAVE].as<FatItem>(), c->q[CLS_RUNS].as<GenItem>()};
     hipLaunchKernelGGL(k_emit, dim3(gp), dim3(256), 0, s, VA, VB, c->lhs.as<uint32_t>(), c->rhs.as<uint32_t>(), UV, op,
                        cardmode, c->cand_start.as<u64>(), O, Q, c->unit_bytes.as<u64>());
     hipLaunchKernelGGL(k_sum_u64, dim3(1), dim3(1024), 0, s, c->unit_bytes.as<u64>(), (u64)NU,
@@ -706,19 +707,20 @@ PlanResult plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t np
     if (!cardmode) {
         // slots beyond the exact candidate count were zeroed, so scanning the upper bound is exact
         exscan(c, O.slot, c->o_off.as<u64>(), ub);
-        HIPCHK(hipMemcpyAsync(hp + 128, c->o_off.as<u64>() + ub, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hp + 160, c->o_off.as<u64>() + ub, 8, hipMemcpyDeviceToHost, s));
     }
-    HIPCHK(hipMemcpyAsync(hp, ranges, 112, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hp, ranges, 128, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    uint64_t r[14];
-    memcpy(r, hp, 112);
+    uint64_t r[16];
+    memcpy(r, hp, 128);
     R.total_cand = r[2 * SEC_CAND + 1] - r[2 * SEC_CAND];
     R.n_bb = r[2 * SEC_BB + 1] - r[2 * SEC_BB];
     R.n_gen = r[2 * SEC_GEN + 1] - r[2 * SEC_GEN];
     R.n_copy = r[2 * SEC_COPY + 1] - r[2 * SEC_COPY];
     R.n_filt = r[2 * SEC_FILT + 1] - r[2 * SEC_FILT];
     R.n_wave = r[2 * SEC_WAVE + 1] - r[2 * SEC_WAVE];
-    if (!cardmode) memcpy(&R.total_bytes, hp + 128, 8);
+    R.n_runs = r[2 * SEC_RUNS + 1] - r[2 * SEC_RUNS];
+    if (!cardmode) memcpy(&R.total_bytes, hp + 160, 8);
     return R;
 }
 
@@ -733,8 +735,8 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
     hipStream_t s = c->stream;
     const u64* ranges = (const u64*)((char*)c->misc.p + MISC_RANGES_OFF);
     uint32_t* retry_count = (uint32_t*)((char*)c->misc.p + MISC_RETRY_OFF);
+    c->q[CLS_RETRY].ensure(sizeof(GenItem) * (R.n_bb + R.n_runs + 1));
     if (R.n_bb) {
-        c->q[CLS_RETRY].ensure(sizeof(GenItem) * (R.n_bb + 1));
         unsigned grid = persistent_grid(R.n_bb, 4, 256 * 32);
         if (c->timing) HIPCHK(hipEventRecord(c->ev[2], s));
         switch (op) {
@@ -744,12 +746,19 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
             default: launch_bb<OP_ANDNOT>(c, grid, VA, VB, O, cardmode); break;
         }
         if (c->timing) HIPCHK(hipEventRecord(c->ev[3], s));
-        if (!cardmode && op != OP_OR) {
-            // bitset x bitset results that must become arrays (card <= 4096): LDS extraction
-            unsigned g2 = persistent_grid(R.n_bb, 4, 256 * 4);
-            hipLaunchKernelGGL(k_genw, dim3(g2), dim3(256), 0, s, VA.arena, VB.arena, O, c->q[CLS_RETRY].as<GenItem>(),
-                               (const u64*)nullptr, retry_count, op, 0, c->pair_acc.as<u64>());
-        }
+    }
+    if (R.n_runs) {
+        unsigned grid = persistent_grid(R.n_runs, 4, 256 * 4);
+        hipLaunchKernelGGL(k_runs, dim3(grid), dim3(256), 0, s, VA.arena, VB.arena, O, c->q[CLS_RUNS].as<GenItem>(),
+                           ranges + 2 * SEC_RUNS, op, cardmode, c->pair_acc.as<u64>(), c->q[CLS_RETRY].as<GenItem>(),
+                           retry_count);
+    }
+    if (!cardmode && ((R.n_bb && op != OP_OR) || R.n_runs)) {
+        // results that need the LDS image path after all: bitset x bitset results that must become
+        // arrays (card <= 4096), interval results that must become bitsets
+        unsigned g2 = persistent_grid(R.n_bb + R.n_runs, 4, 256 * 4);
+        hipLaunchKernelGGL(k_genw, dim3(g2), dim3(256), 0, s, VA.arena, VB.arena, O, c->q[CLS_RETRY].as<GenItem>(),
+                           (const u64*)nullptr, retry_count, op, 0, c->pair_acc.as<u64>());
     }
     if (R.n_filt) {
         unsigned grid = persistent_grid(R.n_filt, 4, 256 * 4);
@@ -780,7 +789,7 @@ void finish_stats(rhip_ctx_t* c, const PlanResult* R) {
     if (c->timing) HIPCHK(hipEventRecord(c->ev[1], s));
     HIPCHK(hipStreamSynchronize(s));
     memcpy(&st, c->h_pinned, sizeof(Stats));
-    c->stats.matched_pairs = R ? R->n_bb + R->n_gen + R->n_filt + R->n_wave : 0;
+    c->stats.matched_pairs = R ? R->n_bb + R->n_gen + R->n_filt + R->n_wave + R->n_runs : 0;
     c->stats.passthrough = R ? R->n_copy : 0;
     c->stats.bytes_in = st.bytes_in;
     c->stats.bytes_out = st.bytes_out;
@@ -803,6 +812,11 @@ extern "C" rhip_pool_t* rhip_pairwise(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A
         int op = (int)op_;
         if (op < 0 || op > 3) { set_err("bad op"); throw (int)RHIP_ERR_ARG; }
         check_pair_args(A, B, npairs, lhs, rhs);
+        if (reuse && (reuse == A || reuse == B)) {
+            reuse = nullptr;  // not ours to recycle
+            set_err("`reuse` must not be one of the operand pools");
+            throw (int)RHIP_ERR_ARG;
+        }
         hipStream_t s = c->stream;
         if (c->timing) HIPCHK(hipEventRecord(c->ev[0], s));
         OutView O;

@@ -29,7 +29,8 @@ typedef unsigned long long u64;
 
 enum { T_BITSET = 1, T_ARRAY = 2, T_RUN = 3 };
 enum { OP_AND = 0, OP_OR = 1, OP_XOR = 2, OP_ANDNOT = 3 };
-enum { CLS_BB = 0, CLS_GEN = 1, CLS_COPY = 2, CLS_RETRY = 3, CLS_FILT = 4, CLS_WAVE = 5, N_CLS = 6 };
+enum { CLS_BB = 0, CLS_GEN = 1, CLS_COPY = 2, CLS_RETRY = 3, CLS_FILT = 4, CLS_WAVE = 5, CLS_RUNS = 6, N_CLS = 7 };
+#define RUNS_MAX_INTERVALS 256u  // per operand, for the interval kernel (k_runs)
 #define NONE32 0xFFFFFFFFu
 
 struct PoolView {
@@ -168,10 +169,15 @@ __device__ __forceinline__ void lower_bound4(const u64* __restrict__ key, u64 lo
 // unmatched containers -- of the right bitmap ("B-tile").  One wave per unit, so a batch of 250 pairs
 // of 4096-container bitmaps plans on 4000 waves instead of 250.
 // Count arrays (and their exclusive scan) have 5 sections of n_units+1 entries:
-enum { SEC_CAND = 0, SEC_M = 1, SEC_BB = 2, SEC_GEN = 3, SEC_COPY = 4, SEC_FILT = 5, SEC_WAVE = 6, N_SEC = 7 };
+enum { SEC_CAND = 0, SEC_M = 1, SEC_BB = 2, SEC_GEN = 3, SEC_COPY = 4, SEC_FILT = 5, SEC_WAVE = 6, SEC_RUNS = 7, N_SEC = 8 };
 // work class of a matched container pair
-__device__ __forceinline__ int classify(int op, int cardmode, uint8_t ta, uint8_t tb) {
+// ia / ib = number of intervals of the operand when it is read as an interval list (runs: n_runs, arrays: card)
+__device__ __forceinline__ int classify(int op, int cardmode, uint8_t ta, uint8_t tb, uint32_t ia, uint32_t ib) {
     if (ta == T_BITSET && tb == T_BITSET) return CLS_BB;
+    // interval algebra in O(n log n) when a run container meets a run / a short array
+    if ((ta == T_RUN || tb == T_RUN) && ta != T_BITSET && tb != T_BITSET && ia <= RUNS_MAX_INTERVALS &&
+        ib <= RUNS_MAX_INTERVALS)
+        return CLS_RUNS;
     // array filtered by membership in an array / bitset: and (either order), array \ x
     if (cardmode || op == OP_AND) {
         if ((ta == T_ARRAY && tb != T_RUN) || (tb == T_ARRAY && ta != T_RUN)) return CLS_FILT;
@@ -218,16 +224,22 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         k[t] = act[t] ? SV.key[s0 + 64 * t + lane] : 0;
     }
     lower_bound4(LV.key, l0, l1, k, act, j);
-    uint32_t matched = 0, nbb = 0, nfilt = 0, nwave = 0;
+    uint32_t matched = 0, nbb = 0, nfilt = 0, nwave = 0, nruns_cls = 0;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const bool found = act[t] && j[t] < l1 && LV.key[j[t]] == k[t];
         int cls = -1;
-        if (found && !bside) cls = classify(op, cardmode, SV.type[s0 + 64 * t + lane], LV.type[j[t]]);
+        if (found && !bside) {
+            const u64 ai = s0 + 64 * t + lane;
+            const uint8_t ta = SV.type[ai], tb = LV.type[j[t]];
+            cls = classify(op, cardmode, ta, tb, ta == T_RUN ? SV.nruns[ai] : SV.card[ai],
+                           tb == T_RUN ? LV.nruns[j[t]] : LV.card[j[t]]);
+        }
         matched += (uint32_t)__popcll(__ballot(found));
         nbb += (uint32_t)__popcll(__ballot(cls == CLS_BB));
         nfilt += (uint32_t)__popcll(__ballot(cls == CLS_FILT));
         nwave += (uint32_t)__popcll(__ballot(cls == CLS_WAVE));
+        nruns_cls += (uint32_t)__popcll(__ballot(cls == CLS_RUNS));
     }
     if (lane == 0) {
         const uint32_t n = (uint32_t)(s1 - s0);
@@ -238,7 +250,8 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         counts[SEC_CAND * S + u] = bside ? ncopy : matched + ncopy;
         counts[SEC_M * S + u] = matched;
         counts[SEC_BB * S + u] = nbb;
-        counts[SEC_GEN * S + u] = bside ? 0u : matched - nbb - nfilt - nwave;
+        counts[SEC_GEN * S + u] = bside ? 0u : matched - nbb - nfilt - nwave - nruns_cls;
+        counts[SEC_RUNS * S + u] = nruns_cls;
         counts[SEC_FILT * S + u] = nfilt;
         counts[SEC_WAVE * S + u] = nwave;
         counts[SEC_COPY * S + u] = ncopy;
@@ -257,6 +270,7 @@ struct EmitQueues {
     Item* copy;   // section SEC_COPY
     FatItem* filt;  // section SEC_FILT
     FatItem* wave;  // section SEC_WAVE
+    GenItem* runs;  // section SEC_RUNS
 };
 __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint32_t* __restrict__ lhs,
                                               const uint32_t* __restrict__ rhs, UnitView U, int op, int cardmode,
@@ -278,6 +292,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
     u64 qcopy = starts[SEC_COPY * S + u] - starts[SEC_COPY * S];
     u64 qfilt = starts[SEC_FILT * S + u] - starts[SEC_FILT * S];
     u64 qwave = starts[SEC_WAVE * S + u] - starts[SEC_WAVE * S];
+    u64 qruns = starts[SEC_RUNS * S + u] - starts[SEC_RUNS * S];
     u64 bytes_in = 0;
     u64 k[4], j[4];
     bool act[4];
@@ -299,7 +314,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
             mbefore += (uint32_t)__popcll(fm);
             const bool emit = act[t] && (found || (!cardmode && op != OP_AND));
             uint8_t ta = 0, tb = 0;
-            uint32_t ca = 0, cb = 0, pa = 0, pos = 0;
+            uint32_t ca = 0, cb = 0, pa = 0, pos = 0, nra = 0, nrb = 0;
             if (emit) {
                 const uint32_t ilocal = (uint32_t)(ai - a0), lbcount = (uint32_t)(j[t] - b0);
                 if (op == OP_AND || cardmode) pos = mb;
@@ -307,12 +322,14 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 else pos = ilocal + lbcount - mb;
                 ta = A.type[ai];
                 ca = A.card[ai];
-                pa = payload_bytes(ta, ca, A.nruns[ai]);
+                nra = A.nruns[ai];
+                pa = payload_bytes(ta, ca, nra);
                 bytes_in += pa;
                 if (found) {
                     tb = B.type[j[t]];
                     cb = B.card[j[t]];
-                    bytes_in += payload_bytes(tb, cb, B.nruns[j[t]]);
+                    nrb = B.nruns[j[t]];
+                    bytes_in += payload_bytes(tb, cb, nrb);
                 }
                 if (!cardmode) {
                     O.key[base + pos] = k[t];
@@ -321,26 +338,28 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 }
             }
             const uint32_t outidx = cardmode ? p : (uint32_t)(base + pos);
-            const int cls = (emit && found) ? classify(op, cardmode, ta, tb) : -1;
+            const int cls = (emit && found) ? classify(op, cardmode, ta, tb, ta == T_RUN ? nra : ca, tb == T_RUN ? nrb : cb) : -1;
             const bool isbb = cls == CLS_BB;
             const bool isgen = cls == CLS_GEN;
             const bool isfilt = cls == CLS_FILT;
             const bool iswave = cls == CLS_WAVE;
+            const bool isruns = cls == CLS_RUNS;
             const bool iscopy = emit && !found;
             const u64 mbb = __ballot(isbb), mgen = __ballot(isgen), mcp = __ballot(iscopy), mfl = __ballot(isfilt);
-            const u64 mwv = __ballot(iswave);
+            const u64 mwv = __ballot(iswave), mrn = __ballot(isruns);
             if (isbb) {
                 BBItem it;
                 it.offa = A.off[ai]; it.offb = B.off[j[t]];
                 it.a = (uint32_t)ai; it.b = (uint32_t)j[t]; it.out = outidx; it.pad = 0;
                 Q.bb[qbb + mbcnt(mbb)] = it;
             }
-            if (isgen) {
+            if (isgen || isruns) {
                 GenItem it;
                 it.offa = A.off[ai]; it.offb = B.off[j[t]];
                 it.out = outidx; it.ca = ca; it.cb = cb; it.types = (uint32_t)ta | ((uint32_t)tb << 8);
-                it.nra = A.nruns[ai]; it.nrb = B.nruns[j[t]]; it.pad0 = 0; it.pad1 = 0;
-                Q.gen[qgen + mbcnt(mgen)] = it;
+                it.nra = nra; it.nrb = nrb; it.pad0 = 0; it.pad1 = 0;
+                if (isgen) Q.gen[qgen + mbcnt(mgen)] = it;
+                else Q.runs[qruns + mbcnt(mrn)] = it;
             }
             if (isfilt || iswave) {
                 FatItem it;
@@ -350,7 +369,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 else Q.wave[qwave + mbcnt(mwv)] = it;
             }
             if (iscopy) Q.copy[qcopy + mbcnt(mcp)] = Item{(uint32_t)ai, NONE32, outidx};
-            qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv);
+            qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv); qruns += __popcll(mrn);
         }
     } else {
         const u64 nAt = (a1 - a0 + 255) / 256;
@@ -725,6 +744,193 @@ __global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA
             }
         }
         if (lane == 0) O.meta[t.out] = pack_meta(ty, rc, 0);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------ interval kernel (K13, K14, K16)
+// run x run, array x run, run x array for all four ops, in O((nA + nB) log(nA + nB)) instead of
+// rasterising 65536 bits: one WAVE per pair, no workgroup barrier.  Replaces the sequential interval
+// merges run_container_{union,intersection,xor,andnot} (src/containers/run.c:231-283, 387-463, 348-383,
+// 575-633), array_run_container_{intersection,union,andnot,lazy_xor}, run_array_container_andnot
+// (mixed_intersection.c:73-111, mixed_union.c:66-108, mixed_andnot.c:277-412, mixed_xor.c:140-173).
+//
+// Each operand is read as a sorted BOUNDARY list b(0) <= b(1) <= ... <= b(2n-1) = s0, e0+1, s1, e1+1, ...
+// (arrays: e = s).  Membership is a parity: x is in the operand iff |{j : b(j) <= x}| is odd.  The result
+// can only change at a boundary p of either operand; with lb/ub = lower/upper bound of p in a list,
+//   f(p-1) = op(lbA & 1, lbB & 1),   f(p) = op(ubA & 1, ubB & 1),
+// so p starts a result run iff f(p) & !f(p-1) and ends one (at p-1) iff !f(p) & f(p-1).  Lanes evaluate
+// boundaries in parallel (one binary search into the other list each); result starts and ends are ranked
+// by ballot prefix counts per list plus a prefix lookup in the other list, and the k-th start pairs with
+// the k-th end.  The run list is then typed by the reference's rules (convert_run_to_efficient_container
+// etc.) and written as runs or expanded into an array; the rare bitset result is re-queued for k_genw.
+struct IvList {
+    const uint8_t* p;
+    uint32_t n2;     // number of boundaries (2 x intervals)
+    bool is_run;
+    __device__ __forceinline__ uint32_t at(uint32_t j) const {
+        if (is_run) {
+            const uint32_t w = ((const uint32_t*)p)[j >> 1];
+            const uint32_t s = w & 0xFFFFu;
+            return (j & 1u) ? s + (w >> 16) + 1u : s;
+        }
+        const uint32_t v = ((const uint16_t*)p)[j >> 1];
+        return v + (j & 1u);
+    }
+    __device__ __forceinline__ uint32_t lower(uint32_t x) const {  // first j with at(j) >= x
+        uint32_t lo = 0, hi = n2;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (at(mid) < x) lo = mid + 1;
+            else hi = mid;
+        }
+        return lo;
+    }
+};
+__device__ __forceinline__ bool bop(int op, uint32_t a, uint32_t b) {
+    a &= 1u; b &= 1u;
+    return op == OP_AND ? (a & b) : op == OP_OR ? (a | b) : op == OP_XOR ? (a ^ b) : (a & ~b & 1u);
+}
+
+__global__ __launch_bounds__(256) void k_runs(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                              OutView O, const GenItem* __restrict__ q,
+                                              const u64* __restrict__ qrange, int op, int cardmode, u64* pair_acc,
+                                              GenItem* retry_q, uint32_t* retry_count) {
+    constexpr uint32_t NB = 2 * RUNS_MAX_INTERVALS;  // max boundaries per list
+    // per wave (~8 KiB): both operand lists staged in LDS (every binary-search probe is an LDS read), the
+    // start/end prefix tables of both lists (bit 15 = flag), result starts / ends
+    __shared__ __attribute__((aligned(16))) uint8_t lists_all[4][2][4 * RUNS_MAX_INTERVALS];
+    __shared__ uint16_t lds_all[4][4 * (NB + 1) + 2 * NB];
+    const uint32_t lane = lane_id();
+    uint16_t* base = lds_all[threadIdx.x >> 6];
+    uint8_t* lsA = lists_all[threadIdx.x >> 6][0];
+    uint8_t* lsB = lists_all[threadIdx.x >> 6][1];
+    uint16_t* PS[2] = {base, base + (NB + 1)};                   // start-prefix of list A / B
+    uint16_t* PE[2] = {base + 2 * (NB + 1), base + 3 * (NB + 1)};  // end-prefix of list A / B
+    uint16_t* RS = base + 4 * (NB + 1);                           // result run starts
+    uint16_t* RE = RS + NB;                                       // result run ends (inclusive)
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
+    for (uint32_t wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wi < n; wi += nwaves) {
+        const GenItem t = q[wi];
+        const uint32_t ta = t.types & 0xFFu, tb = t.types >> 8;
+        IvList L[2];
+        L[0].p = lsA; L[0].is_run = ta == T_RUN; L[0].n2 = 2u * (ta == T_RUN ? t.nra : t.ca);
+        L[1].p = lsB; L[1].is_run = tb == T_RUN; L[1].n2 = 2u * (tb == T_RUN ? t.nrb : t.cb);
+        {   // stage both payloads (<= 1 KiB each, 16-byte padded slots): one 16-byte load per lane
+            const uint32_t na16 = ((L[0].is_run ? 2u : 1u) * L[0].n2 + 15u) >> 4;
+            const uint32_t nb16 = ((L[1].is_run ? 2u : 1u) * L[1].n2 + 15u) >> 4;
+            if (lane < na16) ((uint4*)lsA)[lane] = ((const uint4*)(arenaA + t.offa))[lane];
+            if (lane < nb16) ((uint4*)lsB)[lane] = ((const uint4*)(arenaB + t.offb))[lane];
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- pass 1: start / end flags of every boundary, exclusive prefix counts per list
+        uint32_t tot_s[2], tot_e[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const IvList& own = L[x];
+            const IvList& oth = L[1 - x];
+            uint32_t run_s = 0, run_e = 0;
+            for (uint32_t j0 = 0; j0 < own.n2; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                bool is_s = false, is_e = false;
+                if (j < own.n2) {
+                    const uint32_t p = own.at(j);
+                    const bool dup_own = j > 0 && own.at(j - 1) == p;
+                    const uint32_t lbo = oth.lower(p);
+                    const bool in_oth = lbo < oth.n2 && oth.at(lbo) == p;
+                    // a boundary present in both lists is handled once, by list A
+                    if (!dup_own && !(x == 1 && in_oth)) {
+                        const uint32_t ub_own = j + 1u + ((j + 1u < own.n2 && own.at(j + 1u) == p) ? 1u : 0u);
+                        uint32_t ub_oth = lbo;
+                        if (in_oth) ub_oth = lbo + 1u + ((lbo + 1u < oth.n2 && oth.at(lbo + 1u) == p) ? 1u : 0u);
+                        const uint32_t lbA = x == 0 ? j : lbo, ubA = x == 0 ? ub_own : ub_oth;
+                        const uint32_t lbB = x == 0 ? lbo : j, ubB = x == 0 ? ub_oth : ub_own;
+                        const bool fb = bop(op, lbA, lbB), fa = bop(op, ubA, ubB);
+                        is_s = fa && !fb;
+                        is_e = !fa && fb;
+                    }
+                }
+                const u64 ms = __ballot(is_s), me = __ballot(is_e);
+                if (j < own.n2) {
+                    PS[x][j] = (uint16_t)((run_s + mbcnt(ms)) | (is_s ? 0x8000u : 0u));
+                    PE[x][j] = (uint16_t)((run_e + mbcnt(me)) | (is_e ? 0x8000u : 0u));
+                }
+                run_s += (uint32_t)__popcll(ms);
+                run_e += (uint32_t)__popcll(me);
+            }
+            if (lane == 0) { PS[x][own.n2] = (uint16_t)run_s; PE[x][own.n2] = (uint16_t)run_e; }
+            tot_s[x] = run_s; tot_e[x] = run_e;
+        }
+        const uint32_t rn = tot_s[0] + tot_s[1];  // == tot_e[0] + tot_e[1]
+        __builtin_amdgcn_wave_barrier();
+        // ---- pass 2: rank flagged boundaries over both lists, scatter into RS / RE
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const IvList& own = L[x];
+            const IvList& oth = L[1 - x];
+            for (uint32_t j0 = 0; j0 < own.n2; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                if (j < own.n2) {
+                    const uint32_t fs = PS[x][j], fe = PE[x][j];
+                    if ((fs | fe) & 0x8000u) {
+                        const uint32_t p = own.at(j);
+                        const uint32_t lbo = oth.lower(p);
+                        if (fs & 0x8000u) RS[(fs & 0x7FFFu) + (PS[1 - x][lbo] & 0x7FFFu)] = (uint16_t)p;
+                        if (fe & 0x8000u) RE[(fe & 0x7FFFu) + (PE[1 - x][lbo] & 0x7FFFu)] = (uint16_t)(p - 1u);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- cardinality, typing
+        uint32_t cnt = 0;
+        for (uint32_t k = lane; k < rn; k += 64) cnt += (uint32_t)RE[k] - (uint32_t)RS[k] + 1u;
+        const uint32_t rc = wave_sum(cnt);
+        if (cardmode) {
+            if (lane == 0 && rc) atomicAdd(&pair_acc[t.out], (u64)rc);
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
+        const bool fulla = ta == T_RUN && t.ca == 65536u, fullb = tb == T_RUN && t.cb == 65536u;
+        int ty = T_ARRAY;
+        if (rc) ty = decide_type(op, (int)ta, (int)tb, t.ca, t.cb, fulla, fullb, rc, rn);
+        if (rc && ty == T_BITSET) {
+            // rare for this class: let the image kernel redo the pair
+            if (lane == 0) retry_q[atomicAdd(retry_count, 1u)] = t;
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
+        uint8_t* outp = O.arena + O.off[t.out];
+        if (rc && ty == T_RUN) {
+            uint32_t* __restrict__ o32 = (uint32_t*)outp;
+            for (uint32_t k = lane; k < rn; k += 64)
+                o32[k] = (uint32_t)RS[k] | (((uint32_t)RE[k] - (uint32_t)RS[k]) << 16);
+        } else if (rc) {
+            // expand runs into a sorted array: exclusive prefix of run lengths (reuses PS[0]), then one
+            // binary search per output value
+            uint16_t* PL = PS[0];
+            uint32_t runbase = 0;
+            for (uint32_t k0 = 0; k0 < rn; k0 += 64) {
+                const uint32_t k = k0 + lane;
+                const uint32_t len = k < rn ? (uint32_t)RE[k] - (uint32_t)RS[k] + 1u : 0u;
+                const uint32_t inc = wave_incl_scan(len);
+                if (k < rn) PL[k] = (uint16_t)(runbase + inc - len);
+                runbase += __shfl(inc, 63);
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint16_t* __restrict__ o16 = (uint16_t*)outp;
+            for (uint32_t i = lane; i < rc; i += 64) {
+                uint32_t lo = 0, hi = rn;  // last k with PL[k] <= i
+                while (lo + 1 < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (PL[mid] <= i) lo = mid;
+                    else hi = mid;
+                }
+                o16[i] = (uint16_t)(RS[lo] + (i - PL[lo]));
+            }
+        }
+        if (lane == 0) O.meta[t.out] = pack_meta(ty, rc, (ty == T_RUN) ? rn : 0u);
         __builtin_amdgcn_wave_barrier();
     }
 }
