@@ -117,58 +117,126 @@ __global__ void k_many_slots(PoolView P, ManyView V, const u64* __restrict__ gca
 }
 
 // Accumulate the members [m0, m1) into the LDS image acc (zeroed by the caller).
-__device__ void many_accumulate(uint32_t* acc, uint32_t* tmp, const PoolView& P, const ManyView& V, u64 m0, u64 m1,
-                                int op, BlockScratch* sc) {
+// Member lists built during phase A (relative member indices; a unit has at most 1024 members)
+struct ManyLists {
+    uint32_t n_bitset, n_run;
+    uint16_t bitset[1024], run[1024];
+};
+// During the array scatter the image is addressed through an XOR swizzle of the low 5 word-index bits:
+// arrays whose values are spaced by a multiple of 1024 (any regular stride, e.g. the stratified C4 data)
+// would otherwise put every lane of a ds_or on the same LDS bank.  (On C4 itself the kernel is bound by
+// the random 512-byte member gathers -- ~2 TB/s incl. directory sectors -- so this is insurance, not a
+// measured win.)  The swizzle is an involution inside each aligned 32-word block: one pass converts
+// either way.
+__device__ __forceinline__ uint32_t mswz(uint32_t w) { return w ^ ((w >> 5) & 31u); }
+__device__ __forceinline__ void many_swizzle_pass(uint32_t* acc) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = acc[mswz(8u * tid + k)];
+    __syncthreads();
+    ((uint4*)acc)[2 * tid] = make_uint4(w[0], w[1], w[2], w[3]);
+    ((uint4*)acc)[2 * tid + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+    __syncthreads();
+}
+
+__device__ void many_accumulate_chunk(uint32_t* acc, uint32_t* tmp, const PoolView& P, const ManyView& V, u64 m0,
+                                      u64 m1, int op, BlockScratch* sc, ManyLists* ml) {
     const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    // phase A: array members, one wave per member, LDS atomics (commutative: no ordering needed)
-    for (u64 m = m0 + wave; m < m1; m += 4) {
-        const uint32_t c = V.sval[m];
-        if (P.type[c] != T_ARRAY) continue;
-        const uint32_t n = P.card[c];
-        const uint32_t* __restrict__ a2 = (const uint32_t*)(P.arena + P.off[c]);
-        for (uint32_t i = lane; 2 * i < n; i += 64) {
-            uint32_t v2 = a2[i];
-            uint32_t v = v2 & 0xFFFFu;
-            if (op == OP_OR) atomicOr(&acc[v >> 5], 1u << (v & 31));
-            else atomicXor(&acc[v >> 5], 1u << (v & 31));
-            if (2 * i + 1 < n) {
-                v = v2 >> 16;
-                if (op == OP_OR) atomicOr(&acc[v >> 5], 1u << (v & 31));
-                else atomicXor(&acc[v >> 5], 1u << (v & 31));
+    __syncthreads();
+    if (tid == 0) { ml->n_bitset = 0; ml->n_run = 0; }
+    many_swizzle_pass(acc);  // linear -> swizzled (ends with a barrier)
+    // phase A: array members, LDS atomics (commutative: no ordering needed).  Each wave takes 64
+    // members at a time: their directory entries are fetched lane-parallel (one member per lane) and
+    // broadcast with shuffles, and members are consumed eight at a time so that eight independent
+    // 16-byte payload loads per lane are in flight before the first LDS atomic needs one of them
+    // (a member is a few hundred bytes at a random arena offset: this loop is latency-, not
+    // bandwidth-limited unless loads overlap).
+    for (u64 mb = m0 + 64ull * wave; mb < m1; mb += 256) {
+        const u64 mi = mb + lane;
+        uint32_t cd = 0, of_lo = 0, of_hi = 0;
+        if (mi < m1) {
+            const uint32_t c = V.sval[mi];
+            const uint8_t ty = P.type[c];
+            if (ty == T_ARRAY) {
+                cd = P.card[c];
+                const u64 of = P.off[c];
+                of_lo = (uint32_t)of; of_hi = (uint32_t)(of >> 32);
+            } else if (ty == T_BITSET) {
+                ml->bitset[atomicAdd(&ml->n_bitset, 1u)] = (uint16_t)(mi - m0);
+            } else {
+                ml->run[atomicAdd(&ml->n_run, 1u)] = (uint16_t)(mi - m0);
+            }
+        }
+        const uint32_t cnt = (uint32_t)((m1 - mb) < 64 ? (m1 - mb) : 64);
+        for (uint32_t k = 0; k < cnt; k += 8) {
+            uint4 q4[8];
+            uint32_t cdk[8];
+            const uint4* pk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t src = (k + u < cnt) ? k + u : k;
+                cdk[u] = (k + u < cnt) ? __shfl(cd, src) : 0u;
+                const u64 of = (u64)__shfl(of_lo, src) | ((u64)__shfl(of_hi, src) << 32);
+                pk[u] = (const uint4*)(P.arena + of);
+                q4[u] = (8 * lane < cdk[u]) ? pk[u][lane] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                for (uint32_t i = lane; 8 * i < cdk[u]; i += 64) {
+                    const uint4 x = (i == lane) ? q4[u] : pk[u][i];
+                    const uint32_t d[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                    for (int h = 0; h < 8; ++h) {
+                        if (8 * i + h < cdk[u]) {
+                            const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                            if (op == OP_OR) atomicOr(&acc[mswz(v >> 5)], 1u << (v & 31));
+                            else atomicXor(&acc[mswz(v >> 5)], 1u << (v & 31));
+                        }
+                    }
+                }
             }
         }
     }
     __syncthreads();
-    // phase B: bitset members, thread-owned words
+    many_swizzle_pass(acc);  // swizzled -> linear
+    __syncthreads();
+    // phase B: bitset members (listed by phase A), thread-owned words.  XOR/OR are commutative, so the
+    // arbitrary list order is fine.
     {
-        uint4 r0 = ((uint4*)acc)[2 * tid], r1 = ((uint4*)acc)[2 * tid + 1];
-        bool any = false;
-        for (u64 m = m0; m < m1; ++m) {
-            const uint32_t c = V.sval[m];
-            if (P.type[c] != T_BITSET) continue;
-            const uint4* __restrict__ g = (const uint4*)(P.arena + P.off[c]);
-            uint4 x0 = g[2 * tid], x1 = g[2 * tid + 1];
-            r0 = op4(op, r0, x0);
-            r1 = op4(op, r1, x1);
-            any = true;
-        }
-        if (any) {
+        const uint32_t nb = ml->n_bitset;
+        if (nb) {
+            uint4 r0 = ((uint4*)acc)[2 * tid], r1 = ((uint4*)acc)[2 * tid + 1];
+            for (uint32_t k = 0; k < nb; ++k) {
+                const uint32_t c = V.sval[m0 + ml->bitset[k]];
+                const uint4* __restrict__ g = (const uint4*)(P.arena + P.off[c]);
+                r0 = op4(op, r0, g[2 * tid]);
+                r1 = op4(op, r1, g[2 * tid + 1]);
+            }
             ((uint4*)acc)[2 * tid] = r0;
             ((uint4*)acc)[2 * tid + 1] = r1;
         }
     }
     __syncthreads();
     // phase C: run members, rasterised one at a time into tmp
-    for (u64 m = m0; m < m1; ++m) {
-        const uint32_t c = V.sval[m];
-        if (P.type[c] != T_RUN) continue;  // uniform across the block
-        lds_load(tmp, P, c, sc);
-        uint4 r0 = ((uint4*)acc)[2 * tid], r1 = ((uint4*)acc)[2 * tid + 1];
-        uint4 x0 = ((uint4*)tmp)[2 * tid], x1 = ((uint4*)tmp)[2 * tid + 1];
-        ((uint4*)acc)[2 * tid] = op4(op, r0, x0);
-        ((uint4*)acc)[2 * tid + 1] = op4(op, r1, x1);
-        __syncthreads();
+    {
+        const uint32_t nr = ml->n_run;
+        for (uint32_t k = 0; k < nr; ++k) {
+            const uint32_t c = V.sval[m0 + ml->run[k]];
+            lds_load(tmp, P, c, sc);
+            uint4 r0 = ((uint4*)acc)[2 * tid], r1 = ((uint4*)acc)[2 * tid + 1];
+            uint4 x0 = ((uint4*)tmp)[2 * tid], x1 = ((uint4*)tmp)[2 * tid + 1];
+            ((uint4*)acc)[2 * tid] = op4(op, r0, x0);
+            ((uint4*)acc)[2 * tid + 1] = op4(op, r1, x1);
+            __syncthreads();
+        }
     }
+}
+
+// Accumulate the members [m0, m1) into the LDS image acc (zeroed by the caller), 1024 members at a time.
+__device__ void many_accumulate(uint32_t* acc, uint32_t* tmp, const PoolView& P, const ManyView& V, u64 m0, u64 m1,
+                                int op, BlockScratch* sc, ManyLists* ml) {
+    for (u64 c0 = m0; c0 < m1; c0 += 1024) many_accumulate_chunk(acc, tmp, P, V, c0, (c0 + 1024 < m1) ? c0 + 1024 : m1, op, sc, ml);
 }
 
 struct ManyOut {
@@ -190,7 +258,7 @@ struct ManyOut {
 // "is the union already full after the last bitset member?" -- answered by re-accumulating that prefix.
 // Returns true for a full run, false for a (full) bitset.
 __device__ bool full_union_is_run(uint32_t* acc2, uint32_t* tmp, const PoolView& P, const ManyView& V,
-                                  const ManyOut& MO, u64 gs, u64 ge, BlockScratch* sc) {
+                                  const ManyOut& MO, u64 gs, u64 ge, BlockScratch* sc, ManyLists* ml) {
     const uint32_t c0 = V.sval[gs], c1 = V.sval[gs + 1];
     const bool first = c0 >= MO.first_lo && c0 < MO.first_hi && c1 >= MO.second_lo && c1 < MO.second_hi;
     auto isB = [&](uint32_t c) { return P.type[c] == T_BITSET; };
@@ -217,7 +285,7 @@ __device__ bool full_union_is_run(uint32_t* acc2, uint32_t* tmp, const PoolView&
     __syncthreads();
     lds_zero(acc2);
     __syncthreads();
-    many_accumulate(acc2, tmp, P, V, gs, last_b + 1, OP_OR, sc);
+    many_accumulate(acc2, tmp, P, V, gs, last_b + 1, OP_OR, sc, ml);
     uint4 r0 = ((uint4*)acc2)[2 * threadIdx.x], r1 = ((uint4*)acc2)[2 * threadIdx.x + 1];
     return blk_sum(popc4(r0) + popc4(r1), sc->wsum) == 65536u;
 }
@@ -225,7 +293,8 @@ __device__ bool full_union_is_run(uint32_t* acc2, uint32_t* tmp, const PoolView&
 // canonicalise the LDS image of a finished group: card <= 4096 -> array, else bitset
 // (container_repair_after_lazy, containers.h:344-371); empty -> dropped by compaction
 __device__ void many_finalize(uint32_t* acc, uint16_t* stage, const ManyOut& MO, uint32_t g, BlockScratch* sc,
-                              uint32_t* acc2, uint32_t* tmp, const PoolView& P, const ManyView& V, u64 gs, u64 ge) {
+                              uint32_t* acc2, uint32_t* tmp, const PoolView& P, const ManyView& V, u64 gs, u64 ge,
+                              ManyLists* ml) {
     const uint32_t tid = threadIdx.x;
     uint4 r0 = ((uint4*)acc)[2 * tid], r1 = ((uint4*)acc)[2 * tid + 1];
     if (MO.partial_mode) {
@@ -237,7 +306,7 @@ __device__ void many_finalize(uint32_t* acc, uint16_t* stage, const ManyOut& MO,
     uint32_t r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
     const uint32_t rc = blk_sum(popc4(r0) + popc4(r1), sc->wsum);
     int ty = T_ARRAY;
-    if (rc == 65536u && MO.exact_or_many && ge - gs >= 2 && full_union_is_run(acc2, tmp, P, V, MO, gs, ge, sc)) {
+    if (rc == 65536u && MO.exact_or_many && ge - gs >= 2 && full_union_is_run(acc2, tmp, P, V, MO, gs, ge, sc, ml)) {
         if (tid == 0) {
             *(uint32_t*)(MO.O.arena + MO.O.off[g]) = 0xFFFF0000u;  // one run {value 0, length 0xFFFF}
             MO.O.meta[g] = pack_meta(T_RUN, 65536u, 1u);
@@ -257,6 +326,7 @@ __global__ __launch_bounds__(256) void k_many_l1(PoolView P, ManyView V, ManyOut
     __shared__ __attribute__((aligned(16))) uint32_t tmp[2048];
     __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];  // doubles as the replay image (8 KiB)
     __shared__ BlockScratch sc;
+    __shared__ ManyLists ml;
     const uint32_t G = *V.n_groups;
     const u64 U = *n_units;
     for (u64 u = blockIdx.x; u < U; u += gridDim.x) {
@@ -269,9 +339,9 @@ __global__ __launch_bounds__(256) void k_many_l1(PoolView P, ManyView V, ManyOut
         __syncthreads();
         lds_zero(acc);
         __syncthreads();
-        many_accumulate(acc, tmp, P, V, m0, m1, op, &sc);
+        many_accumulate(acc, tmp, P, V, m0, m1, op, &sc, &ml);
         if (nu == 1) {
-            many_finalize(acc, stage, MO, g, &sc, (uint32_t*)stage, tmp, P, V, gs, ge);
+            many_finalize(acc, stage, MO, g, &sc, (uint32_t*)stage, tmp, P, V, gs, ge, &ml);
         } else {
             uint4* po = (uint4*)(MO.partial + u * 1024ull);
             po[2 * threadIdx.x] = ((uint4*)acc)[2 * threadIdx.x];
@@ -286,6 +356,7 @@ __global__ __launch_bounds__(256) void k_many_l2(PoolView P, ManyView V, ManyOut
     __shared__ __attribute__((aligned(16))) uint32_t tmp[2048];
     __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];
     __shared__ BlockScratch sc;
+    __shared__ ManyLists ml;
     const uint32_t G = *V.n_groups;
     const uint32_t tid = threadIdx.x;
     for (uint32_t g = blockIdx.x; g < G; g += gridDim.x) {
@@ -301,7 +372,7 @@ __global__ __launch_bounds__(256) void k_many_l2(PoolView P, ManyView V, ManyOut
         ((uint4*)acc)[2 * tid] = r0;
         ((uint4*)acc)[2 * tid + 1] = r1;
         __syncthreads();
-        many_finalize(acc, stage, MO, g, &sc, (uint32_t*)stage, tmp, P, V, V.gstart[g], V.gstart[g + 1]);
+        many_finalize(acc, stage, MO, g, &sc, (uint32_t*)stage, tmp, P, V, V.gstart[g], V.gstart[g + 1], &ml);
     }
 }
 
