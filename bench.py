@@ -46,6 +46,9 @@ def parse_args():
     ap.add_argument("--pool", type=int, default=256, help="bitmaps in the pool")
     ap.add_argument("--containers", type=int, default=4096, help="bitset containers per bitmap")
     ap.add_argument("--pairs", type=int, default=250, help="bitmap pairs per batched call (2 calls per step)")
+    ap.add_argument("--workload", default="pairwise", choices=["pairwise", "ormany"],
+                    help="pairwise = the headline C2 line (default); ormany = SURVEY C4 sharded or_many (secondary)")
+    ap.add_argument("--bitmaps", type=int, default=100000, help="ormany: total sparse bitmaps over all ranks")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -127,6 +130,80 @@ def cpu_baseline(args, seconds: float):
                       f"(best of T={sweep}); {rate * args.containers * BB_BYTES_PER_PAIR / 1e9:.1f} GB/s algorithmic"}
 
 
+# ----------------------------------------------------------------------------- C4: sharded or_many (secondary workload)
+def c4_shard(n_bitmaps: int, seed: int):
+    """n_bitmaps sparse bitmaps, 32 array containers each (keys stratified over [0,4096), card uniform in
+    [1,512], values stratified over [0,65536)), packed back to back in portable format."""
+    rng = np.random.default_rng(seed)
+    NB, NK = n_bitmaps, 32
+    keys = (np.arange(NK, dtype=np.uint32)[None, :] * 128 + rng.integers(0, 128, (NB, NK), dtype=np.uint32))
+    cards = rng.integers(1, 513, (NB, NK), dtype=np.uint32)
+    ccum = np.concatenate([[0], np.cumsum(cards.ravel(), dtype=np.int64)])
+    total = int(ccum[-1])
+    cid = np.repeat(np.arange(NB * NK, dtype=np.int64), cards.ravel())
+    within = np.arange(total, dtype=np.int64) - ccum[cid]
+    stride = (65536 // cards.ravel().astype(np.int64))[cid]
+    vals = (within * stride + (rng.integers(0, 1 << 30, total, dtype=np.int64) % stride)).astype(np.uint16)
+    hdr = 8 + 8 * NK
+    per_bm = cards.sum(1).astype(np.int64) * 2 + hdr
+    offs = np.concatenate([[0], np.cumsum(per_bm)]).astype(np.int64)
+    blob = np.zeros(int(offs[-1]), dtype=np.uint8)
+    h32 = np.zeros((NB, hdr // 4), dtype=np.uint32)
+    h32[:, 0] = 12346
+    h32[:, 1] = NK
+    h32[:, 2:2 + NK] = keys | ((cards - 1) << 16)
+    inner = np.concatenate([np.zeros((NB, 1), np.int64), np.cumsum(cards.astype(np.int64) * 2, 1)[:, :-1]], 1) + hdr
+    h32[:, 2 + NK:] = inner.astype(np.uint32)
+    blob[(offs[:-1, None] + np.arange(hdr)[None, :]).ravel()] = h32.view(np.uint8).ravel()
+    vstart = np.concatenate([[0], np.cumsum(cards.sum(1).astype(np.int64))])
+    bm = cid // NK
+    pos = offs[bm] + hdr + 2 * (np.arange(total, dtype=np.int64) - vstart[bm])
+    blob[pos] = (vals & 0xFF).astype(np.uint8)
+    blob[pos + 1] = (vals >> 8).astype(np.uint8)
+    return blob, offs[:-1], per_bm
+
+
+def run_ormany(args, eng, rank, world, barrier):
+    """Strong scaling: --bitmaps sparse bitmaps in total, rank r holds bitmaps/world of them; one step = one
+    or_many over ALL of them = per-rank partial chunks -> key-owner exchange over RCCL -> owner finalize."""
+    import torch.distributed as dist
+    from croaring_amd.distributed import many_sharded
+    n_local = args.bitmaps // world
+    blob, offs, lens = c4_shard(n_local, 4 + 1000 * rank + world)
+    pool = eng.pool_from_packed(blob, offs, lens)
+    payload = pool.payload_bytes()
+
+    def step():
+        return many_sharded(eng, pool, "or") if world > 1 else eng.or_many(pool)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tot_payload = payload
+    if world > 1:
+        import torch
+        t = torch.tensor([dt, float(payload)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, tot_payload = float(tmax[0].item()), float(t[1].item())
+    return {
+        "metric": "set-ops/sec + GB/s (pairwise AND/OR; or_many) on realdata, 1/2/4/8 GPU",
+        "value": args.steps / dt, "unit": "or_many-ops/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"C4 or_many over {n_local * world} sparse bitmaps x 32 array containers, "
+                               f"sharded {n_local} per GPU, key-owner exchange over RCCL",
+                   "algorithmic_GBps": tot_payload * args.steps / dt / 1e9,
+                   "result_cardinality_rank0": int(out.cardinalities()[0])},
+    }
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     args = parse_args()
@@ -144,13 +221,20 @@ def main():
     eng = croaring_amd.Engine(local_rank)
     eng.set_timing(True)
 
-    pool = eng.pool_synth_bitset(args.pool, args.containers, SEED + 1000003 * rank)
-    n_cont = pool.n_containers
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.workload == "ormany":
+        out = run_ormany(args, eng, rank, world, barrier)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    pool = eng.pool_synth_bitset(args.pool, args.containers, SEED + 1000003 * rank)
 
     results = {"and": None, "or": None}
     bb_ms, bb_pairs = [], []

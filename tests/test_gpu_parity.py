@@ -314,3 +314,46 @@ def test_full_size_properties(engine):
     # or_many over 16 half-dense bitmaps: every chunk fills up (65536 * (1 - 2^-16) expected)
     u = engine.or_many(pool, np.arange(16, dtype=np.uint32))
     assert u.n_containers == 4096 and int(u.cardinalities()[0]) > 4096 * 65530
+
+
+def test_directory_and_payload_extremes(engine, oracle):
+    """Key-merge and slot-sizing extremes: a bitmap with all 65536 container keys, a non-efficient run
+    container whose payload exceeds 8192 bytes (passes through unchanged, roaring.c:914-941), and
+    operands whose directories differ by four orders of magnitude."""
+    import struct
+    # (1) every key present, one value each -> 65536 array containers
+    allkeys = (np.arange(65536, dtype=np.uint32) << 16) | (np.arange(65536, dtype=np.uint32) % 7)
+    a = oracle.from_sorted(allkeys)
+    # (2) a run container with 3000 runs (12000-byte payload): valid, just not run-efficient -- built by hand
+    starts = np.arange(3000, dtype=np.uint32) * 20
+    runs = np.stack([starts, np.full(3000, 9, np.uint32)], 1).astype(np.uint16)      # [s, s+9]
+    payload = struct.pack("<H", 3000) + runs.tobytes()
+    card = 3000 * 10
+    big = struct.pack("<I", 12347 | (0 << 16)) + b"\x01" + struct.pack("<HH", 3, card - 1) + payload
+    hb = oracle.deserialize(big)
+    assert oracle.validate(hb) and oracle.serialize(hb) == big
+    # (3) a small bitmap
+    c = oracle.from_sorted(np.array([5, (3 << 16) | 7, (3 << 16) | 100, (70 << 16) | 1], dtype=np.uint32))
+    hs = [a, hb, c]
+    bufs = [oracle.serialize(h) for h in hs]
+    pool = engine.pool_from_serialized(bufs)
+    assert pool.serialize(1) == big
+    idx = [(i, j) for i in range(3) for j in range(3)]
+    lhs = np.array([i for i, _ in idx], np.uint32)
+    rhs = np.array([j for _, j in idx], np.uint32)
+    for op in OPS:
+        res = engine.pairwise(op, pool, lhs, pool, rhs)
+        cards = engine.pairwise_cardinality(op, pool, lhs, pool, rhs)
+        for k, (i, j) in enumerate(idx):
+            oo = oracle.op(op, hs[i], hs[j])
+            assert res.serialize(k) == oracle.serialize(oo), (op, i, j)
+            assert cards[k] == oracle.cardinality(oo)
+            oracle.free(oo)
+    for nm, fn, of in (("or", engine.or_many, oracle.or_many), ("xor", engine.xor_many, oracle.xor_many)):
+        got = oracle.deserialize(fn(pool).serialize(0))
+        want = of(hs)
+        assert np.array_equal(oracle.to_array(got), oracle.to_array(want)), nm
+        oracle.free(got)
+        oracle.free(want)
+    for h in hs:
+        oracle.free(h)
