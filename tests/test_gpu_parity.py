@@ -357,3 +357,38 @@ def test_directory_and_payload_extremes(engine, oracle):
         oracle.free(want)
     for h in hs:
         oracle.free(h)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_randomized_pools(engine, oracle, seed):
+    """Randomised differential test through the C ABI: 120 multi-key bitmaps of mixed container profiles,
+    600 random pairs x 4 ops (+ cardinalities) against the oracle, byte level; random or_many subsets."""
+    from gen_inputs import random_bitmap
+    rng = np.random.default_rng(seed)
+    hs = [oracle.from_sorted(random_bitmap(rng, max_keys=10, key_space=14)) for _ in range(120)]
+    bufs = [oracle.serialize(h) for h in hs]
+    pool = engine.pool_from_serialized(bufs)
+    lhs = rng.integers(0, 120, 600).astype(np.uint32)
+    rhs = rng.integers(0, 120, 600).astype(np.uint32)
+    for op in OPS:
+        res = engine.pairwise(op, pool, lhs, pool, rhs)
+        cards = engine.pairwise_cardinality(op, pool, lhs, pool, rhs)
+        bad = []
+        for k in range(600):
+            oo = oracle.op(op, hs[lhs[k]], hs[rhs[k]])
+            if res.serialize(k) != oracle.serialize(oo) or cards[k] != oracle.cardinality(oo):
+                bad.append(k)
+            oracle.free(oo)
+        assert not bad, f"seed {seed} {op}: {len(bad)} mismatches, first {bad[:5]}"
+    for _ in range(12):
+        ids = rng.choice(120, int(rng.integers(2, 40)), replace=False).astype(np.uint32)
+        want = oracle.or_many([hs[i] for i in ids])
+        assert engine.or_many(pool, ids).serialize(0) == oracle.serialize(want)
+        oracle.free(want)
+        wx = oracle.xor_many([hs[i] for i in ids])
+        gx = oracle.deserialize(engine.xor_many(pool, ids).serialize(0))
+        assert np.array_equal(oracle.to_array(gx), oracle.to_array(wx))
+        oracle.free(wx)
+        oracle.free(gx)
+    for h in hs:
+        oracle.free(h)
