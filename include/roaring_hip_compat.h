@@ -12,6 +12,8 @@
  *   roaring_bitmap_andnot_cardinality roaring.h:264  roaring_bitmap_xor_cardinality roaring.h:270
  *   roaring_bitmap_or_many        roaring.h:304    roaring_bitmap_or_many_heap      roaring.h:312
  *   roaring_bitmap_xor_many       roaring.h:334
+ *   roaring_bitmap_lazy_or(_inplace) roaring.h:932,944   roaring_bitmap_lazy_xor(_inplace) roaring.h:968,976
+ *   roaring_bitmap_repair_after_lazy roaring.h:954
  *
  * They operate on the reference's own host structs (roaring_bitmap_t / roaring_array_t and the three
  * container structs are part of CRoaring's ABI, include/roaring/roaring_types.h:61-68,
@@ -36,6 +38,9 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#ifdef __cplusplus
+#define _Bool bool
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -62,6 +67,14 @@ uint64_t roaring_bitmap_xor_cardinality(const roaring_bitmap_t *r1, const roarin
 roaring_bitmap_t *roaring_bitmap_or_many(size_t number, const roaring_bitmap_t **rs);
 roaring_bitmap_t *roaring_bitmap_or_many_heap(uint32_t number, const roaring_bitmap_t **rs);
 roaring_bitmap_t *roaring_bitmap_xor_many(size_t number, const roaring_bitmap_t **rs);
+
+/* lazy family, roaring.h:932-978: eager on the device (results are always canonical);
+ * repair_after_lazy re-canonicalises any bitmap (also one left unrepaired by the reference's lazy ops) */
+roaring_bitmap_t *roaring_bitmap_lazy_or(const roaring_bitmap_t *r1, const roaring_bitmap_t *r2, const _Bool bitsetconversion);
+void roaring_bitmap_lazy_or_inplace(roaring_bitmap_t *r1, const roaring_bitmap_t *r2, const _Bool bitsetconversion);
+roaring_bitmap_t *roaring_bitmap_lazy_xor(const roaring_bitmap_t *r1, const roaring_bitmap_t *r2);
+void roaring_bitmap_lazy_xor_inplace(roaring_bitmap_t *r1, const roaring_bitmap_t *r2);
+void roaring_bitmap_repair_after_lazy(roaring_bitmap_t *r1);
 
 #ifdef __cplusplus
 }

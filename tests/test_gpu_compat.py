@@ -88,3 +88,38 @@ def test_dropin_many(hip, ref):
             ref.free(want)
         for h in hs:
             ref.free(h)
+
+
+def test_dropin_lazy_family(hip, ref):
+    """lazy_or / lazy_xor are eager on the device; repair_after_lazy must also canonicalise a bitmap that
+    the REFERENCE's lazy functions left unrepaired (unknown bitset cardinalities, non-efficient runs)."""
+    vp = C.c_void_p
+    hip.roaring_bitmap_lazy_or.restype = vp; hip.roaring_bitmap_lazy_or.argtypes = [vp, vp, C.c_bool]
+    hip.roaring_bitmap_lazy_xor.restype = vp; hip.roaring_bitmap_lazy_xor.argtypes = [vp, vp]
+    hip.roaring_bitmap_lazy_or_inplace.restype = None; hip.roaring_bitmap_lazy_or_inplace.argtypes = [vp, vp, C.c_bool]
+    hip.roaring_bitmap_lazy_xor_inplace.restype = None; hip.roaring_bitmap_lazy_xor_inplace.argtypes = [vp, vp]
+    hip.roaring_bitmap_repair_after_lazy.restype = None; hip.roaring_bitmap_repair_after_lazy.argtypes = [vp]
+    R = ref.L
+    R.roaring_bitmap_lazy_or.restype = vp; R.roaring_bitmap_lazy_or.argtypes = [vp, vp, C.c_bool]
+    R.roaring_bitmap_lazy_xor.restype = vp; R.roaring_bitmap_lazy_xor.argtypes = [vp, vp]
+    R.roaring_bitmap_lazy_or_inplace.restype = None; R.roaring_bitmap_lazy_or_inplace.argtypes = [vp, vp, C.c_bool]
+    rng = np.random.default_rng(8)
+    for it in range(15):
+        a, b, c = (ref.from_sorted(random_bitmap(rng)) for _ in range(3))
+        want_or, want_xor = ref.op("or", a, b), ref.op("xor", a, b)
+        got = hip.roaring_bitmap_lazy_or(a, b, bool(it & 1))
+        assert ref.validate(got) and ref.serialize(got) == ref.serialize(want_or)
+        gx = hip.roaring_bitmap_lazy_xor(a, b)
+        assert ref.validate(gx) and ref.serialize(gx) == ref.serialize(want_xor)
+        # reference-made lazy bitmap (a | b | c, unrepaired) repaired by OUR repair_after_lazy
+        lazy = R.roaring_bitmap_lazy_or(a, b, bool(it & 1))
+        R.roaring_bitmap_lazy_or_inplace(lazy, c, bool(it & 1))
+        hip.roaring_bitmap_repair_after_lazy(lazy)
+        abc = ref.op("or", want_or, c)
+        assert ref.validate(lazy)
+        assert np.array_equal(ref.to_array(lazy), ref.to_array(abc)), it
+        lx = R.roaring_bitmap_lazy_xor(a, b)
+        hip.roaring_bitmap_repair_after_lazy(lx)
+        assert ref.validate(lx) and np.array_equal(ref.to_array(lx), ref.to_array(want_xor))
+        for h in (a, b, c, want_or, want_xor, got, gx, lazy, abc, lx):
+            ref.free(h)

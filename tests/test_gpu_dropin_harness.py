@@ -1,6 +1,6 @@
 """SURVEY G13 acceptance harness on the GPU: the reference's own UNMODIFIED tests/toplevel_unit.c
 (169 registered tests, prebuilt by `make -C oracle dropin` into oracle/_ref/toplevel_unit_dropin) with
-the 15 hot-path symbols resolved to libroaring_hip.so and everything else to the (symbol-renamed)
+the 20 hot-path symbols (incl. the lazy family) resolved to libroaring_hip.so and everything else to the (symbol-renamed)
 reference library."""
 import os
 import re
