@@ -756,7 +756,7 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
     if (!cardmode && ((R.n_bb && op != OP_OR) || R.n_runs)) {
         // results that need the LDS image path after all: bitset x bitset results that must become
         // arrays (card <= 4096), interval results that must become bitsets
-        unsigned g2 = persistent_grid(R.n_bb + R.n_runs, 4, 256 * 4);
+        unsigned g2 = persistent_grid(R.n_bb + R.n_runs, 4, 256 * 2);  // 248 VGPRs: 2 workgroups resident per CU
         hipLaunchKernelGGL(k_genw, dim3(g2), dim3(256), 0, s, VA.arena, VB.arena, O, c->q[CLS_RETRY].as<GenItem>(),
                            (const u64*)nullptr, retry_count, op, 0, c->pair_acc.as<u64>());
     }
@@ -771,7 +771,7 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
                            ranges + 2 * SEC_WAVE, op);
     }
     if (R.n_gen) {
-        unsigned grid = persistent_grid(R.n_gen, 4, 256 * 4);
+        unsigned grid = persistent_grid(R.n_gen, 4, 256 * 2);  // 248 VGPRs: 2 workgroups resident per CU
         hipLaunchKernelGGL(k_genw, dim3(grid), dim3(256), 0, s, VA.arena, VB.arena, O, c->q[CLS_GEN].as<GenItem>(),
                            ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, cardmode, c->pair_acc.as<u64>());
     }

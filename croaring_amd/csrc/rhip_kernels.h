@@ -541,8 +541,12 @@ __global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ aren
     uint32_t* img = img_all[threadIdx.x >> 6];
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
-        const FatItem t = q[w];
+    uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    FatItem tnext;
+    if (w < n) tnext = q[w];
+    for (; w < n; w += nwaves) {
+        const FatItem t = tnext;
+        if (w + nwaves < n) tnext = q[w + nwaves];  // next work item in flight while this one is processed
         const uint8_t ta = (uint8_t)(t.types & 0xFF), tb = (uint8_t)(t.types >> 8);
         const uint32_t ca = t.ca, cb = t.cb;
         // Y = the streamed array, X = the membership side
@@ -554,6 +558,9 @@ __global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ aren
         const bool x_bitset = (y_is_a ? tb : ta) == T_BITSET;
         const bool keep_present = op == OP_AND;
         const uint32_t* __restrict__ xw = (const uint32_t*)xp;
+        const uint4* __restrict__ y4 = (const uint4*)yp;
+        uint4 yfirst = make_uint4(0, 0, 0, 0);
+        if (8 * lane < ny) yfirst = y4[lane];  // first 512 values of Y: in flight during the X scatter
         if (!x_bitset) {
             const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
@@ -572,13 +579,12 @@ __global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ aren
             }
             __builtin_amdgcn_wave_barrier();
         }
-        const uint4* __restrict__ y4 = (const uint4*)yp;
         uint16_t* __restrict__ out = cardmode ? nullptr : (uint16_t*)(O.arena + O.off[t.out]);
         uint32_t run = 0;
         for (uint32_t base = 0; base < ny; base += 512) {
             const uint32_t i0 = base + 8 * lane;
-            uint4 q4 = make_uint4(0, 0, 0, 0);
-            if (i0 < ny) q4 = y4[(base >> 3) + lane];
+            uint4 q4 = yfirst;
+            if (base) q4 = (i0 < ny) ? y4[(base >> 3) + lane] : make_uint4(0, 0, 0, 0);
             const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
             uint32_t vals[8];
             uint32_t keepmask = 0;
@@ -814,8 +820,12 @@ __global__ __launch_bounds__(256) void k_runs(const uint8_t* __restrict__ arenaA
     uint16_t* RE = RS + NB;                                       // result run ends (inclusive)
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    for (uint32_t wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wi < n; wi += nwaves) {
-        const GenItem t = q[wi];
+    uint32_t wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    GenItem tnext;
+    if (wi < n) tnext = q[wi];
+    for (; wi < n; wi += nwaves) {
+        const GenItem t = tnext;
+        if (wi + nwaves < n) tnext = q[wi + nwaves];  // next work item in flight while this one is processed
         const uint32_t ta = t.types & 0xFFu, tb = t.types >> 8;
         IvList L[2];
         L[0].p = lsA; L[0].is_run = ta == T_RUN; L[0].n2 = 2u * (ta == T_RUN ? t.nra : t.ca);

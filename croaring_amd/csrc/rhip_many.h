@@ -148,7 +148,7 @@ __device__ void many_accumulate_chunk(uint32_t* acc, uint32_t* tmp, const PoolVi
     many_swizzle_pass(acc);  // linear -> swizzled (ends with a barrier)
     // phase A: array members, LDS atomics (commutative: no ordering needed).  Each wave takes 64
     // members at a time: their directory entries are fetched lane-parallel (one member per lane) and
-    // broadcast with shuffles, and members are consumed eight at a time so that eight independent
+    // broadcast with shuffles, and members are consumed four at a time so that four independent
     // 16-byte payload loads per lane are in flight before the first LDS atomic needs one of them
     // (a member is a few hundred bytes at a random arena offset: this loop is latency-, not
     // bandwidth-limited unless loads overlap).
@@ -169,12 +169,12 @@ __device__ void many_accumulate_chunk(uint32_t* acc, uint32_t* tmp, const PoolVi
             }
         }
         const uint32_t cnt = (uint32_t)((m1 - mb) < 64 ? (m1 - mb) : 64);
-        for (uint32_t k = 0; k < cnt; k += 8) {
-            uint4 q4[8];
-            uint32_t cdk[8];
-            const uint4* pk[8];
+        for (uint32_t k = 0; k < cnt; k += 4) {
+            uint4 q4[4];
+            uint32_t cdk[4];
+            const uint4* pk[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 const uint32_t src = (k + u < cnt) ? k + u : k;
                 cdk[u] = (k + u < cnt) ? __shfl(cd, src) : 0u;
                 const u64 of = (u64)__shfl(of_lo, src) | ((u64)__shfl(of_hi, src) << 32);
@@ -182,7 +182,7 @@ __device__ void many_accumulate_chunk(uint32_t* acc, uint32_t* tmp, const PoolVi
                 q4[u] = (8 * lane < cdk[u]) ? pk[u][lane] : make_uint4(0, 0, 0, 0);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 for (uint32_t i = lane; 8 * i < cdk[u]; i += 64) {
                     const uint4 x = (i == lane) ? q4[u] : pk[u][i];
                     const uint32_t d[4] = {x.x, x.y, x.z, x.w};
