@@ -1,0 +1,30 @@
+"""C2 pool (256 x 4096 bitset containers): every pairwise op and the cardinality-only form, ms per 250-pair batch."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch  # noqa
+import croaring_amd, bench
+eng = croaring_amd.Engine(0); eng.set_timing(True)
+pool = eng.pool_synth_bitset(256, 4096, bench.SEED)
+res = None
+for op in ("and", "or", "xor", "andnot"):
+    ts, ks = [], []
+    for i in range(7):
+        lhs, rhs = bench.schedule(i * 250, 250, 256)
+        t0 = time.perf_counter(); res = eng.pairwise(op, pool, lhs, pool, rhs, reuse=res); dt = time.perf_counter() - t0
+        st = eng.last_stats()
+        if i >= 2: ts.append(dt); ks.append(st["ms_bitset_kernel"])
+    t, k = float(np.mean(ts)), float(np.mean(ks))
+    print(json.dumps({"op": op, "ms_call": t * 1e3, "ops_per_s": 250 / t, "alg_GBps": 250 * 4096 * 24576 / t / 1e9,
+                      "k_bb_ms": k, "k_bb_GBps": 250 * 4096 * 24576 / k / 1e6}), flush=True)
+for op in ("and", "or"):
+    ts, ks = [], []
+    for i in range(7):
+        lhs, rhs = bench.schedule(i * 250, 250, 256)
+        t0 = time.perf_counter(); c = eng.pairwise_cardinality(op, pool, lhs, pool, rhs); dt = time.perf_counter() - t0
+        st = eng.last_stats()
+        if i >= 2: ts.append(dt); ks.append(st["ms_bitset_kernel"])
+    t, k = float(np.mean(ts)), float(np.mean(ks))
+    print(json.dumps({"op": op + "_cardinality", "ms_call": t * 1e3, "ops_per_s": 250 / t, "alg_GBps": 250 * 4096 * 16384 / t / 1e9,
+                      "k_bb_ms": k, "k_bb_GBps": 250 * 4096 * 16384 / k / 1e6}), flush=True)
