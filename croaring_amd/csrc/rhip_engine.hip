@@ -84,8 +84,9 @@ struct rhip_pool_s {
     bool is64 = false;
     DBuf bm_start, key, type, card, nruns, off, arena;
     uint64_t arena_used = 0;
-    // host mirror of the directory (filled lazily for serialization)
+    // host mirror of the directory (filled lazily for serialization); planning only needs bm_start
     bool host_dir = false;
+    bool host_bm = false;
     std::vector<uint64_t> h_bm_start, h_key, h_off;
     std::vector<uint8_t> h_type;
     std::vector<uint32_t> h_card, h_nruns;
@@ -431,6 +432,14 @@ extern "C" rhip_pool_t* rhip_pool_synth_bitset(rhip_ctx_t* ctx, uint32_t n_bitma
 }
 
 // ------------------------------------------------------------------ download (portable format)
+static void fetch_bm_start(rhip_pool_t* P) {
+    if (P->host_dir || P->host_bm) return;
+    P->h_bm_start.resize((size_t)P->n_bitmaps + 1);
+    HIPCHK(hipMemcpyAsync(P->h_bm_start.data(), P->bm_start.p, 8 * P->h_bm_start.size(), hipMemcpyDeviceToHost,
+                          P->ctx->stream));
+    HIPCHK(hipStreamSynchronize(P->ctx->stream));
+    P->host_bm = true;
+}
 static void fetch_dir(rhip_pool_t* P) {
     if (P->host_dir) return;
     hipStream_t s = P->ctx->stream;
@@ -623,6 +632,7 @@ void launch_bb(rhip_ctx_t* c, unsigned grid, const PoolView& A, const PoolView& 
 void check_pair_args(rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs, const uint32_t* rhs) {
     if (!A || !B) { set_err("null pool"); throw (int)RHIP_ERR_ARG; }
     if (A->is64 != B->is64) { set_err("mixing 32-bit and 64-bit pools"); throw (int)RHIP_ERR_ARG; }
+    if (A->ctx->device != B->ctx->device) { set_err("operand pools live on different devices"); throw (int)RHIP_ERR_ARG; }
     if (npairs >= 0x3FFFFFF0ull) { set_err("too many pairs"); throw (int)RHIP_ERR_ARG; }
     for (size_t i = 0; i < npairs; ++i)
         if (lhs[i] >= A->n_bitmaps || rhs[i] >= B->n_bitmaps) {
@@ -638,8 +648,8 @@ PlanResult plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t np
     hipStream_t s = c->stream;
     PlanResult R;
     // ---- units (host: directory mirrors) + upper bounds, no sync needed
-    if (!A->host_dir) fetch_dir(A);
-    if (!B->host_dir) fetch_dir(B);
+    fetch_bm_start(A);
+    fetch_bm_start(B);
     const bool btiles = !cardmode && (op == OP_OR || op == OP_XOR);
     std::vector<uint32_t> upair, utile;
     std::vector<uint64_t> pair0(npairs + 1);
@@ -827,6 +837,7 @@ extern "C" rhip_pool_t* rhip_pairwise(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A
         R->n_bitmaps = (uint32_t)npairs;
         R->is64 = A->is64;
         R->host_dir = false;
+        R->host_bm = false;
         R->h_cards.clear();
         ensure_dir(R, (uint32_t)npairs, P.total_cand);
         R->arena.ensure(P.total_bytes + 64);
