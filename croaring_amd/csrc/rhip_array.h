@@ -1,0 +1,236 @@
+// rhip_array.h -- wave-per-pair kernels for pairs with an array operand: k_filter (and / andnot), k_wave (or / xor / bitset \\ array)
+#pragma once
+#include "rhip_common.h"
+
+// ------------------------------------------------------------------ array filter (K8, K9, K12)
+// One WAVE per container pair, no workgroup barriers: the array operand Y is streamed 64 values at
+// a time, each lane tests its value for membership in X and survivors are compacted with a ballot +
+// mbcnt prefix.  X = bitset: one gathered dword test per value (array_bitset_container_intersection
+// / _andnot, mixed_intersection.c:19-46, mixed_andnot.c:24-39).  X = array: X is first scattered into
+// a wave-private 8 KiB LDS bitset (ds_or_b32), replacing the SIMD merge / galloping intersections of
+// array_util.c:385-459, 801-906 (intersect_vector16, intersect_skewed_uint16) and difference_uint16.
+// The result is always an array (containers.h:741-746, 1799-1803).
+__global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                                OutView O, const FatItem* __restrict__ q,
+                                                const u64* __restrict__ qrange, int op, int cardmode,
+                                                u64* pair_acc) {
+    __shared__ __attribute__((aligned(16))) uint32_t img_all[4][2048];
+    const uint32_t lane = lane_id();
+    uint32_t* img = img_all[threadIdx.x >> 6];
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
+    uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    FatItem tnext;
+    if (w < n) tnext = q[w];
+    for (; w < n; w += nwaves) {
+        const FatItem t = tnext;
+        if (w + nwaves < n) tnext = q[w + nwaves];  // next work item in flight while this one is processed
+        const uint8_t ta = (uint8_t)(t.types & 0xFF), tb = (uint8_t)(t.types >> 8);
+        const uint32_t ca = t.ca, cb = t.cb;
+        // Y = the streamed array, X = the membership side
+        bool y_is_a = true;
+        if (op == OP_AND) y_is_a = (ta == T_ARRAY) && (tb != T_ARRAY || ca <= cb);
+        const uint8_t* yp = y_is_a ? arenaA + t.offa : arenaB + t.offb;
+        const uint8_t* xp = y_is_a ? arenaB + t.offb : arenaA + t.offa;
+        const uint32_t ny = y_is_a ? ca : cb, nx = y_is_a ? cb : ca;
+        const bool x_bitset = (y_is_a ? tb : ta) == T_BITSET;
+        const bool keep_present = op == OP_AND;
+        const uint32_t* __restrict__ xw = (const uint32_t*)xp;
+        const uint4* __restrict__ y4 = (const uint4*)yp;
+        uint4 yfirst = make_uint4(0, 0, 0, 0);
+        if (8 * lane < ny) yfirst = y4[lane];  // first 512 values of Y: in flight during the X scatter
+        if (!x_bitset) {
+            const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ((uint4*)img)[i * 64 + lane] = z;
+            const uint4* __restrict__ x4 = (const uint4*)xp;  // 8 values per lane per step (slots are 16-byte padded)
+            for (uint32_t i = lane; 8 * i < nx; i += 64) {
+                const uint4 q4 = x4[i];
+                const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    if (8 * i + h < nx) {
+                        const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                        atomicOr(&img[v >> 5], 1u << (v & 31));
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        uint16_t* __restrict__ out = cardmode ? nullptr : (uint16_t*)(O.arena + O.off[t.out]);
+        uint32_t run = 0;
+        for (uint32_t base = 0; base < ny; base += 512) {
+            const uint32_t i0 = base + 8 * lane;
+            uint4 q4 = yfirst;
+            if (base) q4 = (i0 < ny) ? y4[(base >> 3) + lane] : make_uint4(0, 0, 0, 0);
+            const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
+            uint32_t vals[8];
+            uint32_t keepmask = 0;
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                vals[h] = v;
+                const uint32_t word = x_bitset ? xw[v >> 5] : img[v >> 5];
+                const bool present = (word >> (v & 31)) & 1u;
+                if (i0 + h < ny && present == keep_present) keepmask |= 1u << h;
+            }
+            const uint32_t cnt = __popc(keepmask);
+            const uint32_t inc = wave_incl_scan(cnt);
+            if (!cardmode) {
+                uint32_t pos = run + inc - cnt;
+#pragma unroll
+                for (int h = 0; h < 8; ++h)
+                    if ((keepmask >> h) & 1u) out[pos++] = (uint16_t)vals[h];
+            }
+            run += __shfl(inc, 63);
+        }
+        if (cardmode) {
+            if (lane == 0 && run) atomicAdd(&pair_acc[t.out], (u64)run);
+        } else if (lane == 0) {
+            O.meta[t.out] = pack_meta(T_ARRAY, run, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------ wave-private LDS image kernel (K6, K10, K11)
+// One WAVE per container pair for {array,bitset} x {array,bitset} pairs with at least one array under
+// or / xor, and bitset \ array.  The wave owns an 8 KiB LDS image: X is loaded into it (bitset: 8
+// coalesced 16-byte loads per lane; array: zero + ds_or scatter), then Y's values are applied with
+// returning LDS atomics (ds_or_rtn / ds_xor_rtn / ds_and_rtn) whose old values give the cardinality
+// delta -- bitset_set_list_withcard / bitset_flip_list_withcard / bitset_clear_list
+// (bitset_util.c:978-1141) without their serial dependence.  The result is typed by the reference's
+// rules and either streamed out as a bitset or extracted as a sorted array (lane owns 32 consecutive
+// words; wave prefix sum of popcounts).  No workgroup barrier anywhere.
+__global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                              OutView O, const FatItem* __restrict__ q,
+                                              const u64* __restrict__ qrange, int op) {
+    __shared__ __attribute__((aligned(16))) uint32_t img_all[4][2048];
+    const uint32_t lane = lane_id();
+    uint32_t* img = img_all[threadIdx.x >> 6];
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
+    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
+        const FatItem t = q[w];
+        const uint8_t ta = (uint8_t)(t.types & 0xFF), tb = (uint8_t)(t.types >> 8);
+        const uint32_t ca = t.ca, cb = t.cb;
+        // X = image side, Y = applied array.  andnot: X = a (bitset), Y = b.  or/xor are symmetric:
+        // take the bitset (or the larger array) as X.
+        bool x_is_a = true;
+        if (op != OP_ANDNOT) x_is_a = (ta == T_BITSET) || (tb != T_BITSET && ca >= cb);
+        const uint8_t tx = x_is_a ? ta : tb;
+        const uint32_t cx = x_is_a ? ca : cb, cy = x_is_a ? cb : ca;
+        const uint8_t* xp = x_is_a ? arenaA + t.offa : arenaB + t.offb;
+        const uint32_t* __restrict__ y2 = (const uint32_t*)(x_is_a ? arenaB + t.offb : arenaA + t.offa);
+        if (tx == T_BITSET) {
+            const uint4* __restrict__ g = (const uint4*)xp;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ((uint4*)img)[i * 64 + lane] = g[i * 64 + lane];
+        } else {
+            const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ((uint4*)img)[i * 64 + lane] = z;
+            const uint4* __restrict__ x4 = (const uint4*)xp;
+            for (uint32_t i = lane; 8 * i < cx; i += 64) {
+                const uint4 q4 = x4[i];
+                const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    if (8 * i + h < cx) {
+                        const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                        atomicOr(&img[v >> 5], 1u << (v & 31));
+                    }
+                }
+            }
+        }
+        int delta = 0;
+        {
+            const uint4* __restrict__ y4 = (const uint4*)y2;
+            for (uint32_t i = lane; 8 * i < cy; i += 64) {
+                const uint4 q4 = y4[i];
+                const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
+                uint32_t old[8], bit[8];
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                    bit[h] = (8 * i + h < cy) ? (1u << (v & 31)) : 0u;
+                    if (op == OP_OR) old[h] = atomicOr(&img[v >> 5], bit[h]);
+                    else if (op == OP_XOR) old[h] = atomicXor(&img[v >> 5], bit[h]);
+                    else old[h] = atomicAnd(&img[v >> 5], ~bit[h]);
+                }
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    if (bit[h]) {
+                        const bool was = (old[h] & bit[h]) != 0;
+                        if (op == OP_OR) delta += was ? 0 : 1;
+                        else if (op == OP_XOR) delta += was ? -1 : 1;
+                        else delta -= was ? 1 : 0;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) delta += __shfl_xor(delta, o);
+        const uint32_t rc = (uint32_t)((int)cx + delta);
+        int ty = T_ARRAY;
+        if (rc) ty = decide_type(op, ta, tb, ca, cb, false, false, rc, 0);
+        uint8_t* outp = O.arena + O.off[t.out];
+        __builtin_amdgcn_wave_barrier();
+        if (rc && ty == T_BITSET) {
+            uint4* __restrict__ po = (uint4*)outp;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) po[i * 64 + lane] = ((const uint4*)img)[i * 64 + lane];
+        } else if (rc) {
+            // Balanced extraction.  Words are owned strided (lane l: words 64 r + l), so clustered values
+            // spread over all lanes; the output position of each word comes from a two-level prefix:
+            // per-word popcounts -> LDS, each lane prefix-sums 32 CONSECUTIVE counts, one wave scan of the
+            // lane totals, word bases back to LDS.  The image is dead once the words are in registers,
+            // so its first 4 KiB hold the u16 count/base table.
+            uint32_t wv[32];
+#pragma unroll
+            for (int r = 0; r < 32; ++r) wv[r] = img[64 * r + lane];
+            __builtin_amdgcn_wave_barrier();
+            uint16_t* tab = (uint16_t*)img;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) tab[64 * r + lane] = (uint16_t)__popc(wv[r]);
+            __builtin_amdgcn_wave_barrier();
+            {
+                uint4 c4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c4[i] = ((const uint4*)tab)[4 * lane + i];
+                const uint32_t cw[16] = {c4[0].x, c4[0].y, c4[0].z, c4[0].w, c4[1].x, c4[1].y, c4[1].z, c4[1].w,
+                                         c4[2].x, c4[2].y, c4[2].z, c4[2].w, c4[3].x, c4[3].y, c4[3].z, c4[3].w};
+                uint32_t tot = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tot += (cw[i] & 0xFFFFu) + (cw[i] >> 16);
+                uint32_t base = wave_incl_scan(tot) - tot;
+                uint32_t ow[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t lo = base;
+                    base += cw[i] & 0xFFFFu;
+                    const uint32_t hi = base;
+                    base += cw[i] >> 16;
+                    ow[i] = lo | (hi << 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    ((uint4*)tab)[4 * lane + i] = make_uint4(ow[4 * i], ow[4 * i + 1], ow[4 * i + 2], ow[4 * i + 3]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint16_t* __restrict__ o16 = (uint16_t*)outp;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                uint32_t x = wv[r];
+                uint32_t pos = tab[64 * r + lane];
+                const uint32_t vbase = (64u * r + lane) * 32u;
+                while (x) {
+                    o16[pos++] = (uint16_t)(vbase + (__ffs((int)x) - 1));
+                    x &= x - 1;
+                }
+            }
+        }
+        if (lane == 0) O.meta[t.out] = pack_meta(ty, rc, 0);
+        __builtin_amdgcn_wave_barrier();
+    }
+}

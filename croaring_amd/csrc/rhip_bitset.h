@@ -1,0 +1,143 @@
+// rhip_bitset.h -- bitset x bitset streaming kernel (the HBM-roofline kernel), pass-through copy, synthetic C2 pool
+#pragma once
+#include "rhip_common.h"
+
+// ------------------------------------------------------------------ bitset x bitset (K1-K3)
+// One wave per container pair, persistent waves striding over the queue.  Each lane issues
+// 16 independent 16-byte loads (8 per operand) before the first use: 16 KiB in flight per
+// wave.  Result words stay in registers; popcount is fused; the typed result is written once.
+// Replaces bitset_container_{and,or,xor,andnot}{,_nocard,_justcard} (src/containers/bitset.c:
+// 343-942) and the two-pass justcard->nocard structure of mixed_intersection.c:305-325.
+__device__ __forceinline__ uint4 op4(int op, uint4 a, uint4 b) {
+    uint4 r;
+    switch (op) {
+        case OP_AND: r.x = a.x & b.x; r.y = a.y & b.y; r.z = a.z & b.z; r.w = a.w & b.w; break;
+        case OP_OR: r.x = a.x | b.x; r.y = a.y | b.y; r.z = a.z | b.z; r.w = a.w | b.w; break;
+        case OP_XOR: r.x = a.x ^ b.x; r.y = a.y ^ b.y; r.z = a.z ^ b.z; r.w = a.w ^ b.w; break;
+        default: r.x = a.x & ~b.x; r.y = a.y & ~b.y; r.z = a.z & ~b.z; r.w = a.w & ~b.w; break;
+    }
+    return r;
+}
+__device__ __forceinline__ uint32_t popc4(uint4 v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+
+// native 128-bit vector for the streaming kernel (the nontemporal builtins need a native vector type)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int OP>
+__device__ __forceinline__ u32x4 vop(u32x4 a, u32x4 b) {
+    if (OP == OP_AND) return a & b;
+    if (OP == OP_OR) return a | b;
+    if (OP == OP_XOR) return a ^ b;
+    return a & ~b;
+}
+__device__ __forceinline__ uint32_t vpopc(u32x4 v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_bb(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                            OutView O, const BBItem* __restrict__ q, const u64* __restrict__ qrange,
+                                            int cardmode, u64* pair_acc, GenItem* retry_q, uint32_t* retry_count) {
+    const uint32_t lane = lane_id();
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
+    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
+        const BBItem t = q[w];
+        const u32x4* __restrict__ pa = (const u32x4*)(arenaA + t.offa);
+        const u32x4* __restrict__ pb = (const u32x4*)(arenaB + t.offb);
+        u32x4 va[8], vb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) va[i] = __builtin_nontemporal_load(pa + i * 64 + lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vb[i] = __builtin_nontemporal_load(pb + i * 64 + lane);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            va[i] = vop<OP>(va[i], vb[i]);
+            cnt += vpopc(va[i]);
+        }
+        const uint32_t card = wave_sum(cnt);
+        if (cardmode) {
+            if (lane == 0 && card) atomicAdd(&pair_acc[t.out], (u64)card);
+            continue;
+        }
+        // result typing: OR is always a bitset (containers.h:1015-1020); and/xor/andnot are a
+        // bitset iff card > 4096 (mixed_intersection.c:305-325, mixed_xor.c:260-273,
+        // mixed_andnot.c:482-497)
+        if (OP == OP_OR || card > 4096u) {
+            u32x4* __restrict__ po = (u32x4*)(O.arena + O.off[t.out]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) __builtin_nontemporal_store(va[i], po + i * 64 + lane);
+            if (lane == 0) O.meta[t.out] = pack_meta(T_BITSET, card, 0);
+        } else if (card == 0) {
+            if (lane == 0) O.meta[t.out] = pack_meta(T_ARRAY, 0, 0);
+        } else {
+            // rare: result becomes an array -> re-queue for the LDS extraction kernel
+            if (lane == 0) {
+                GenItem g;
+                g.offa = t.offa; g.offb = t.offb; g.out = t.out; g.ca = 65536u; g.cb = 65536u;
+                g.types = (uint32_t)T_BITSET | ((uint32_t)T_BITSET << 8);
+                g.nra = 0; g.nrb = 0; g.pad0 = 0; g.pad1 = 0;
+                retry_q[atomicAdd(retry_count, 1u)] = g;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ pass-through copy
+__global__ __launch_bounds__(256) void k_copy(PoolView A, PoolView B, OutView O, const Item* __restrict__ q,
+                                              const u64* __restrict__ qrange) {
+    const uint32_t lane = lane_id();
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
+    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
+        Item t = q[w];
+        const PoolView& S = (t.b == NONE32) ? A : B;
+        const uint32_t c = (t.b == NONE32) ? t.a : t.b;
+        const uint8_t ty = S.type[c];
+        const uint32_t card = S.card[c], nr = S.nruns[c];
+        const uint32_t n16 = (payload_bytes(ty, card, nr) + 15u) >> 4;
+        const uint4* __restrict__ ps = (const uint4*)(S.arena + S.off[c]);
+        uint4* __restrict__ po = (uint4*)(O.arena + O.off[t.out]);
+        for (uint32_t i = lane; i < n16; i += 64) po[i] = ps[i];
+        if (lane == 0) O.meta[t.out] = pack_meta(ty, card, nr);
+    }
+}
+
+
+
+
+// ------------------------------------------------------------------ synthetic C2 pool
+__device__ __forceinline__ u64 splitmix64_at(u64 seed, u64 idx) {  // idx-th output (1-based) of splitmix64(seed)
+    u64 z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void k_synth_fill(u64* words, uint32_t n_bitmaps, uint32_t n_containers, u64 seed) {
+    const u64 per_bm = (u64)n_containers * 1024ull;
+    const u64 total = per_bm * n_bitmaps;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x) {
+        u64 b = i / per_bm, w = i % per_bm;
+        words[i] = splitmix64_at(seed + b, w + 1);
+    }
+}
+__global__ __launch_bounds__(256) void k_synth_dir(const u64* words, uint32_t n_bitmaps, uint32_t n_containers,
+                                                   u64* bm_start, u64* key, uint8_t* type, uint32_t* card,
+                                                   uint32_t* nruns, u64* off) {
+    // one wave per container: popcount its 1024 words
+    u64 c = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const u64 total = (u64)n_bitmaps * n_containers;
+    if (c >= total) return;
+    const uint4* p = (const uint4*)(words + c * 1024ull);
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cnt += popc4(p[i * 64 + lane_id()]);
+    cnt = wave_sum(cnt);
+    if (lane_id() == 0) {
+        key[c] = c % n_containers;
+        type[c] = T_BITSET;
+        card[c] = cnt;
+        nruns[c] = 0;
+        off[c] = c * 8192ull;
+        if (c % n_containers == 0) bm_start[c / n_containers] = c;
+        if (c == total - 1) bm_start[n_bitmaps] = total;
+    }
+}

@@ -1,0 +1,176 @@
+// rhip_common.h -- types shared by every kernel: pool / work-item views, wave64 helpers, the reference's result-typing rules
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+
+enum { T_BITSET = 1, T_ARRAY = 2, T_RUN = 3 };
+enum { OP_AND = 0, OP_OR = 1, OP_XOR = 2, OP_ANDNOT = 3 };
+enum { CLS_BB = 0, CLS_GEN = 1, CLS_COPY = 2, CLS_RETRY = 3, CLS_FILT = 4, CLS_WAVE = 5, CLS_RUNS = 6, N_CLS = 7 };
+#define RUNS_MAX_INTERVALS 256u  // per operand, for the interval kernel (k_runs)
+#define NONE32 0xFFFFFFFFu
+
+struct PoolView {
+    const u64* bm_start;  // [n_bitmaps+1] first container of each bitmap
+    const u64* key;       // [n_cont] 16-bit (or 48-bit) container key
+    const uint8_t* type;  // [n_cont]
+    const uint32_t* card; // [n_cont] cardinality
+    const uint32_t* nruns;// [n_cont] run count (runs only)
+    const u64* off;       // [n_cont] byte offset of the payload in arena
+    const uint8_t* arena;
+};
+
+struct OutView {  // candidate (pre-compaction) result directory + the result arena
+    u64* key;
+    u64* meta;       // card | nruns << 32 | type << 56 : one 8-byte store per result container
+    const u64* off;  // exclusive scan of slot[]
+    uint8_t* arena;
+    uint32_t* slot;  // upper-bound payload bytes of each candidate (multiple of 16)
+};
+__device__ __forceinline__ u64 pack_meta(uint32_t type, uint32_t card, uint32_t nruns) {
+    return (u64)card | ((u64)nruns << 32) | ((u64)type << 56);
+}
+__device__ __forceinline__ uint32_t meta_card(u64 m) { return (uint32_t)m; }
+__device__ __forceinline__ uint32_t meta_nruns(u64 m) { return (uint32_t)(m >> 32) & 0xFFFFFFu; }
+__device__ __forceinline__ uint32_t meta_type(u64 m) { return (uint32_t)(m >> 56); }
+
+struct Item {
+    uint32_t a;    // container index in pool A (NONE32: pass-through from B)
+    uint32_t b;    // container index in pool B (NONE32: pass-through from A)
+    uint32_t out;  // candidate index (cardinality mode: pair index)
+};
+struct __attribute__((aligned(16))) FatItem {  // array/bitset pair item: everything the kernel needs, resolved at plan time
+    u64 offa, offb;      // payload offsets in arena A / arena B
+    uint32_t out;        // candidate index (cardinality mode: pair index)
+    uint32_t ca, cb;     // cardinalities
+    uint32_t types;      // ta | tb << 8
+};
+struct __attribute__((aligned(16))) GenItem {  // general pair item (any type pair, runs included)
+    u64 offa, offb;
+    uint32_t out, ca, cb, types;   // types = ta | tb << 8
+    uint32_t nra, nrb, pad0, pad1; // run counts
+};
+struct __attribute__((aligned(16))) BBItem {  // bitset x bitset work item: payload offsets resolved at plan time
+    u64 offa, offb;
+    uint32_t a, b, out, pad;
+};
+
+struct Stats {  // device-side counters, see rhip_stats_t
+    u64 matched_pairs, passthrough, bytes_in, bytes_out, n_bb, result_containers;
+};
+
+
+// ------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint32_t mbcnt(u64 m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ u64 wave_sum64(u64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o);
+        if (lane_id() >= (uint32_t)o) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t payload_bytes(uint8_t type, uint32_t card, uint32_t nruns) {
+    return type == T_BITSET ? 8192u : (type == T_ARRAY ? 2u * card : 4u * nruns);
+}
+__device__ __forceinline__ uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
+
+// first index in [lo,hi) with key[idx] >= k
+__device__ __forceinline__ u64 lower_bound(const u64* __restrict__ key, u64 lo, u64 hi, u64 k) {
+    while (lo < hi) {
+        u64 mid = (lo + hi) >> 1;
+        if (key[mid] < k) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// upper bound on the result cardinality of op over a matched pair
+__device__ __forceinline__ uint32_t ub_card(int op, uint32_t ca, uint32_t cb) {
+    if (op == OP_AND) return ca < cb ? ca : cb;
+    if (op == OP_ANDNOT) return ca;
+    uint32_t s = ca + cb;
+    return s > 65536u ? 65536u : s;
+}
+// Upper bound on the result payload: whatever type the reference's rules pick, the payload is
+// <= min(8192, 2*ub_card) (bitset 8192 needs card > 4096; array = 2*card; a run survives
+// convert_run_to_efficient_container only if 2+4*n_runs <= min(8192, 2*card), convert.c:154-170).
+__device__ __forceinline__ uint32_t matched_slot(int op, uint32_t ca, uint32_t cb) {
+    uint32_t ub = 2u * ub_card(op, ca, cb);
+    if (ub > 8192u) ub = 8192u;
+    ub = align16(ub);
+    return ub < 16u ? 16u : ub;
+}
+
+
+// ------------------------------------------------------------------ result typing
+__device__ __forceinline__ int type_eff(uint32_t rc, uint32_t rn) {
+    // convert_run_to_efficient_container, convert.c:154-200
+    uint32_t size_run = 2u + 4u * rn, size_arr = 2u * rc;
+    uint32_t mn = size_arr < 8192u ? size_arr : 8192u;
+    if (size_run <= mn) return T_RUN;
+    return rc <= 4096u ? T_ARRAY : T_BITSET;
+}
+__device__ __forceinline__ int type_ba(uint32_t rc) { return rc <= 4096u ? T_ARRAY : T_BITSET; }
+
+// The reference's result-type rules, as a pure function of the operand
+// types/cardinalities and the result's cardinality / canonical run count.
+__device__ int decide_type(int op, int ta, int tb, uint32_t ca, uint32_t cb, bool fulla, bool fullb, uint32_t rc,
+                           uint32_t rn) {
+    const bool aA = ta == T_ARRAY, aB = ta == T_BITSET, aR = ta == T_RUN;
+    const bool bA = tb == T_ARRAY, bB = tb == T_BITSET, bR = tb == T_RUN;
+    switch (op) {
+        case OP_AND:  // containers.h:726-806
+            if (aA || bA) return T_ARRAY;
+            if (aB && bB) return type_ba(rc);
+            if (aR && bR) return type_eff(rc, rn);
+            {   // bitset x run, mixed_intersection.c:117-202
+                const bool full = aR ? fulla : fullb;
+                const uint32_t crun = aR ? ca : cb;
+                if (full) return T_BITSET;
+                if (crun <= 4096u) return T_ARRAY;
+                return type_ba(rc);
+            }
+        case OP_OR:  // containers.h:1008-1103
+            if (aB && bB) return T_BITSET;
+            if (aA && bA) return (ca + cb <= 4096u) ? T_ARRAY : type_ba(rc);  // mixed_union.c:162-191
+            if (aR && bR) return type_eff(rc, rn);
+            if ((aB && bA) || (aA && bB)) return T_BITSET;
+            if (aB || bB) return (aR ? fulla : fullb) ? T_RUN : T_BITSET;
+            return type_eff(rc, rn);  // array x run, mixed_union.c:66-108
+        case OP_XOR:  // containers.h:1449-1524
+            if (aA && bA) return (ca + cb <= 4096u) ? T_ARRAY : type_ba(rc);  // mixed_xor.c:196-219
+            if (aR && bR) return type_eff(rc, rn);
+            if (aB || bB) return type_ba(rc);
+            {   // array x run, mixed_xor.c:104-138
+                const uint32_t carr = aA ? ca : cb, crun = aA ? cb : ca;
+                if (carr < 32u) return type_eff(rc, rn);
+                if (crun <= 4096u) return (carr + crun <= 4096u) ? T_ARRAY : type_ba(rc);
+                return type_ba(rc);
+            }
+        default:  // OP_ANDNOT, containers.h:1783-1876
+            if (aA) return T_ARRAY;
+            if (aB) return type_ba(rc);
+            // a is a run
+            if (bR) return type_eff(rc, rn);                       // mixed_andnot.c:430-438
+            if (bB) return ca <= 4096u ? T_ARRAY : type_ba(rc);    // mixed_andnot.c:104-150
+            if (ca <= 32u) return type_eff(rc, rn);                // mixed_andnot.c:277-361
+            return ca <= 4096u ? T_ARRAY : type_ba(rc);
+    }
+}
