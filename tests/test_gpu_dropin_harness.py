@@ -26,3 +26,21 @@ def test_reference_toplevel_unit_against_dropin():
     c = re.search(r"pairwise (\d+), in-place (\d+), cardinality (\d+), many-way (\d+)", p.stderr)
     assert c, tail
     assert int(c.group(1)) > 100 and int(c.group(2)) > 20 and int(c.group(4)) > 10, c.group(0)
+
+
+BIN_CPP = os.path.join(ROOT, "oracle", "_ref", "cpp_random_unit_dropin")
+
+
+def test_reference_cpp_random_unit_against_dropin():
+    """tests/cpp_random_unit.cpp, unmodified: the reference's own randomised differential test (C++ wrappers
+    Roaring / Roaring64Map, every step double-checked against std::set by tests/roaring_checked.hh)."""
+    if not os.path.exists(BIN_CPP):
+        pytest.skip("oracle/_ref/cpp_random_unit_dropin not prebuilt")
+    env = dict(os.environ, RHIP_COMPAT_STATS="1")
+    p = subprocess.run([BIN_CPP], capture_output=True, text=True, timeout=1500, env=env)
+    tail = (p.stdout + p.stderr)[-3000:]
+    m = re.search(r"(\d+) tests, (\d+) failed", p.stdout)
+    assert m, tail
+    assert int(m.group(1)) >= 5 and int(m.group(2)) == 0 and p.returncode == 0, tail
+    c = re.search(r"pairwise (\d+), in-place (\d+), cardinality (\d+), many-way (\d+)", p.stderr)
+    assert c and int(c.group(1)) + int(c.group(2)) > 100, tail
