@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 typedef void (*CMUnitTestFunction)(void **state);
 struct CMUnitTest {
@@ -32,6 +33,7 @@ static void shim_fail(const char *file, int line, const char *what) {
 #define assert_non_null(p) do { if ((p) == NULL) shim_fail(__FILE__, __LINE__, "assert_non_null(" #p ")"); } while (0)
 #define assert_null(p) do { if ((p) != NULL) shim_fail(__FILE__, __LINE__, "assert_null(" #p ")"); } while (0)
 #define assert_ptr_equal(a, b) do { if ((const void *)(a) != (const void *)(b)) shim_fail(__FILE__, __LINE__, "assert_ptr_equal(" #a ", " #b ")"); } while (0)
+#define assert_ptr_not_equal(a, b) do { if ((const void *)(a) == (const void *)(b)) shim_fail(__FILE__, __LINE__, "assert_ptr_not_equal(" #a ", " #b ")"); } while (0)
 #define assert_int_equal(a, b) do { long long a_ = (long long)(a), b_ = (long long)(b); if (a_ != b_) { \
     fprintf(stderr, "  %lld != %lld\n", a_, b_); shim_fail(__FILE__, __LINE__, "assert_int_equal(" #a ", " #b ")"); } } while (0)
 #define assert_int_not_equal(a, b) do { if ((long long)(a) == (long long)(b)) shim_fail(__FILE__, __LINE__, "assert_int_not_equal"); } while (0)
