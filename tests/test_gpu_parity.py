@@ -258,8 +258,13 @@ def test_many_sharded_nccl_world1(engine, oracle):
     import torch.distributed as dist
     from croaring_amd.distributed import gather_serialized, many_sharded
     os_env = __import__("os").environ
-    os_env.setdefault("MASTER_ADDR", "127.0.0.1")
-    os_env.setdefault("MASTER_PORT", "29571")
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    os_env["MASTER_ADDR"] = "127.0.0.1"
+    os_env["MASTER_PORT"] = str(port)
     created = False
     if not dist.is_initialized():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
