@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ aren
             const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 8; ++i) ((uint4*)img)[i * 64 + lane] = z;
+            __builtin_amdgcn_wave_barrier();  // every lane's slice is zero before any lane scatters into it
             const uint4* __restrict__ x4 = (const uint4*)xp;  // 8 values per lane per step (slots are 16-byte padded)
             for (uint32_t i = lane; 8 * i < nx; i += 64) {
                 const uint4 q4 = x4[i];
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA
             const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 8; ++i) ((uint4*)img)[i * 64 + lane] = z;
+            __builtin_amdgcn_wave_barrier();
             const uint4* __restrict__ x4 = (const uint4*)xp;
             for (uint32_t i = lane; 8 * i < cx; i += 64) {
                 const uint4 q4 = x4[i];
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();  // X is complete in the image before Y is applied (xor / clear are order-sensitive)
         int delta = 0;
         {
             const uint4* __restrict__ y4 = (const uint4*)y2;

@@ -222,6 +222,7 @@ __device__ void wimg_build(uint32_t* img, const uint8_t* __restrict__ p, uint32_
     const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) ((uint4*)img)[i * 64 + lane] = z;
+    __builtin_amdgcn_wave_barrier();  // the whole image is zero before any lane scatters into another lane's words
     const uint4* __restrict__ q4p = (const uint4*)p;
     if (type == T_ARRAY) {
         for (uint32_t i = lane; 8 * i < card; i += 64) {

@@ -1,0 +1,28 @@
+"""hipemu: runs the HIP kernels of croaring_amd/csrc on the host through a wave64 SIMT emulator.
+TEST INFRASTRUCTURE ONLY (see shim/hip/hip_runtime.h); the croaring_amd package never uses it."""
+from __future__ import annotations
+
+import ctypes as C
+
+from .build_emu import build
+
+
+def emu_engine():
+    """A croaring_amd.Engine object whose C ABI calls land in librhip_emu.so (kernels under hipemu)."""
+    from croaring_amd import _lib
+    from croaring_amd.engine import Engine
+
+    lib = C.CDLL(build())
+    for name, res, args in _lib.SYMBOLS:
+        f = getattr(lib, name)
+        f.restype = res
+        f.argtypes = args
+
+    class EmuEngine(Engine):
+        def __init__(self):  # noqa: D401 -- deliberately bypasses _lib.load(): no HIP device involved
+            self.lib = lib
+            self.h = lib.rhip_ctx_create(-1)
+            if not self.h:
+                raise RuntimeError("emu ctx_create failed: " + (lib.rhip_last_error() or b"").decode())
+
+    return EmuEngine()

@@ -1,0 +1,226 @@
+// hipemu -- a single-threaded wave64 SIMT emulator, just large enough to execute the kernels of
+// croaring_amd/csrc on a host CPU.  TEST INFRASTRUCTURE ONLY (same status as oracle/): it exists so
+// the kernel *logic* (indexing, LDS protocols, wave collectives, result typing) can be exercised by
+// `pytest -m "not gpu"` in a container without a GPU.  Nothing in the croaring_amd package loads,
+// links or references it; the product library has no CPU path.
+//
+// Model: one block at a time; every thread of the block is a fiber (hand-rolled x86-64 context
+// switch); fibers run until they reach a block barrier or a wave collective.  A wave collective
+// (__shfl*, __ballot, wave_barrier, ...) completes when every lane of the wave that has not exited
+// has arrived at it, and all arriving lanes must come from the same call site, otherwise the run
+// aborts ("divergent collective") -- the kernels promise wave-uniform control flow around
+// collectives and the emulator holds them to it.  Lanes of a wave are NOT otherwise in lockstep, so
+// cross-lane LDS traffic that is not ordered by a collective or barrier shows up as a wrong result
+// (with HIPEMU_SHUFFLE=seed the lane order inside a wave is permuted to shake such races out).
+// Device memory from hipMalloc is poisoned (0xA5) so reliance on zeroed memory is caught.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <tuple>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct alignas(16) uint4 {
+    unsigned x, y, z, w;
+};
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+struct alignas(8) uint2 {
+    unsigned x, y;
+};
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+
+// ---------------------------------------------------------------- runtime API subset
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+typedef struct hipemu_stream* hipStream_t;
+struct hipemu_event {
+    std::chrono::steady_clock::time_point t;
+};
+typedef hipemu_event* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0 };
+
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)malloc(8); return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t n) {
+    void* q = nullptr;
+    if (posix_memalign(&q, 256, n ? n : 1)) return hipErrorOutOfMemory;
+    memset(q, 0xA5, n);
+    *p = q;
+    return hipSuccess;
+}
+template <class T>
+static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <class T>
+static inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipHostMalloc((void**)p, n, f); }
+static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { if (n) memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { if (n) memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemu_event(); return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return hipSuccess;
+}
+
+// ---------------------------------------------------------------- SIMT core (hipemu_core.cpp)
+namespace hipemu {
+struct WaveBuf {
+    uint64_t vals[64];
+    uint64_t present;
+    int site;
+};
+struct Wave {
+    WaveBuf buf[2];
+    unsigned gen, arrived, live;
+};
+struct Fiber {
+    void* sp;
+    dim3 tid;
+    unsigned lane;
+    Wave* wave;
+    int status;  // 0 runnable, 1 waiting on the wave, 2 waiting on the block, 3 done
+    unsigned wait_gen;
+    char* stack;
+};
+extern Fiber* cur;
+extern dim3 cur_block, cur_bdim, cur_gdim;
+// arrive at a wave collective with value v; returns the buffer holding every lane's value
+const WaveBuf& wave_sync(int site, uint64_t v);
+void block_sync();
+void run_grid(dim3 grid, dim3 block, void (*fn)(void*), void* arg);
+
+template <class F>
+static void thunk(void* p) { (*(F*)p)(); }
+// kernel arguments are converted to the parameter types once, then every thread gets a copy
+template <class... P, class... A>
+static inline void launch_k(dim3 g, dim3 b, void (*k)(P...), A&&... a) {
+    std::tuple<P...> t{P(a)...};
+    auto f = [&]() { std::apply(k, t); };
+    run_grid(g, b, &thunk<decltype(f)>, &f);
+}
+
+template <class T>
+static inline uint64_t pack(T v) {
+    static_assert(sizeof(T) <= 8, "shuffle operand too wide");
+    uint64_t u = 0;
+    memcpy(&u, &v, sizeof(T));
+    return u;
+}
+template <class T>
+static inline T unpack(uint64_t u) {
+    T v;
+    memcpy(&v, &u, sizeof(T));
+    return v;
+}
+template <class T>
+static inline T shfl(int site, T v, int src) {
+    const WaveBuf& b = wave_sync(site, pack(v));
+    src &= 63;
+    return ((b.present >> src) & 1) ? unpack<T>(b.vals[src]) : v;
+}
+template <class T>
+static inline T shfl_up(int site, T v, unsigned d) {
+    const unsigned lane = cur->lane;
+    const WaveBuf& b = wave_sync(site, pack(v));
+    return (lane >= d && ((b.present >> (lane - d)) & 1)) ? unpack<T>(b.vals[lane - d]) : v;
+}
+template <class T>
+static inline T shfl_down(int site, T v, unsigned d) {
+    const unsigned lane = cur->lane;
+    const WaveBuf& b = wave_sync(site, pack(v));
+    return (lane + d < 64 && ((b.present >> (lane + d)) & 1)) ? unpack<T>(b.vals[lane + d]) : v;
+}
+template <class T>
+static inline T shfl_xor(int site, T v, unsigned m) {
+    const unsigned lane = cur->lane;
+    const WaveBuf& b = wave_sync(site, pack(v));
+    const unsigned s = (lane ^ m) & 63;
+    return ((b.present >> s) & 1) ? unpack<T>(b.vals[s]) : v;
+}
+static inline uint64_t ballot(int site, int pred) {
+    const WaveBuf& b = wave_sync(site, pred ? 1 : 0);
+    uint64_t m = 0;
+    for (int i = 0; i < 64; ++i)
+        if (((b.present >> i) & 1) && b.vals[i]) m |= 1ull << i;
+    return m;
+}
+static inline unsigned mbcnt(unsigned mask, unsigned add, int hi) {
+    const unsigned lane = cur->lane;
+    unsigned below;
+    if (!hi)
+        below = lane >= 32 ? 0xffffffffu : ((1u << lane) - 1u);
+    else
+        below = lane <= 32 ? 0u : ((1u << (lane - 32)) - 1u);
+    return add + (unsigned)__builtin_popcount(mask & below);
+}
+}  // namespace hipemu
+
+#define threadIdx (hipemu::cur->tid)
+#define blockIdx (hipemu::cur_block)
+#define blockDim (hipemu::cur_bdim)
+#define gridDim (hipemu::cur_gdim)
+#define warpSize 64
+
+#define HIPEMU_SITE ((int)(__LINE__ * 131 + sizeof(__FILE__)))
+#define __syncthreads() hipemu::block_sync()
+#define __shfl(v, src, ...) hipemu::shfl(HIPEMU_SITE, (v), (src))
+#define __shfl_up(v, d, ...) hipemu::shfl_up(HIPEMU_SITE, (v), (d))
+#define __shfl_down(v, d, ...) hipemu::shfl_down(HIPEMU_SITE, (v), (d))
+#define __shfl_xor(v, m, ...) hipemu::shfl_xor(HIPEMU_SITE, (v), (m))
+#define __ballot(p) hipemu::ballot(HIPEMU_SITE, (p))
+#define __builtin_amdgcn_wave_barrier() ((void)hipemu::wave_sync(-1, 0))
+#define __builtin_amdgcn_mbcnt_lo(m, a) hipemu::mbcnt((m), (a), 0)
+#define __builtin_amdgcn_mbcnt_hi(m, a) hipemu::mbcnt((m), (a), 1)
+
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __ffs(int v) { return __builtin_ffs(v); }
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
+
+// one OS thread executes everything, so the "atomics" are plain read-modify-writes
+template <class T, class U>
+static inline T atomicAdd(T* p, U v) { T o = *p; *p = (T)(o + (T)v); return o; }
+template <class T, class U>
+static inline T atomicOr(T* p, U v) { T o = *p; *p = (T)(o | (T)v); return o; }
+template <class T, class U>
+static inline T atomicXor(T* p, U v) { T o = *p; *p = (T)(o ^ (T)v); return o; }
+template <class T, class U>
+static inline T atomicAnd(T* p, U v) { T o = *p; *p = (T)(o & (T)v); return o; }
+template <class T, class U>
+static inline T atomicMax(T* p, U v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
+template <class T, class U>
+static inline T atomicMin(T* p, U v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hipemu::launch_k((grid), (block), kernel, ##__VA_ARGS__)
+#define HIP_KERNEL_NAME(...) __VA_ARGS__

@@ -1,0 +1,98 @@
+"""Kernel-logic tests WITHOUT a GPU: the engine sources of croaring_amd/csrc compiled against the hipemu shim
+(tests/emu: a wave64 SIMT emulator -- test infrastructure, never part of the product) run the same parity
+bodies as tests/test_gpu_parity.py, against the same golden fixtures and the same oracle.
+
+What this can and cannot show: it executes the real kernel source (indexing, LDS protocols, ballots /
+shuffles, queue planning, result typing, serialization) and holds it to a stricter cross-lane ordering
+model than the hardware (lanes of a wave are only ordered by collectives and barriers).  It says nothing
+about performance, memory coalescing or hardware-only behaviour; `-m gpu` on an MI355X stays the parity
+gate."""
+import numpy as np
+import pytest
+
+import test_gpu_parity as G
+import test_gpu_64bit as G64
+from util import OPS, crc, load_bundle, load_pairs
+
+synth = G.synth  # module-scoped fixture, shared with the GPU suite
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from emu import emu_engine
+    eng = emu_engine()
+    yield eng
+    eng.close()
+
+
+@pytest.mark.parametrize("op", OPS)
+def test_emu_synth_every_type_pair(emu, oracle, synth, op):
+    G.test_synth_every_type_pair(emu, oracle, synth, op)
+
+
+@pytest.mark.parametrize("name", ["census1881", "weather_sept_85", "wikileaks-noquotes"])
+def test_emu_realdata_pair_sample(emu, name):
+    """A seeded sample of the all-pairs fixture (the full 19 900-pair sets are the GPU suite's job):
+    cardinality, portable size and crc32 of every sampled result equal the reference's."""
+    bufs = load_bundle(name)
+    gold = load_pairs(name)
+    pool = emu.pool_from_serialized(bufs)
+    rng = np.random.default_rng(5)
+    sel = np.sort(rng.choice(len(gold["pairs"]), 700, replace=False))
+    lhs = gold["pairs"][sel, 0].astype(np.uint32)
+    rhs = gold["pairs"][sel, 1].astype(np.uint32)
+    for op in OPS:
+        res = emu.pairwise(op, pool, lhs, pool, rhs)
+        cards = res.cardinalities()
+        assert np.array_equal(cards, gold[f"{op}_card"][sel].astype(np.uint64)), (name, op)
+        assert np.array_equal(emu.pairwise_cardinality(op, pool, lhs, pool, rhs), cards), (name, op)
+        bad = [k for k in range(len(sel)) if len(s := res.serialize(k)) != gold[f"{op}_size"][sel[k]]
+               or crc(s) != gold[f"{op}_crc"][sel[k]]]
+        assert not bad, f"{name} {op}: {len(bad)} of {len(sel)} sampled results differ from the reference"
+
+
+def test_emu_lane_order_independence(emu, oracle, synth):
+    """Same batch with the emulator resuming the lanes of each wave in shuffled order: any cross-lane LDS
+    exchange that is not ordered by a collective or barrier changes the result."""
+    try:
+        for seed in (1, 2):
+            emu.lib.hipemu_set_shuffle(seed)
+            for op in OPS:
+                G.test_synth_every_type_pair(emu, oracle, synth, op)
+            G.test_synth_many(emu, oracle, synth)
+    finally:
+        emu.lib.hipemu_set_shuffle(0)
+
+
+@pytest.mark.parametrize("name", ["census1881", "weather_sept_85"])
+def test_emu_realdata_many(emu, oracle, name):
+    G.test_realdata_many(emu, oracle, name)
+
+
+def test_emu_synth_many(emu, oracle, synth):
+    G.test_synth_many(emu, oracle, synth)
+
+
+def test_emu_bitset_only_synthetic_pool(emu, oracle):
+    G.test_bitset_only_synthetic_pool(emu, oracle)
+
+
+def test_emu_edge_cases(emu, oracle):
+    G.test_edge_cases(emu, oracle)
+
+
+def test_emu_or_many_full_container_typing(emu, oracle):
+    G.test_or_many_full_container_typing(emu, oracle)
+
+
+def test_emu_directory_and_payload_extremes(emu, oracle):
+    G.test_directory_and_payload_extremes(emu, oracle)
+
+
+def test_emu_randomized_pools(emu, oracle):
+    G.test_randomized_pools(emu, oracle, 11)
+
+
+def test_emu_64bit(emu, oracle):
+    G64.test_64bit_pairwise_and_many(emu, oracle)
+    G64.test_64bit_reference_fixtures(emu)
