@@ -17,6 +17,7 @@
 #include "../../include/roaring_hip.h"
 #include "rhip_kernels.h"
 #include "rhip_many.h"
+#include "rhip_poolops.h"
 #include "rhip_prims.h"
 
 // ------------------------------------------------------------------ errors
@@ -71,6 +72,7 @@ struct rhip_ctx_s {
     // scratch (grow-only): candidate directory + queues + scan temporaries
     DBuf lhs, rhs, u_pair, u_tile, u_pair0, unit_bytes, cand, cand_start, o_key, o_meta, o_slot, o_off, flag, newidx, q[N_CLS], misc, prim_tmp, pair_acc;
     DBuf many[16];
+    DBuf sel[5];  // pool_select / pool_convert scratch
     void* h_pinned = nullptr;  // small pinned readback area
     rhip_stats_t stats{};
     bool timing = false;
@@ -148,6 +150,7 @@ extern "C" void rhip_ctx_destroy(rhip_ctx_t* c) {
     for (auto* b : all) b->release();
     for (auto& b : c->q) b.release();
     for (auto& b : c->many) b.release();
+    for (auto& b : c->sel) b.release();
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     (void)hipHostFree(c->h_pinned);
     (void)hipStreamDestroy(c->stream);
@@ -909,4 +912,5 @@ extern "C" int rhip_pairwise_cardinality(rhip_ctx_t* c, rhip_op op_, rhip_pool_t
 }
 
 #include "rhip_many_host.inc"
+#include "rhip_pool_ops.inc"
 #include "roaring_compat.inc"

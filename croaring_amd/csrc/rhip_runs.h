@@ -324,76 +324,8 @@ __global__ __launch_bounds__(256) void k_genw(const uint8_t* __restrict__ arenaA
         int ty = T_ARRAY;
         if (rc) ty = decide_type(op, (int)ta, (int)tb, t.ca, t.cb, fulla, fullb, rc, rn);
         uint8_t* outp = O.arena + O.off[t.out];
-        __builtin_amdgcn_wave_barrier();
-        if (rc && ty == T_BITSET) {
-#pragma unroll
-            for (int k = 0; k < 32; ++k) ia[wown(lane, k)] = r[k];
-            __builtin_amdgcn_wave_barrier();
-            uint4* __restrict__ po = (uint4*)outp;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint32_t w0 = 4u * (i * 64 + lane);
-                po[i * 64 + lane] = make_uint4(ia[wphys(w0)], ia[wphys(w0 + 1)], ia[wphys(w0 + 2)], ia[wphys(w0 + 3)]);
-            }
-        } else if (rc && ty == T_ARRAY) {
-            uint16_t* st16 = (uint16_t*)ib;  // both images are dead: ib becomes the u16 staging buffer
-            uint32_t pos = wave_incl_scan(cnt) - cnt;
-#pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                uint32_t x = r[k];
-                const uint32_t vbase = (32u * lane + k) * 32u;
-                while (x) {
-                    st16[pos++] = (uint16_t)(vbase + (__ffs((int)x) - 1));
-                    x &= x - 1;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t n16 = (2u * rc + 15u) >> 4;
-            uint4* __restrict__ po = (uint4*)outp;
-            for (uint32_t i = lane; i < n16; i += 64) po[i] = ((const uint4*)ib)[i];
-        } else if (rc) {
-            // runs: k-th start pairs with k-th end (run_container layout {value, length}, run.h:48-73)
-            uint16_t* st16 = (uint16_t*)ib;
-            uint32_t ne = 0;
-#pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                const uint32_t nl = k < 31 ? (r[k + 1] & 1u) : next_lsb;
-                ne += __popc(r[k] & ~((r[k] >> 1) | (nl << 31)));
-            }
-            uint32_t bs = wave_incl_scan(ns) - ns;
-            uint32_t be = wave_incl_scan(ne) - ne;
-            {
-                uint32_t pm = prev_msb;
-#pragma unroll
-                for (int k = 0; k < 32; ++k) {
-                    uint32_t x = r[k] & ~((r[k] << 1) | pm);
-                    pm = r[k] >> 31;
-                    const uint32_t vbase = (32u * lane + k) * 32u;
-                    while (x) {
-                        st16[2 * bs] = (uint16_t)(vbase + (__ffs((int)x) - 1));
-                        ++bs;
-                        x &= x - 1;
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                const uint32_t nl = k < 31 ? (r[k + 1] & 1u) : next_lsb;
-                uint32_t x = r[k] & ~((r[k] >> 1) | (nl << 31));
-                const uint32_t vbase = (32u * lane + k) * 32u;
-                while (x) {
-                    const uint32_t e = vbase + (__ffs((int)x) - 1);
-                    st16[2 * be + 1] = (uint16_t)(e - st16[2 * be]);
-                    ++be;
-                    x &= x - 1;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t n16 = (4u * rn + 15u) >> 4;
-            uint4* __restrict__ po = (uint4*)outp;
-            for (uint32_t i = lane; i < n16; i += 64) po[i] = ((const uint4*)ib)[i];
-        }
+        uint32_t* img = ia;
+#include "rhip_wemit.inc"
         if (lane == 0) O.meta[t.out] = pack_meta(ty, rc, (ty == T_RUN) ? rn : 0u);
         __builtin_amdgcn_wave_barrier();
     }

@@ -16,6 +16,7 @@ from . import _lib
 from ._lib import RoaringHipError, Stats, Partials
 
 OPS = {"and": 0, "or": 1, "xor": 2, "andnot": 3}
+PREDS = {"intersect": 0, "is_subset": 1, "is_strict_subset": 2, "equals": 3}
 
 
 def _u32(a) -> np.ndarray:
@@ -29,7 +30,10 @@ class Engine:
         self.lib = _lib.load()
         self.h = self.lib.rhip_ctx_create(device)
         if not self.h:
-            raise RoaringHipError("rhip_ctx_create failed: " + _lib.last_error())
+            raise RoaringHipError("rhip_ctx_create failed: " + self._err())
+
+    def _err(self) -> str:
+        return (self.lib.rhip_last_error() or b"").decode()
 
     def close(self):
         if getattr(self, "h", None):
@@ -48,7 +52,7 @@ class Engine:
 
     def synchronize(self):
         if self.lib.rhip_ctx_synchronize(self.h) != 0:
-            raise RoaringHipError(_lib.last_error())
+            raise RoaringHipError(self._err())
 
     def set_timing(self, on: bool):
         self.lib.rhip_ctx_set_timing(self.h, 1 if on else 0)
@@ -65,7 +69,7 @@ class Engine:
         lens = (C.c_size_t * max(n, 1))(*[len(b) for b in bufs])
         h = fn(self.h, n, arr, lens)
         if not h:
-            raise RoaringHipError("deserialize failed: " + _lib.last_error())
+            raise RoaringHipError("deserialize failed: " + self._err())
         return Pool(self, h)
 
     def pool_from_serialized(self, bufs: Sequence[bytes]) -> "Pool":
@@ -82,7 +86,7 @@ class Engine:
         fn = self.lib.rhip_pool_from_portable64 if is64 else self.lib.rhip_pool_from_portable
         h = fn(self.h, len(offsets), ptrs.ctypes.data, lens.ctypes.data)
         if not h:
-            raise RoaringHipError("deserialize failed: " + _lib.last_error())
+            raise RoaringHipError("deserialize failed: " + self._err())
         return Pool(self, h)
 
     def pool_from_serialized64(self, bufs: Sequence[bytes]) -> "Pool":
@@ -92,7 +96,7 @@ class Engine:
     def pool_synth_bitset(self, n_bitmaps: int, n_containers: int, seed: int) -> "Pool":
         h = self.lib.rhip_pool_synth_bitset(self.h, n_bitmaps, n_containers, seed & (2**64 - 1))
         if not h:
-            raise RoaringHipError("synth failed: " + _lib.last_error())
+            raise RoaringHipError("synth failed: " + self._err())
         return Pool(self, h)
 
     # ---- pairwise ------------------------------------------------------
@@ -108,7 +112,7 @@ class Engine:
             rh, reuse.h = reuse.h, None  # consumed
         h = self.lib.rhip_pairwise(self.h, OPS[op], A.h, B.h, lhs.size, lhs.ctypes.data, rhs.ctypes.data, rh)
         if not h:
-            raise RoaringHipError(f"pairwise {op} failed: " + _lib.last_error())
+            raise RoaringHipError(f"pairwise {op} failed: " + self._err())
         return Pool(self, h)
 
     def pairwise_cardinality(self, op: str, A: "Pool", lhs, B: Optional["Pool"] = None, rhs=None) -> np.ndarray:
@@ -119,8 +123,57 @@ class Engine:
         rc = self.lib.rhip_pairwise_cardinality(self.h, OPS[op], A.h, B.h, lhs.size, lhs.ctypes.data,
                                                 rhs.ctypes.data, out.ctypes.data)
         if rc != 0:
-            raise RoaringHipError(f"pairwise_cardinality {op} failed: " + _lib.last_error())
+            raise RoaringHipError(f"pairwise_cardinality {op} failed: " + self._err())
         return out
+
+    def pairwise_predicate(self, pred: str, A: "Pool", lhs, B: Optional["Pool"] = None, rhs=None) -> np.ndarray:
+        """roaring_bitmap_intersect / is_subset / is_strict_subset / equals batched; bool array."""
+        B = A if B is None else B
+        lhs, rhs = _u32(lhs), _u32(rhs)
+        if lhs.shape != rhs.shape:
+            raise ValueError("lhs/rhs length mismatch")
+        out = np.zeros(lhs.size, dtype=np.uint8)
+        rc = self.lib.rhip_pairwise_predicate(self.h, PREDS[pred], A.h, B.h, lhs.size, lhs.ctypes.data,
+                                              rhs.ctypes.data, out.ctypes.data)
+        if rc != 0:
+            raise RoaringHipError(f"pairwise_predicate {pred} failed: " + self._err())
+        return out.astype(bool)
+
+    def pairwise_inplace(self, op: str, A: "Pool", lhs, B: Optional["Pool"] = None, rhs=None) -> None:
+        """A[lhs[k]] <- op(A[lhs[k]], B[rhs[k]]) -- roaring_bitmap_*_inplace batched; lhs must not repeat."""
+        B = A if B is None else B
+        lhs, rhs = _u32(lhs), _u32(rhs)
+        if lhs.shape != rhs.shape:
+            raise ValueError("lhs/rhs length mismatch")
+        rc = self.lib.rhip_pairwise_inplace(self.h, OPS[op], A.h, B.h, lhs.size, lhs.ctypes.data, rhs.ctypes.data)
+        if rc != 0:
+            raise RoaringHipError(f"pairwise_inplace {op} failed: " + self._err())
+
+    # ---- reshaping -----------------------------------------------------
+    def pool_select(self, pools: Sequence["Pool"], src_pool, src_bitmap) -> "Pool":
+        """New pool whose bitmap i is pools[src_pool[i]][src_bitmap[i]] (device-side gather)."""
+        sp, sb = _u32(src_pool), _u32(src_bitmap)
+        if sp.shape != sb.shape:
+            raise ValueError("src_pool/src_bitmap length mismatch")
+        arr = (C.c_void_p * max(len(pools), 1))(*[p.h for p in pools])
+        h = self.lib.rhip_pool_select(self.h, len(pools), arr, sp.size, sp.ctypes.data, sb.ctypes.data)
+        if not h:
+            raise RoaringHipError("pool_select failed: " + self._err())
+        return Pool(self, h)
+
+    def run_optimize(self, P: "Pool") -> "Pool":
+        """roaring_bitmap_run_optimize applied to every bitmap of P (new pool)."""
+        h = self.lib.rhip_pool_run_optimize(self.h, P.h)
+        if not h:
+            raise RoaringHipError("run_optimize failed: " + self._err())
+        return Pool(self, h)
+
+    def remove_run_compression(self, P: "Pool") -> "Pool":
+        """roaring_bitmap_remove_run_compression applied to every bitmap of P (new pool)."""
+        h = self.lib.rhip_pool_remove_run_compression(self.h, P.h)
+        if not h:
+            raise RoaringHipError("remove_run_compression failed: " + self._err())
+        return Pool(self, h)
 
     # ---- many-way ------------------------------------------------------
     def _many(self, fn, P: "Pool", ids) -> "Pool":
@@ -130,7 +183,7 @@ class Engine:
             ids = _u32(ids)
             h = fn(self.h, P.h, ids.size, ids.ctypes.data)
         if not h:
-            raise RoaringHipError("many-way aggregation failed: " + _lib.last_error())
+            raise RoaringHipError("many-way aggregation failed: " + self._err())
         return Pool(self, h)
 
     def or_many(self, P: "Pool", ids=None) -> "Pool":
@@ -149,14 +202,14 @@ class Engine:
             ids = _u32(ids)
             rc = self.lib.rhip_many_partials(self.h, OPS[op], P.h, ids.size, ids.ctypes.data, C.byref(out))
         if rc != 0:
-            raise RoaringHipError("many_partials failed: " + _lib.last_error())
+            raise RoaringHipError("many_partials failed: " + self._err())
         return PartialChunks(self, out)
 
     def many_finalize(self, op: str, is64: bool, n_chunks: int, d_keys: int, d_words: int) -> "Pool":
         """Stage 2: combine (key, chunk) records by key and canonicalise; device pointers in."""
         h = self.lib.rhip_many_finalize(self.h, OPS[op], 1 if is64 else 0, n_chunks, d_keys, d_words)
         if not h:
-            raise RoaringHipError("many_finalize failed: " + _lib.last_error())
+            raise RoaringHipError("many_finalize failed: " + self._err())
         return Pool(self, h)
 
 
@@ -214,25 +267,25 @@ class Pool:
     def type_counts(self) -> tuple:
         out = (C.c_uint64 * 3)()
         if self.eng.lib.rhip_pool_type_counts(self.h, out) != 0:
-            raise RoaringHipError(_lib.last_error())
+            raise RoaringHipError(self.eng._err())
         return tuple(int(x) for x in out)  # (bitset, array, run)
 
     def cardinalities(self) -> np.ndarray:
         """roaring_bitmap_get_cardinality of every bitmap."""
         out = np.zeros(len(self), dtype=np.uint64)
         if self.eng.lib.rhip_pool_cardinalities(self.h, out.ctypes.data) != 0:
-            raise RoaringHipError(_lib.last_error())
+            raise RoaringHipError(self.eng._err())
         return out
 
     def serialize(self, i: int) -> bytes:
         """roaring_bitmap_portable_serialize of bitmap i."""
         n = self.eng.lib.rhip_pool_portable_size(self.h, i)
         if n == 0:
-            raise RoaringHipError("portable_size failed: " + _lib.last_error())
+            raise RoaringHipError("portable_size failed: " + self.eng._err())
         buf = C.create_string_buffer(n)
         w = self.eng.lib.rhip_pool_portable_serialize(self.h, i, buf)
         if w != n:
-            raise RoaringHipError(f"serialize wrote {w} of {n} bytes: " + _lib.last_error())
+            raise RoaringHipError(f"serialize wrote {w} of {n} bytes: " + self.eng._err())
         return buf.raw
 
     def serialize_all(self) -> list:

@@ -37,6 +37,12 @@ typedef struct rhip_pool_s rhip_pool_t; /* a device-resident, immutable set of b
 
 typedef enum { RHIP_AND = 0, RHIP_OR = 1, RHIP_XOR = 2, RHIP_ANDNOT = 3 } rhip_op;
 typedef enum {
+    RHIP_PRED_INTERSECT = 0,        /* roaring_bitmap_intersect        (roaring.h:237) */
+    RHIP_PRED_IS_SUBSET = 1,        /* roaring_bitmap_is_subset        (roaring.h:905) */
+    RHIP_PRED_IS_STRICT_SUBSET = 2, /* roaring_bitmap_is_strict_subset (roaring.h:912) */
+    RHIP_PRED_EQUALS = 3            /* roaring_bitmap_equals           (roaring.h:899) */
+} rhip_pred;
+typedef enum {
     RHIP_OK = 0,
     RHIP_ERR_DEVICE = -1,   /* no device / HIP runtime error */
     RHIP_ERR_ALLOC = -2,    /* device or host allocation failed */
@@ -106,6 +112,32 @@ rhip_pool_t *rhip_pairwise(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *A, rhip_poo
  * src/roaring.c:3048-3107): nothing is materialised. */
 int rhip_pairwise_cardinality(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *A, rhip_pool_t *B, size_t npairs,
                               const uint32_t *lhs, const uint32_t *rhs, uint64_t *out);
+/* out[k] = pred(A[lhs[k]], B[rhs[k]]) as 0 / 1: roaring_bitmap_intersect (src/roaring.c:2998-3027), _is_subset
+ * (:2151-2183, "A[lhs] is a subset of B[rhs]"), _is_strict_subset (:3172-3177), _equals (:2128-2149).  Evaluated
+ * by the cardinality-only kernels (a batch has no use for the reference's early exit); nothing is materialised. */
+int rhip_pairwise_predicate(rhip_ctx_t *ctx, rhip_pred pred, rhip_pool_t *A, rhip_pool_t *B, size_t npairs,
+                            const uint32_t *lhs, const uint32_t *rhs, uint8_t *out);
+/* roaring_bitmap_{and,or,xor,andnot}_inplace (roaring.h:280,295,326,348; src/roaring.c:812-875, 1063-1119,
+ * 1200-1273, 1342-1434) for a batch, on device-resident handles: A[lhs[k]] <- op(A[lhs[k]], B[rhs[k]]), every
+ * other bitmap of A unchanged; the handle A stays valid and now names the updated pool.  lhs must not repeat.
+ * B may be A.  (Pools are immutable images: the update builds the new image with rhip_pool_select and swaps it
+ * in, so the cost is the op plus one copy of A's payload.) */
+int rhip_pairwise_inplace(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *A, rhip_pool_t *B, size_t npairs,
+                          const uint32_t *lhs, const uint32_t *rhs);
+
+/* ---- reshaping pools on the device ---------------------------------------- */
+/* A new pool of n bitmaps: bitmap i is a copy of srcs[src_pool[i]] bitmap src_bitmap[i].  Gathers operands and
+ * results of earlier calls into one pool so that chained expressions ((a & b) | c ...) never leave HBM; all
+ * sources must be of the same key width. */
+rhip_pool_t *rhip_pool_select(rhip_ctx_t *ctx, size_t n_src, rhip_pool_t *const *srcs, size_t n,
+                              const uint32_t *src_pool, const uint32_t *src_bitmap);
+/* roaring_bitmap_run_optimize (roaring.h:621, src/roaring.c:1530-1546 -> convert_run_optimize,
+ * src/containers/convert.c:217-321) applied to every bitmap: a new pool whose containers have the type the
+ * reference would leave them in (byte-identical portable serialization). */
+rhip_pool_t *rhip_pool_run_optimize(rhip_ctx_t *ctx, rhip_pool_t *pool);
+/* roaring_bitmap_remove_run_compression (roaring.h:612, src/roaring.c:1564-1592): run containers become arrays
+ * (cardinality <= 4096) or bitsets. */
+rhip_pool_t *rhip_pool_remove_run_compression(rhip_ctx_t *ctx, rhip_pool_t *pool);
 
 /* ---- many-way aggregation ------------------------------------------------ */
 /* roaring_bitmap_or_many (roaring.h:304, src/roaring.c:775-790) /

@@ -50,6 +50,9 @@ class Oracle:
         L.oc_free.restype = None; L.oc_free.argtypes = [vp]
         L.oc_from_sorted.restype = vp; L.oc_from_sorted.argtypes = [vp, sz]
         L.oc_run_optimize.restype = C.c_int; L.oc_run_optimize.argtypes = [vp]
+        L.oc_remove_run_compression.restype = C.c_int; L.oc_remove_run_compression.argtypes = [vp]
+        for nm in ("oc_intersect", "oc_is_subset", "oc_is_strict_subset", "oc_equals"):
+            f = getattr(L, nm); f.restype = C.c_int; f.argtypes = [vp, vp]
         L.oc_validate.restype = C.c_int; L.oc_validate.argtypes = [vp]
         L.oc_to_uint32.restype = None; L.oc_to_uint32.argtypes = [vp, vp]
         L.oc_type_counts.restype = None; L.oc_type_counts.argtypes = [vp, vp]
@@ -84,6 +87,16 @@ class Oracle:
         if run_optimize:
             self.L.oc_run_optimize(h)
         return h
+
+    def run_optimize(self, h) -> bool:
+        return bool(self.L.oc_run_optimize(h))
+
+    def remove_run_compression(self, h) -> bool:
+        return bool(self.L.oc_remove_run_compression(h))
+
+    def predicate(self, pred, a, b) -> bool:
+        return bool(getattr(self.L, {"intersect": "oc_intersect", "is_subset": "oc_is_subset",
+                                     "is_strict_subset": "oc_is_strict_subset", "equals": "oc_equals"}[pred])(a, b))
 
     def op(self, op, a, b):
         return self.L.oc_op(OPS[op], a, b)
@@ -185,6 +198,10 @@ class Ref:
         L.roaring_bitmap_of_ptr.restype = vp; L.roaring_bitmap_of_ptr.argtypes = [sz, vp]
         L.roaring_bitmap_run_optimize.restype = C.c_bool; L.roaring_bitmap_run_optimize.argtypes = [vp]
         L.roaring_bitmap_shrink_to_fit.restype = sz; L.roaring_bitmap_shrink_to_fit.argtypes = [vp]
+        L.roaring_bitmap_remove_run_compression.restype = C.c_bool
+        L.roaring_bitmap_remove_run_compression.argtypes = [vp]
+        for nm in ("intersect", "is_subset", "is_strict_subset", "equals"):
+            f = getattr(L, f"roaring_bitmap_{nm}"); f.restype = C.c_bool; f.argtypes = [vp, vp]
         L.roaring_bitmap_to_uint32_array.restype = None; L.roaring_bitmap_to_uint32_array.argtypes = [vp, vp]
         L.roaring_bitmap_internal_validate.restype = C.c_bool
         L.roaring_bitmap_internal_validate.argtypes = [vp, C.POINTER(C.c_char_p)]
@@ -222,6 +239,15 @@ class Ref:
             self.L.roaring_bitmap_run_optimize(h)
         self.L.roaring_bitmap_shrink_to_fit(h)
         return h
+
+    def run_optimize(self, h) -> bool:
+        return bool(self.L.roaring_bitmap_run_optimize(h))
+
+    def remove_run_compression(self, h) -> bool:
+        return bool(self.L.roaring_bitmap_remove_run_compression(h))
+
+    def predicate(self, pred, a, b) -> bool:
+        return bool(getattr(self.L, f"roaring_bitmap_{pred}")(a, b))
 
     def op(self, op, a, b):
         return getattr(self.L, f"roaring_bitmap_{op}")(a, b)

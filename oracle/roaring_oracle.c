@@ -750,6 +750,29 @@ int oc_run_optimize(oc_bitmap_t *b) {
     return any;
 }
 
+/* roaring_bitmap_remove_run_compression, roaring.c:1564-1592 -> convert_to_bitset_or_array_container,
+ * convert.c:118-147: every run container becomes an array (card <= 4096) or a bitset. */
+int oc_remove_run_compression(oc_bitmap_t *b) {
+    int any = 0;
+    for (int i = 0; i < b->n; i++) {
+        oc_container_t *c = &b->c[i];
+        if (c->type != OC_RUN) continue;
+        any = 1;
+        oc_container_t r = c->card <= MAXARR ? array_from_run(c) : mk_bitset(words_from(c), c->card);
+        c_free(c);
+        *c = r;
+    }
+    return any;
+}
+
+/* roaring_bitmap_intersect (roaring.c:2998-3027), _is_subset (:2151-2183), _is_strict_subset (:3172-3177):
+ * restated through the cardinality identities; the reference's container walks decide the same sets. */
+int oc_intersect(const oc_bitmap_t *a, const oc_bitmap_t *b) { return oc_op_cardinality(OC_AND, a, b) != 0; }
+int oc_is_subset(const oc_bitmap_t *a, const oc_bitmap_t *b) { return oc_op_cardinality(OC_ANDNOT, a, b) == 0; }
+int oc_is_strict_subset(const oc_bitmap_t *a, const oc_bitmap_t *b) {
+    return oc_get_cardinality(b) > oc_get_cardinality(a) && oc_is_subset(a, b);
+}
+
 /* ------------------------------------------------------ portable format */
 static int bm_has_run(const oc_bitmap_t *b) {
     for (int i = 0; i < b->n; i++)

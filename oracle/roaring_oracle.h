@@ -66,6 +66,10 @@ oc_bitmap_t *oc_copy(const oc_bitmap_t *b);
 oc_bitmap_t *oc_from_sorted(const uint32_t *vals, size_t n);
 /* roaring_bitmap_run_optimize, roaring.c:1530-1546 */
 int oc_run_optimize(oc_bitmap_t *b);
+int oc_remove_run_compression(oc_bitmap_t *b);
+int oc_intersect(const oc_bitmap_t *a, const oc_bitmap_t *b);
+int oc_is_subset(const oc_bitmap_t *a, const oc_bitmap_t *b);
+int oc_is_strict_subset(const oc_bitmap_t *a, const oc_bitmap_t *b);
 
 /* ---- portable format, roaring_array.c:445-531, 633-813 ---- */
 oc_bitmap_t *oc_deserialize(const char *buf, size_t maxbytes);

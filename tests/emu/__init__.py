@@ -3,8 +3,9 @@ TEST INFRASTRUCTURE ONLY (see shim/hip/hip_runtime.h); the croaring_amd package 
 from __future__ import annotations
 
 import ctypes as C
+import os
 
-from .build_emu import build
+from .build_emu import asan_runtime, build  # noqa: F401
 
 
 def emu_engine():
@@ -12,7 +13,8 @@ def emu_engine():
     from croaring_amd import _lib
     from croaring_amd.engine import Engine
 
-    lib = C.CDLL(build())
+    # HIPEMU_ASAN=1 (with LD_PRELOAD=asan_runtime()): AddressSanitizer build, see build_emu.build
+    lib = C.CDLL(build(asan=os.environ.get("HIPEMU_ASAN") == "1"))
     for name, res, args in _lib.SYMBOLS:
         f = getattr(lib, name)
         f.restype = res

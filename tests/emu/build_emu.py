@@ -27,25 +27,39 @@ def sources():
     return deps
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def asan_runtime() -> str:
+    r = subprocess.run([CXX, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    return r.stdout.strip()
+
+
+def build(force: bool = False, verbose: bool = False, asan: bool = False) -> str:
+    """asan=True builds librhip_emu_asan.so (AddressSanitizer: out-of-bounds global / LDS / stack accesses of the
+    kernels abort); the process using it must run with LD_PRELOAD=asan_runtime()."""
+    if asan:
+        return _build(os.path.join(OUT, "librhip_emu_asan.so"), ["-fsanitize=address", "-fno-omit-frame-pointer",
+                                                                  "-shared-libasan"], force, verbose)
+    return _build(LIB, [], force, verbose)
+
+
+def _build(lib: str, extra, force: bool, verbose: bool) -> str:
     if not os.path.exists(CXX):
         raise RuntimeError(f"{CXX} not found: hipemu needs clang (ext_vector_type, nontemporal builtins)")
     os.makedirs(OUT, exist_ok=True)
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest(sources()):
-        return LIB
-    cmd = [CXX, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-DRHIP_EMU=1",
+    if not force and os.path.exists(lib) and os.path.getmtime(lib) >= _newest(sources()):
+        return lib
+    cmd = [CXX, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-DRHIP_EMU=1", *extra,
            "-Wno-unused-value", "-Wno-deprecated-declarations",
            "-I", os.path.join(HERE, "shim"), "-I", CSRC, "-I", os.path.join(ROOT, "include"),
            "-x", "c++", os.path.join(CSRC, "rhip_engine.hip"),
            os.path.join(HERE, "hipemu_core.cpp"), os.path.join(HERE, "prims_emu.cpp"),
-           "-o", LIB]
+           "-o", lib]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipemu build failed:\n" + r.stdout[-4000:] + r.stderr[-8000:])
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, asan="--asan" in sys.argv))

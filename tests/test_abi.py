@@ -61,5 +61,6 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".inc")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "pyoracle" not in txt and "liboracle" not in txt and "roaring_oracle" not in txt, f
+                assert "hipemu" not in txt and "rhip_emu" not in txt, f  # the CPU emulator is test-only too
     out = os.popen(f"readelf -d {os.path.join(pkg, 'libroaring_hip.so')}").read()
     assert "oracle" not in out and "croaring_ref" not in out

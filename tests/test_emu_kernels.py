@@ -96,3 +96,30 @@ def test_emu_randomized_pools(emu, oracle):
 def test_emu_64bit(emu, oracle):
     G64.test_64bit_pairwise_and_many(emu, oracle)
     G64.test_64bit_reference_fixtures(emu)
+
+
+def test_emu_dropin_entry_points(emu, ref):
+    """The CRoaring-named per-call drop-ins (include/roaring_hip_compat.h) on reference-made structs."""
+    import test_gpu_compat as GC
+    lib = GC.bind(emu.lib)
+    GC.test_dropin_pairwise(lib, ref)
+    GC.test_dropin_many(lib, ref)
+    GC.test_dropin_lazy_family(lib, ref)
+
+
+def test_emu_pool_reshaping(emu, oracle):
+    """rhip_pool_select / rhip_pairwise_inplace / run_optimize / remove_run_compression / predicates."""
+    import test_gpu_poolops as GP
+    GP.test_pool_select(emu, oracle)
+    GP.test_pool_select_64bit(emu, oracle)
+    for op in OPS:
+        GP.test_pairwise_inplace(emu, oracle, op)
+    for mode in ("run_optimize", "remove_run_compression"):
+        GP.test_container_conversions(emu, oracle, mode)
+    GP.test_pairwise_predicates(emu, oracle)
+
+
+def test_emu_pool_reshaping_vs_reference(emu, ref):
+    import test_gpu_poolops as GP
+    GP.test_container_conversions_vs_reference(emu, ref)
+    GP.test_pairwise_predicates_vs_reference(emu, ref)

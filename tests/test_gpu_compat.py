@@ -15,7 +15,11 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def hip():
     import croaring_amd
-    lib = croaring_amd.load()
+    return bind(croaring_amd.load())
+
+
+def bind(lib):
+    """ctypes prototypes of the CRoaring-named entry points (shared with tests/test_emu_kernels.py)."""
     vp = C.c_void_p
     for op in OPS:
         f = getattr(lib, f"roaring_bitmap_{op}"); f.restype = vp; f.argtypes = [vp, vp]

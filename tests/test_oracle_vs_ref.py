@@ -91,3 +91,38 @@ def test_or_many_full_container_orderings(oracle, ref):
             assert ref.serialize(a) == oracle.serialize(b), [names[i] for i in combo]
             ref.free(a)
             oracle.free(b)
+
+
+def test_conversions_and_predicates(oracle, ref):
+    """oc_run_optimize / oc_remove_run_compression / oc_intersect / oc_is_subset / oc_is_strict_subset / oc_equals
+    vs roaring_bitmap_run_optimize (roaring.c:1530), _remove_run_compression (:1564), _intersect (:2998),
+    _is_subset (:2151), _is_strict_subset (:3172), _equals (:2128)."""
+    from gen_inputs import random_bitmap
+    rng = np.random.default_rng(31)
+    vals = [random_bitmap(rng, max_keys=6, key_space=8) for _ in range(80)]
+    oh = [oracle.from_sorted(v, run_optimize=bool(i & 1)) for i, v in enumerate(vals)]
+    rh = [ref.from_sorted(v, run_optimize=bool(i & 1)) for i, v in enumerate(vals)]
+    for a, b in zip(oh, rh):
+        assert oracle.serialize(a) == ref.serialize(b)
+    # engineered subsets
+    for i in range(0, 40, 2):
+        oh.append(oracle.op("and", oh[i], oh[i + 1]))
+        rh.append(ref.op("and", rh[i], rh[i + 1]))
+    n = len(oh)
+    pairs = [(int(a), int(b)) for a, b in zip(rng.integers(0, n, 500), rng.integers(0, n, 500))]
+    pairs += [(80 + k, 2 * k) for k in range(20)] + [(k, k) for k in range(10)]
+    for pred in ("intersect", "is_subset", "is_strict_subset", "equals"):
+        for a, b in pairs:
+            assert oracle.predicate(pred, oh[a], oh[b]) == ref.predicate(pred, rh[a], rh[b]), (pred, a, b)
+    for mode in ("run_optimize", "remove_run_compression"):
+        for a, b in zip(oh, rh):
+            ca, cb = oracle.deserialize(oracle.serialize(a)), ref.deserialize(ref.serialize(b))
+            assert getattr(oracle, mode)(ca) == getattr(ref, mode)(cb), mode
+            assert oracle.serialize(ca) == ref.serialize(cb), mode
+            assert oracle.validate(ca)
+            oracle.free(ca)
+            ref.free(cb)
+    for h in oh:
+        oracle.free(h)
+    for h in rh:
+        ref.free(h)
