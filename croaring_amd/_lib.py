@@ -51,6 +51,8 @@ SYMBOLS = [
     ("rhip_pool_portable_size", _sz, [_vp, _u32]),
     ("rhip_pool_portable_serialize", _sz, [_vp, _u32, _vp]),
     ("rhip_pool_cardinalities", _i, [_vp, _vp]),
+    ("rhip_pool_portable_sizes", _i, [_vp, _sz, _vp, _vp]),
+    ("rhip_pool_portable_serialize_many", _sz, [_vp, _sz, _vp, _vp, _sz, _vp]),
     ("rhip_pairwise", _vp, [_vp, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     ("rhip_pairwise_cardinality", _i, [_vp, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     ("rhip_pairwise_predicate", _i, [_vp, _i, _vp, _vp, _sz, _vp, _vp, _vp]),

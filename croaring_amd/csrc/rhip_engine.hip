@@ -18,6 +18,7 @@
 #include "rhip_kernels.h"
 #include "rhip_many.h"
 #include "rhip_poolops.h"
+#include "rhip_serial.h"
 #include "rhip_prims.h"
 
 // ------------------------------------------------------------------ errors

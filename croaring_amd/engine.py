@@ -288,5 +288,25 @@ class Pool:
             raise RoaringHipError(f"serialize wrote {w} of {n} bytes: " + self.eng._err())
         return buf.raw
 
+    def serialize_many(self, ids=None):
+        """Portable images of bitmaps `ids` (None: all) packed back to back: (uint8 blob, uint64 offsets[n+1]).
+        32-bit pools: assembled on the device, one download."""
+        ids_a = None if ids is None else _u32(ids)
+        n = len(self) if ids_a is None else ids_a.size
+        ip = None if ids_a is None else ids_a.ctypes.data
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        if self.eng.lib.rhip_pool_portable_sizes(self.h, n, ip, offs.ctypes.data) != 0:
+            raise RoaringHipError("portable_sizes failed: " + self.eng._err())
+        blob = np.empty(int(offs[n]), dtype=np.uint8)
+        if n and int(offs[n]):
+            w = self.eng.lib.rhip_pool_portable_serialize_many(self.h, n, ip, blob.ctypes.data, blob.size, None)
+            if w != blob.size:
+                raise RoaringHipError(f"serialize_many wrote {w} of {blob.size} bytes: " + self.eng._err())
+        return blob, offs
+
     def serialize_all(self) -> list:
-        return [self.serialize(i) for i in range(len(self))]
+        if self.is64:
+            return [self.serialize(i) for i in range(len(self))]
+        blob, offs = self.serialize_many()
+        raw = blob.tobytes()
+        return [raw[int(offs[i]):int(offs[i + 1])] for i in range(len(self))]

@@ -96,6 +96,14 @@ size_t rhip_pool_portable_size(rhip_pool_t *pool, uint32_t i);
 size_t rhip_pool_portable_serialize(rhip_pool_t *pool, uint32_t i, char *buf);
 /* roaring_bitmap_get_cardinality (roaring.h:537, src/roaring.c:1436-1443) of every bitmap */
 int rhip_pool_cardinalities(rhip_pool_t *pool, uint64_t *out /* [rhip_pool_size] */);
+/* Bulk form of the two calls above for 32-bit pools: the portable images of pool[ids[0..n)] (ids == NULL: every
+ * bitmap, in order; ids must not repeat) are assembled on the device back to back and downloaded in one copy.
+ * rhip_pool_portable_sizes fills offsets[0..n_sel] (offsets[k] = start of image k, offsets[n_sel] = total bytes);
+ * rhip_pool_portable_serialize_many writes the images into buf (capacity cap), optionally the same offsets, and
+ * returns the bytes written (0 on error).  Each image is byte-identical to rhip_pool_portable_serialize's. */
+int rhip_pool_portable_sizes(rhip_pool_t *pool, size_t n, const uint32_t *ids, uint64_t *offsets);
+size_t rhip_pool_portable_serialize_many(rhip_pool_t *pool, size_t n, const uint32_t *ids, char *buf, size_t cap,
+                                         uint64_t *offsets);
 
 /* ---- pairwise set operations ------------------------------------------- */
 /* For k in [0,npairs): result k = op(A[lhs[k]], B[rhs[k]]) with the exact

@@ -33,11 +33,13 @@ def asan_runtime() -> str:
 
 
 def build(force: bool = False, verbose: bool = False, asan: bool = False) -> str:
-    """asan=True builds librhip_emu_asan.so (AddressSanitizer: out-of-bounds global / LDS / stack accesses of the
-    kernels abort); the process using it must run with LD_PRELOAD=asan_runtime()."""
+    """asan=True builds librhip_emu_asan.so: AddressSanitizer (out-of-bounds global / LDS / stack accesses of the
+    kernels abort) plus alignment traps (a misaligned typed access -- which x86 would forgive and the GPU would
+    not -- raises SIGILL); the process using it must run with LD_PRELOAD=asan_runtime()."""
     if asan:
-        return _build(os.path.join(OUT, "librhip_emu_asan.so"), ["-fsanitize=address", "-fno-omit-frame-pointer",
-                                                                  "-shared-libasan"], force, verbose)
+        return _build(os.path.join(OUT, "librhip_emu_asan.so"), ["-fsanitize=address,alignment",
+                                                                  "-fsanitize-trap=alignment",
+                                                                  "-fno-omit-frame-pointer", "-shared-libasan"], force, verbose)
     return _build(LIB, [], force, verbose)
 
 

@@ -117,6 +117,7 @@ def test_emu_pool_reshaping(emu, oracle):
     for mode in ("run_optimize", "remove_run_compression"):
         GP.test_container_conversions(emu, oracle, mode)
     GP.test_pairwise_predicates(emu, oracle)
+    GP.test_bulk_serialization(emu, oracle)
 
 
 def test_emu_pool_reshaping_vs_reference(emu, ref):

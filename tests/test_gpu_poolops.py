@@ -242,3 +242,51 @@ def test_pairwise_predicates_vs_reference(engine, ref):
         assert np.array_equal(got, want), pred
     for h in hs:
         ref.free(h)
+
+
+def test_bulk_serialization(engine, oracle):
+    """rhip_pool_portable_serialize_many: device-assembled images are byte-identical to the per-bitmap path and to
+    the oracle, for every header variant (no runs; runs with < 4 and >= 4 containers; empty) and every payload
+    alignment the run-flag bytes can produce."""
+    rng = np.random.default_rng(28)
+    hs = []
+    for nk in list(range(0, 20)) + [33, 64, 65]:          # (n + 7) / 8 odd and even, n < 4 and n >= 4
+        for ro in (False, True):
+            keys = np.sort(rng.choice(200, nk, replace=False)).astype(np.uint32)
+            parts = [(k << np.uint32(16)) | chunk_values(rng, PROFILES[int(rng.integers(0, len(PROFILES)))]).astype(np.uint32)
+                     for k in keys]
+            v = np.concatenate(parts) if parts else np.zeros(0, np.uint32)
+            hs.append(oracle.from_sorted(v, run_optimize=ro))
+    bufs = [oracle.serialize(h) for h in hs]
+    P = engine.pool_from_serialized(bufs)
+    blob, offs = P.serialize_many()
+    assert offs[0] == 0 and int(offs[-1]) == blob.size == sum(len(b) for b in bufs)
+    raw = blob.tobytes()
+    for i, b in enumerate(bufs):
+        assert raw[int(offs[i]):int(offs[i + 1])] == b, i
+    assert P.serialize_all() == bufs
+    # subset, arbitrary order
+    ids = rng.permutation(len(bufs))[:17].astype(np.uint32)
+    blob2, offs2 = P.serialize_many(ids)
+    raw2 = blob2.tobytes()
+    for k, i in enumerate(ids):
+        assert raw2[int(offs2[k]):int(offs2[k + 1])] == bufs[i]
+    # a result pool (slots are upper bounds, directory compacted) through the same path
+    lhs = rng.integers(0, len(bufs), 120).astype(np.uint32)
+    rhs = rng.integers(0, len(bufs), 120).astype(np.uint32)
+    for op in OPS:
+        R = engine.pairwise(op, P, lhs, P, rhs)
+        allr = R.serialize_all()
+        for k in range(0, 120):
+            assert allr[k] == R.serialize(k), (op, k)
+        oo = oracle.op(op, hs[lhs[5]], hs[rhs[5]])
+        assert allr[5] == oracle.serialize(oo)
+        oracle.free(oo)
+    with pytest.raises(Exception):
+        P.serialize_many([1, 1])
+    with pytest.raises(Exception):
+        P.serialize_many([len(bufs)])
+    b0, o0 = P.serialize_many([])
+    assert b0.size == 0 and list(o0) == [0]
+    for h in hs:
+        oracle.free(h)
