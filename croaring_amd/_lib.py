@@ -41,6 +41,7 @@ SYMBOLS = [
     ("rhip_version", C.c_char_p, []),
     ("rhip_pool_from_portable", _vp, [_vp, _sz, _vp, _vp]),
     ("rhip_pool_from_portable64", _vp, [_vp, _sz, _vp, _vp]),
+    ("rhip_pool_from_blob", _vp, [_vp, _vp, _sz, _sz, _vp, _vp, _i]),
     ("rhip_pool_synth_bitset", _vp, [_vp, _u32, _u32, _u64]),
     ("rhip_pool_free", None, [_vp]),
     ("rhip_pool_size", _u32, [_vp]),

@@ -19,6 +19,7 @@
 #include "rhip_many.h"
 #include "rhip_poolops.h"
 #include "rhip_serial.h"
+#include "rhip_deser.h"
 #include "rhip_prims.h"
 
 // ------------------------------------------------------------------ errors

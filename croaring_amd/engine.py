@@ -89,6 +89,24 @@ class Engine:
             raise RoaringHipError("deserialize failed: " + self._err())
         return Pool(self, h)
 
+    def pool_from_blob(self, blob, offsets, lens=None, is64: bool = False) -> "Pool":
+        """n portable images packed in one uint8 array (image i = blob[offsets[i] : offsets[i] + lens[i]]; lens
+        defaults to the gaps of an (n+1)-entry offsets array, i.e. the output of Pool.serialize_many): ONE upload,
+        parsed and validated on the device."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        if lens is None:
+            lens = np.diff(offsets)
+            offsets = np.ascontiguousarray(offsets[:-1])
+        lens = np.ascontiguousarray(lens, dtype=np.uint64)
+        if offsets.shape != lens.shape:
+            raise ValueError("offsets/lens length mismatch")
+        h = self.lib.rhip_pool_from_blob(self.h, blob.ctypes.data, blob.size, offsets.size, offsets.ctypes.data,
+                                         lens.ctypes.data, 1 if is64 else 0)
+        if not h:
+            raise RoaringHipError("deserialize failed: " + self._err())
+        return Pool(self, h)
+
     def pool_from_serialized64(self, bufs: Sequence[bytes]) -> "Pool":
         """roaring64_bitmap_portable_deserialize_safe for every buffer."""
         return self._from_bufs(self.lib.rhip_pool_from_portable64, bufs)

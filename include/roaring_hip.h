@@ -75,6 +75,12 @@ rhip_pool_t *rhip_pool_from_portable(rhip_ctx_t *ctx, size_t n, const char *cons
  * (include/roaring/roaring64.h:652, src/roaring64.c:2442-2535).  Keys are the
  * high 48 bits. */
 rhip_pool_t *rhip_pool_from_portable64(rhip_ctx_t *ctx, size_t n, const char *const *bufs, const size_t *lens);
+/* Same loaders for n images packed in ONE host blob (image i = blob[offsets[i], offsets[i] + lens[i]), e.g. the
+ * output of rhip_pool_portable_serialize_many): a single host-to-device copy, then headers are parsed and every
+ * container is validated and moved into place by kernels.  Accepts and rejects exactly what the loaders above
+ * do.  is64 != 0: the images are roaring64 portable images. */
+rhip_pool_t *rhip_pool_from_blob(rhip_ctx_t *ctx, const char *blob, size_t blob_bytes, size_t n,
+                                 const uint64_t *offsets, const uint64_t *lens, int is64);
 /* SURVEY §8d C2 generator: n_bitmaps bitmaps with keys 0..n_containers-1, all
  * bitset containers, word w of bitmap b = splitmix64 stream seeded
  * seed + b (generated on the device). */

@@ -120,6 +120,13 @@ def test_emu_pool_reshaping(emu, oracle):
     GP.test_bulk_serialization(emu, oracle)
 
 
+def test_emu_device_deserialization(emu, oracle):
+    import test_gpu_poolops as GP
+    GP.test_device_deserialization_roundtrip(emu, oracle)
+    GP.test_device_deserialization_64bit(emu, oracle)
+    GP.test_device_deserialization_rejects_what_the_host_loader_rejects(emu, oracle)
+
+
 def test_emu_pool_reshaping_vs_reference(emu, ref):
     import test_gpu_poolops as GP
     GP.test_container_conversions_vs_reference(emu, ref)

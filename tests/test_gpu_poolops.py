@@ -290,3 +290,154 @@ def test_bulk_serialization(engine, oracle):
     assert b0.size == 0 and list(o0) == [0]
     for h in hs:
         oracle.free(h)
+
+
+def _pack(bufs):
+    lens = np.array([len(b) for b in bufs], dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    return np.frombuffer(b"".join(bufs), dtype=np.uint8), offs
+
+
+def test_device_deserialization_roundtrip(engine, oracle):
+    """rhip_pool_from_blob on every fixture family: the pool re-serializes to the input bytes, and matches the
+    host-parsed pool in types and cardinalities."""
+    from util import load_bundle
+    rng = np.random.default_rng(29)
+    families = {
+        "census1881": load_bundle("census1881"),
+        "weather": load_bundle("weather_sept_85")[:64],
+        "wikileaks": load_bundle("wikileaks-noquotes"),
+    }
+    hs = _conversion_inputs(oracle, rng)
+    families["profiles"] = [oracle.serialize(h) for h in hs]
+    for h in hs:
+        oracle.free(h)
+    for name, bufs in families.items():
+        blob, offs = _pack(bufs)
+        P = engine.pool_from_blob(blob, offs)
+        H = engine.pool_from_serialized(bufs)
+        assert len(P) == len(bufs) and P.n_containers == H.n_containers, name
+        assert P.type_counts() == H.type_counts(), name
+        assert np.array_equal(P.cardinalities(), H.cardinalities()), name
+        assert P.serialize_all() == bufs, name
+        # the device-parsed pool is an ordinary operand
+        k = min(len(bufs) - 1, 20)
+        a = engine.pairwise("xor", P, np.arange(k, dtype=np.uint32), P, np.arange(1, k + 1, dtype=np.uint32))
+        b = engine.pairwise("xor", H, np.arange(k, dtype=np.uint32), H, np.arange(1, k + 1, dtype=np.uint32))
+        assert a.serialize_all() == b.serialize_all(), name
+    # images need not be contiguous or ordered inside the blob; trailing bytes after an image are ignored
+    bufs = families["wikileaks"][:10]
+    pad = [b + bytes(rng.integers(0, 256, int(rng.integers(0, 9)), dtype=np.uint8)) for b in bufs]
+    order = rng.permutation(10)
+    pos, chunks, cur = {}, [], 3
+    chunks.append(b"\xEE" * 3)
+    for i in order:
+        pos[i] = cur
+        chunks.append(pad[i])
+        cur += len(pad[i])
+    blob = np.frombuffer(b"".join(chunks), dtype=np.uint8)
+    P = engine.pool_from_blob(blob, [pos[i] for i in range(10)], [len(pad[i]) for i in range(10)])
+    assert P.serialize_all() == bufs
+    assert len(engine.pool_from_blob(np.zeros(0, np.uint8), [0])) == 0
+    with pytest.raises(Exception):
+        engine.pool_from_blob(blob, [0], [blob.size + 1])
+
+
+def test_device_deserialization_64bit(engine, oracle):
+    import os
+    from util import GOLD
+    rng = np.random.default_rng(30)
+    bufs = []
+    for _ in range(12):
+        nb = int(rng.integers(0, 5))
+        highs = np.sort(rng.choice(50, nb, replace=False)).astype(np.uint64)
+        parts = [(h << np.uint64(32)) | random_bitmap(rng, max_keys=5, key_space=9).astype(np.uint64) for h in highs]
+        v = np.unique(np.concatenate(parts)) if parts else np.zeros(0, np.uint64)
+        h = oracle.from_sorted64(v)
+        bufs.append(oracle.serialize64(h))
+        oracle.free64(h)
+    for f in sorted(os.listdir(GOLD)):
+        if f.startswith("64map") and f.endswith(".bin"):
+            bufs.append(open(os.path.join(GOLD, f), "rb").read())
+    blob, offs = _pack(bufs)
+    P = engine.pool_from_blob(blob, offs, is64=True)
+    H = engine.pool_from_serialized64(bufs)
+    assert P.is64 and P.n_containers == H.n_containers and P.type_counts() == H.type_counts()
+    assert np.array_equal(P.cardinalities(), H.cardinalities())
+    for i in range(len(bufs)):
+        assert P.serialize(i) == H.serialize(i), i
+
+
+def _mutations(rng, buf, count):
+    out = []
+    b = bytearray(buf)
+    for _ in range(count):
+        m = bytearray(b)
+        kind = int(rng.integers(0, 5))
+        if kind == 0 and len(m) > 1:                       # truncate
+            m = m[:int(rng.integers(0, len(m)))]
+        elif kind == 1:                                    # flip a byte in the header region
+            i = int(rng.integers(0, min(len(m), 64)))
+            m[i] ^= int(rng.integers(1, 256))
+        elif kind == 2:                                    # flip a byte anywhere
+            i = int(rng.integers(0, len(m)))
+            m[i] ^= int(rng.integers(1, 256))
+        elif kind == 3 and len(m) >= 8:                    # overwrite a random aligned u16 with an extreme value
+            i = int(rng.integers(0, len(m) // 2)) * 2
+            m[i:i + 2] = [b"\x00\x00", b"\xff\xff", b"\x01\x00", b"\x00\x10"][int(rng.integers(0, 4))]
+        else:                                              # swap two u16s (breaks sortedness somewhere)
+            if len(m) >= 8:
+                i, j = (int(x) * 2 for x in rng.integers(0, len(m) // 2, 2))
+                m[i:i + 2], m[j:j + 2] = m[j:j + 2], m[i:i + 2]
+        out.append(bytes(m))
+    return out
+
+
+def test_device_deserialization_rejects_what_the_host_loader_rejects(engine, oracle):
+    """Differential fuzzing of the two loaders: mutated images are accepted by the device parser iff the host
+    parser accepts them, and then produce the same pool (the offset header, which the reference ignores, may be
+    garbage without consequence)."""
+    rng = np.random.default_rng(31)
+    hs = _conversion_inputs(oracle, rng)
+    seeds = [oracle.serialize(h) for h in hs if oracle.cardinality(h)]
+    for h in hs:
+        oracle.free(h)
+    seeds = [s for s in seeds if len(s) < 40000][:40]
+    cases = []
+    for s in seeds:
+        cases += _mutations(rng, s, 12)
+    # garbage offset header on otherwise valid images (n >= 4 with runs, and no-run images)
+    for s in seeds:
+        n_run = (int.from_bytes(s[:4], "little") >> 16) + 1 if s[:2] == b"\x3b\x30" else None
+        if n_run is None:
+            n = int.from_bytes(s[4:8], "little")
+            o = 8 + 4 * n
+        elif n_run >= 4:
+            n = n_run
+            o = 4 + (n + 7) // 8 + 4 * n
+        else:
+            continue
+        m = bytearray(s)
+        m[o:o + 4 * n] = bytes(rng.integers(0, 256, 4 * n, dtype=np.uint8))
+        cases.append(bytes(m))
+    accepted = rejected = 0
+    for k, m in enumerate(cases):
+        try:
+            H = engine.pool_from_serialized([m])
+        except Exception:
+            H = None
+        blob = np.frombuffer(m, dtype=np.uint8) if len(m) else np.zeros(0, np.uint8)
+        try:
+            P = engine.pool_from_blob(blob, [0], [len(m)])
+        except Exception:
+            P = None
+        assert (H is None) == (P is None), f"case {k}: host loader {'rejects' if H is None else 'accepts'}, device differs"
+        if H is not None:
+            accepted += 1
+            assert P.serialize(0) == H.serialize(0), k
+            h = oracle.deserialize(P.serialize(0))
+            assert oracle.validate(h)
+            oracle.free(h)
+        else:
+            rejected += 1
+    assert accepted > 30 and rejected > 100, (accepted, rejected)
