@@ -1,0 +1,21 @@
+"""rocprofv3 target: C3 weather_sept_85 all-pairs, one op per run (argv[1]), 10 timed batches."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch  # noqa
+import croaring_amd
+from util import load_bundle, all_pairs
+op = sys.argv[1] if len(sys.argv) > 1 else "and"
+name = sys.argv[2] if len(sys.argv) > 2 else "weather_sept_85"
+eng = croaring_amd.Engine(0)
+bufs = load_bundle(name)
+pool = eng.pool_from_serialized(bufs)
+lhs, rhs = all_pairs(len(bufs))
+res = None
+ts = []
+for _ in range(12):
+    t = time.perf_counter()
+    res = eng.pairwise(op, pool, lhs, pool, rhs, reuse=res)
+    ts.append(time.perf_counter() - t)
+print(op, name, "min ms", min(ts) * 1e3)
