@@ -33,6 +33,8 @@ def _stale(obj: str, src: str) -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
+    extra = os.environ.get("RHIP_EXTRA_FLAGS", "").split()  # diagnostic builds, e.g. -DRHIP_PHASES
+    force = force or bool(extra)
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
     objs, rebuilt = [], False
@@ -42,7 +44,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             continue
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         if force or _stale(obj, sp):
-            cmd = [hipcc, *FLAGS, "-x", "hip", "-c", sp, "-o", obj]
+            cmd = [hipcc, *FLAGS, *extra, "-x", "hip", "-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

@@ -22,11 +22,13 @@ __global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ aren
     uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     FatItem tnext;
     if (w < n) tnext = q[w];
+    PH_BEGIN();
     for (; w < n; w += nwaves) {
         const FatItem t = tnext;
         if (w + nwaves < n) tnext = q[w + nwaves];  // next work item in flight while this one is processed
         const uint8_t ta = (uint8_t)(t.types & 0xFF), tb = (uint8_t)(t.types >> 8);
         const uint32_t ca = t.ca, cb = t.cb;
+        PH(0);
         // Y = the streamed array, X = the membership side
         bool y_is_a = true;
         if (op == OP_AND) y_is_a = (ta == T_ARRAY) && (tb != T_ARRAY || ca <= cb);
@@ -58,6 +60,7 @@ __global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ aren
             }
             __builtin_amdgcn_wave_barrier();
         }
+        PH(1);
         uint16_t* __restrict__ out = cardmode ? nullptr : (uint16_t*)(O.arena + O.off[t.out]);
         uint32_t run = 0;
         for (uint32_t base = 0; base < ny; base += 512) {
@@ -85,13 +88,16 @@ __global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ aren
             }
             run += __shfl(inc, 63);
         }
+        PH(2);
         if (cardmode) {
             if (lane == 0 && run) atomicAdd(&pair_acc[t.out], (u64)run);
         } else if (lane == 0) {
             O.meta[t.out] = pack_meta(T_ARRAY, run, 0);
         }
         __builtin_amdgcn_wave_barrier();
+        PH(3);
     }
+    PH_FLUSH(0);
 }
 
 // ------------------------------------------------------------------ wave-private LDS image kernel (K6, K10, K11)
@@ -111,10 +117,12 @@ __global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA
     uint32_t* img = img_all[threadIdx.x >> 6];
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
+    PH_BEGIN();
     for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
         const FatItem t = q[w];
         const uint8_t ta = (uint8_t)(t.types & 0xFF), tb = (uint8_t)(t.types >> 8);
         const uint32_t ca = t.ca, cb = t.cb;
+        PH(0);
         // X = image side, Y = applied array.  andnot: X = a (bitset), Y = b.  or/xor are symmetric:
         // take the bitset (or the larger array) as X.
         bool x_is_a = true;
@@ -146,6 +154,7 @@ __global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA
             }
         }
         __builtin_amdgcn_wave_barrier();  // X is complete in the image before Y is applied (xor / clear are order-sensitive)
+        PH(1);
         int delta = 0;
         {
             const uint4* __restrict__ y4 = (const uint4*)y2;
@@ -172,6 +181,7 @@ __global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA
                 }
             }
         }
+        PH(2);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) delta += __shfl_xor(delta, o);
         const uint32_t rc = (uint32_t)((int)cx + delta);
@@ -179,6 +189,7 @@ __global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA
         if (rc) ty = decide_type(op, ta, tb, ca, cb, false, false, rc, 0);
         uint8_t* outp = O.arena + O.off[t.out];
         __builtin_amdgcn_wave_barrier();
+        PH(3);
         if (rc && ty == T_BITSET) {
             uint4* __restrict__ po = (uint4*)outp;
 #pragma unroll
@@ -221,6 +232,7 @@ __global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA
                     ((uint4*)tab)[4 * lane + i] = make_uint4(ow[4 * i], ow[4 * i + 1], ow[4 * i + 2], ow[4 * i + 3]);
             }
             __builtin_amdgcn_wave_barrier();
+            PH(4);
             uint16_t* __restrict__ o16 = (uint16_t*)outp;
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
@@ -233,7 +245,10 @@ __global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA
                 }
             }
         }
+        PH(5);
         if (lane == 0) O.meta[t.out] = pack_meta(ty, rc, 0);
         __builtin_amdgcn_wave_barrier();
+        PH(6);
     }
+    PH_FLUSH(8);
 }

@@ -62,6 +62,20 @@ struct Stats {  // device-side counters, see rhip_stats_t
 };
 
 
+// ------------------------------------------------------------------ phase clocks (diagnostic builds only)
+// -DRHIP_PHASES: the wave-per-pair kernels accumulate s_memrealtime ticks (100 MHz) per phase into g_phase[],
+// read back with rhip_debug_phases().  Compiled out of the product build (the macros expand to nothing).
+#ifdef RHIP_PHASES
+__device__ u64 g_phase[32];
+#define PH_BEGIN() u64 ph_t_ = wall_clock64(); u64 ph_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PH(n) do { const u64 t__ = wall_clock64(); ph_acc_[n] += t__ - ph_t_; ph_t_ = t__; } while (0)
+#define PH_FLUSH(base) do { if (lane_id() == 0) for (int k__ = 0; k__ < 8; ++k__) atomicAdd(&g_phase[(base) + k__], ph_acc_[k__]); } while (0)
+#else
+#define PH_BEGIN() do { } while (0)
+#define PH(n) do { } while (0)
+#define PH_FLUSH(base) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------ wave helpers
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t mbcnt(u64 m) {

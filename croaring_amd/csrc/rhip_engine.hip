@@ -79,6 +79,11 @@ struct rhip_ctx_s {
     rhip_stats_t stats{};
     bool timing = false;
     hipEvent_t ev[4]{};
+    // independent class kernels of one batch run concurrently: fork after planning, join before compaction
+    static constexpr int N_AUX = 4;
+    hipStream_t aux[N_AUX]{};
+    hipEvent_t ev_fork = nullptr, ev_join[N_AUX]{}, ev_runs = nullptr;
+    bool overlap = true;
 };
 
 struct rhip_pool_s {
@@ -139,6 +144,11 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIPCHK(hipHostMalloc(&c->h_pinned, 4096, hipHostMallocDefault));
         for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
+        for (auto& a : c->aux) HIPCHK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_runs, hipEventDisableTiming));
+        for (auto& e : c->ev_join) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if (const char* e = getenv("RHIP_NO_OVERLAP")) c->overlap = !(e[0] == '1');
         return c;
     } catch (int) {
         return nullptr;
@@ -154,6 +164,10 @@ extern "C" void rhip_ctx_destroy(rhip_ctx_t* c) {
     for (auto& b : c->many) b.release();
     for (auto& b : c->sel) b.release();
     for (auto& e : c->ev) (void)hipEventDestroy(e);
+    for (auto& a : c->aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_runs) (void)hipEventDestroy(c->ev_runs);
+    for (auto& e : c->ev_join) if (e) (void)hipEventDestroy(e);
     (void)hipHostFree(c->h_pinned);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -745,12 +759,64 @@ unsigned persistent_grid(uint64_t n_items, unsigned items_per_block, unsigned ma
     return (unsigned)std::min<uint64_t>(need, max_blocks);
 }
 
+// The class kernels of one batch are independent of each other (disjoint work queues, disjoint result slots;
+// pair_acc and the retry counter are only touched with atomics), except that the retry pass of k_genw consumes what
+// k_bb and k_runs re-queue.  When more than one class has work they are forked onto auxiliary streams after
+// planning and joined before compaction, so the latency-bound wave-per-pair kernels overlap each other and the
+// bandwidth-bound copies:
+//     main : k_bb ----------------------> [wait k_runs] k_genw(retry) -> [join] ...
+//     aux0 : k_runs
+//     aux1 : k_filter      aux2 : k_wave      aux3 : k_genw(general), k_copy
+// A batch with a single class (the bitset-only C2 workload) stays on the main stream with no events at all.
 void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, const OutView& O,
                  const PlanResult& R, int cardmode) {
     hipStream_t s = c->stream;
     const u64* ranges = (const u64*)((char*)c->misc.p + MISC_RANGES_OFF);
     uint32_t* retry_count = (uint32_t*)((char*)c->misc.p + MISC_RETRY_OFF);
     c->q[CLS_RETRY].ensure(sizeof(GenItem) * (R.n_bb + R.n_runs + 1));
+    const bool has_wave = R.n_wave && !cardmode, has_copy = R.n_copy && !cardmode;
+    const int n_classes = (R.n_bb != 0) + (R.n_runs != 0) + (R.n_filt != 0) + (has_wave ? 1 : 0) + (R.n_gen != 0) +
+                          (has_copy ? 1 : 0);
+    const bool fork = c->overlap && n_classes > 1;
+    bool used[rhip_ctx_s::N_AUX] = {false, false, false, false};
+    auto on = [&](int a) -> hipStream_t {
+        if (!fork) return s;
+        if (!used[a]) {
+            HIPCHK(hipStreamWaitEvent(c->aux[a], c->ev_fork, 0));
+            used[a] = true;
+        }
+        return c->aux[a];
+    };
+    if (fork) HIPCHK(hipEventRecord(c->ev_fork, s));
+    // largest, latency-bound kernels first so that they get the machine's first workgroup slots
+    if (R.n_filt) {
+        unsigned grid = persistent_grid(R.n_filt, 4, 256 * 4);
+        hipLaunchKernelGGL(k_filter, dim3(grid), dim3(256), 0, on(1), VA.arena, VB.arena, O, c->q[CLS_FILT].as<FatItem>(),
+                           ranges + 2 * SEC_FILT, op, cardmode, c->pair_acc.as<u64>());
+    }
+    if (has_wave) {
+        unsigned grid = persistent_grid(R.n_wave, 4, 256 * 4);
+        hipLaunchKernelGGL(k_wave, dim3(grid), dim3(256), 0, on(2), VA.arena, VB.arena, O, c->q[CLS_WAVE].as<FatItem>(),
+                           ranges + 2 * SEC_WAVE, op);
+    }
+    if (R.n_runs) {
+        unsigned grid = persistent_grid(R.n_runs, 4, 256 * 4);
+        hipStream_t sr = on(0);
+        hipLaunchKernelGGL(k_runs, dim3(grid), dim3(256), 0, sr, VA.arena, VB.arena, O, c->q[CLS_RUNS].as<GenItem>(),
+                           ranges + 2 * SEC_RUNS, op, cardmode, c->pair_acc.as<u64>(), c->q[CLS_RETRY].as<GenItem>(),
+                           retry_count);
+        if (fork) HIPCHK(hipEventRecord(c->ev_runs, sr));
+    }
+    if (R.n_gen) {
+        unsigned grid = persistent_grid(R.n_gen, 4, 256 * 2);  // 248 VGPRs: 2 workgroups resident per CU
+        hipLaunchKernelGGL(k_genw, dim3(grid), dim3(256), 0, on(3), VA.arena, VB.arena, O, c->q[CLS_GEN].as<GenItem>(),
+                           ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, cardmode, c->pair_acc.as<u64>());
+    }
+    if (has_copy) {
+        unsigned grid = persistent_grid(R.n_copy, 4, 256 * 8);
+        hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, on(3), VA, VB, O, c->q[CLS_COPY].as<Item>(),
+                           ranges + 2 * SEC_COPY);
+    }
     if (R.n_bb) {
         unsigned grid = persistent_grid(R.n_bb, 4, 256 * 32);
         if (c->timing) HIPCHK(hipEventRecord(c->ev[2], s));
@@ -762,39 +828,20 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
         }
         if (c->timing) HIPCHK(hipEventRecord(c->ev[3], s));
     }
-    if (R.n_runs) {
-        unsigned grid = persistent_grid(R.n_runs, 4, 256 * 4);
-        hipLaunchKernelGGL(k_runs, dim3(grid), dim3(256), 0, s, VA.arena, VB.arena, O, c->q[CLS_RUNS].as<GenItem>(),
-                           ranges + 2 * SEC_RUNS, op, cardmode, c->pair_acc.as<u64>(), c->q[CLS_RETRY].as<GenItem>(),
-                           retry_count);
-    }
     if (!cardmode && ((R.n_bb && op != OP_OR) || R.n_runs)) {
         // results that need the LDS image path after all: bitset x bitset results that must become
         // arrays (card <= 4096), interval results that must become bitsets
+        if (fork && R.n_runs) HIPCHK(hipStreamWaitEvent(s, c->ev_runs, 0));
         unsigned g2 = persistent_grid(R.n_bb + R.n_runs, 4, 256 * 2);  // 248 VGPRs: 2 workgroups resident per CU
         hipLaunchKernelGGL(k_genw, dim3(g2), dim3(256), 0, s, VA.arena, VB.arena, O, c->q[CLS_RETRY].as<GenItem>(),
                            (const u64*)nullptr, retry_count, op, 0, c->pair_acc.as<u64>());
     }
-    if (R.n_filt) {
-        unsigned grid = persistent_grid(R.n_filt, 4, 256 * 4);
-        hipLaunchKernelGGL(k_filter, dim3(grid), dim3(256), 0, s, VA.arena, VB.arena, O, c->q[CLS_FILT].as<FatItem>(),
-                           ranges + 2 * SEC_FILT, op, cardmode, c->pair_acc.as<u64>());
-    }
-    if (R.n_wave && !cardmode) {
-        unsigned grid = persistent_grid(R.n_wave, 4, 256 * 4);
-        hipLaunchKernelGGL(k_wave, dim3(grid), dim3(256), 0, s, VA.arena, VB.arena, O, c->q[CLS_WAVE].as<FatItem>(),
-                           ranges + 2 * SEC_WAVE, op);
-    }
-    if (R.n_gen) {
-        unsigned grid = persistent_grid(R.n_gen, 4, 256 * 2);  // 248 VGPRs: 2 workgroups resident per CU
-        hipLaunchKernelGGL(k_genw, dim3(grid), dim3(256), 0, s, VA.arena, VB.arena, O, c->q[CLS_GEN].as<GenItem>(),
-                           ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, cardmode, c->pair_acc.as<u64>());
-    }
-    if (R.n_copy && !cardmode) {
-        unsigned grid = persistent_grid(R.n_copy, 4, 256 * 8);
-        hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, s, VA, VB, O, c->q[CLS_COPY].as<Item>(),
-                           ranges + 2 * SEC_COPY);
-    }
+    if (fork)
+        for (int a = 0; a < rhip_ctx_s::N_AUX; ++a)
+            if (used[a]) {
+                HIPCHK(hipEventRecord(c->ev_join[a], c->aux[a]));
+                HIPCHK(hipStreamWaitEvent(s, c->ev_join[a], 0));
+            }
 }
 
 void finish_stats(rhip_ctx_t* c, const PlanResult* R) {
@@ -912,6 +959,19 @@ extern "C" int rhip_pairwise_cardinality(rhip_ctx_t* c, rhip_op op_, rhip_pool_t
         return RHIP_OK;
     } catch (int e) { return e; }
 }
+
+#ifdef RHIP_PHASES
+// diagnostic builds only: per-phase tick totals of k_filter ([0, 8)) and k_wave ([8, 16)); reset != 0 clears them
+extern "C" int rhip_debug_phases(rhip_ctx_t* c, unsigned long long out[32], int reset) {
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return RHIP_ERR_DEVICE;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 32) != hipSuccess) return RHIP_ERR_DEVICE;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z) != hipSuccess) return RHIP_ERR_DEVICE;
+    }
+    return RHIP_OK;
+}
+#endif
 
 #include "rhip_many_host.inc"
 #include "rhip_pool_ops.inc"

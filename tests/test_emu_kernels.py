@@ -89,6 +89,10 @@ def test_emu_directory_and_payload_extremes(emu, oracle):
     G.test_directory_and_payload_extremes(emu, oracle)
 
 
+def test_emu_array_array_union_boundaries(emu, oracle):
+    G.test_array_array_union_boundaries(emu, oracle)
+
+
 def test_emu_randomized_pools(emu, oracle):
     G.test_randomized_pools(emu, oracle, 11)
 

@@ -397,3 +397,43 @@ def test_randomized_pools(engine, oracle, seed):
         oracle.free(gx)
     for h in hs:
         oracle.free(h)
+
+
+def test_array_array_union_boundaries(engine, oracle):
+    """array x array or / xor around every size boundary of the typing rule (ca + cb <= 4096 -> array, else by
+    cardinality) and of the kernels' 64-lane / 512-value steps: identical / disjoint / interleaved / nested operands."""
+    rng = np.random.default_rng(77)
+    cases = []
+    ident = np.sort(rng.choice(65536, 1020, replace=False))
+    cases += [(ident, ident), (ident, ident[::2]), (ident[::2], ident), (ident[:1], ident), (ident, ident[-1:])]
+    cases += [(np.arange(0, 2000, 2), np.arange(1, 2001, 2)), (np.arange(0, 1000), np.arange(1000, 2000)),
+              (np.arange(1000, 2000), np.arange(0, 1000)), (np.arange(0, 1020), np.arange(0, 1020) + 1),
+              (np.arange(0, 4000, 2), np.arange(1, 4001, 2)), (np.arange(0, 2044), np.arange(0, 2044) + 1)]
+    for tot in (2, 3, 63, 64, 65, 127, 128, 129, 1000, 2039, 2040, 2041, 2047, 2048, 4088, 4095, 4096, 4097, 5000, 8000):
+        for frac in (0.02, 0.5, 0.98):
+            ca = max(1, min(4096, int(tot * frac)))
+            cb = max(1, min(4096, tot - ca))
+            univ = rng.choice(65536, min(65536, int((ca + cb) * rng.choice([1.0, 1.3, 4.0]))), replace=False)
+            a = np.sort(rng.choice(univ, min(ca, univ.size), replace=False))
+            b = np.sort(rng.choice(univ, min(cb, univ.size), replace=False))
+            cases.append((a, b))
+    hs = []
+    for a, b in cases:
+        hs.append(oracle.from_sorted(np.asarray(a, np.uint32) + (7 << 16), run_optimize=False))
+        hs.append(oracle.from_sorted(np.asarray(b, np.uint32) + (7 << 16), run_optimize=False))
+    bufs = [oracle.serialize(h) for h in hs]
+    pool = engine.pool_from_serialized(bufs)
+    assert pool.type_counts()[1] == len(hs)          # all array containers
+    n = len(cases)
+    lhs, rhs = np.arange(n, dtype=np.uint32) * 2, np.arange(n, dtype=np.uint32) * 2 + 1
+    for op in ("or", "xor"):
+        for l, r in ((lhs, rhs), (rhs, lhs)):
+            res = engine.pairwise(op, pool, l, pool, r)
+            cards = engine.pairwise_cardinality(op, pool, l, pool, r)
+            for k in range(n):
+                oo = oracle.op(op, hs[l[k]], hs[r[k]])
+                assert res.serialize(k) == oracle.serialize(oo), (op, k, len(cases[k][0]), len(cases[k][1]))
+                assert cards[k] == oracle.cardinality(oo)
+                oracle.free(oo)
+    for h in hs:
+        oracle.free(h)
