@@ -340,9 +340,15 @@ rhip_pool_t* upload(rhip_ctx_t* ctx, HostDir& D, uint32_t n_bitmaps, bool is64) 
 }
 }  // namespace
 
+static bool use_device_parser(size_t n, const size_t* lens, size_t& total);
+static rhip_pool_t* portable_via_device(rhip_ctx_t* c, size_t n, const char* const* bufs, const size_t* lens, size_t total,
+                                        int is64);
+
 extern "C" rhip_pool_t* rhip_pool_from_portable(rhip_ctx_t* ctx, size_t n, const char* const* bufs,
                                                 const size_t* lens) {
     if (!ctx) { set_err("null context"); return nullptr; }
+    size_t total = 0;
+    if (n && use_device_parser(n, lens, total)) return portable_via_device(ctx, n, bufs, lens, total, 0);
     HostDir D;
     D.bm_start.reserve(n + 1);
     for (size_t i = 0; i < n; ++i) {
@@ -359,6 +365,8 @@ extern "C" rhip_pool_t* rhip_pool_from_portable(rhip_ctx_t* ctx, size_t n, const
 extern "C" rhip_pool_t* rhip_pool_from_portable64(rhip_ctx_t* ctx, size_t n, const char* const* bufs,
                                                   const size_t* lens) {
     if (!ctx) { set_err("null context"); return nullptr; }
+    size_t total = 0;
+    if (n && use_device_parser(n, lens, total)) return portable_via_device(ctx, n, bufs, lens, total, 1);
     HostDir D;
     for (size_t i = 0; i < n; ++i) {
         D.bm_start.push_back(D.key.size());

@@ -19,7 +19,9 @@ synth = G.synth  # module-scoped fixture, shared with the GPU suite
 
 @pytest.fixture(scope="module")
 def emu():
-    from emu import emu_engine
+    from emu import build_emu, emu_engine
+    if not __import__("os").path.exists(build_emu.CXX):
+        pytest.skip("hipemu needs the ROCm clang++ to compile the kernels for the host")
     eng = emu_engine()
     yield eng
     eng.close()
