@@ -42,6 +42,10 @@ SYMBOLS = [
     ("rhip_pool_from_portable", _vp, [_vp, _sz, _vp, _vp]),
     ("rhip_pool_from_portable64", _vp, [_vp, _sz, _vp, _vp]),
     ("rhip_pool_from_blob", _vp, [_vp, _vp, _sz, _sz, _vp, _vp, _i]),
+    ("rhip_pool_from_sorted_u32", _vp, [_vp, _sz, _vp, _vp]),
+    ("rhip_pool_from_sorted_u64", _vp, [_vp, _sz, _vp, _vp]),
+    ("rhip_pool_to_u32", _i, [_vp, _vp, _sz, _vp]),
+    ("rhip_pool_to_u64", _i, [_vp, _vp, _sz, _vp]),
     ("rhip_pool_synth_bitset", _vp, [_vp, _u32, _u32, _u64]),
     ("rhip_pool_free", None, [_vp]),
     ("rhip_pool_size", _u32, [_vp]),

@@ -20,6 +20,7 @@
 #include "rhip_poolops.h"
 #include "rhip_serial.h"
 #include "rhip_deser.h"
+#include "rhip_values.h"
 #include "rhip_prims.h"
 
 // ------------------------------------------------------------------ errors

@@ -107,6 +107,25 @@ class Engine:
             raise RoaringHipError("deserialize failed: " + self._err())
         return Pool(self, h)
 
+    def pool_from_values(self, lists: Sequence, is64: bool = False) -> "Pool":
+        """roaring_bitmap_of_ptr for every list, on the device; each list sorted and free of duplicates."""
+        dt = np.uint64 if is64 else np.uint32
+        arrs = [np.ascontiguousarray(v, dtype=dt) for v in lists]
+        offs = np.zeros(len(arrs) + 1, dtype=np.uint64)
+        if arrs:
+            offs[1:] = np.cumsum([a.size for a in arrs])
+        vals = np.concatenate(arrs) if arrs else np.zeros(0, dt)
+        return self.pool_from_packed_values(vals, offs, is64)
+
+    def pool_from_packed_values(self, values, offsets, is64: bool = False) -> "Pool":
+        values = np.ascontiguousarray(values, dtype=np.uint64 if is64 else np.uint32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        fn = self.lib.rhip_pool_from_sorted_u64 if is64 else self.lib.rhip_pool_from_sorted_u32
+        h = fn(self.h, offsets.size - 1, values.ctypes.data, offsets.ctypes.data)
+        if not h:
+            raise RoaringHipError("from_values failed: " + self._err())
+        return Pool(self, h)
+
     def pool_from_serialized64(self, bufs: Sequence[bytes]) -> "Pool":
         """roaring64_bitmap_portable_deserialize_safe for every buffer."""
         return self._from_bufs(self.lib.rhip_pool_from_portable64, bufs)
@@ -305,6 +324,19 @@ class Pool:
         if w != n:
             raise RoaringHipError(f"serialize wrote {w} of {n} bytes: " + self.eng._err())
         return buf.raw
+
+    def to_values(self):
+        """roaring_bitmap_to_uint32_array (to_uint64_array for 64-bit pools) of every bitmap, decoded on the device:
+        (values, offsets[n+1]); bitmap i = values[offsets[i]:offsets[i+1]]."""
+        n = len(self)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        fn = self.eng.lib.rhip_pool_to_u64 if self.is64 else self.eng.lib.rhip_pool_to_u32
+        if fn(self.h, None, 0, offs.ctypes.data) != 0:
+            raise RoaringHipError("to_values failed: " + self.eng._err())
+        vals = np.empty(int(offs[n]), dtype=np.uint64 if self.is64 else np.uint32)
+        if vals.size and fn(self.h, vals.ctypes.data, vals.size, None) != 0:
+            raise RoaringHipError("to_values failed: " + self.eng._err())
+        return vals, offs
 
     def serialize_many(self, ids=None):
         """Portable images of bitmaps `ids` (None: all) packed back to back: (uint8 blob, uint64 offsets[n+1]).

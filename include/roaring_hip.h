@@ -81,6 +81,13 @@ rhip_pool_t *rhip_pool_from_portable64(rhip_ctx_t *ctx, size_t n, const char *co
  * do.  is64 != 0: the images are roaring64 portable images. */
 rhip_pool_t *rhip_pool_from_blob(rhip_ctx_t *ctx, const char *blob, size_t blob_bytes, size_t n,
                                  const uint64_t *offsets, const uint64_t *lens, int is64);
+/* roaring_bitmap_of_ptr (roaring.h:88, src/roaring.c:195-199) / roaring64_bitmap_of_ptr (roaring64.h:92) for n
+ * bitmaps at once, built on the device: bitmap i = values[offsets[i] .. offsets[i+1]) (offsets[0] = 0), STRICTLY
+ * INCREASING inside a bitmap (anything else is rejected -- sort and deduplicate first).  Containers come out as the
+ * reference leaves them after add_many: arrays up to 4096 values, bitsets above; apply rhip_pool_run_optimize for
+ * the benchmark pipeline of_ptr -> run_optimize (benchmarks/benchmark.cpp:1938-1942). */
+rhip_pool_t *rhip_pool_from_sorted_u32(rhip_ctx_t *ctx, size_t n, const uint32_t *values, const uint64_t *offsets);
+rhip_pool_t *rhip_pool_from_sorted_u64(rhip_ctx_t *ctx, size_t n, const uint64_t *values, const uint64_t *offsets);
 /* SURVEY §8d C2 generator: n_bitmaps bitmaps with keys 0..n_containers-1, all
  * bitset containers, word w of bitmap b = splitmix64 stream seeded
  * seed + b (generated on the device). */
@@ -110,6 +117,11 @@ int rhip_pool_cardinalities(rhip_pool_t *pool, uint64_t *out /* [rhip_pool_size]
 int rhip_pool_portable_sizes(rhip_pool_t *pool, size_t n, const uint32_t *ids, uint64_t *offsets);
 size_t rhip_pool_portable_serialize_many(rhip_pool_t *pool, size_t n, const uint32_t *ids, char *buf, size_t cap,
                                          uint64_t *offsets);
+/* roaring_bitmap_to_uint32_array (roaring.h:571, src/roaring.c:1510-1512) / roaring64_bitmap_to_uint64_array
+ * (roaring64.h:768) for the whole pool: the sorted values of bitmap 0, then bitmap 1, ...; offsets (n+1 entries,
+ * may be NULL) receives where each bitmap starts.  out == NULL: offsets only.  capacity is in values. */
+int rhip_pool_to_u32(rhip_pool_t *pool, uint32_t *out, size_t capacity, uint64_t *offsets);
+int rhip_pool_to_u64(rhip_pool_t *pool, uint64_t *out, size_t capacity, uint64_t *offsets);
 
 /* ---- pairwise set operations ------------------------------------------- */
 /* For k in [0,npairs): result k = op(A[lhs[k]], B[rhs[k]]) with the exact

@@ -133,6 +133,12 @@ def test_emu_device_deserialization(emu, oracle):
     GP.test_device_deserialization_rejects_what_the_host_loader_rejects(emu, oracle)
 
 
+def test_emu_value_lists(emu, oracle):
+    import test_gpu_poolops as GP
+    GP.test_value_lists_roundtrip(emu, oracle)
+    GP.test_value_lists_64bit(emu, oracle)
+
+
 def test_emu_pool_reshaping_vs_reference(emu, ref):
     import test_gpu_poolops as GP
     GP.test_container_conversions_vs_reference(emu, ref)

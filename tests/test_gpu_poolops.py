@@ -441,3 +441,69 @@ def test_device_deserialization_rejects_what_the_host_loader_rejects(engine, ora
         else:
             rejected += 1
     assert accepted > 30 and rejected > 100, (accepted, rejected)
+
+
+def test_value_lists_roundtrip(engine, oracle):
+    """rhip_pool_from_sorted_u32 == roaring_bitmap_of_ptr (bytes), + run_optimize == the benchmark pipeline;
+    rhip_pool_to_u32 == roaring_bitmap_to_uint32_array, for every container type."""
+    rng = np.random.default_rng(40)
+    lists = [random_bitmap(rng, max_keys=10, key_space=40) for _ in range(50)]
+    lists += [np.zeros(0, np.uint32), np.array([0], np.uint32), np.array([0xFFFFFFFF], np.uint32),
+              np.arange(0, 70000, dtype=np.uint32), np.arange(65535, 65538, dtype=np.uint32),
+              np.arange(0, 4096, dtype=np.uint32) * 3, np.arange(0, 4097, dtype=np.uint32) * 3, np.zeros(0, np.uint32)]
+    for prof in PROFILES:
+        lists.append(((np.uint32(9) << np.uint32(16)) | chunk_values(rng, prof).astype(np.uint32)))
+    P = engine.pool_from_values(lists)
+    assert len(P) == len(lists) and P.type_counts()[2] == 0
+    for i, v in enumerate(lists):
+        h = oracle.from_sorted(v, run_optimize=False)
+        assert P.serialize(i) == oracle.serialize(h), i
+        oracle.free(h)
+    Q = engine.run_optimize(P)
+    for i, v in enumerate(lists):
+        h = oracle.from_sorted(v, run_optimize=True)
+        assert Q.serialize(i) == oracle.serialize(h), i
+        oracle.free(h)
+    for pool in (P, Q):                      # decode: arrays, bitsets (P) and runs (Q)
+        vals, offs = pool.to_values()
+        assert offs[0] == 0 and int(offs[-1]) == vals.size == sum(len(v) for v in lists)
+        for i, v in enumerate(lists):
+            assert np.array_equal(vals[int(offs[i]):int(offs[i + 1])], np.asarray(v, np.uint32)), i
+    # results of set operations decode to what the oracle enumerates
+    lhs = rng.integers(0, len(lists), 60).astype(np.uint32)
+    rhs = rng.integers(0, len(lists), 60).astype(np.uint32)
+    R = engine.pairwise("xor", Q, lhs, P, rhs)
+    vals, offs = R.to_values()
+    for k in range(60):
+        want = np.setxor1d(lists[lhs[k]], lists[rhs[k]]).astype(np.uint32)
+        assert np.array_equal(vals[int(offs[k]):int(offs[k + 1])], want), k
+    # unsorted / duplicated input is rejected, naming the bitmap
+    with pytest.raises(Exception):
+        engine.pool_from_values([np.array([1, 2, 3], np.uint32), np.array([5, 4], np.uint32)])
+    with pytest.raises(Exception):
+        engine.pool_from_values([np.array([7, 7], np.uint32)])
+    assert len(engine.pool_from_values([])) == 0
+    E = engine.pool_from_values([np.zeros(0, np.uint32)] * 3)
+    assert len(E) == 3 and E.n_containers == 0 and E.to_values()[0].size == 0
+
+
+def test_value_lists_64bit(engine, oracle):
+    rng = np.random.default_rng(41)
+    lists = []
+    for _ in range(10):
+        nb = int(rng.integers(0, 4))
+        highs = np.sort(rng.choice(1 << 20, nb, replace=False)).astype(np.uint64)
+        parts = [(h << np.uint64(32)) | random_bitmap(rng, max_keys=4, key_space=9).astype(np.uint64) for h in highs]
+        lists.append(np.unique(np.concatenate(parts)) if parts else np.zeros(0, np.uint64))
+    lists.append(np.array([0, 1 << 40, (1 << 64) - 1], dtype=np.uint64))
+    P = engine.pool_from_values(lists, is64=True)
+    assert P.is64
+    Q = engine.run_optimize(P)
+    for i, v in enumerate(lists):
+        h = oracle.from_sorted64(v, run_optimize=True)
+        assert Q.serialize(i) == oracle.serialize64(h), i
+        oracle.free64(h)
+    vals, offs = Q.to_values()
+    assert vals.dtype == np.uint64
+    for i, v in enumerate(lists):
+        assert np.array_equal(vals[int(offs[i]):int(offs[i + 1])], v), i
