@@ -65,6 +65,7 @@ SYMBOLS = [
     ("rhip_pool_select", _vp, [_vp, _sz, _vp, _sz, _vp, _vp]),
     ("rhip_pool_run_optimize", _vp, [_vp, _vp]),
     ("rhip_pool_remove_run_compression", _vp, [_vp, _vp]),
+    ("rhip_pool_flip", _vp, [_vp, _vp, _vp, _vp]),
     ("rhip_or_many", _vp, [_vp, _vp, _sz, _vp]),
     ("rhip_xor_many", _vp, [_vp, _vp, _sz, _vp]),
     ("rhip_many_partials", _i, [_vp, _i, _vp, _sz, _vp, C.POINTER(Partials)]),

@@ -21,6 +21,7 @@
 #include "rhip_serial.h"
 #include "rhip_deser.h"
 #include "rhip_values.h"
+#include "rhip_flip.h"
 #include "rhip_prims.h"
 
 // ------------------------------------------------------------------ errors

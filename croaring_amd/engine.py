@@ -205,6 +205,17 @@ class Engine:
             raise RoaringHipError("run_optimize failed: " + self._err())
         return Pool(self, h)
 
+    def flip(self, P: "Pool", starts, ends) -> "Pool":
+        """roaring_bitmap_flip(P[i], starts[i], ends[i]) for every bitmap (new pool)."""
+        st = np.ascontiguousarray(starts, dtype=np.uint64)
+        en = np.ascontiguousarray(ends, dtype=np.uint64)
+        if st.size != len(P) or en.size != len(P):
+            raise ValueError("one [start, end) range per bitmap")
+        h = self.lib.rhip_pool_flip(self.h, P.h, st.ctypes.data, en.ctypes.data)
+        if not h:
+            raise RoaringHipError("flip failed: " + self._err())
+        return Pool(self, h)
+
     def remove_run_compression(self, P: "Pool") -> "Pool":
         """roaring_bitmap_remove_run_compression applied to every bitmap of P (new pool)."""
         h = self.lib.rhip_pool_remove_run_compression(self.h, P.h)

@@ -164,6 +164,12 @@ rhip_pool_t *rhip_pool_run_optimize(rhip_ctx_t *ctx, rhip_pool_t *pool);
 /* roaring_bitmap_remove_run_compression (roaring.h:612, src/roaring.c:1564-1592): run containers become arrays
  * (cardinality <= 4096) or bitsets. */
 rhip_pool_t *rhip_pool_remove_run_compression(rhip_ctx_t *ctx, rhip_pool_t *pool);
+/* roaring_bitmap_flip (roaring.h:986, src/roaring.c:2289-2342) for every bitmap of a 32-bit pool: bitmap i is
+ * negated on [starts[i], ends[i]) with the reference's own argument handling (start >= end, or a start beyond
+ * 2^32: plain copy; both ends are truncated to 32 bits as roaring_bitmap_flip does) and its container typing
+ * (container_not_range / container_not, containers.h:2009-2073; container_range_of_ones where the source has no
+ * container under a key).  Returns a new pool; byte-identical portable serialization. */
+rhip_pool_t *rhip_pool_flip(rhip_ctx_t *ctx, rhip_pool_t *pool, const uint64_t *starts, const uint64_t *ends);
 
 /* ---- many-way aggregation ------------------------------------------------ */
 /* roaring_bitmap_or_many (roaring.h:304, src/roaring.c:775-790) /

@@ -51,6 +51,7 @@ class Oracle:
         L.oc_from_sorted.restype = vp; L.oc_from_sorted.argtypes = [vp, sz]
         L.oc_run_optimize.restype = C.c_int; L.oc_run_optimize.argtypes = [vp]
         L.oc_remove_run_compression.restype = C.c_int; L.oc_remove_run_compression.argtypes = [vp]
+        L.oc_flip.restype = vp; L.oc_flip.argtypes = [vp, u64, u64]
         for nm in ("oc_intersect", "oc_is_subset", "oc_is_strict_subset", "oc_equals"):
             f = getattr(L, nm); f.restype = C.c_int; f.argtypes = [vp, vp]
         L.oc_validate.restype = C.c_int; L.oc_validate.argtypes = [vp]
@@ -93,6 +94,9 @@ class Oracle:
 
     def remove_run_compression(self, h) -> bool:
         return bool(self.L.oc_remove_run_compression(h))
+
+    def flip(self, h, start: int, end: int):
+        return self.L.oc_flip(h, start, end)
 
     def predicate(self, pred, a, b) -> bool:
         return bool(getattr(self.L, {"intersect": "oc_intersect", "is_subset": "oc_is_subset",
@@ -200,6 +204,7 @@ class Ref:
         L.roaring_bitmap_shrink_to_fit.restype = sz; L.roaring_bitmap_shrink_to_fit.argtypes = [vp]
         L.roaring_bitmap_remove_run_compression.restype = C.c_bool
         L.roaring_bitmap_remove_run_compression.argtypes = [vp]
+        L.roaring_bitmap_flip.restype = vp; L.roaring_bitmap_flip.argtypes = [vp, u64, u64]
         for nm in ("intersect", "is_subset", "is_strict_subset", "equals"):
             f = getattr(L, f"roaring_bitmap_{nm}"); f.restype = C.c_bool; f.argtypes = [vp, vp]
         L.roaring_bitmap_to_uint32_array.restype = None; L.roaring_bitmap_to_uint32_array.argtypes = [vp, vp]
@@ -245,6 +250,9 @@ class Ref:
 
     def remove_run_compression(self, h) -> bool:
         return bool(self.L.roaring_bitmap_remove_run_compression(h))
+
+    def flip(self, h, start: int, end: int):
+        return self.L.roaring_bitmap_flip(h, start, end)
 
     def predicate(self, pred, a, b) -> bool:
         return bool(getattr(self.L, f"roaring_bitmap_{pred}")(a, b))

@@ -773,6 +773,64 @@ int oc_is_strict_subset(const oc_bitmap_t *a, const oc_bitmap_t *b) {
     return oc_get_cardinality(b) > oc_get_cardinality(a) && oc_is_subset(a, b);
 }
 
+/* roaring_bitmap_flip (roaring.c:2289-2342) on [range_start, range_end): containers outside the key range are
+ * copied; inside it every key gets container_not_range / container_not of the source container
+ * (containers.h:2009-2073: bitset and array sources -> bitset or array by cardinality, mixed_negation.c:97-196;
+ * run sources -> convert_run_to_efficient_container, mixed_negation.c:235-266) or, where the source has no
+ * container, container_range_of_ones (containers.h:300-312: one value -> array, else one run); empty results are
+ * dropped (roaring.c:2185-2211). */
+static oc_container_t flip_container(const oc_container_t *src, uint32_t lo, uint32_t hi_excl) {
+    if (!src) {
+        /* container_range_of_ones is called with an EXCLUSIVE end but sizes the range as end - start + 1
+         * (containers.h:304-305), so only a single value becomes an array; two or more become a run */
+        uint32_t card = hi_excl - lo;
+        if (card + 1 <= 2) {
+            uint16_t *a = (uint16_t *)malloc(2 * card + 2);
+            for (uint32_t k = 0; k < card; k++) a[k] = (uint16_t)(lo + k);
+            return mk_array(a, (int)card);
+        }
+        uint16_t *r = (uint16_t *)malloc(4);
+        r[0] = (uint16_t)lo;
+        r[1] = (uint16_t)(card - 1);
+        oc_container_t out = mk_run(r, 1);
+        out.card = (int)card;
+        return out;
+    }
+    uint64_t *w = words_from(src);
+    for (uint32_t v = lo; v < hi_excl; v++) w[v >> 6] ^= (uint64_t)1 << (v & 63);
+    if (src->type == OC_RUN) {
+        int nr = words_nruns(w);
+        if (nr == 0) {
+            free(w);
+            return mk_empty();
+        }
+        oc_container_t r = run_from_words(w, nr);
+        free(w);
+        return run_to_efficient(r);
+    }
+    return bitset_or_array(w);
+}
+oc_bitmap_t *oc_flip(const oc_bitmap_t *x, uint64_t range_start, uint64_t range_end) {
+    if (range_start >= range_end || range_start > (uint64_t)0xFFFFFFFFu + 1) return oc_copy(x);
+    /* roaring_bitmap_flip truncates both ends to 32 bits before roaring_bitmap_flip_closed (roaring.c:2295-2296) */
+    uint32_t s = (uint32_t)range_start, e = (uint32_t)(range_end - 1); /* closed */
+    if (s > e) return oc_copy(x); /* roaring_bitmap_flip_closed, roaring.c:2302-2304 */
+    uint32_t ks = s >> 16, ke = e >> 16;
+    oc_bitmap_t *r = oc_create();
+    int i = 0;
+    for (; i < x->n && x->keys[i] < ks; i++) bm_push(r, x->keys[i], c_clone(&x->c[i]));
+    for (uint32_t k = ks; k <= ke; k++) {
+        uint32_t lo = k == ks ? (s & 0xFFFF) : 0, hi = k == ke ? (e & 0xFFFF) + 1 : 65536;
+        const oc_container_t *src = NULL;
+        if (i < x->n && x->keys[i] == k) src = &x->c[i++];
+        oc_container_t f = flip_container(src, lo, hi);
+        if (f.card > 0) bm_push(r, (uint16_t)k, f);
+        else c_free(&f);
+    }
+    for (; i < x->n; i++) bm_push(r, x->keys[i], c_clone(&x->c[i]));
+    return r;
+}
+
 /* ------------------------------------------------------ portable format */
 static int bm_has_run(const oc_bitmap_t *b) {
     for (int i = 0; i < b->n; i++)

@@ -67,6 +67,7 @@ oc_bitmap_t *oc_from_sorted(const uint32_t *vals, size_t n);
 /* roaring_bitmap_run_optimize, roaring.c:1530-1546 */
 int oc_run_optimize(oc_bitmap_t *b);
 int oc_remove_run_compression(oc_bitmap_t *b);
+oc_bitmap_t *oc_flip(const oc_bitmap_t *x, uint64_t range_start, uint64_t range_end);
 int oc_intersect(const oc_bitmap_t *a, const oc_bitmap_t *b);
 int oc_is_subset(const oc_bitmap_t *a, const oc_bitmap_t *b);
 int oc_is_strict_subset(const oc_bitmap_t *a, const oc_bitmap_t *b);

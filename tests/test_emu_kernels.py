@@ -133,6 +133,11 @@ def test_emu_device_deserialization(emu, oracle):
     GP.test_device_deserialization_rejects_what_the_host_loader_rejects(emu, oracle)
 
 
+def test_emu_flip(emu, oracle):
+    import test_gpu_poolops as GP
+    GP.test_flip(emu, oracle)
+
+
 def test_emu_value_lists(emu, oracle):
     import test_gpu_poolops as GP
     GP.test_value_lists_roundtrip(emu, oracle)

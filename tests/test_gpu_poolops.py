@@ -507,3 +507,40 @@ def test_value_lists_64bit(engine, oracle):
     assert vals.dtype == np.uint64
     for i, v in enumerate(lists):
         assert np.array_equal(vals[int(offs[i]):int(offs[i + 1])], v), i
+
+
+def test_flip(engine, oracle):
+    """rhip_pool_flip == roaring_bitmap_flip for every bitmap, byte level: ranges inside one container, spanning
+    many keys (with and without source containers), touching 0 and 2^32, empty / reversed / beyond 32 bits."""
+    from test_oracle_vs_ref import _flip_ranges
+    rng = np.random.default_rng(50)
+    base = [random_bitmap(rng, max_keys=8, key_space=20) for _ in range(30)] + [np.zeros(0, np.uint32)]
+    full = np.arange(0, 65536, dtype=np.uint32) + (2 << 16)
+    base += [full, np.concatenate([full, full + (1 << 16)]), np.array([7], np.uint32)]
+    ranges = _flip_ranges(rng, 40)
+    hs, rs = [], []
+    for k, (s, e) in enumerate(ranges):
+        v = base[k % len(base)]
+        hs.append(oracle.from_sorted(v, run_optimize=bool(k & 1)))
+        rs.append((s, e))
+    P = engine.pool_from_serialized([oracle.serialize(h) for h in hs])
+    F = engine.flip(P, [s for s, _ in rs], [e for _, e in rs])
+    assert len(F) == len(hs)
+    bad = []
+    for i, (h, (s, e)) in enumerate(zip(hs, rs)):
+        want = oracle.flip(h, s, e)
+        if F.serialize(i) != oracle.serialize(want):
+            bad.append((i, s, e))
+        oracle.free(want)
+    assert not bad, f"{len(bad)} flips differ, first {bad[:5]}"
+    # flipping twice restores the set (not necessarily the container types); flip is an ordinary operand
+    FF = engine.flip(F, [s for s, _ in rs], [e for _, e in rs])
+    assert np.array_equal(FF.cardinalities(), P.cardinalities())
+    assert engine.pairwise_predicate("equals", FF, np.arange(len(hs)), P, np.arange(len(hs))).all()
+    # complement inside one container range: |x| + |flip(x)| = 65536 for a bitmap living in key 2 only
+    one = engine.pool_from_values([np.arange(0, 65536, 3, dtype=np.uint32) + (2 << 16)])
+    comp = engine.flip(one, [2 << 16], [3 << 16])
+    assert int(comp.cardinalities()[0]) + int(one.cardinalities()[0]) == 65536
+    assert engine.pairwise_cardinality("and", one, [0], comp, [0])[0] == 0
+    for h in hs:
+        oracle.free(h)

@@ -126,3 +126,33 @@ def test_conversions_and_predicates(oracle, ref):
         oracle.free(h)
     for h in rh:
         ref.free(h)
+
+
+def _flip_ranges(rng, n):
+    """Ranges that hit every branch of roaring_bitmap_flip: inside one container, container-aligned, spanning many
+    keys, touching 0 / 2^32, empty, reversed, beyond 32 bits."""
+    out = [(0, 1 << 32), (0, 0), (5, 5), (9, 3), (0, 65536), (65536, 131072), (1, 65535), (65535, 65537),
+           ((1 << 32) - 1, 1 << 32), (1 << 32, (1 << 32) + 10), ((1 << 32) + 1, (1 << 32) + 9), (100, (1 << 32) + 4),
+           (3 << 16, (9 << 16) + 17), ((3 << 16) + 5, 9 << 16)]
+    for _ in range(n):
+        a = int(rng.integers(0, 1 << 21))
+        b = a + int(rng.choice([1, 2, 3, 100, 5000, 65536, 70000, 300000, 1 << 20]))
+        out.append((a, b))
+    return out
+
+
+def test_flip(oracle, ref):
+    """oc_flip vs roaring_bitmap_flip (roaring.c:2289-2342), byte level."""
+    from gen_inputs import random_bitmap
+    rng = np.random.default_rng(33)
+    vals = [random_bitmap(rng, max_keys=8, key_space=20) for _ in range(40)] + [np.zeros(0, np.uint32)]
+    for i, v in enumerate(vals):
+        a, b = oracle.from_sorted(v, run_optimize=bool(i & 1)), ref.from_sorted(v, run_optimize=bool(i & 1))
+        for s, e in _flip_ranges(rng, 12):
+            fa, fb = oracle.flip(a, s, e), ref.flip(b, s, e)
+            assert oracle.serialize(fa) == ref.serialize(fb), (i, s, e)
+            assert oracle.validate(fa)
+            oracle.free(fa)
+            ref.free(fb)
+        oracle.free(a)
+        ref.free(b)
