@@ -21,15 +21,18 @@ __device__ __forceinline__ void st_le32(uint8_t* p, uint32_t v) {
     p[3] = (uint8_t)(v >> 24);
 }
 
-// One WAVE per selected bitmap: serialized size and whether the run cookie is needed
+// A SEGMENT is the container range [seg_c0[i], seg_c1[i]) that becomes one 32-bit portable image: a whole bitmap of
+// a 32-bit pool, or one high-32 bucket of a 64-bit bitmap (roaring64 images are a bucket count followed by
+// (u32 high, 32-bit image) pairs, roaring64.c:2262-2393).
+// One WAVE per segment: serialized size and whether the run cookie is needed
 // (ra_portable_size_in_bytes, roaring_array.c:458-466).
-__global__ __launch_bounds__(256) void k_ser_size(PoolView P, const uint32_t* __restrict__ ids, uint32_t n_sel,
-                                                  uint32_t* __restrict__ size, uint8_t* __restrict__ hasrun) {
+__global__ __launch_bounds__(256) void k_ser_size(PoolView P, const u64* __restrict__ seg_c0, const u64* __restrict__ seg_c1,
+                                                  uint32_t n_sel, uint32_t* __restrict__ size,
+                                                  uint8_t* __restrict__ hasrun) {
     const uint32_t lane = lane_id();
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (i >= n_sel) return;  // wave-uniform
-    const uint32_t b = ids ? ids[i] : i;
-    const u64 c0 = P.bm_start[b], c1 = P.bm_start[b + 1];
+    const u64 c0 = seg_c0[i], c1 = seg_c1[i];
     u64 bytes = 0;
     uint32_t anyrun = 0;
     for (u64 c = c0 + lane; c < c1; c += 64) {
@@ -45,19 +48,22 @@ __global__ __launch_bounds__(256) void k_ser_size(PoolView P, const uint32_t* __
     }
 }
 
-// One WAVE per selected bitmap: cookie, run flags, descriptive header, offset header; the destination of
-// every container payload (absolute byte offset in the blob) goes to dst[] for the copy kernel.
-__global__ __launch_bounds__(256) void k_ser_header(PoolView P, const uint32_t* __restrict__ ids, uint32_t n_sel,
-                                                    const u64* __restrict__ boff, const uint8_t* __restrict__ hasrun,
-                                                    uint8_t* __restrict__ blob, u64* __restrict__ dst) {
+// One WAVE per segment: cookie, run flags, descriptive header, offset header; the destination of every container
+// payload (absolute byte offset in the blob) goes to dst[] for the copy kernel.  The image of segment i starts at
+// boff[i] (+ add[i], the bytes of the 64-bit framing in front of it, when add != NULL).
+__global__ __launch_bounds__(256) void k_ser_header(PoolView P, const u64* __restrict__ seg_c0,
+                                                    const u64* __restrict__ seg_c1, uint32_t n_sel,
+                                                    const u64* __restrict__ boff, const u64* __restrict__ add,
+                                                    const uint8_t* __restrict__ hasrun, uint8_t* __restrict__ blob,
+                                                    u64* __restrict__ dst) {
     const uint32_t lane = lane_id();
     const uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (i >= n_sel) return;  // wave-uniform
-    const uint32_t b = ids ? ids[i] : i;
-    const u64 c0 = P.bm_start[b], c1 = P.bm_start[b + 1];
+    const u64 c0 = seg_c0[i], c1 = seg_c1[i];
     const uint32_t n = (uint32_t)(c1 - c0);
     const bool hr = hasrun[i] != 0;
-    uint8_t* base = blob + boff[i];
+    const u64 image0 = boff[i] + (add ? add[i] : 0);
+    uint8_t* base = blob + image0;
     uint8_t* p = base;
     if (hr) {
         if (lane == 0) st_le32(p, 12347u | ((n - 1u) << 16));
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(256) void k_ser_header(PoolView P, const uint32_t* 
         if (j < n) {
             const u64 o = run + inc - sz;
             if (with_offsets) st_le32(offh + 4u * j, (uint32_t)o);
-            u64 d = boff[i] + o;
+            u64 d = image0 + o;
             if (t == T_RUN) {
                 st_le16(blob + d, P.nruns[c0 + j]);
                 d += 2;
@@ -134,14 +140,14 @@ __device__ __forceinline__ void wave_copy_unaligned(uint8_t* dst, const uint8_t*
     for (uint32_t k = 4u * (nfull + 1u) - d + lane; k < B; k += 64) dst[k] = src[k];
 }
 
-// One WORKGROUP per selected bitmap, its waves striding over the bitmap's containers.
-__global__ __launch_bounds__(256) void k_ser_copy(PoolView P, const uint32_t* __restrict__ ids, uint32_t n_sel,
-                                                  const u64* __restrict__ dst, uint8_t* __restrict__ blob) {
+// One WORKGROUP per segment, its waves striding over the segment's containers.
+__global__ __launch_bounds__(256) void k_ser_copy(PoolView P, const u64* __restrict__ seg_c0, const u64* __restrict__ seg_c1,
+                                                  uint32_t n_sel, const u64* __restrict__ dst,
+                                                  uint8_t* __restrict__ blob) {
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (uint32_t i = blockIdx.x; i < n_sel; i += gridDim.x) {
-        const uint32_t b = ids ? ids[i] : i;
-        const u64 c0 = P.bm_start[b], c1 = P.bm_start[b + 1];
+        const u64 c0 = seg_c0[i], c1 = seg_c1[i];
         for (u64 c = c0 + wave; c < c1; c += nw)
             wave_copy_unaligned(blob + dst[c], P.arena + P.off[c], payload_bytes(P.type[c], P.card[c], P.nruns[c]), lane);
     }

@@ -350,8 +350,8 @@ class Pool:
         return vals, offs
 
     def serialize_many(self, ids=None):
-        """Portable images of bitmaps `ids` (None: all) packed back to back: (uint8 blob, uint64 offsets[n+1]).
-        32-bit pools: assembled on the device, one download."""
+        """Portable images of bitmaps `ids` (None: all) packed back to back: (uint8 blob, uint64 offsets[n+1]),
+        assembled on the device, one download (64-bit pools: whole pool only)."""
         ids_a = None if ids is None else _u32(ids)
         n = len(self) if ids_a is None else ids_a.size
         ip = None if ids_a is None else ids_a.ctypes.data
@@ -366,8 +366,6 @@ class Pool:
         return blob, offs
 
     def serialize_all(self) -> list:
-        if self.is64:
-            return [self.serialize(i) for i in range(len(self))]
         blob, offs = self.serialize_many()
         raw = blob.tobytes()
         return [raw[int(offs[i]):int(offs[i + 1])] for i in range(len(self))]

@@ -109,8 +109,9 @@ size_t rhip_pool_portable_size(rhip_pool_t *pool, uint32_t i);
 size_t rhip_pool_portable_serialize(rhip_pool_t *pool, uint32_t i, char *buf);
 /* roaring_bitmap_get_cardinality (roaring.h:537, src/roaring.c:1436-1443) of every bitmap */
 int rhip_pool_cardinalities(rhip_pool_t *pool, uint64_t *out /* [rhip_pool_size] */);
-/* Bulk form of the two calls above for 32-bit pools: the portable images of pool[ids[0..n)] (ids == NULL: every
- * bitmap, in order; ids must not repeat) are assembled on the device back to back and downloaded in one copy.
+/* Bulk form of the two calls above: the portable images of pool[ids[0..n)] (ids == NULL: every bitmap, in order;
+ * ids must not repeat; 64-bit pools: ids must be NULL) are assembled on the device back to back and downloaded in
+ * one copy.
  * rhip_pool_portable_sizes fills offsets[0..n_sel] (offsets[k] = start of image k, offsets[n_sel] = total bytes);
  * rhip_pool_portable_serialize_many writes the images into buf (capacity cap), optionally the same offsets, and
  * returns the bytes written (0 on error).  Each image is byte-identical to rhip_pool_portable_serialize's. */

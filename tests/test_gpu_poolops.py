@@ -366,6 +366,16 @@ def test_device_deserialization_64bit(engine, oracle):
     assert np.array_equal(P.cardinalities(), H.cardinalities())
     for i in range(len(bufs)):
         assert P.serialize(i) == H.serialize(i), i
+    # bulk serialization of 64-bit pools: per-bucket images assembled on the device, framing patched by the host
+    blob2, offs2 = H.serialize_many()
+    raw = blob2.tobytes()
+    for i in range(len(bufs)):
+        assert raw[int(offs2[i]):int(offs2[i + 1])] == H.serialize(i), i
+    assert H.serialize_all() == [H.serialize(i) for i in range(len(bufs))]
+    R = engine.pairwise("or", H, np.arange(len(bufs) - 1, dtype=np.uint32), H, np.arange(1, len(bufs), dtype=np.uint32))
+    assert R.serialize_all() == [R.serialize(i) for i in range(len(R))]
+    with pytest.raises(Exception):
+        H.serialize_many([0, 1])            # 64-bit pools are serialized whole
 
 
 def _mutations(rng, buf, count):
