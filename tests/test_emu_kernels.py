@@ -131,6 +131,7 @@ def test_emu_device_deserialization(emu, oracle):
     GP.test_device_deserialization_roundtrip(emu, oracle)
     GP.test_device_deserialization_64bit(emu, oracle)
     GP.test_device_deserialization_rejects_what_the_host_loader_rejects(emu, oracle)
+    GP.test_device_deserialization_fuzz_64bit(emu, oracle)
 
 
 def test_emu_flip(emu, oracle):

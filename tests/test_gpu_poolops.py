@@ -554,3 +554,49 @@ def test_flip(engine, oracle):
     assert engine.pairwise_cardinality("and", one, [0], comp, [0])[0] == 0
     for h in hs:
         oracle.free(h)
+
+
+def test_device_deserialization_fuzz_64bit(engine, oracle):
+    """The same differential fuzzing for roaring64 images (bucket count, high keys, nested 32-bit images)."""
+    rng = np.random.default_rng(32)
+    seeds = []
+    for _ in range(12):
+        nb = int(rng.integers(1, 4))
+        highs = np.sort(rng.choice(1000, nb, replace=False)).astype(np.uint64)
+        parts = [(h << np.uint64(32)) | random_bitmap(rng, max_keys=3, key_space=6).astype(np.uint64) for h in highs]
+        v = np.unique(np.concatenate(parts))
+        h = oracle.from_sorted64(v)
+        seeds.append(oracle.serialize64(h))
+        oracle.free64(h)
+    seeds = [s for s in seeds if len(s) < 60000]
+    cases = []
+    for s in seeds:
+        cases += _mutations(rng, s, 25)
+        for _ in range(6):                      # targeted: bucket count, a high key, the first nested cookie
+            m = bytearray(s)
+            which = int(rng.integers(0, 3))
+            if which == 0:
+                m[0:8] = int(rng.integers(0, 6)).to_bytes(8, "little")
+            elif which == 1:
+                m[8:12] = int(rng.integers(0, 1 << 32)).to_bytes(4, "little")
+            else:
+                m[12 + int(rng.integers(0, 4))] ^= int(rng.integers(1, 256))
+            cases.append(bytes(m))
+    accepted = rejected = 0
+    for k, m in enumerate(cases):
+        try:
+            H = engine.pool_from_serialized64([m])
+        except Exception:
+            H = None
+        blob = np.frombuffer(m, dtype=np.uint8) if len(m) else np.zeros(0, np.uint8)
+        try:
+            P = engine.pool_from_blob(blob, [0], [len(m)], is64=True)
+        except Exception:
+            P = None
+        assert (H is None) == (P is None), f"case {k}: host loader {'rejects' if H is None else 'accepts'}, device differs"
+        if H is not None:
+            accepted += 1
+            assert P.serialize(0) == H.serialize(0), k
+        else:
+            rejected += 1
+    assert accepted > 10 and rejected > 50, (accepted, rejected)
