@@ -1,0 +1,107 @@
+"""Property-based differential testing of the kernels through the CPU emulator (tests/emu): hypothesis builds pairs
+of bitmaps out of the shapes that sit on container / typing boundaries (single values, dense ranges, runs ending at
+65535 / starting at 0, full containers, 4096 / 4097-value arrays) and every op, flip, run_optimize and the value-list
+round trip is compared with the oracle at byte level.  Deterministic (derandomize=True): the same examples every run."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from util import OPS
+
+KEYS = st.integers(0, 5)
+EDGE16 = st.sampled_from([0, 1, 2, 31, 32, 63, 64, 4095, 4096, 4097, 32767, 32768, 65534, 65535])
+V16 = st.one_of(EDGE16, st.integers(0, 65535))
+
+
+@st.composite
+def chunk(draw):
+    """Low-16 values of one container."""
+    kind = draw(st.sampled_from(["few", "range", "runs", "full", "stride", "boundary"]))
+    if kind == "few":
+        return np.unique(np.array(draw(st.lists(V16, min_size=1, max_size=12)), dtype=np.uint32))
+    if kind == "range":
+        a, b = sorted((draw(V16), draw(V16)))
+        return np.arange(a, b + 1, dtype=np.uint32)
+    if kind == "runs":
+        parts = []
+        for _ in range(draw(st.integers(1, 6))):
+            a = draw(V16)
+            n = draw(st.sampled_from([1, 2, 3, 17, 300, 5000]))
+            parts.append(np.arange(a, min(a + n, 65536), dtype=np.uint32))
+        return np.unique(np.concatenate(parts))
+    if kind == "full":
+        return np.arange(0, 65536, dtype=np.uint32)
+    if kind == "stride":
+        step = draw(st.sampled_from([2, 3, 7, 15, 16, 17]))
+        return np.arange(draw(st.integers(0, step - 1)), 65536, step, dtype=np.uint32)
+    n = draw(st.sampled_from([4095, 4096, 4097]))           # array / bitset boundary
+    off = draw(st.sampled_from([0, 1, 61439]))
+    return (np.arange(n, dtype=np.uint32) + off) % 65536 if off else np.arange(n, dtype=np.uint32) * 2 % 65536
+
+
+@st.composite
+def bitmap(draw):
+    keys = sorted(set(draw(st.lists(KEYS, min_size=0, max_size=4))))
+    parts = [(np.uint32(k) << np.uint32(16)) | np.unique(draw(chunk())) for k in keys]
+    v = np.unique(np.concatenate(parts)) if parts else np.zeros(0, np.uint32)
+    return v.astype(np.uint32), draw(st.booleans())
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from emu import build_emu, emu_engine
+    if not __import__("os").path.exists(build_emu.CXX):
+        pytest.skip("hipemu needs the ROCm clang++ to compile the kernels for the host")
+    eng = emu_engine()
+    yield eng
+    eng.close()
+
+
+CFG = dict(max_examples=120, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+
+
+@settings(**CFG)
+@given(a=bitmap(), b=bitmap())
+def test_pairwise_ops_match_the_oracle(emu, oracle, a, b):
+    (va, ra), (vb, rb) = a, b
+    ha, hb = oracle.from_sorted(va, run_optimize=ra), oracle.from_sorted(vb, run_optimize=rb)
+    pool = emu.pool_from_serialized([oracle.serialize(ha), oracle.serialize(hb)])
+    for op in OPS:
+        for l, r, x, y in ((0, 1, ha, hb), (1, 0, hb, ha), (0, 0, ha, ha)):
+            want = oracle.op(op, x, y)
+            got = emu.pairwise(op, pool, [l], pool, [r])
+            assert got.serialize(0) == oracle.serialize(want), (op, l, r)
+            assert emu.pairwise_cardinality(op, pool, [l], pool, [r])[0] == oracle.cardinality(want)
+            oracle.free(want)
+    for nm, fn, of in (("or", emu.or_many, oracle.or_many), ("xor", emu.xor_many, oracle.xor_many)):
+        want = of([ha, hb])
+        g = oracle.deserialize(fn(pool).serialize(0))
+        assert np.array_equal(oracle.to_array(g), oracle.to_array(want)), nm
+        oracle.free(want)
+        oracle.free(g)
+    oracle.free(ha)
+    oracle.free(hb)
+
+
+@settings(**CFG)
+@given(a=bitmap(), s=st.integers(0, (6 << 16) + 10), n=st.sampled_from([0, 1, 2, 3, 65535, 65536, 65537, 200000, 1 << 32]))
+def test_flip_convert_and_value_lists_match_the_oracle(emu, oracle, a, s, n):
+    va, ra = a
+    h = oracle.from_sorted(va, run_optimize=ra)
+    pool = emu.pool_from_serialized([oracle.serialize(h)])
+    want = oracle.flip(h, s, s + n)
+    assert emu.flip(pool, [s], [s + n]).serialize(0) == oracle.serialize(want)
+    oracle.free(want)
+    built = emu.pool_from_values([va])
+    plain = oracle.from_sorted(va, run_optimize=False)
+    assert built.serialize(0) == oracle.serialize(plain)
+    oracle.run_optimize(plain)
+    assert emu.run_optimize(built).serialize(0) == oracle.serialize(plain)
+    oracle.remove_run_compression(plain)
+    assert emu.remove_run_compression(pool).serialize(0) == oracle.serialize(plain)
+    vals, offs = pool.to_values()
+    assert np.array_equal(vals, va)
+    blob, boffs = pool.serialize_many()
+    assert emu.pool_from_blob(blob, boffs).serialize(0) == pool.serialize(0)
+    oracle.free(plain)
+    oracle.free(h)
