@@ -149,3 +149,42 @@ def test_emu_pool_reshaping_vs_reference(emu, ref):
     import test_gpu_poolops as GP
     GP.test_container_conversions_vs_reference(emu, ref)
     GP.test_pairwise_predicates_vs_reference(emu, ref)
+
+
+@pytest.mark.parametrize("op", ["or", "xor"])
+def test_emu_sharded_many_partials_and_finalize(emu, oracle, op):
+    """The two kernels of the multi-GPU or_many / xor_many with G logical shards: per-shard partial
+    chunks (rhip_many_partials) -> chunks routed to key owners -> owner combine + canonicalise (rhip_many_finalize).
+    Under the emulator device memory is host memory, so the routing that torch does on the GPU is numpy here."""
+    import ctypes as C
+    from croaring_amd.distributed import shard_ids
+    from util import load_bundle
+    bufs = load_bundle("census-income")[:48] + load_bundle("wikileaks-noquotes")[:24]
+    hs = [oracle.deserialize(b) for b in bufs]
+    pool = emu.pool_from_serialized(bufs)
+    want = (oracle.or_many if op == "or" else oracle.xor_many)(hs)
+    for shards in (2, 5):
+        parts = [emu.many_partials(op, pool, shard_ids(len(bufs), s, shards)) for s in range(shards)]
+        emu.synchronize()
+        keys, words = [], []
+        for p in parts:
+            if p.n_keys:
+                keys.append(np.ctypeslib.as_array(C.cast(p.d_keys, C.POINTER(C.c_uint64)), (p.n_keys,)).copy())
+                words.append(np.ctypeslib.as_array(C.cast(p.d_words, C.POINTER(C.c_uint64)), (p.n_keys, 1024)).copy())
+        K, W = np.concatenate(keys), np.concatenate(words)
+        got = []
+        for owner in range(shards):
+            sel = (K % np.uint64(shards)) == owner
+            k, w = np.ascontiguousarray(K[sel]), np.ascontiguousarray(W[sel])
+            res = emu.many_finalize(op, False, k.size, k.ctypes.data if k.size else 0, w.ctypes.data if k.size else 0)
+            h = oracle.deserialize(res.serialize(0))
+            assert oracle.validate(h)
+            v = oracle.to_array(h)
+            assert np.all((v >> 16) % shards == owner)
+            got.append(v)
+            oracle.free(h)
+        assert np.array_equal(np.sort(np.concatenate(got)), oracle.to_array(want)), (op, shards)
+        for p in parts:
+            p.free()
+    for h in hs + [want]:
+        oracle.free(h)
