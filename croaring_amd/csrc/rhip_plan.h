@@ -32,7 +32,7 @@ __device__ __forceinline__ void lower_bound4(const u64* __restrict__ key, u64 lo
 // left bitmap of a pair ("A-tile"), or -- for OR/XOR, whose result also carries the right bitmap's
 // unmatched containers -- of the right bitmap ("B-tile").  One wave per unit, so a batch of 250 pairs
 // of 4096-container bitmaps plans on 4000 waves instead of 250.
-// Count arrays (and their exclusive scan) have 5 sections of n_units+1 entries:
+// Count arrays (and their exclusive scan) have N_SEC sections of n_units+1 entries:
 enum { SEC_CAND = 0, SEC_M = 1, SEC_BB = 2, SEC_GEN = 3, SEC_COPY = 4, SEC_FILT = 5, SEC_WAVE = 6, SEC_RUNS = 7, N_SEC = 8 };
 // work class of a matched container pair
 // ia / ib = number of intervals of the operand when it is read as an interval list (runs: n_runs, arrays: card)
