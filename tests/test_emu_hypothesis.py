@@ -57,7 +57,7 @@ def emu():
     eng.close()
 
 
-CFG = dict(max_examples=120, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+CFG = dict(max_examples=120, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
 
 
 @settings(**CFG)
