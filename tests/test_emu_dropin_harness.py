@@ -1,0 +1,61 @@
+"""The reference's own UNMODIFIED unit tests driving the kernels WITHOUT a GPU: tests/toplevel_unit.c (169 registered
+tests) and tests/cpp_random_unit.cpp (randomised, double-checked against std::set) are linked against the symbol-renamed
+reference library (everything that is not on the hot path) and the CPU-emulator build of the engine
+(tests/emu/_build/librhip_emu.so, test infrastructure) for the 20 hot-path symbols.  Same harness as
+tests/test_gpu_dropin_harness.py, which links the real libroaring_hip.so and needs an MI355X.
+
+Built by `make -C oracle dropin_emu` (only where /root/reference exists); skipped when the binaries are absent."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def _build():
+    if not os.path.isdir("/root/reference/src"):
+        return
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from emu import build_emu
+    if not os.path.exists(build_emu.CXX):
+        return
+    lib = build_emu.build()
+    for b in ("toplevel_unit_emu", "cpp_random_unit_emu"):
+        exe = os.path.join(REF, b)
+        if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(lib):
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "dropin_emu"], check=False, capture_output=True)
+            break
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    _build()
+
+
+def _run(name, min_tests):
+    exe = os.path.join(REF, name)
+    if not os.path.exists(exe):
+        pytest.skip(f"oracle/_ref/{name} not built (needs /root/reference and the emulator build)")
+    env = dict(os.environ, RHIP_COMPAT_STATS="1")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env, cwd=REF)
+    tail = (p.stdout + p.stderr)[-3000:]
+    m = re.search(r"(\d+) tests, (\d+) failed", p.stdout)
+    assert m, tail
+    assert int(m.group(1)) >= min_tests and int(m.group(2)) == 0 and p.returncode == 0, tail
+    c = re.search(r"pairwise (\d+), in-place (\d+), cardinality (\d+), many-way (\d+)", p.stderr)
+    assert c, tail
+    return tuple(int(x) for x in c.groups())
+
+
+def test_reference_toplevel_unit_through_the_emulator():
+    pw, ip, card, many = _run("toplevel_unit_emu", 160)
+    assert pw > 100 and ip > 20 and many > 10, (pw, ip, card, many)   # the calls really went through the engine
+
+
+def test_reference_cpp_random_unit_through_the_emulator():
+    pw, ip, card, many = _run("cpp_random_unit_emu", 5)
+    assert pw + ip > 100, (pw, ip, card, many)
