@@ -59,3 +59,19 @@ def test_reference_toplevel_unit_through_the_emulator():
 def test_reference_cpp_random_unit_through_the_emulator():
     pw, ip, card, many = _run("cpp_random_unit_emu", 5)
     assert pw + ip > 100, (pw, ip, card, many)
+
+
+def test_reference_realdata_unit_through_the_emulator():
+    """tests/realdata_unit.c, unmodified: every realdata directory, with and without copy-on-write (213 000 pairwise,
+    28 400 in-place, 71 000 cardinality and 108 many-way calls through the emulated kernels).  9 minutes: opt-in;
+    the last run is recorded in profiles/r01_emu_realdata_unit.txt."""
+    if not os.environ.get("RHIP_SLOW_HARNESS"):
+        pytest.skip("slow (9 min): set RHIP_SLOW_HARNESS=1")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "dropin_emu_realdata"], check=False, capture_output=True)
+    exe = os.path.join(REF, "realdata_unit_emu")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/realdata_unit_emu not built (needs /root/reference/benchmarks/realdata)")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=3000, env=dict(os.environ, RHIP_COMPAT_STATS="1"))
+    assert p.returncode == 0 and "failure" not in p.stdout, (p.stdout + p.stderr)[-2000:]
+    c = re.search(r"pairwise (\d+), in-place (\d+), cardinality (\d+), many-way (\d+)", p.stderr)
+    assert c and int(c.group(1)) > 100000, (p.stdout + p.stderr)[-500:]
