@@ -6,6 +6,6 @@ reference's operator interface.  Importing the package does not need a GPU; crea
 `Engine` does, and fails loudly without one.
 """
 from ._lib import LIB_PATH, RoaringHipError, load  # noqa: F401
-from .engine import Engine, Pool, OPS  # noqa: F401
+from .engine import Engine, Pool, OPS, synth_sparse_portable  # noqa: F401
 
-__all__ = ["Engine", "Pool", "OPS", "RoaringHipError", "load", "LIB_PATH"]
+__all__ = ["Engine", "Pool", "OPS", "synth_sparse_portable", "RoaringHipError", "load", "LIB_PATH"]

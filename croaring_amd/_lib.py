@@ -47,6 +47,8 @@ SYMBOLS = [
     ("rhip_pool_to_u32", _i, [_vp, _vp, _sz, _vp]),
     ("rhip_pool_to_u64", _i, [_vp, _vp, _sz, _vp]),
     ("rhip_pool_synth_bitset", _vp, [_vp, _u32, _u32, _u64]),
+    ("rhip_synth_sparse_sizes", _i, [_u64, _u64, _sz, _vp]),
+    ("rhip_synth_sparse_fill", _i, [_u64, _u64, _sz, _vp, _vp]),
     ("rhip_pool_free", None, [_vp]),
     ("rhip_pool_size", _u32, [_vp]),
     ("rhip_pool_containers", _u64, [_vp]),

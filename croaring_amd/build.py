@@ -10,9 +10,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "libroaring_hip.so")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-pthread", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 SOURCES = ["rhip_prims.hip", "rhip_engine.hip"]
-DEPS = ["rhip_kernels.h", "rhip_common.h", "rhip_plan.h", "rhip_bitset.h", "rhip_array.h", "rhip_runs.h", "rhip_block.h", "rhip_many.h", "rhip_many_host.inc", "rhip_prims.h", "roaring_compat.inc", "rhip_poolops.h", "rhip_pool_ops.inc", "rhip_wemit.inc", "rhip_serial.h", "rhip_deser.h", "rhip_values.h", "rhip_flip.h",
+DEPS = ["rhip_kernels.h", "rhip_common.h", "rhip_plan.h", "rhip_bitset.h", "rhip_array.h", "rhip_runs.h", "rhip_block.h", "rhip_many.h", "rhip_many_host.inc", "rhip_synth.inc", "rhip_prims.h", "roaring_compat.inc", "rhip_poolops.h", "rhip_pool_ops.inc", "rhip_wemit.inc", "rhip_serial.h", "rhip_deser.h", "rhip_values.h", "rhip_flip.h",
         os.path.join("..", "..", "include", "roaring_hip.h"), os.path.join("..", "..", "include", "roaring_hip_compat.h")]
 
 
@@ -51,7 +51,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             rebuilt = True
         objs.append(obj)
     if rebuilt or not os.path.exists(OUT):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", OUT]
+        cmd = [hipcc, "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", *objs, "-o", OUT]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

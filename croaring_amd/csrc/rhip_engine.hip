@@ -984,5 +984,6 @@ extern "C" int rhip_debug_phases(rhip_ctx_t* c, unsigned long long out[32], int 
 #endif
 
 #include "rhip_many_host.inc"
+#include "rhip_synth.inc"
 #include "rhip_pool_ops.inc"
 #include "roaring_compat.inc"

@@ -23,6 +23,19 @@ def _u32(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.uint32)
 
 
+def synth_sparse_portable(first: int, stride: int, count: int):
+    """SURVEY §8d C4 generator (rhip_synth_sparse_sizes / _fill): portable images of the sparse bitmaps first,
+    first + stride, ... packed back to back -> (uint8 blob, uint64 offsets[count + 1]).  Host only, no device."""
+    lib = _lib.load()
+    offs = np.zeros(count + 1, dtype=np.uint64)
+    if lib.rhip_synth_sparse_sizes(first, stride, count, offs.ctypes.data) != 0:
+        raise RoaringHipError("synth_sparse_sizes failed: " + _lib.last_error())
+    blob = np.empty(int(offs[count]), dtype=np.uint8)
+    if count and lib.rhip_synth_sparse_fill(first, stride, count, offs.ctypes.data, blob.ctypes.data) != 0:
+        raise RoaringHipError("synth_sparse_fill failed: " + _lib.last_error())
+    return blob, offs
+
+
 class Engine:
     """One per process and device (rhip_ctx_t): owns the HIP stream and scratch buffers."""
 

@@ -92,6 +92,16 @@ rhip_pool_t *rhip_pool_from_sorted_u64(rhip_ctx_t *ctx, size_t n, const uint64_t
  * bitset containers, word w of bitmap b = splitmix64 stream seeded
  * seed + b (generated on the device). */
 rhip_pool_t *rhip_pool_synth_bitset(rhip_ctx_t *ctx, uint32_t n_bitmaps, uint32_t n_containers, uint64_t seed);
+/* SURVEY §8d C4 generator (BASELINE config[3]: or_many over 100 000 sparse array-dominant bitmaps), HOST side, no
+ * device needed: portable images of the sparse bitmaps first, first + stride, ... (count of them).
+ * Bitmap b draws from its own pcg32 stream (benchmarks/random.h:18-31; state = b, inc = 2 b + 1): 32 distinct keys
+ * k = pcg32() & 4095 (duplicates rejected), then per key in ascending order card = 1 + (pcg32() & 511) and `card`
+ * distinct values v = pcg32() & 0xFFFF (duplicates rejected) -- all array containers.
+ * rhip_synth_sparse_sizes fills offsets[0..count] (offsets[k] = start of image k in a back-to-back packing,
+ * offsets[count] = total bytes); rhip_synth_sparse_fill writes the images into buf at those offsets.  Feed the
+ * blob to rhip_pool_from_blob (and the same bytes to the CPU reference). */
+int rhip_synth_sparse_sizes(uint64_t first, uint64_t stride, size_t count, uint64_t *offsets);
+int rhip_synth_sparse_fill(uint64_t first, uint64_t stride, size_t count, const uint64_t *offsets, char *buf);
 void rhip_pool_free(rhip_pool_t *pool); /* roaring_bitmap_free, roaring.h:365 */
 
 uint32_t rhip_pool_size(const rhip_pool_t *pool);          /* number of bitmaps */

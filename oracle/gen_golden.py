@@ -14,6 +14,10 @@ Outputs (committed; the GPU box cannot see /root/reference):
                                     results (serialized) over the whole dataset.
   tests/golden/bitmapwith{,out}runs.bin   Java-produced format fixtures, verbatim copies of
                                     tests/testdata/* (format_portability_unit.c:51-90).
+  tests/golden/c5_wikileaks64_pairs.npz  BASELINE config C5: roaring64, wikileaks-noquotes x 10 high-32 buckets -- all pairs x
+                                    4 ops (cardinality, portable size, crc32) + the 200-way union (serialized).
+  tests/golden/c4_or_many.npz       BASELINE config C4: roaring_bitmap_or_many over the 100 000 seeded sparse bitmaps
+                                    (cardinality, size, crc32 of the reference's result; crc32 of the inputs).
   tests/golden/synth_mixed.npz      crc32/size/cardinality of the reference's results on seeded synthetic
                                     bitmaps hitting every container-type pair and result-typing branch
                                     (inputs are regenerated from the seed; their crc32 is pinned too).
@@ -139,6 +143,75 @@ def synth_golden(R):
     print(f"  synth: {len(singles)} pairs, {len(many)} many-way groups")
 
 
+def c5_golden(R):
+    """All unordered pairs x 4 ops through the real roaring64_bitmap_{and,or,xor,andnot} (roaring64.c:1332-1373,
+    1541-1593, 1663-1720, 1809-1861) + the 200-way union as a left fold of roaring64_bitmap_or_inplace."""
+    from util import c5_inputs, load_bundle
+    base = load_bundle("wikileaks-noquotes")
+    bufs = c5_inputs(base)
+    hs = [R.deserialize64(b) for b in bufs]
+    # the constructed images ARE what the reference writes for these bitmaps (pins the construction), and the
+    # bitmaps are what inserting v + (r << 32) + run_optimize gives
+    for k in (0, 57, 199):
+        assert R.serialize64(hs[k]) == bufs[k]
+        h32 = R.deserialize(base[k])
+        v = R.to_array(h32).astype(np.uint64)
+        R.free(h32)
+        vals = np.sort(np.concatenate([v + (np.uint64(r) << np.uint64(32)) for r in range(10)]))
+        hv = R.from_sorted64(vals)
+        assert R.serialize64(hv) == bufs[k]
+        R.free64(hv)
+    n = len(hs)
+    idx = [(i, j) for i in range(n) for j in range(i + 1, n)]
+    out = {"in_crc": np.array([zlib.crc32(b) for b in bufs], np.uint32)}
+    for op in OPS:
+        card = np.zeros(len(idx), np.uint64)
+        size = np.zeros(len(idx), np.uint32)
+        crc = np.zeros(len(idx), np.uint32)
+        for k, (i, j) in enumerate(idx):
+            r = R.op64(op, hs[i], hs[j])
+            s = R.serialize64(r)
+            card[k], size[k], crc[k] = R.cardinality64(r), len(s), zlib.crc32(s)
+            R.free64(r)
+        out[f"{op}_card"], out[f"{op}_size"], out[f"{op}_crc"] = card, size, crc
+        print(f"  c5 {op}: sum card = {int(card.sum())}")
+    r = R.or_many64(hs)
+    out["fold_or"] = np.frombuffer(R.serialize64(r), dtype=np.uint8)
+    out["fold_or_card"] = np.array([R.cardinality64(r)], np.uint64)
+    print(f"  c5 200-way union: card = {R.cardinality64(r)}, {out['fold_or'].size} bytes")
+    R.free64(r)
+    out["pairs"] = np.array(idx, dtype=np.uint16)
+    np.savez_compressed(os.path.join(GOLD, "c5_wikileaks64_pairs.npz"), **out)
+    for h in hs:
+        R.free64(h)
+
+
+def c4_golden(R, n_bitmaps=100000):
+    """SURVEY §8d C4 at FULL size: roaring_bitmap_or_many (roaring.c:775-790) over the 100 000 seeded sparse bitmaps
+    of rhip_synth_sparse_sizes/_fill (the generator's definition is in include/roaring_hip.h); also the G-way
+    sharded variants' common answer is this one.  Stored: crc32 of the input blob, cardinality / size / crc32 of the
+    reference's serialized result, and the same for the first 10 000 and first 1 000 bitmaps."""
+    import croaring_amd
+    blob, offs = croaring_amd.synth_sparse_portable(0, 1, n_bitmaps)
+    mv = memoryview(blob)
+    hs = [R.deserialize(bytes(mv[int(offs[b]):int(offs[b + 1])])) for b in range(n_bitmaps)]
+    assert all(R.validate(h) for h in hs[:64])
+    out = {"n_bitmaps": np.array([n_bitmaps], np.uint64), "in_crc": np.array([zlib.crc32(blob)], np.uint32),
+           "in_bytes": np.array([blob.size], np.uint64)}
+    for n in (1000, 10000, n_bitmaps):
+        r = R.or_many(hs[:n])
+        s = R.serialize(r)
+        out[f"or_many_{n}"] = np.array([R.cardinality(r), len(s), zlib.crc32(s)], np.uint64)
+        print(f"  c4 or_many over {n}: card {R.cardinality(r)}, {len(s)} bytes, crc {zlib.crc32(s)}")
+        R.free(r)
+    r = R.xor_many(hs[:1000])
+    out["xor_many_1000_card"] = np.array([R.cardinality(r)], np.uint64)
+    R.free(r)
+    np.savez_compressed(os.path.join(GOLD, "c4_or_many.npz"), **out)
+    for h in hs:
+        R.free(h)
+
+
 def main():
     R = Ref()
     os.makedirs(GOLD, exist_ok=True)
@@ -146,8 +219,14 @@ def main():
         shutil.copy(os.path.join(REF, "tests", "testdata", f), os.path.join(GOLD, f))
     for f in ("64map32bitvals.bin", "64mapspreadvals.bin", "64maphighvals.bin", "64mapempty.bin"):
         shutil.copy(os.path.join(REF, "tests", "testdata", f), os.path.join(GOLD, f))
-    synth_golden(R)
-    for name in sys.argv[1:] or ["census1881", "weather_sept_85", "wikileaks-noquotes", "census-income"]:
+    names = sys.argv[1:] or ["synth", "census1881", "weather_sept_85", "wikileaks-noquotes", "census-income", "c5", "c4"]
+    if "synth" in names:
+        synth_golden(R)
+    if "c5" in names:
+        c5_golden(R)
+    if "c4" in names:
+        c4_golden(R)
+    for name in [n for n in names if n not in ("synth", "c4", "c5")]:
         print(name)
         hs = load_text_dataset(R, name)
         write_bundle(os.path.join(GOLD, f"{name}.rbnd.xz"), [R.serialize(h) for h in hs])

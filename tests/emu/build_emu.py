@@ -49,7 +49,7 @@ def _build(lib: str, extra, force: bool, verbose: bool) -> str:
     os.makedirs(OUT, exist_ok=True)
     if not force and os.path.exists(lib) and os.path.getmtime(lib) >= _newest(sources()):
         return lib
-    cmd = [CXX, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-DRHIP_EMU=1", *extra,
+    cmd = [CXX, "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-DRHIP_EMU=1", *extra,
            "-Wno-unused-value", "-Wno-deprecated-declarations",
            "-I", os.path.join(HERE, "shim"), "-I", CSRC, "-I", os.path.join(ROOT, "include"),
            "-x", "c++", os.path.join(CSRC, "rhip_engine.hip"),

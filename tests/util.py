@@ -48,3 +48,10 @@ def synth_inputs():
     gg = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gg)
     return gg.synth_inputs()
+
+
+def c5_inputs(base=None) -> list:
+    """wikileaks-noquotes replicated into 10 high-32 buckets, v + (r << 32), as roaring64 portable
+    images (src/roaring64.c:2323-2393: u64 bucket count, then per bucket u32 high + the 32-bit portable image)."""
+    base = load_bundle("wikileaks-noquotes") if base is None else base
+    return [struct.pack("<Q", 10) + b"".join(struct.pack("<I", r) + b for r in range(10)) for b in base]
