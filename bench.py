@@ -2,22 +2,32 @@
 """bench.py -- headline benchmark of the MI355X Roaring set-operation engine.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W   -> ONE JSON line on rank 0.
+With N > 1 and no torchrun environment the script re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`; it refuses to print a
+line whose n_gpus differs from --gpus.
 
-Workload (BASELINE.json configs[1], made concrete in SURVEY.md §8d "C2"): a device-resident pool of
-256 bitmaps x 4096 bitset containers (8 GiB, words = splitmix64 stream, density 0.5) and the pair
-schedule  k -> (k mod 256, (97 k + 1) mod 256).  One STEP = one batched roaring_bitmap_and call plus
-one batched roaring_bitmap_or call over `--pairs` bitmap pairs each (default 250+250 = 500 set-ops;
-the default 20 steps are the 10 000 ops of the config).  A step runs the whole hot path: key merge /
-planning, the bitset x bitset kernel, result typing, directory compaction.  Inputs are resident in
-HBM before the timed region; results are materialised in HBM (a result pool is recycled between
-steps because 10 000 x 32 MiB of distinct outputs cannot exist at once).
+Headline workload (BASELINE.json configs[1], made concrete in SURVEY.md §8d "C2"): a device-resident pool of
+256 bitmaps x 4096 bitset containers (8 GiB, words = splitmix64 stream, density 0.5) and the pair schedule
+k -> (k mod 256, (97 k + 1) mod 256).  One STEP = `--rounds` x (one batched roaring_bitmap_and call + one batched
+roaring_bitmap_or call over `--pairs` bitmap pairs each): default 6 x (250 + 250) = 3000 set-ops, so the default
+20 steps time > 1 s.  A step runs the whole hot path: key merge / planning, the bitset x bitset kernel, result
+typing, directory compaction.  Inputs are resident in HBM before the timed region; results are materialised in HBM
+(result pools are recycled between calls: 60 000 x 32 MiB of distinct outputs cannot exist at once).
+N > 1: every rank runs the same schedule on its own pool (pairwise ops shard with no data-path collective,
+SURVEY §8e): scaling = "weak".
 
-With N > 1 (torchrun, one process per GPU) every rank runs the same schedule on its own pool
-(pairwise ops shard with no data-path collective): scaling = "weak".
+config.secondary (same line, measured after the timed region of the headline):
+  c3_* / c1_*   realdata weather_sept_85 / census1881 (tests/golden bundles): ALL unordered pairs, one batched call
+                per op (and / or / xor / andnot / and_cardinality), wall time of the whole call; the SURVEY §8d
+                checksums are asserted; pairs are partitioned over ranks (strong scaling); CRoaring on 1 host core
+                beside it.
+  c4_or_many    BASELINE configs[3]: roaring_bitmap_or_many over 100 000 seeded sparse bitmaps (pcg32 generator in
+                the library), bitmaps b mod N on rank b mod N, key-owner exchange over RCCL (strong scaling).
+  c5_*          BASELINE configs[4]: roaring64, wikileaks-noquotes x 10 buckets, all pairs and/or + 200-way union.
 
-Extra keys: "roofline" (bitset x bitset kernel vs the 8 TB/s HBM peak, from HIP events on the
-engine's stream) and "cpu_baseline" (CRoaring itself -- oracle/_ref -- or the C port when the
-prebuilt reference is absent, on a bounded sample of the same workload on the host cores).
+Extra keys: "roofline" (bitset x bitset kernel vs the 8 TB/s HBM peak, from HIP events on the engine's stream) and
+"cpu_baseline" (CRoaring itself -- oracle/_ref -- or the C port when the prebuilt reference is absent, on a bounded
+sample of the same workload on the host cores: 1 core, all cores, best T, and the ISA variants when prebuilt).
 """
 from __future__ import annotations
 
@@ -36,6 +46,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 SEED = 0x9E3779B97F4A7C15
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BB_BYTES_PER_PAIR = 3 * 8192  # payload(a) + payload(b) + payload(result)
+METRIC = "set-ops/sec + GB/s (pairwise AND/OR; or_many) on realdata, 1/2/4/8 GPU"
+# SURVEY §8d checksums (sum over all unordered pairs of the result cardinality), asserted inside the bench
+CHECKSUMS = {
+    "weather_sept_85": {"and": 24220711, "or": 1232335437, "xor": 1208114726, "andnot": 581541349},
+    "census1881": {"and": 15213, "or": 199753126, "xor": 199737913, "andnot": 83195751},
+}
 
 
 def parse_args():
@@ -45,18 +61,34 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pool", type=int, default=256, help="bitmaps in the pool")
     ap.add_argument("--containers", type=int, default=4096, help="bitset containers per bitmap")
-    ap.add_argument("--pairs", type=int, default=250, help="bitmap pairs per batched call (2 calls per step)")
+    ap.add_argument("--pairs", type=int, default=250, help="bitmap pairs per batched call")
+    ap.add_argument("--rounds", type=int, default=6, help="(AND call + OR call) rounds per step")
     ap.add_argument("--workload", default="pairwise", choices=["pairwise", "ormany"],
-                    help="pairwise = the headline C2 line (default); ormany = SURVEY C4 sharded or_many (secondary)")
-    ap.add_argument("--bitmaps", type=int, default=100000, help="ormany: total sparse bitmaps over all ranks")
+                    help="pairwise = the headline C2 line (default); ormany = C4 sharded or_many as the headline")
+    ap.add_argument("--bitmaps", type=int, default=100000, help="C4: total sparse bitmaps over all ranks")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-secondary", action="store_true", help="skip config.secondary (realdata, C4, C5)")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0)
     return ap.parse_args()
 
 
 def schedule(k0: int, n: int, pool: int):
     k = np.arange(k0, k0 + n, dtype=np.uint64)
     return (k % pool).astype(np.uint32), ((k * 97 + 1) % pool).astype(np.uint32)
+
+
+# ----------------------------------------------------------------------------- launch
+def maybe_spawn(args):
+    """--gpus N > 1 without a torchrun environment: become `torch.distributed.run` with N ranks."""
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
 
 
 # ----------------------------------------------------------------------------- CPU baseline
@@ -91,12 +123,39 @@ def _cpu_worker(a):
     return done
 
 
+def _one_core(chk, hs, lhs, rhs, min_reps=10, min_s=0.2):
+    """SURVEY §8d timing rule (the reference harness's own: >= 10 repetitions and >= 200 ms): one repetition = one
+    and + one or (materialise + cardinality + free); returns (min, median) seconds per OP."""
+    ts, k, t_all = [], 0, time.perf_counter()
+    while len(ts) < min_reps or time.perf_counter() - t_all < min_s:
+        t0 = time.perf_counter()
+        for op in ("and", "or"):
+            r = chk.op(op, hs[lhs[k]], hs[rhs[k]])
+            chk.cardinality(r)
+            chk.free(r)
+        ts.append((time.perf_counter() - t0) / 2)
+        k += 1
+    return float(np.min(ts)), float(np.median(ts))
+
+
+def _ref_variants():
+    from oracle.pyoracle import Ref
+    out = []
+    for label, fname in (("avx512", "libcroaring_ref.so"), ("avx2", "libcroaring_ref_noavx512.so"),
+                         ("scalar", "libcroaring_ref_noavx.so")):
+        path = os.path.join(ROOT, "oracle", "_ref", fname)
+        if os.path.exists(path):
+            out.append((label, type("RefVariant", (Ref,), {"PATH": path})))
+    return out
+
+
 def cpu_baseline(args, seconds: float):
-    """Times the CPU reference (CRoaring itself when oracle/_ref is prebuilt, else the C port) on a
-    bounded sample of the same workload.  CRoaring is single-threaded, so host cores are used the way
-    SURVEY App. C does: the pair list is striped over T forked worker processes sharing the read-only
-    inputs.  The box's memory system saturates long before all hardware threads are busy (measured:
-    T=16 is the knee on the 256-thread host), so a short sweep picks the best T and reports it."""
+    """Times the CPU reference (CRoaring itself when oracle/_ref is prebuilt, else the C port) on a bounded sample of
+    the headline workload: 8 bitmaps x 4096 bitset containers (256 MiB of inputs: past the CPU caches), the same
+    pair schedule, and + or per repetition, each op materialised + cardinality + free.  CRoaring is single-threaded,
+    so "cores" means forked worker processes striping the pair list over shared read-only inputs.
+    Reported: 1 core (min / median of >= 10 reps), all hardware threads, and the best of a short sweep (the host's
+    memory system saturates long before all threads are busy); `value` is the best."""
     import multiprocessing as mp
     from gen_inputs import splitmix64
     from oracle.pyoracle import Oracle, Ref, build
@@ -105,129 +164,248 @@ def cpu_baseline(args, seconds: float):
     else:
         build()
         chk, kind = Oracle(), "port"
-    n_bm = 8  # 8 x 4096 containers = 256 MiB of inputs: past the CPU caches
-    hs = [chk.deserialize(portable_bitset_bitmap(splitmix64((SEED + b) & (2**64 - 1), args.containers * 1024)))
-          for b in range(n_bm)]
+    n_bm = 8
+    bufs = [portable_bitset_bitmap(splitmix64((SEED + b) & (2**64 - 1), args.containers * 1024)) for b in range(n_bm)]
+    hs = [chk.deserialize(b) for b in bufs]
     lhs, rhs = schedule(0, 1 << 20, n_bm)
     _CPU.update(chk=chk, hs=hs, lhs=lhs, rhs=rhs)
     ncpu = os.cpu_count() or 1
-    sweep = sorted({t for t in (1, 8, 16, 32, 64) if t <= ncpu})
-    per = max(1.0, seconds / len(sweep))
-    best = None
+    gb = args.containers * BB_BYTES_PER_PAIR / 1e9
+    tmin, tmed = _one_core(chk, hs, lhs, rhs)
+    one = {"ops_per_s_best": 1 / tmin, "ops_per_s_median": 1 / tmed, "GBps_median": gb / tmed}
+    sweep = sorted({t for t in (16, 64, ncpu) if 1 < t <= ncpu})
+    per = max(1.0, (seconds - 2.0) / max(1, len(sweep) + 1))
+    multi = {}
     for T in sweep:
-        with mp.get_context("fork").Pool(T) as pool:
+        windows = 2 if T == ncpu else 1
+        rates = []
+        for _ in range(windows):
+            with mp.get_context("fork").Pool(T) as pool:
+                t0 = time.perf_counter()
+                res = pool.map(_cpu_worker, [(t, T, per / windows) for t in range(T)])
+                dt = time.perf_counter() - t0
+            rates.append(sum(res) / dt)
+        multi[T] = {"ops_per_s_median": float(np.median(rates)), "ops_per_s_min": float(np.min(rates))}
+    best_T, best = 1, one["ops_per_s_median"]
+    for T, r in multi.items():
+        if r["ops_per_s_median"] > best:
+            best_T, best = T, r["ops_per_s_median"]
+    isa = {}
+    for label, cls in _ref_variants():
+        try:
+            v = cls()
+            vh = [v.deserialize(b) for b in bufs[:4]]
+            a, m = _one_core(v, vh, lhs % 4, rhs % 4, min_reps=10, min_s=0.2)
+            isa[label] = {"ops_per_s_median_1core": 1 / m, "GBps_median": gb / m}
+            for h in vh:
+                v.free(h)
+        except Exception as e:  # a variant that does not load on this host is reported, not fatal
+            isa[label] = {"error": str(e)[:80]}
+    for h in hs:
+        chk.free(h)
+    return {"value": best, "unit": "set-ops/s", "cores": best_T, "kind": kind, "host_threads": ncpu,
+            "one_core": one, "all_cores": dict(multi.get(ncpu, {}), procs=ncpu) if ncpu in multi else None,
+            "sweep": {str(T): r for T, r in multi.items()}, "isa_1core": isa or None,
+            "sample": f"pairwise and+or (materialise + cardinality + free) over {n_bm} bitmaps x {args.containers} "
+                      f"bitset containers, schedule k -> (k mod 8, (97k+1) mod 8); 1 core: >= 10 reps and >= 200 ms, "
+                      f"min/median; T worker processes for {per:.1f} s per T in {sweep}; best = T={best_T}: "
+                      f"{best * gb:.1f} GB/s algorithmic"}
+
+
+# ----------------------------------------------------------------------------- secondary workloads
+class Dist:
+    """The little bit of torch.distributed the bench needs, degenerate at world 1."""
+
+    def __init__(self, rank, world, torch, dist):
+        self.rank, self.world, self.torch, self.dist = rank, world, torch, dist
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max(self, x: float) -> float:
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum(self, x: float) -> float:
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+
+def timed_calls(D: Dist, fn, reps=10, min_s=0.05):
+    """>= reps repetitions (and >= min_s in total) of fn, each bracketed by a barrier; returns (min, median) of the
+    max-over-ranks wall time."""
+    fn()
+    ts, t_all = [], time.perf_counter()
+    while len(ts) < reps or time.perf_counter() - t_all < min_s:
+        D.barrier()
+        t0 = time.perf_counter()
+        fn()
+        D.barrier()
+        ts.append(D.max(time.perf_counter() - t0))
+        if len(ts) >= 200:
+            break
+    return float(np.min(ts)), float(np.median(ts))
+
+
+def cpu_pairs_rate(chk, hs, lhs, rhs, op, budget=0.4, is64=False):
+    """CRoaring on one host core over the same pair list (bounded to `budget` seconds), ops/s."""
+    fop, fcard, ffree = (chk.op64, chk.cardinality64, chk.free64) if is64 else (chk.op, chk.cardinality, chk.free)
+    n, t0 = 0, time.perf_counter()
+    for i, j in zip(lhs, rhs):
+        r = fop(op, hs[i], hs[j])
+        fcard(r)
+        ffree(r)
+        n += 1
+        if (n & 255) == 0 and time.perf_counter() - t0 > budget:
+            break
+    return n / (time.perf_counter() - t0)
+
+
+def run_realdata(eng, D: Dist, name: str, tag: str, chk, is64=False, ops=("and", "or", "xor", "andnot")):
+    from util import all_pairs, c5_inputs, load_bundle
+    if is64:
+        bufs = c5_inputs()
+        pool = eng.pool_from_serialized64(bufs)
+    else:
+        bufs = load_bundle(name)
+        pool = eng.pool_from_serialized(bufs)
+    L, R = all_pairs(len(bufs))
+    lhs, rhs = L[D.rank::D.world].copy(), R[D.rank::D.world].copy()
+    hs = None
+    if chk is not None and D.rank == 0:
+        hs = [(chk.deserialize64 if is64 else chk.deserialize)(b) for b in bufs]
+    out = {}
+    for op in ops:
+        res = [None]
+
+        def call():
+            res[0] = eng.pairwise(op, pool, lhs, pool, rhs, reuse=res[0])
+        tmin, tmed = timed_calls(D, call)
+        st = eng.last_stats()
+        alg = D.sum(float(st["bytes_in"] + st["bytes_out"]))
+        csum = D.sum(float(res[0].cardinalities().sum()))
+        want = CHECKSUMS.get(name, {}).get(op)
+        if want is not None and D.rank == 0:
+            assert int(csum) == want, f"{name} {op}: checksum {int(csum)} != SURVEY §8d {want}"
+        row = {"pairs": int(L.size), "ops_per_s": L.size / tmed, "ops_per_s_best": L.size / tmin,
+               "ms_batch_median": tmed * 1e3, "ms_batch_min": tmin * 1e3, "alg_GBps": alg / tmed / 1e9,
+               "frac": alg / tmed / 1e9 / HBM_PEAK_GBS, "checksum": int(csum), "checksum_ok": want is None or int(csum) == want,
+               "matched_pairs_rank0": int(st["matched_pairs"]), "passthrough_rank0": int(st["passthrough"])}
+        if hs is not None:
+            row["cpu1_ops_per_s"] = cpu_pairs_rate(chk, hs, L, R, op, is64=is64)
+            row["cpu_kind"] = chk.name
+        out[f"{tag}_{op}"] = row
+    tmin, tmed = timed_calls(D, lambda: eng.pairwise_cardinality("and", pool, lhs, pool, rhs))
+    out[f"{tag}_and_cardinality"] = {"pairs": int(L.size), "ops_per_s": L.size / tmed, "ms_batch_median": tmed * 1e3,
+                                     "ms_batch_min": tmin * 1e3}
+    if is64:
+        tmin, tmed = timed_calls(D, lambda: eng.or_many(pool))
+        row = {"n": len(bufs), "ms_median": tmed * 1e3, "ms_min": tmin * 1e3,
+               "cardinality": int(eng.or_many(pool).cardinalities()[0])}
+        if hs is not None:
             t0 = time.perf_counter()
-            res = pool.map(_cpu_worker, [(t, T, per) for t in range(T)])
-            dt = time.perf_counter() - t0
-        rate = sum(res) / dt
-        if best is None or rate > best[0]:
-            best = (rate, T, sum(res), dt)
-    rate, T, ops, dt = best
-    one = None
-    return {"value": rate, "unit": "set-ops/s", "cores": T, "kind": kind, "host_threads": ncpu,
-            "sample": f"{ops} pairwise and/or ops (materialise + cardinality + free) over {n_bm} bitmaps x "
-                      f"{args.containers} bitset containers in {dt:.1f} s on {T} worker processes "
-                      f"(best of T={sweep}); {rate * args.containers * BB_BYTES_PER_PAIR / 1e9:.1f} GB/s algorithmic"}
+            r = chk.or_many64(hs)
+            row["cpu1_ms_fold"] = (time.perf_counter() - t0) * 1e3
+            row["cardinality_ok"] = bool(chk.cardinality64(r) == row["cardinality"])
+            chk.free64(r)
+        out[f"{tag}_union_{len(bufs)}"] = row
+    if hs is not None:
+        for h in hs:
+            (chk.free64 if is64 else chk.free)(h)
+    return out
 
 
-# ----------------------------------------------------------------------------- C4: sharded or_many (secondary workload)
-def c4_shard(n_bitmaps: int, seed: int):
-    """n_bitmaps sparse bitmaps, 32 array containers each (keys stratified over [0,4096), card uniform in
-    [1,512], values stratified over [0,65536)), packed back to back in portable format."""
-    rng = np.random.default_rng(seed)
-    NB, NK = n_bitmaps, 32
-    keys = (np.arange(NK, dtype=np.uint32)[None, :] * 128 + rng.integers(0, 128, (NB, NK), dtype=np.uint32))
-    cards = rng.integers(1, 513, (NB, NK), dtype=np.uint32)
-    ccum = np.concatenate([[0], np.cumsum(cards.ravel(), dtype=np.int64)])
-    total = int(ccum[-1])
-    cid = np.repeat(np.arange(NB * NK, dtype=np.int64), cards.ravel())
-    within = np.arange(total, dtype=np.int64) - ccum[cid]
-    stride = (65536 // cards.ravel().astype(np.int64))[cid]
-    vals = (within * stride + (rng.integers(0, 1 << 30, total, dtype=np.int64) % stride)).astype(np.uint16)
-    hdr = 8 + 8 * NK
-    per_bm = cards.sum(1).astype(np.int64) * 2 + hdr
-    offs = np.concatenate([[0], np.cumsum(per_bm)]).astype(np.int64)
-    blob = np.zeros(int(offs[-1]), dtype=np.uint8)
-    h32 = np.zeros((NB, hdr // 4), dtype=np.uint32)
-    h32[:, 0] = 12346
-    h32[:, 1] = NK
-    h32[:, 2:2 + NK] = keys | ((cards - 1) << 16)
-    inner = np.concatenate([np.zeros((NB, 1), np.int64), np.cumsum(cards.astype(np.int64) * 2, 1)[:, :-1]], 1) + hdr
-    h32[:, 2 + NK:] = inner.astype(np.uint32)
-    blob[(offs[:-1, None] + np.arange(hdr)[None, :]).ravel()] = h32.view(np.uint8).ravel()
-    vstart = np.concatenate([[0], np.cumsum(cards.sum(1).astype(np.int64))])
-    bm = cid // NK
-    pos = offs[bm] + hdr + 2 * (np.arange(total, dtype=np.int64) - vstart[bm])
-    blob[pos] = (vals & 0xFF).astype(np.uint8)
-    blob[pos + 1] = (vals >> 8).astype(np.uint8)
-    return blob, offs[:-1], per_bm
-
-
-def run_ormany(args, eng, rank, world, barrier):
-    """Strong scaling: --bitmaps sparse bitmaps in total, rank r holds bitmaps/world of them; one step = one
-    or_many over ALL of them = per-rank partial chunks -> key-owner exchange over RCCL -> owner finalize."""
-    import torch.distributed as dist
+def run_ormany(args, eng, D: Dist, steps: int, warmup: int, chk=None):
+    """C4, strong scaling: --bitmaps sparse bitmaps in total, rank r holds bitmaps b with b mod world == r; one step
+    = one or_many over ALL of them = per-rank partial chunks -> key-owner exchange over RCCL -> owner finalize."""
+    import croaring_amd
     from croaring_amd.distributed import many_sharded
-    n_local = args.bitmaps // world
-    blob, offs, lens = c4_shard(n_local, 4 + 1000 * rank + world)
-    pool = eng.pool_from_packed(blob, offs, lens)
+    n_local = (args.bitmaps - D.rank + D.world - 1) // D.world
+    blob, offs = croaring_amd.synth_sparse_portable(D.rank, D.world, n_local)
+    pool = eng.pool_from_blob(blob, offs)
     payload = pool.payload_bytes()
+    out = [None]
 
     def step():
-        return many_sharded(eng, pool, "or") if world > 1 else eng.or_many(pool)
+        out[0] = many_sharded(eng, pool, "or", key_space=4096) if D.world > 1 else eng.or_many(pool)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    tot_payload = payload
-    if world > 1:
-        import torch
-        t = torch.tensor([dt, float(payload)], dtype=torch.float64, device="cuda")
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dt, tot_payload = float(tmax[0].item()), float(t[1].item())
-    return {
-        "metric": "set-ops/sec + GB/s (pairwise AND/OR; or_many) on realdata, 1/2/4/8 GPU",
-        "value": args.steps / dt, "unit": "or_many-ops/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"C4 or_many over {n_local * world} sparse bitmaps x 32 array containers, "
-                               f"sharded {n_local} per GPU, key-owner exchange over RCCL",
-                   "algorithmic_GBps": tot_payload * args.steps / dt / 1e9,
-                   "result_cardinality_rank0": int(out.cardinalities()[0])},
-    }
+    ts = []
+    for _ in range(steps):
+        D.barrier()
+        t0 = time.perf_counter()
+        step()
+        D.barrier()
+        ts.append(D.max(time.perf_counter() - t0))
+    tmed, tmin = float(np.median(ts)), float(np.min(ts))
+    tot_payload = D.sum(float(payload))
+    card = D.sum(float(out[0].cardinalities()[0]))
+    row = {"bitmaps": args.bitmaps, "containers": 32 * args.bitmaps, "ms_median": tmed * 1e3, "ms_min": tmin * 1e3,
+           "ops_per_s": 1 / tmed, "alg_GBps": (tot_payload + D.sum(float(eng.last_stats()["bytes_out"]))) / tmed / 1e9,
+           "result_cardinality": int(card), "scaling": "strong",
+           "parallelism": f"bitmaps b mod {D.world}; key-owner exchange over RCCL" if D.world > 1 else "single GPU"}
+    row["frac"] = row["alg_GBps"] / HBM_PEAK_GBS
+    gp = os.path.join(ROOT, "tests", "golden", "c4_or_many.npz")
+    if os.path.exists(gp) and args.bitmaps == 100000:
+        row["cardinality_ok"] = bool(int(np.load(gp)["or_many_100000"][0]) == int(card))
+        assert row["cardinality_ok"], "C4 or_many cardinality differs from the reference fixture"
+    if chk is not None and D.rank == 0 and D.world == 1:
+        # CPU reference on a bounded sample: the first 10 000 bitmaps (deserialisation untimed)
+        n = min(10000, n_local)
+        mv = memoryview(blob)
+        hs = [chk.deserialize(bytes(mv[int(offs[b]):int(offs[b + 1])])) for b in range(n)]
+        t0 = time.perf_counter()
+        r = chk.or_many(hs)
+        row["cpu1_ms_first_10000"] = (time.perf_counter() - t0) * 1e3
+        row["cpu_kind"] = chk.name
+        chk.free(r)
+        for h in hs:
+            chk.free(h)
+    return row
 
 
 # ----------------------------------------------------------------------------- main
 def main():
     args = parse_args()
+    maybe_spawn(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a mislabelled line")
     import torch  # first: the engine then binds to the HIP runtime torch already loaded
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible")
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import croaring_amd
     eng = croaring_amd.Engine(local_rank)
     eng.set_timing(True)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    D = Dist(rank, world, torch, dist)
+    chk = None
+    if rank == 0 and not args.no_cpu:
+        from oracle.pyoracle import best_checker
+        chk = best_checker()
 
     if args.workload == "ormany":
-        out = run_ormany(args, eng, rank, world, barrier)
+        row = run_ormany(args, eng, D, args.steps, args.warmup, chk)
+        out = {"metric": METRIC, "value": row["ops_per_s"], "unit": "or_many-ops/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": row["ms_median"], "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+               "config": {"workload": f"C4 or_many over {args.bitmaps} sparse bitmaps x 32 array containers", **row}}
         if rank == 0:
             print(json.dumps(out), flush=True)
         if world > 1:
@@ -235,49 +413,50 @@ def main():
         return
 
     pool = eng.pool_synth_bitset(args.pool, args.containers, SEED + 1000003 * rank)
-
     results = {"and": None, "or": None}
     bb_ms, bb_pairs = [], []
 
     def step(i: int, timed: bool):
-        for j, op in enumerate(("and", "or")):
-            lhs, rhs = schedule((2 * i + j) * args.pairs, args.pairs, args.pool)
-            results[op] = eng.pairwise(op, pool, lhs, pool, rhs, reuse=results[op])
-            if timed:
-                st = eng.last_stats()
-                bb_ms.append(st["ms_bitset_kernel"])
-                bb_pairs.append(st["n_bitset_pairs"])
+        for r in range(args.rounds):
+            for j, op in enumerate(("and", "or")):
+                lhs, rhs = schedule(((i * args.rounds + r) * 2 + j) * args.pairs, args.pairs, args.pool)
+                results[op] = eng.pairwise(op, pool, lhs, pool, rhs, reuse=results[op])
+                if timed:
+                    st = eng.last_stats()
+                    bb_ms.append(st["ms_bitset_kernel"])
+                    bb_pairs.append(st["n_bitset_pairs"])
 
     for i in range(args.warmup):
         step(i, False)
-    barrier()
+    D.barrier()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i, True)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    D.barrier()
+    dt = D.max(time.perf_counter() - t0)
 
-    # sanity: every result container of the last OR batch is a bitset, cardinalities are plausible
+    # sanity: every result container of the last OR batch is a bitset
     assert results["or"].type_counts() == (args.pairs * args.containers, 0, 0)
+    results["and"].free()
+    results["or"].free()
 
-    ops_per_step = 2 * args.pairs
+    ops_per_step = 2 * args.pairs * args.rounds
     total_ops = ops_per_step * args.steps * world
     ms_kernel = float(np.mean(bb_ms)) if bb_ms else 0.0
     pairs_per_launch = float(np.mean(bb_pairs)) if bb_pairs else 0.0
     achieved = (pairs_per_launch * BB_BYTES_PER_PAIR) / (ms_kernel * 1e-3) / 1e9 if ms_kernel > 0 else 0.0
-    traffic = None
+    traffic, traffic_source = None, None
     tp = os.path.join(ROOT, "profiles", "bb_traffic.json")
     if os.path.exists(tp):
         try:
-            traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tp))
+            traffic = tj.get("hbm_bytes_per_launch")
+            traffic_source = (f"profiles/bb_traffic.json <- {tj.get('source', 'profiles/r01_pmc_summary.md')} "
+                              "(rocprofv3 --pmc passes recorded earlier; NOT re-measured in this run)")
         except Exception:
             traffic = None
     out = {
-        "metric": "set-ops/sec + GB/s (pairwise AND/OR; or_many) on realdata, 1/2/4/8 GPU",
+        "metric": METRIC,
         "value": total_ops / dt,
         "unit": "set-ops/s",
         "n_gpus": world,
@@ -290,14 +469,27 @@ def main():
         "dtype": "u64",
         "data": "synthetic",
         "config": {"workload": f"C2 synthetic bitset-only: pool {args.pool} bitmaps x {args.containers} bitset "
-                               f"containers (density 0.5), batched pairwise AND+OR, {args.pairs} pairs per call",
+                               f"containers (density 0.5), batched pairwise AND+OR, {args.pairs} pairs per call, "
+                               f"{args.rounds} x (AND call + OR call) per step",
                    "ops_per_step": ops_per_step,
+                   "timed_region_s": dt,
                    "algorithmic_GBps": total_ops * args.containers * BB_BYTES_PER_PAIR / dt / 1e9,
                    "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
         "roofline": {"bound": "hbm", "kernel": "k_bb (bitset x bitset fused op+popcount)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "avg_launch_ms": ms_kernel, "pairs_per_launch": pairs_per_launch},
+                     "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": ms_kernel,
+                     "pairs_per_launch": pairs_per_launch, "launches_timed": len(bb_ms)},
     }
+    del pool
+    if not args.no_secondary:
+        sec = {}
+        sec.update(run_realdata(eng, D, "weather_sept_85", "c3", chk))
+        sec.update(run_realdata(eng, D, "census1881", "c1", chk))
+        sec.update(run_realdata(eng, D, "wikileaks-noquotes x10 (roaring64)", "c5", chk, is64=True, ops=("and", "or")))
+        sec["c4_or_many"] = run_ormany(args, eng, D, steps=10, warmup=2, chk=chk)
+        sec["note"] = ("realdata: ALL unordered pairs in one batched call per op, wall time of the whole call incl. "
+                       "planning and the final sync, median of >= 10 calls; pairs partitioned over ranks")
+        out["config"]["secondary"] = sec
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
     elif rank == 0:

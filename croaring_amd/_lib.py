@@ -23,7 +23,8 @@ class Stats(C.Structure):
 
 
 class Partials(C.Structure):
-    _fields_ = [("n_keys", C.c_uint64), ("d_keys", C.c_void_p), ("d_words", C.c_void_p)]
+    _fields_ = [("n_keys", C.c_uint64), ("d_keys", C.c_void_p), ("d_words", C.c_void_p), ("max_key", C.c_uint64),
+                ("capacity", C.c_uint64)]
 
 
 # every symbol include/roaring_hip.h declares: (name, restype, argtypes)

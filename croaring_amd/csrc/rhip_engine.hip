@@ -34,6 +34,11 @@ static void set_err(const char* fmt, ...) {
     va_end(ap);
     g_err = buf;
 }
+// status of the last failed pointer-returning entry point on this thread (they can only return NULL)
+static int& last_status() {
+    static thread_local int s = 0;
+    return s;
+}
 #define HIPCHK(x)                                                                      \
     do {                                                                               \
         hipError_t e_ = (x);                                                           \
@@ -70,8 +75,52 @@ struct DBuf {
     T* as() const { return (T*)p; }
 };
 
+// RAII: make `device` current for the calling thread for the duration of an entry point (allocations and
+// launches of a context must land on ITS device whatever the caller's current device is), restore on exit
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) {
+            if (hipSetDevice(device) != hipSuccess) {
+                set_err("hipSetDevice(%d) failed", device);
+                throw (int)RHIP_ERR_DEVICE;
+            }
+            switched = true;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+struct PartialBuf {  // chunk buffers of rhip_many_partials, recycled through the context
+    void* keys = nullptr;
+    void* words = nullptr;
+    uint64_t cap = 0;  // chunks
+};
+
 struct rhip_ctx_s {
     int device = 0;
+    std::vector<PartialBuf> partial_cache;
+    PartialBuf take_partial_buf(uint64_t chunks) {
+        for (size_t i = 0; i < partial_cache.size(); ++i)
+            if (partial_cache[i].cap >= chunks) {
+                PartialBuf b = partial_cache[i];
+                partial_cache.erase(partial_cache.begin() + i);
+                return b;
+            }
+        PartialBuf b;
+        b.cap = chunks;
+        if (hipMalloc(&b.keys, 8 * chunks) != hipSuccess || hipMalloc(&b.words, 8192 * chunks) != hipSuccess) {
+            if (b.keys) (void)hipFree(b.keys);
+            set_err("hipMalloc of partial chunks failed");
+            throw (int)RHIP_ERR_ALLOC;
+        }
+        return b;
+    }
     hipStream_t stream = nullptr;
     // scratch (grow-only): candidate directory + queues + scan temporaries
     DBuf lhs, rhs, u_pair, u_tile, u_pair0, unit_bytes, cand, cand_start, o_key, o_meta, o_slot, o_off, flag, newidx, q[N_CLS], misc, prim_tmp, pair_acc;
@@ -140,7 +189,8 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
             return nullptr;
         }
         if (device < 0) HIPCHK(hipGetDevice(&device));
-        HIPCHK(hipSetDevice(device));
+        if (device >= ndev) { set_err("device %d out of range (%d visible)", device, ndev); return nullptr; }
+        DeviceGuard dguard_(device);  // the caller's current device is left as it was
         rhip_ctx_t* c = new rhip_ctx_s();
         c->device = device;
         HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -158,6 +208,8 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
 }
 extern "C" void rhip_ctx_destroy(rhip_ctx_t* c) {
     if (!c) return;
+    int prev_dev_ = -1;
+    const bool sw_ = hipGetDevice(&prev_dev_) == hipSuccess && prev_dev_ != c->device && hipSetDevice(c->device) == hipSuccess;
     (void)hipStreamSynchronize(c->stream);
     DBuf* all[] = {&c->lhs, &c->rhs, &c->u_pair, &c->u_tile, &c->u_pair0, &c->unit_bytes, &c->cand, &c->cand_start, &c->o_key, &c->o_meta,
                    &c->o_slot, &c->o_off, &c->flag, &c->newidx, &c->misc, &c->prim_tmp, &c->pair_acc};
@@ -165,6 +217,7 @@ extern "C" void rhip_ctx_destroy(rhip_ctx_t* c) {
     for (auto& b : c->q) b.release();
     for (auto& b : c->many) b.release();
     for (auto& b : c->sel) b.release();
+    for (auto& b : c->partial_cache) { (void)hipFree(b.keys); (void)hipFree(b.words); }
     for (auto& e : c->ev) (void)hipEventDestroy(e);
     for (auto& a : c->aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -172,6 +225,7 @@ extern "C" void rhip_ctx_destroy(rhip_ctx_t* c) {
     for (auto& e : c->ev_join) if (e) (void)hipEventDestroy(e);
     (void)hipHostFree(c->h_pinned);
     (void)hipStreamDestroy(c->stream);
+    if (sw_) (void)hipSetDevice(prev_dev_);
     delete c;
 }
 extern "C" void* rhip_ctx_stream(rhip_ctx_t* c) { return (void*)c->stream; }
@@ -306,6 +360,7 @@ size_t parse_portable32(const char* buf, size_t len, uint64_t key_hi, HostDir& D
 rhip_pool_t* upload(rhip_ctx_t* ctx, HostDir& D, uint32_t n_bitmaps, bool is64) {
     rhip_pool_t* P = new rhip_pool_s();
     try {
+        DeviceGuard dguard_(ctx->device);
         P->ctx = ctx;
         P->n_bitmaps = n_bitmaps;
         P->n_cont = D.key.size();
@@ -416,6 +471,7 @@ static void pool_payload_stats(rhip_pool_t* P, uint64_t out[4]) {
 }
 extern "C" uint64_t rhip_pool_payload_bytes(rhip_pool_t* P) {
     try {
+        DeviceGuard dguard_(P->ctx->device);
         uint64_t o[4];
         pool_payload_stats(P, o);
         return o[0];
@@ -423,6 +479,7 @@ extern "C" uint64_t rhip_pool_payload_bytes(rhip_pool_t* P) {
 }
 extern "C" int rhip_pool_type_counts(rhip_pool_t* P, uint64_t out[3]) {
     try {
+        DeviceGuard dguard_(P->ctx->device);
         uint64_t o[4];
         pool_payload_stats(P, o);
         out[0] = o[1]; out[1] = o[2]; out[2] = o[3];
@@ -435,6 +492,7 @@ extern "C" rhip_pool_t* rhip_pool_synth_bitset(rhip_ctx_t* ctx, uint32_t n_bitma
     if (!ctx) { set_err("null context"); return nullptr; }
     rhip_pool_t* P = new rhip_pool_s();
     try {
+        DeviceGuard dguard_(ctx->device);
         P->ctx = ctx;
         P->n_bitmaps = n_bitmaps;
         P->n_cont = (uint64_t)n_bitmaps * n_containers;
@@ -552,6 +610,7 @@ static size_t portable32_write(const rhip_pool_t* P, uint64_t c0, uint64_t c1, c
 extern "C" size_t rhip_pool_portable_size(rhip_pool_t* P, uint32_t i) {
     try {
         if (!P || i >= P->n_bitmaps) { set_err("bitmap index out of range"); return 0; }
+        DeviceGuard dguard_(P->ctx->device);
         fetch_dir(P);
         uint64_t c0 = P->h_bm_start[i], c1 = P->h_bm_start[i + 1];
         if (!P->is64) return portable32_size(P, c0, c1);
@@ -570,6 +629,7 @@ extern "C" size_t rhip_pool_portable_size(rhip_pool_t* P, uint32_t i) {
 extern "C" size_t rhip_pool_portable_serialize(rhip_pool_t* P, uint32_t i, char* buf) {
     try {
         if (!P || i >= P->n_bitmaps) { set_err("bitmap index out of range"); return 0; }
+        DeviceGuard dguard_(P->ctx->device);
         fetch_dir(P);
         uint64_t c0 = P->h_bm_start[i], c1 = P->h_bm_start[i + 1];
         // payload span of this bitmap: slots are assigned in directory order, so it is one range
@@ -611,6 +671,7 @@ extern "C" size_t rhip_pool_portable_serialize(rhip_pool_t* P, uint32_t i, char*
 
 extern "C" int rhip_pool_cardinalities(rhip_pool_t* P, uint64_t* out) {
     try {
+        DeviceGuard dguard_(P->ctx->device);
         if (P->h_cards.size() != P->n_bitmaps) {
             rhip_ctx_t* c = P->ctx;
             std::vector<uint64_t> tmp(P->n_bitmaps);
@@ -660,6 +721,7 @@ void launch_bb(rhip_ctx_t* c, unsigned grid, const PoolView& A, const PoolView& 
 
 void check_pair_args(rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs, const uint32_t* rhs) {
     if (!A || !B) { set_err("null pool"); throw (int)RHIP_ERR_ARG; }
+    if (npairs && (!lhs || !rhs)) { set_err("null pair index array"); throw (int)RHIP_ERR_ARG; }
     if (A->is64 != B->is64) { set_err("mixing 32-bit and 64-bit pools"); throw (int)RHIP_ERR_ARG; }
     if (A->ctx->device != B->ctx->device) { set_err("operand pools live on different devices"); throw (int)RHIP_ERR_ARG; }
     if (npairs >= 0x3FFFFFF0ull) { set_err("too many pairs"); throw (int)RHIP_ERR_ARG; }
@@ -883,6 +945,7 @@ extern "C" rhip_pool_t* rhip_pairwise(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A
         if (!c) { set_err("null context"); throw (int)RHIP_ERR_ARG; }
         int op = (int)op_;
         if (op < 0 || op > 3) { set_err("bad op"); throw (int)RHIP_ERR_ARG; }
+        DeviceGuard dguard_(c->device);
         check_pair_args(A, B, npairs, lhs, rhs);
         if (reuse && (reuse == A || reuse == B)) {
             reuse = nullptr;  // not ours to recycle
@@ -926,7 +989,8 @@ extern "C" rhip_pool_t* rhip_pairwise(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A
         finish_stats(c, &P);
         memcpy(&R->n_cont, (char*)c->h_pinned + 512, 8);
         return R;
-    } catch (int) {
+    } catch (int e) {
+        last_status() = e;
         if (R) { R->release(); delete R; }
         if (reuse) { reuse->release(); delete reuse; }
         return nullptr;
@@ -939,7 +1003,9 @@ extern "C" int rhip_pairwise_cardinality(rhip_ctx_t* c, rhip_op op_, rhip_pool_t
         if (!c) { set_err("null context"); throw (int)RHIP_ERR_ARG; }
         int op = (int)op_;
         if (op < 0 || op > 3) { set_err("bad op"); throw (int)RHIP_ERR_ARG; }
+        DeviceGuard dguard_(c->device);
         check_pair_args(A, B, npairs, lhs, rhs);
+        if (npairs && !out) { set_err("null output array"); throw (int)RHIP_ERR_ARG; }
         hipStream_t s = c->stream;
         // per-bitmap cardinalities for inclusion-exclusion (roaring.c:3086-3107)
         std::vector<uint64_t> cA(A->n_bitmaps), cB(B->n_bitmaps);

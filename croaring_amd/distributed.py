@@ -5,17 +5,25 @@ xor_many over a set of bitmaps sharded across ranks needs ONE exchange step (SUR
 
   1. rank r reduces ITS bitmaps to one uncompressed 1024-word chunk per distinct container key
      (Engine.many_partials -> rhip_many_partials; no cardinality, no typing);
-  2. every chunk travels to the owner of its key (owner = key mod world) -- a personalised
-     all-to-all built from grouped point-to-point sends/receives, which is what maps onto xGMI's
-     point-to-point links (RCCL has no OR/XOR reduction, SURVEY G10, and a ring all-reduce would be
-     bound by a single link);
-  3. the owner combines equal keys and canonicalises (Engine.many_finalize -> rhip_many_finalize).
+  2. every chunk travels to the owner of its key (owner = key mod world).  RCCL has no OR/XOR
+     reduction and a ring all-reduce would be bound by one xGMI link, so the exchange is a
+     personalised all-to-all, which keeps all point-to-point links busy.  Two forms:
+       * dense  (`key_space` given, e.g. 4096 for BASELINE config C4 where every rank sees every key):
+         chunks are scattered into a zero-filled [world, key_space / world, 1024] table and exchanged
+         with ONE fixed-shape `all_to_all_single` -- no count exchange, no host round trip; everything
+         between stage 1 and stage 3 is stream-ordered on the engine's stream;
+       * sparse (default): counts are all-gathered (one small host readback), then grouped
+         point-to-point sends/receives move exactly the chunks that exist;
+  3. the owner combines equal keys and canonicalises (Engine.many_finalize -> rhip_many_finalize);
+     all-zero chunks of the dense form vanish there (empty results are dropped).
 
 The result stays sharded by key (each rank holds a one-bitmap pool with the keys it owns);
 `gather_serialized` collects it on one rank when a single portable bitmap is wanted.
 
-`exchange_chunks` only touches torch tensors, so the same code runs on CPU tensors with the gloo
-backend (tests/test_distributed_cpu.py, world_size 2) and on device tensors with nccl (= RCCL).
+The exchange functions only touch torch tensors, so the same code runs on CPU tensors with the gloo
+backend (tests/test_distributed_cpu.py, world_size 2) and on device tensors with nccl (= RCCL); with
+a gloo group and device-resident chunks (two test ranks sharing one GPU) `many_sharded` stages the
+chunks through host memory.
 """
 from __future__ import annotations
 
@@ -38,7 +46,7 @@ def owner_of(keys: torch.Tensor, world: int) -> torch.Tensor:
 
 
 def exchange_chunks(keys: torch.Tensor, words: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Send every (key, 1024-word chunk) record to rank key % world; return what this rank owns.
+    """Sparse form: send every (key, 1024-word chunk) record to rank key % world; return what this rank owns.
 
     keys: int64 [n]; words: int64 [n, 1024] (same device).  Received records are in source-rank order;
     duplicates of a key (one per source rank that saw it) are combined later by many_finalize.
@@ -84,6 +92,32 @@ def exchange_chunks(keys: torch.Tensor, words: torch.Tensor, group=None) -> Tupl
     return recv_keys, recv_words
 
 
+def dense_block(key_space: int, world: int) -> int:
+    """Keys owned by one rank in the dense form: ceil(key_space / world)."""
+    return (int(key_space) + world - 1) // world
+
+
+def exchange_dense(keys: torch.Tensor, words: torch.Tensor, key_space: int, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Dense form: ONE fixed-shape all_to_all_single, no counts, no host synchronisation.
+
+    Every key must be < key_space (the caller checks it against rhip_partials_t.max_key, a host value).  The chunk
+    of key k is placed in row (k % world) * B + k // world of a zero-filled [world * B, 1024] table, B =
+    ceil(key_space / world); block d of the table goes to rank d.  Returns (keys [world * B], words [world * B,
+    1024]): row s * B + j is source rank s's chunk (all zero if s never saw the key) for key rank + world * j."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = keys.device
+    B = dense_block(key_space, world)
+    table = torch.zeros((world * B, WORDS), dtype=torch.int64, device=dev)
+    if keys.numel():
+        slot = (keys % world) * B + torch.div(keys, world, rounding_mode="floor")
+        table.index_copy_(0, slot, words.reshape(-1, WORDS))
+    recv = torch.empty_like(table)
+    dist.all_to_all_single(recv, table, group=group)
+    rkeys = (torch.arange(B, dtype=torch.int64, device=dev) * world + rank).repeat(world)
+    return rkeys, recv
+
+
 class _DevArray:
     """Zero-copy view of engine-owned device memory for torch (via __cuda_array_interface__)."""
 
@@ -92,27 +126,40 @@ class _DevArray:
                                          "version": 2, "strides": None}
 
 
-def many_sharded(engine, local_pool, op: str = "or", ids=None, group=None):
+def many_sharded(engine, local_pool, op: str = "or", ids=None, group=None, key_space: Optional[int] = None):
     """or_many / xor_many over the union of every rank's `local_pool[ids]`.
 
     Returns this rank's share of the result: a one-bitmap Pool holding the container keys with
-    key % world == rank.  Must be called by every rank of the group.
-    """
+    key % world == rank.  Must be called by every rank of the group, all with the same `key_space`.
+    key_space = an exclusive upper bound of the container keys on EVERY rank (e.g. 4096) selects the dense
+    fixed-shape exchange; None selects the sparse one."""
     parts = engine.many_partials(op, local_pool, ids)
     n = parts.n_keys
-    dev = torch.device("cuda", torch.cuda.current_device())
-    if n:
-        keys = torch.as_tensor(_DevArray(parts.d_keys, (n,)), device=dev)
-        words = torch.as_tensor(_DevArray(parts.d_words, (n, WORDS)), device=dev)
-    else:
-        keys = torch.empty(0, dtype=torch.int64, device=dev)
-        words = torch.empty((0, WORDS), dtype=torch.int64, device=dev)
-    engine.synchronize()
-    rk, rw = exchange_chunks(keys, words, group)
-    torch.cuda.synchronize()
-    out = engine.many_finalize(op, local_pool.is64, rk.numel(), rk.data_ptr() if rk.numel() else 0,
-                               rw.data_ptr() if rk.numel() else 0)
-    parts.free()
+    dev = engine.torch_device()
+    # test configuration: ranks without RCCL between them (two ranks sharing one GPU) stage chunks through the host
+    staged = dist.get_backend(group) == "gloo" and dev.type != "cpu"
+    # torch work is issued on the ENGINE's stream: stage 1, the table scatter, the collective's input/output
+    # dependencies and stage 3 are then ordered by the stream itself, with no host synchronisation in between
+    with engine.torch_stream():
+        if n:
+            keys, words = engine.as_tensor(parts.d_keys, (n,)), engine.as_tensor(parts.d_words, (n, WORDS))
+        else:
+            keys = torch.empty(0, dtype=torch.int64, device=dev)
+            words = torch.empty((0, WORDS), dtype=torch.int64, device=dev)
+        if key_space is not None and n and parts.max_key >= key_space:
+            raise ValueError(f"key {parts.max_key} >= key_space {key_space}: use the sparse exchange")
+        if staged:
+            keys, words = keys.cpu(), words.cpu()
+        if key_space is not None:
+            rk, rw = exchange_dense(keys, words, key_space, group)
+        else:
+            rk, rw = exchange_chunks(keys, words, group)
+        if staged:
+            rk, rw = rk.to(dev), rw.to(dev)
+        rk, rw = rk.contiguous(), rw.contiguous()
+        nk = rk.numel()
+        out = engine.many_finalize(op, local_pool.is64, nk, rk.data_ptr() if nk else 0, rw.data_ptr() if nk else 0)
+    parts.free()  # buffers go back to the context's cache; their next writer is on the same stream
     return out
 
 

@@ -23,6 +23,16 @@ def _u32(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.uint32)
 
 
+def _pair_ids(lhs, rhs):
+    """Validated (lhs, rhs) index arrays of a pairwise batch: both given, one-dimensional, equally long."""
+    if lhs is None or rhs is None:
+        raise ValueError("pairwise batches need both lhs and rhs index arrays")
+    lhs, rhs = _u32(lhs).ravel(), _u32(rhs).ravel()
+    if lhs.shape != rhs.shape:
+        raise ValueError("lhs/rhs length mismatch")
+    return lhs, rhs
+
+
 def synth_sparse_portable(first: int, stride: int, count: int):
     """SURVEY §8d C4 generator (rhip_synth_sparse_sizes / _fill): portable images of the sparse bitmaps first,
     first + stride, ... packed back to back -> (uint8 blob, uint64 offsets[count + 1]).  Host only, no device."""
@@ -154,9 +164,7 @@ class Engine:
                  reuse: Optional["Pool"] = None) -> "Pool":
         """result[k] = op(A[lhs[k]], B[rhs[k]]) -- roaring_bitmap_{and,or,xor,andnot} batched."""
         B = A if B is None else B
-        lhs, rhs = _u32(lhs), _u32(rhs)
-        if lhs.shape != rhs.shape:
-            raise ValueError("lhs/rhs length mismatch")
+        lhs, rhs = _pair_ids(lhs, rhs)
         rh = None
         if reuse is not None:
             rh, reuse.h = reuse.h, None  # consumed
@@ -168,7 +176,7 @@ class Engine:
     def pairwise_cardinality(self, op: str, A: "Pool", lhs, B: Optional["Pool"] = None, rhs=None) -> np.ndarray:
         """roaring_bitmap_{and,or,xor,andnot}_cardinality batched."""
         B = A if B is None else B
-        lhs, rhs = _u32(lhs), _u32(rhs)
+        lhs, rhs = _pair_ids(lhs, rhs)
         out = np.zeros(lhs.size, dtype=np.uint64)
         rc = self.lib.rhip_pairwise_cardinality(self.h, OPS[op], A.h, B.h, lhs.size, lhs.ctypes.data,
                                                 rhs.ctypes.data, out.ctypes.data)
@@ -179,9 +187,7 @@ class Engine:
     def pairwise_predicate(self, pred: str, A: "Pool", lhs, B: Optional["Pool"] = None, rhs=None) -> np.ndarray:
         """roaring_bitmap_intersect / is_subset / is_strict_subset / equals batched; bool array."""
         B = A if B is None else B
-        lhs, rhs = _u32(lhs), _u32(rhs)
-        if lhs.shape != rhs.shape:
-            raise ValueError("lhs/rhs length mismatch")
+        lhs, rhs = _pair_ids(lhs, rhs)
         out = np.zeros(lhs.size, dtype=np.uint8)
         rc = self.lib.rhip_pairwise_predicate(self.h, PREDS[pred], A.h, B.h, lhs.size, lhs.ctypes.data,
                                               rhs.ctypes.data, out.ctypes.data)
@@ -192,9 +198,7 @@ class Engine:
     def pairwise_inplace(self, op: str, A: "Pool", lhs, B: Optional["Pool"] = None, rhs=None) -> None:
         """A[lhs[k]] <- op(A[lhs[k]], B[rhs[k]]) -- roaring_bitmap_*_inplace batched; lhs must not repeat."""
         B = A if B is None else B
-        lhs, rhs = _u32(lhs), _u32(rhs)
-        if lhs.shape != rhs.shape:
-            raise ValueError("lhs/rhs length mismatch")
+        lhs, rhs = _pair_ids(lhs, rhs)
         rc = self.lib.rhip_pairwise_inplace(self.h, OPS[op], A.h, B.h, lhs.size, lhs.ctypes.data, rhs.ctypes.data)
         if rc != 0:
             raise RoaringHipError(f"pairwise_inplace {op} failed: " + self._err())
@@ -274,6 +278,28 @@ class Engine:
         return Pool(self, h)
 
 
+    # ---- torch interop (only croaring_amd.distributed uses these; torch is imported lazily) ---------------
+    def torch_device(self):
+        import torch
+        return torch.device("cuda", torch.cuda.current_device())
+
+    def torch_stream(self):
+        """Context manager making the engine's HIP stream torch's current stream: torch work issued inside is
+        ordered with the engine's kernels by the stream itself, no host synchronisation needed."""
+        import torch
+        return torch.cuda.stream(torch.cuda.ExternalStream(self.stream, device=self.torch_device()))
+
+    def as_tensor(self, ptr: int, shape):
+        """Zero-copy int64 torch view of engine-owned device memory."""
+        import torch
+
+        class _DevArray:
+            def __init__(self, ptr, shape):
+                self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<i8", "data": (ptr, False),
+                                                 "version": 2, "strides": None}
+        return torch.as_tensor(_DevArray(ptr, shape), device=self.torch_device())
+
+
 class PartialChunks:
     def __init__(self, eng: Engine, p: Partials):
         self.eng, self.p = eng, p
@@ -281,6 +307,7 @@ class PartialChunks:
     n_keys = property(lambda self: int(self.p.n_keys))
     d_keys = property(lambda self: int(self.p.d_keys or 0))
     d_words = property(lambda self: int(self.p.d_words or 0))
+    max_key = property(lambda self: int(self.p.max_key))
 
     def free(self):
         if self.p is not None:

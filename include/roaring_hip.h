@@ -186,7 +186,12 @@ rhip_pool_t *rhip_pool_flip(rhip_ctx_t *ctx, rhip_pool_t *pool, const uint64_t *
 /* roaring_bitmap_or_many (roaring.h:304, src/roaring.c:775-790) /
  * roaring_bitmap_xor_many (roaring.h:334, src/roaring.c:795-809) over
  * pool[ids[0..n)] (ids == NULL: the whole pool, in order).  Returns a pool
- * holding ONE bitmap.  n == 0 gives an empty bitmap, n == 1 a copy. */
+ * holding ONE bitmap.  n == 0 gives an empty bitmap, n == 1 a copy.
+ * Parity level: rhip_or_many is byte-identical to roaring_bitmap_or_many (container types included, the
+ * fold-order dependent full-run / full-bitset choice replayed).  rhip_xor_many guarantees SET EQUALITY and a
+ * valid, canonical bitmap (array iff cardinality <= 4096, else bitset; single-member keys keep their container)
+ * -- not the reference's container types: roaring_bitmap_xor_many's lazy_xor -> repair path leaves types that
+ * depend on the fold order, and the reference's own or_many / or_many_heap disagree the same way. */
 rhip_pool_t *rhip_or_many(rhip_ctx_t *ctx, rhip_pool_t *pool, size_t n, const uint32_t *ids);
 rhip_pool_t *rhip_xor_many(rhip_ctx_t *ctx, rhip_pool_t *pool, size_t n, const uint32_t *ids);
 
@@ -198,6 +203,8 @@ typedef struct rhip_partials_s {
     uint64_t n_keys;       /* distinct keys in this shard */
     uint64_t *d_keys;      /* device: [n_keys] ascending */
     uint64_t *d_words;     /* device: [n_keys][1024] */
+    uint64_t max_key;      /* d_keys[n_keys - 1] (0 when n_keys == 0): lets the caller pick a fixed-shape exchange */
+    uint64_t capacity;     /* internal: chunks the buffers can hold (they are recycled by rhip_partials_free) */
 } rhip_partials_t;
 int rhip_many_partials(rhip_ctx_t *ctx, rhip_op op /* RHIP_OR | RHIP_XOR */, rhip_pool_t *pool, size_t n,
                        const uint32_t *ids, rhip_partials_t *out);

@@ -27,7 +27,13 @@
  * downloads the result: correct, but latency-bound.  Throughput users bind the batched
  * API in roaring_hip.h instead.  A process-wide context on the current HIP device is created on
  * first use; without a device pointer-returning functions return NULL (roaring.h:216-226), the
- * *_cardinality functions return UINT64_MAX and the in-place functions leave x1 untouched.
+ * *_cardinality functions return UINT64_MAX.  The void in-place / repair functions have no error channel: a
+ * device or allocation failure inside them prints rhip_last_error() to stderr and abort()s rather than
+ * silently leaving x1 unchanged.
+ * Parity: pairwise, in-place, cardinality and or_many(_heap = or_many) results are byte-identical to the
+ * reference's (container types included); roaring_bitmap_xor_many is SET-EQUAL and canonical (array iff
+ * cardinality <= 4096, else bitset), not type-identical -- the reference's lazy_xor fold leaves order-dependent
+ * container types.
  *
  * How a program uses it: keep including <roaring/roaring.h>, link libroaring_hip.so BEFORE libroaring
  * (or build libroaring with these symbols renamed): these symbols then resolve here,

@@ -27,4 +27,20 @@ def emu_engine():
             if not self.h:
                 raise RuntimeError("emu ctx_create failed: " + (lib.rhip_last_error() or b"").decode())
 
+        # the emulator's "device" memory is host memory: torch sees it as CPU tensors, and there is no stream
+        def torch_device(self):
+            import torch
+            return torch.device("cpu")
+
+        def torch_stream(self):
+            import contextlib
+            return contextlib.nullcontext()
+
+        def as_tensor(self, ptr, shape):
+            import numpy as np
+            import torch
+            n = int(np.prod(shape))
+            a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int64)), shape=(n,)).reshape(shape)
+            return torch.from_numpy(a)
+
     return EmuEngine()

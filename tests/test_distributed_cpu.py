@@ -1,9 +1,12 @@
-"""world_size-2 gloo test of the sharded or_many exchange on CPU tensors.
+"""world_size-2 gloo tests of the sharded or_many / xor_many without a GPU.
 
-The GPU stages (rhip_many_partials / rhip_many_finalize) are stood in for by the oracle here -- this
-test covers what cannot be validated on one GPU: the key-owner partition, the personalised
-all-to-all (counts + grouped send/recv) and that combining received chunks by key reproduces
-roaring_bitmap_or_many over ALL bitmaps."""
+* test_sharded_many_composed_gloo: croaring_amd.distributed.many_sharded END TO END with two ranks -- the real
+  rhip_many_partials and rhip_many_finalize (the kernel sources running under the tests/emu SIMT emulator, whose
+  "device" memory torch sees as CPU tensors), both exchange forms (sparse: counts + grouped send/recv; dense:
+  one fixed-shape all_to_all_single), or and xor, checked against the oracle's or_many / xor_many over ALL bitmaps.
+* test_sharded_or_many_exchange_gloo: the exchange alone with the oracle standing in for both stages (kept: it
+  isolates a routing bug from a kernel bug).
+The same composed path runs on a real MI355X in tests/test_gpu_distributed.py."""
 import os
 import socket
 import sys
@@ -94,3 +97,105 @@ def test_shard_ids_partition():
     for world in (1, 2, 4, 8):
         parts = [shard_ids(1000, r, world) for r in range(world)]
         assert np.array_equal(np.sort(np.concatenate(parts)), np.arange(1000))
+
+
+def _composed_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from croaring_amd.distributed import gather_serialized, many_sharded, shard_ids
+        from emu import emu_engine
+        from gen_inputs import random_bitmap
+        from oracle.pyoracle import Oracle
+        oracle = Oracle()
+        eng = emu_engine()
+        rng = np.random.default_rng(4242)  # same stream on every rank: identical global input set
+        allv = [random_bitmap(rng, max_keys=8, key_space=16) for _ in range(23)]
+        hs_all = [oracle.from_sorted(v) for v in allv]
+        mine = [int(i) for i in shard_ids(len(allv), rank, world)]
+        pool = eng.pool_from_serialized([oracle.serialize(hs_all[i]) for i in mine])
+        ok = []
+        for op, fn in (("or", oracle.or_many), ("xor", oracle.xor_many)):
+            want = oracle.to_array(fn(hs_all))
+            for key_space in (None, 16, 21):
+                owned = many_sharded(eng, pool, op, key_space=key_space)
+                hv = oracle.deserialize(owned.serialize(0))
+                v = oracle.to_array(hv)
+                ok.append(bool(oracle.validate(hv)) and bool(np.all((v >> 16) % world == rank))
+                          and bool(np.array_equal(v, want[((want >> 16) % world) == rank])))
+                blob = gather_serialized(eng, owned)
+                if rank == 0:
+                    hg = oracle.deserialize(blob)
+                    ok.append(bool(np.array_equal(oracle.to_array(hg), want)))
+        try:
+            many_sharded(eng, pool, "or", key_space=3)  # a key >= key_space must be refused, on every rank alike
+            ok.append(False)
+        except ValueError:
+            ok.append(True)
+        q.put((rank, all(ok), len(ok)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_many_composed_gloo():
+    from emu import build_emu
+    if not os.path.exists(build_emu.CXX):
+        pytest.skip("hipemu needs the ROCm clang++")
+    build_emu.build()
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_composed_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] for r in res), res
+
+
+def _dense_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from croaring_amd.distributed import dense_block, exchange_dense
+    # rank r holds keys {k : k % 3 != r} of [0, 11), chunk content = key * 1000 + source rank
+    ks = 11
+    keys = torch.tensor([k for k in range(ks) if k % 3 != rank], dtype=torch.int64)
+    words = (keys * 1000 + rank).reshape(-1, 1).repeat(1, 1024)
+    rk, rw = exchange_dense(keys, words, ks)
+    B = dense_block(ks, world)
+    ok = rk.numel() == world * B and rw.shape == (world * B, 1024)
+    for s_ in range(world):
+        for j in range(B):
+            k = rank + world * j
+            row = rw[s_ * B + j]
+            ok = ok and int(rk[s_ * B + j]) == k
+            has = k < ks and k % 3 != s_
+            ok = ok and bool((row == (k * 1000 + s_ if has else 0)).all())
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_dense_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dense_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res

@@ -56,6 +56,7 @@ def test_dropin_pairwise(hip, ref):
         for op in OPS:
             want = ref.op(op, a, b)
             got = getattr(hip, f"roaring_bitmap_{op}")(a, b)
+            assert got, f"drop-in roaring_bitmap_{op} returned NULL (no device?)"
             assert got, "drop-in returned NULL"
             assert ref.validate(got)
             assert ref.serialize(got) == ref.serialize(want), (it, op)
@@ -85,6 +86,7 @@ def test_dropin_many(hip, ref):
                            ("or_many_heap", hip.roaring_bitmap_or_many_heap, ref.or_many),
                            ("xor_many", hip.roaring_bitmap_xor_many, ref.xor_many)):
             got = fn(n, arr)
+            assert got, "drop-in many-way aggregation returned NULL (no device?)"
             want = rf(hs)
             assert got and ref.validate(got)
             assert np.array_equal(ref.to_array(got), ref.to_array(want)), (it, nm)
@@ -112,8 +114,10 @@ def test_dropin_lazy_family(hip, ref):
         a, b, c = (ref.from_sorted(random_bitmap(rng)) for _ in range(3))
         want_or, want_xor = ref.op("or", a, b), ref.op("xor", a, b)
         got = hip.roaring_bitmap_lazy_or(a, b, bool(it & 1))
+        assert got, "drop-in roaring_bitmap_lazy_or returned NULL (no device?)"
         assert ref.validate(got) and ref.serialize(got) == ref.serialize(want_or)
         gx = hip.roaring_bitmap_lazy_xor(a, b)
+        assert gx, "drop-in roaring_bitmap_lazy_xor returned NULL (no device?)"
         assert ref.validate(gx) and ref.serialize(gx) == ref.serialize(want_xor)
         # reference-made lazy bitmap (a | b | c, unrepaired) repaired by OUR repair_after_lazy
         lazy = R.roaring_bitmap_lazy_or(a, b, bool(it & 1))

@@ -1,0 +1,113 @@
+"""The sharded or_many / xor_many on real hardware with world > 1: two ranks (two processes, each
+with its own engine context) share the one GPU of the test box and talk over a gloo group, so the chunks are
+staged through host memory between the REAL rhip_many_partials and rhip_many_finalize; both exchange forms.
+The RCCL transport itself is covered with a 1-rank nccl group (the only size one GPU allows) in
+test_many_sharded_nccl_world1_dense."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import croaring_amd
+        from croaring_amd.distributed import gather_serialized, many_sharded, shard_ids
+        from oracle.pyoracle import Oracle
+        from util import load_bundle
+        oracle = Oracle()
+        eng = croaring_amd.Engine(0)
+        bufs = load_bundle("census-income")[:60] + load_bundle("wikileaks-noquotes")[:40] + load_bundle("weather_sept_85")[:30]
+        hs_all = [oracle.deserialize(b) for b in bufs]
+        mine = [int(i) for i in shard_ids(len(bufs), rank, world)]
+        pool = eng.pool_from_serialized([bufs[i] for i in mine])
+        kmax = max(int(oracle.to_array(h)[-1]) >> 16 for h in hs_all if oracle.cardinality(h))
+        ok = []
+        for op, fn in (("or", oracle.or_many), ("xor", oracle.xor_many)):
+            want = oracle.to_array(fn(hs_all))
+            for key_space in (None, kmax + 1):
+                owned = many_sharded(eng, pool, op, key_space=key_space)
+                hv = oracle.deserialize(owned.serialize(0))
+                v = oracle.to_array(hv)
+                ok.append(bool(oracle.validate(hv)) and bool(np.all((v >> 16) % world == rank))
+                          and bool(np.array_equal(v, want[((want >> 16) % world) == rank])))
+                blob = gather_serialized(eng, owned)
+                if rank == 0:
+                    ok.append(bool(np.array_equal(oracle.to_array(oracle.deserialize(blob)), want)))
+        q.put((rank, all(ok), len(ok)))
+        dist.barrier()
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_many_sharded_two_ranks_one_gpu():
+    import torch.multiprocessing as mp
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] for r in res), res
+
+
+def test_many_sharded_nccl_world1_dense(engine, oracle):
+    """The dense (fixed-shape all_to_all_single) and sparse exchange on the RCCL backend with a 1-rank group,
+    issued on the engine's stream with no host synchronisation between the stages."""
+    import torch
+    import torch.distributed as dist
+    from croaring_amd.distributed import gather_serialized, many_sharded
+    from util import load_bundle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        bufs = load_bundle("weather_sept_85")[:64]
+        hs = [oracle.deserialize(b) for b in bufs]
+        pool = engine.pool_from_serialized(bufs)
+        for op, fn in (("or", oracle.or_many), ("xor", oracle.xor_many)):
+            want = fn(hs)
+            for key_space in (None, 64, 4096):
+                for _ in range(3):  # repeated calls recycle the partial-chunk buffers through the context cache
+                    owned = many_sharded(engine, pool, op, key_space=key_space)
+                hg = oracle.deserialize(gather_serialized(engine, owned))
+                assert oracle.validate(hg)
+                assert np.array_equal(oracle.to_array(hg), oracle.to_array(want)), (op, key_space)
+                oracle.free(hg)
+            oracle.free(want)
+        for h in hs:
+            oracle.free(h)
+    finally:
+        if created:
+            dist.destroy_process_group()
