@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ aren
             __builtin_amdgcn_wave_barrier();
         }
         PH(1);
-        uint16_t* __restrict__ out = cardmode ? nullptr : (uint16_t*)(O.arena + O.off[t.out]);
+        uint16_t* __restrict__ out = cardmode ? nullptr : (uint16_t*)(O.arena + t.offo);
         uint32_t run = 0;
         for (uint32_t base = 0; base < ny; base += 512) {
             const uint32_t i0 = base + 8 * lane;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA
         const uint32_t rc = (uint32_t)((int)cx + delta);
         int ty = T_ARRAY;
         if (rc) ty = decide_type(op, ta, tb, ca, cb, false, false, rc, 0);
-        uint8_t* outp = O.arena + O.off[t.out];
+        uint8_t* outp = O.arena + t.offo;
         __builtin_amdgcn_wave_barrier();
         PH(3);
         if (rc && ty == T_BITSET) {

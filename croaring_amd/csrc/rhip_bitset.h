@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_bb(const uint8_t* __restrict__ arenaA, 
         // bitset iff card > 4096 (mixed_intersection.c:305-325, mixed_xor.c:260-273,
         // mixed_andnot.c:482-497)
         if (OP == OP_OR || card > 4096u) {
-            u32x4* __restrict__ po = (u32x4*)(O.arena + O.off[t.out]);
+            u32x4* __restrict__ po = (u32x4*)(O.arena + t.offo);
 #pragma unroll
             for (int i = 0; i < 8; ++i) __builtin_nontemporal_store(va[i], po + i * 64 + lane);
             if (lane == 0) O.meta[t.out] = pack_meta(T_BITSET, card, 0);
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_bb(const uint8_t* __restrict__ arenaA, 
                 GenItem g;
                 g.offa = t.offa; g.offb = t.offb; g.out = t.out; g.ca = 65536u; g.cb = 65536u;
                 g.types = (uint32_t)T_BITSET | ((uint32_t)T_BITSET << 8);
-                g.nra = 0; g.nrb = 0; g.pad0 = 0; g.pad1 = 0;
+                g.nra = 0; g.nrb = 0; g.offo = t.offo;
                 retry_q[atomicAdd(retry_count, 1u)] = g;
             }
         }
@@ -82,22 +82,24 @@ __global__ __launch_bounds__(256) void k_bb(const uint8_t* __restrict__ arenaA, 
 }
 
 // ------------------------------------------------------------------ pass-through copy
-__global__ __launch_bounds__(256) void k_copy(PoolView A, PoolView B, OutView O, const Item* __restrict__ q,
+// One wave per container while the queue is long; the item says where from, where to, how much -- no directory loads.
+__global__ __launch_bounds__(256) void k_copy(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                              OutView O, const CopyItem* __restrict__ q,
                                               const u64* __restrict__ qrange) {
     const uint32_t lane = lane_id();
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
-        Item t = q[w];
-        const PoolView& S = (t.b == NONE32) ? A : B;
-        const uint32_t c = (t.b == NONE32) ? t.a : t.b;
-        const uint8_t ty = S.type[c];
-        const uint32_t card = S.card[c], nr = S.nruns[c];
-        const uint32_t n16 = (payload_bytes(ty, card, nr) + 15u) >> 4;
-        const uint4* __restrict__ ps = (const uint4*)(S.arena + S.off[c]);
-        uint4* __restrict__ po = (uint4*)(O.arena + O.off[t.out]);
-        for (uint32_t i = lane; i < n16; i += 64) po[i] = ps[i];
-        if (lane == 0) O.meta[t.out] = pack_meta(ty, card, nr);
+    uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    CopyItem tn;
+    if (w < n) tn = q[w];
+    for (; w < n; w += nwaves) {
+        const CopyItem t = tn;
+        if (w + nwaves < n) tn = q[w + nwaves];
+        const uint8_t* base = (t.src & COPY_FROM_B) ? arenaB : arenaA;
+        const uint4* __restrict__ ps = (const uint4*)(base + (t.src & ~COPY_FROM_B));
+        uint4* __restrict__ po = (uint4*)(O.arena + t.offo);
+        for (uint32_t i = lane; i < t.n16; i += 64) po[i] = ps[i];
+        if (lane == 0) O.meta[t.out] = t.meta;
     }
 }
 

@@ -36,29 +36,40 @@ __device__ __forceinline__ uint32_t meta_card(u64 m) { return (uint32_t)m; }
 __device__ __forceinline__ uint32_t meta_nruns(u64 m) { return (uint32_t)(m >> 32) & 0xFFFFFFu; }
 __device__ __forceinline__ uint32_t meta_type(u64 m) { return (uint32_t)(m >> 56); }
 
-struct Item {
-    uint32_t a;    // container index in pool A (NONE32: pass-through from B)
-    uint32_t b;    // container index in pool B (NONE32: pass-through from A)
-    uint32_t out;  // candidate index (cardinality mode: pair index)
+// Work items carry everything a class kernel needs, resolved at plan time: operand payload offsets, the byte offset
+// of the result slot in the result arena (offo), the candidate index whose meta word the kernel writes (out; in
+// cardinality mode: the pair index whose accumulator it adds to), cardinalities / types / run counts.
+struct __attribute__((aligned(16))) CopyItem {  // pass-through container
+    u64 src;       // payload offset in arena A, or in arena B with COPY_FROM_B set
+    u64 offo;
+    u64 meta;      // pack_meta(type, card, nruns) of the container, stored unchanged
+    uint32_t out;
+    uint32_t n16;  // payload length in 16-byte units
 };
-struct __attribute__((aligned(16))) FatItem {  // array/bitset pair item: everything the kernel needs, resolved at plan time
-    u64 offa, offb;      // payload offsets in arena A / arena B
-    uint32_t out;        // candidate index (cardinality mode: pair index)
+#define COPY_FROM_B (1ull << 63)
+struct __attribute__((aligned(16))) FatItem {  // array/bitset pair item
+    u64 offa, offb, offo;
+    uint32_t out;
     uint32_t ca, cb;     // cardinalities
     uint32_t types;      // ta | tb << 8
+    uint32_t pad0, pad1;
 };
 struct __attribute__((aligned(16))) GenItem {  // general pair item (any type pair, runs included)
     u64 offa, offb;
     uint32_t out, ca, cb, types;   // types = ta | tb << 8
-    uint32_t nra, nrb, pad0, pad1; // run counts
+    uint32_t nra, nrb;             // run counts
+    u64 offo;
 };
-struct __attribute__((aligned(16))) BBItem {  // bitset x bitset work item: payload offsets resolved at plan time
-    u64 offa, offb;
-    uint32_t a, b, out, pad;
+struct __attribute__((aligned(16))) BBItem {  // bitset x bitset work item
+    u64 offa, offb, offo;
+    uint32_t out, pad;
 };
 
-struct Stats {  // device-side counters, see rhip_stats_t
+struct Stats {  // device-side counters of one call, see rhip_stats_t
     u64 matched_pairs, passthrough, bytes_in, bytes_out, n_bb, result_containers;
+    u64 n_cand;      // candidates before empty results were dropped
+    u64 slot_bytes;  // result arena bytes handed out (slots are upper bounds, 16-byte granular)
+    u64 n_type[3];   // result containers by type: bitset, array, run
 };
 
 

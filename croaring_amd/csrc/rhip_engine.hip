@@ -123,7 +123,10 @@ struct rhip_ctx_s {
     }
     hipStream_t stream = nullptr;
     // scratch (grow-only): candidate directory + queues + scan temporaries
-    DBuf lhs, rhs, u_pair, u_tile, u_pair0, unit_bytes, cand, cand_start, o_key, o_meta, o_slot, o_off, flag, newidx, q[N_CLS], misc, prim_tmp, pair_acc;
+    DBuf plan_in, match, cand, cand_start, o_key, o_meta, o_slot, o_off, o_pair, flag, newidx, q[N_CLS], misc, misc2, prim_tmp, pair_acc;
+    void* h_stage = nullptr;  // pinned staging of one batch description (grow-only)
+    size_t h_stage_cap = 0;
+    void ensure_stage(size_t n);
     DBuf many[16];
     DBuf sel[5];  // pool_select / pool_convert scratch
     void* h_pinned = nullptr;  // small pinned readback area
@@ -136,6 +139,20 @@ struct rhip_ctx_s {
     hipEvent_t ev_fork = nullptr, ev_join[N_AUX]{}, ev_runs = nullptr;
     bool overlap = true;
 };
+
+void rhip_ctx_s::ensure_stage(size_t n) {
+    if (n <= h_stage_cap) return;
+    if (h_stage) (void)hipHostFree(h_stage);
+    h_stage = nullptr;
+    h_stage_cap = 0;
+    const size_t want = n + n / 4 + 4096;
+    if (hipHostMalloc(&h_stage, want, hipHostMallocDefault) != hipSuccess) {
+        h_stage = nullptr;
+        set_err("hipHostMalloc(%zu) failed", want);
+        throw (int)RHIP_ERR_ALLOC;
+    }
+    h_stage_cap = want;
+}
 
 struct rhip_pool_s {
     rhip_ctx_t* ctx = nullptr;
@@ -151,6 +168,9 @@ struct rhip_pool_s {
     std::vector<uint8_t> h_type;
     std::vector<uint32_t> h_card, h_nruns;
     std::vector<uint64_t> h_cards;  // per-bitmap cardinalities cache
+    std::vector<uint64_t> h_w;      // per-bitmap result-slot bound (k_bitmap_bounds), see fetch_bounds
+    bool host_w = false;
+    int8_t census[3] = {1, 1, 1};   // does the pool hold bitset / array / run containers (1 until known otherwise)
     PoolView view() const {
         PoolView v;
         v.bm_start = bm_start.as<u64>();
@@ -211,8 +231,9 @@ extern "C" void rhip_ctx_destroy(rhip_ctx_t* c) {
     int prev_dev_ = -1;
     const bool sw_ = hipGetDevice(&prev_dev_) == hipSuccess && prev_dev_ != c->device && hipSetDevice(c->device) == hipSuccess;
     (void)hipStreamSynchronize(c->stream);
-    DBuf* all[] = {&c->lhs, &c->rhs, &c->u_pair, &c->u_tile, &c->u_pair0, &c->unit_bytes, &c->cand, &c->cand_start, &c->o_key, &c->o_meta,
-                   &c->o_slot, &c->o_off, &c->flag, &c->newidx, &c->misc, &c->prim_tmp, &c->pair_acc};
+    DBuf* all[] = {&c->plan_in, &c->match, &c->cand, &c->cand_start, &c->o_key, &c->o_meta, &c->o_slot, &c->o_off, &c->o_pair,
+                   &c->flag, &c->newidx, &c->misc, &c->misc2, &c->prim_tmp, &c->pair_acc};
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (auto* b : all) b->release();
     for (auto& b : c->q) b.release();
     for (auto& b : c->many) b.release();
@@ -692,32 +713,61 @@ extern "C" int rhip_pool_cardinalities(rhip_pool_t* P, uint64_t* out) {
 
 // ------------------------------------------------------------------ pairwise pipeline
 namespace {
-struct PlanResult {
-    uint64_t total_cand = 0;
-    uint64_t total_bytes = 0;
-    uint64_t n_bb = 0, n_gen = 0, n_copy = 0, n_filt = 0, n_wave = 0, n_runs = 0;
+// Host mirrors a batch plan needs from an operand pool: container counts per bitmap (h_bm_start), the per-bitmap
+// result-slot bound W (k_bitmap_bounds) and which container types occur at all.  Fetched once per pool, lazily.
+static void fetch_bounds(rhip_pool_t* P) {
+    fetch_bm_start(P);
+    if (P->host_w) return;
+    rhip_ctx_t* c = P->ctx;
+    P->h_w.assign((size_t)P->n_bitmaps, 0);
+    uint32_t census[3] = {0, 0, 0};
+    if (P->n_bitmaps && P->n_cont) {
+        c->misc2.ensure(8 * (size_t)P->n_bitmaps + 64);
+        uint32_t* dcensus = (uint32_t*)((char*)c->misc2.p + 8 * (size_t)P->n_bitmaps);
+        HIPCHK(hipMemsetAsync(dcensus, 0, 12, c->stream));
+        hipLaunchKernelGGL(k_bitmap_bounds, dim3((unsigned)(((size_t)P->n_bitmaps * 64 + 255) / 256)), dim3(256), 0, c->stream,
+                           P->view(), P->n_bitmaps, c->misc2.as<u64>(), dcensus);
+        HIPCHK(hipMemcpyAsync(P->h_w.data(), c->misc2.p, 8 * (size_t)P->n_bitmaps, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(census, dcensus, 12, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    for (int t = 0; t < 3; ++t) P->census[t] = census[t] ? 1 : 0;
+    P->host_w = true;
+}
+
+// device scratch of one call (inside ctx->misc, all of it cleared by k_count): u64 words
+struct PlanScratch {
+    size_t n_scan_tiles, n_tail_tiles;
+    size_t w_scan_status, w_tail_status, w_tickets, w_retry, w_ranges, w_stats, n_words;
+    void layout(size_t n_scan_elems, size_t ub_cand) {
+        n_scan_tiles = (n_scan_elems + SCAN_TILE - 1) / SCAN_TILE + 1;
+        n_tail_tiles = (ub_cand + TAIL_TILE - 1) / TAIL_TILE + 1;
+        size_t w = 0;
+        w_scan_status = w; w += n_scan_tiles;
+        w_tail_status = w; w += n_tail_tiles;
+        w_tickets = w; w += 2;
+        w_retry = w; w += 1;
+        w_ranges = w; w += 2 * N_SEC;
+        w_stats = w; w += (sizeof(Stats) + 7) / 8;
+        n_words = w;
+    }
 };
 
-// misc layout (device): [0, 128) eight {begin,end} u64 section ranges; [128, 132) retry counter;
-// [192, ...) Stats
-constexpr size_t MISC_RANGES_OFF = 0;
-constexpr size_t MISC_RETRY_OFF = 128;
-constexpr size_t MISC_STATS_OFF = 192;
-
-__global__ void k_plan_totals(const u64* __restrict__ starts, u64 S, u64* __restrict__ ranges) {
-    const uint32_t k = threadIdx.x;
-    if (k < N_SEC) {
-        ranges[2 * k] = starts[k * S];
-        ranges[2 * k + 1] = starts[k * S + (S - 1)];
-    }
-}
-
-template <int OP>
-void launch_bb(rhip_ctx_t* c, unsigned grid, const PoolView& A, const PoolView& B, const OutView& O, int cardmode) {
-    hipLaunchKernelGGL(k_bb<OP>, dim3(grid), dim3(256), 0, c->stream, A.arena, B.arena, O, c->q[CLS_BB].as<BBItem>(),
-                       (const u64*)((char*)c->misc.p + MISC_RANGES_OFF) + 2 * SEC_BB, cardmode, c->pair_acc.as<u64>(),
-                       c->q[CLS_RETRY].as<GenItem>(), (uint32_t*)((char*)c->misc.p + MISC_RETRY_OFF));
-}
+struct Plan {
+    PlanScratch sc;
+    size_t npairs = 0, NU = 0, S = 0;
+    uint64_t ub_match = 0, ub_cand = 0, arena_bound = 0;
+    bool may_bb = true, may_filt = true, may_wave = true, may_runs = true, may_copy = true;
+    // device pointers
+    uint32_t *d_lhs = nullptr, *d_rhs = nullptr, *d_upair = nullptr, *d_utile = nullptr;
+    u64* d_pair0 = nullptr;
+    u64* words = nullptr;
+    u64* ranges() const { return words + sc.w_ranges; }
+    uint32_t* retry_count() const { return (uint32_t*)(words + sc.w_retry); }
+    Stats* stats() const { return (Stats*)(words + sc.w_stats); }
+    LbState scan_lb() const { return LbState{words + sc.w_scan_status, (uint32_t*)(words + sc.w_tickets)}; }
+    LbState tail_lb() const { return LbState{words + sc.w_tail_status, (uint32_t*)(words + sc.w_tickets + 1)}; }
+};
 
 void check_pair_args(rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs, const uint32_t* rhs) {
     if (!A || !B) { set_err("null pool"); throw (int)RHIP_ERR_ARG; }
@@ -732,97 +782,12 @@ void check_pair_args(rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32
         }
 }
 
-// count -> one scan -> emit -> slot scan.  On return the class queues are filled (at
-// deterministic positions) and the host knows the totals (ONE small readback).
-PlanResult plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs,
-                const uint32_t* rhs, int cardmode, OutView& O) {
-    hipStream_t s = c->stream;
-    PlanResult R;
-    // ---- units (host: directory mirrors) + upper bounds, no sync needed
-    fetch_bm_start(A);
-    fetch_bm_start(B);
-    const bool btiles = !cardmode && (op == OP_OR || op == OP_XOR);
-    std::vector<uint32_t> upair, utile;
-    std::vector<uint64_t> pair0(npairs + 1);
-    uint64_t ub_match = 0, ub = 0;
-    for (size_t i = 0; i < npairs; ++i) {
-        const uint64_t nA = A->h_bm_start[lhs[i] + 1] - A->h_bm_start[lhs[i]];
-        const uint64_t nB = B->h_bm_start[rhs[i] + 1] - B->h_bm_start[rhs[i]];
-        pair0[i] = upair.size();
-        for (uint64_t t = 0; t < (nA + 255) / 256; ++t) { upair.push_back((uint32_t)i); utile.push_back((uint32_t)t); }
-        if (btiles)
-            for (uint64_t t = 0; t < (nB + 255) / 256; ++t) { upair.push_back((uint32_t)i); utile.push_back((uint32_t)t | UNIT_B); }
-        ub_match += std::min(nA, nB);
-        if (cardmode || op == OP_AND) ub += std::min(nA, nB);
-        else if (op == OP_ANDNOT) ub += nA;
-        else ub += nA + nB;
-    }
-    const size_t NU = upair.size();
-    pair0[npairs] = NU;
-    if (ub >= 0xFFFFFFF0ull || NU >= 0x7FFFFFF0ull) { set_err("batch too large: %llu candidate containers", (unsigned long long)ub); throw (int)RHIP_ERR_ARG; }
-    const size_t S = NU + 1;
-    c->lhs.ensure(4 * (npairs + 1));
-    c->rhs.ensure(4 * (npairs + 1));
-    c->u_pair.ensure(4 * S); c->u_tile.ensure(4 * S); c->u_pair0.ensure(8 * (npairs + 1));
-    c->cand.ensure(4 * (N_SEC * S + 1));
-    c->cand_start.ensure(8 * (N_SEC * S + 1));
-    c->misc.ensure(512);
-    HIPCHK(hipMemcpyAsync(c->lhs.p, lhs, 4 * npairs, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->rhs.p, rhs, 4 * npairs, hipMemcpyHostToDevice, s));
-    if (NU) {
-        HIPCHK(hipMemcpyAsync(c->u_pair.p, upair.data(), 4 * NU, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(c->u_tile.p, utile.data(), 4 * NU, hipMemcpyHostToDevice, s));
-    }
-    HIPCHK(hipMemcpyAsync(c->u_pair0.p, pair0.data(), 8 * (npairs + 1), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemsetAsync(c->misc.p, 0, 512, s));
-    HIPCHK(hipMemsetAsync(c->cand.p, 0, 4 * (N_SEC * S + 1), s));
-    PoolView VA = A->view(), VB = B->view();
-    UnitView UV{c->u_pair.as<uint32_t>(), c->u_tile.as<uint32_t>(), c->u_pair0.as<u64>(), (uint32_t)NU};
-    unsigned gp = (unsigned)std::max<size_t>(1, (NU * 64 + 255) / 256);
-    hipLaunchKernelGGL(k_count, dim3(gp), dim3(256), 0, s, VA, VB, c->lhs.as<uint32_t>(), c->rhs.as<uint32_t>(), UV, op,
-                       cardmode, c->cand.as<uint32_t>());
-    exscan(c, c->cand.as<uint32_t>(), c->cand_start.as<u64>(), N_SEC * S - 1);
-    u64* ranges = (u64*)((char*)c->misc.p + MISC_RANGES_OFF);
-    hipLaunchKernelGGL(k_plan_totals, dim3(1), dim3(64), 0, s, c->cand_start.as<u64>(), (u64)S, ranges);
-    c->q[CLS_BB].ensure(sizeof(BBItem) * (ub_match + 1));
-    c->q[CLS_GEN].ensure(sizeof(GenItem) * (ub_match + 1));
-    c->q[CLS_FILT].ensure(sizeof(FatItem) * (ub_match + 1));
-    c->q[CLS_WAVE].ensure(sizeof(FatItem) * (ub_match + 1));
-    c->q[CLS_RUNS].ensure(sizeof(GenItem) * (ub_match + 1));
-    c->unit_bytes.ensure(8 * (NU + 1));
-    c->q[CLS_COPY].ensure(sizeof(Item) * (ub + 1));
-    if (!cardmode) {
-        c->o_key.ensure(8 * (ub + 1)); c->o_meta.ensure(8 * (ub + 1));
-        c->o_slot.ensure(4 * (ub + 2)); c->o_off.ensure(8 * (ub + 2));
-        HIPCHK(hipMemsetAsync(c->o_slot.p, 0, 4 * (ub + 2), s));
-    }
-    O.key = c->o_key.as<u64>(); O.meta = c->o_meta.as<u64>();
-    O.slot = c->o_slot.as<uint32_t>(); O.off = c->o_off.as<u64>();
-    O.arena = nullptr;
-    EmitQueues Q{c->q[CLS_BB].as<BBItem>(), c->q[CLS_GEN].as<GenItem>(), c->q[CLS_COPY].as<Item>(), c->q[CLS_FILT].as<FatItem>(), c->q[CLS_WAVE].as<FatItem>(), c->q[CLS_RUNS].as<GenItem>()};
-    hipLaunchKernelGGL(k_emit, dim3(gp), dim3(256), 0, s, VA, VB, c->lhs.as<uint32_t>(), c->rhs.as<uint32_t>(), UV, op,
-                       cardmode, c->cand_start.as<u64>(), O, Q, c->unit_bytes.as<u64>());
-    hipLaunchKernelGGL(k_sum_u64, dim3(1), dim3(1024), 0, s, c->unit_bytes.as<u64>(), (u64)NU,
-                       &((Stats*)((char*)c->misc.p + MISC_STATS_OFF))->bytes_in);
-    char* hp = (char*)c->h_pinned;
-    if (!cardmode) {
-        // slots beyond the exact candidate count were zeroed, so scanning the upper bound is exact
-        exscan(c, O.slot, c->o_off.as<u64>(), ub);
-        HIPCHK(hipMemcpyAsync(hp + 160, c->o_off.as<u64>() + ub, 8, hipMemcpyDeviceToHost, s));
-    }
-    HIPCHK(hipMemcpyAsync(hp, ranges, 128, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    uint64_t r[16];
-    memcpy(r, hp, 128);
-    R.total_cand = r[2 * SEC_CAND + 1] - r[2 * SEC_CAND];
-    R.n_bb = r[2 * SEC_BB + 1] - r[2 * SEC_BB];
-    R.n_gen = r[2 * SEC_GEN + 1] - r[2 * SEC_GEN];
-    R.n_copy = r[2 * SEC_COPY + 1] - r[2 * SEC_COPY];
-    R.n_filt = r[2 * SEC_FILT + 1] - r[2 * SEC_FILT];
-    R.n_wave = r[2 * SEC_WAVE + 1] - r[2 * SEC_WAVE];
-    R.n_runs = r[2 * SEC_RUNS + 1] - r[2 * SEC_RUNS];
-    if (!cardmode) memcpy(&R.total_bytes, hp + 160, 8);
-    return R;
+template <int OP>
+void launch_bb(rhip_ctx_t* c, unsigned grid, const PoolView& A, const PoolView& B, const OutView& O, const Plan& P,
+               int cardmode) {
+    hipLaunchKernelGGL(k_bb<OP>, dim3(grid), dim3(256), 0, c->stream, A.arena, B.arena, O, c->q[CLS_BB].as<BBItem>(),
+                       P.ranges() + 2 * SEC_BB, cardmode, c->pair_acc.as<u64>(), c->q[CLS_RETRY].as<GenItem>(),
+                       P.retry_count());
 }
 
 unsigned persistent_grid(uint64_t n_items, unsigned items_per_block, unsigned max_blocks) {
@@ -831,24 +796,138 @@ unsigned persistent_grid(uint64_t n_items, unsigned items_per_block, unsigned ma
     return (unsigned)std::min<uint64_t>(need, max_blocks);
 }
 
+// Host half of the plan: units, upper bounds (nothing here waits for the device), ONE host-to-device copy of the
+// batch description, then k_count -> k_scan -> k_emit.  On return the class queues are filled at deterministic
+// positions and `ranges` (device) holds every section's [begin, end).
+Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs,
+          const uint32_t* rhs, int cardmode, const CandOut& CO) {
+    hipStream_t s = c->stream;
+    Plan P;
+    P.npairs = npairs;
+    fetch_bounds(A);
+    fetch_bounds(B);
+    const bool btiles = !cardmode && (op == OP_OR || op == OP_XOR);
+    // ---- units + upper bounds from the directory mirrors
+    size_t NU = 0;
+    for (size_t i = 0; i < npairs; ++i) {
+        const uint64_t nA = A->h_bm_start[lhs[i] + 1] - A->h_bm_start[lhs[i]];
+        const uint64_t nB = B->h_bm_start[rhs[i] + 1] - B->h_bm_start[rhs[i]];
+        NU += (nA + 255) / 256 + (btiles ? (nB + 255) / 256 : 0);
+    }
+    if (NU >= 0x7FFFFFF0ull) { set_err("batch too large: %zu planning units", NU); throw (int)RHIP_ERR_ARG; }
+    // staging layout (host pinned == device): pair0[npairs+1] u64 | lhs | rhs | upair | utile (u32 each)
+    const size_t o_pair0 = 0, o_lhs = 8 * (npairs + 1), o_rhs = o_lhs + 4 * npairs, o_upair = o_rhs + 4 * npairs,
+                 o_utile = o_upair + 4 * NU, stage_bytes = o_utile + 4 * NU;
+    c->ensure_stage(stage_bytes + 16);
+    char* hs = (char*)c->h_stage;
+    uint64_t* pair0 = (uint64_t*)(hs + o_pair0);
+    uint32_t* upair = (uint32_t*)(hs + o_upair);
+    uint32_t* utile = (uint32_t*)(hs + o_utile);
+    if (npairs) {
+        memcpy(hs + o_lhs, lhs, 4 * npairs);
+        memcpy(hs + o_rhs, rhs, 4 * npairs);
+    }
+    uint64_t ub_match = 0, ub = 0, bound = 0;
+    size_t u = 0;
+    for (size_t i = 0; i < npairs; ++i) {
+        const uint64_t nA = A->h_bm_start[lhs[i] + 1] - A->h_bm_start[lhs[i]];
+        const uint64_t nB = B->h_bm_start[rhs[i] + 1] - B->h_bm_start[rhs[i]];
+        const uint64_t wA = A->h_w[lhs[i]], wB = B->h_w[rhs[i]];
+        pair0[i] = u;
+        for (uint64_t t = 0; t < (nA + 255) / 256; ++t) { upair[u] = (uint32_t)i; utile[u] = (uint32_t)t; ++u; }
+        if (btiles)
+            for (uint64_t t = 0; t < (nB + 255) / 256; ++t) { upair[u] = (uint32_t)i; utile[u] = (uint32_t)t | UNIT_B; ++u; }
+        ub_match += std::min(nA, nB);
+        if (cardmode || op == OP_AND) { ub += std::min(nA, nB); bound += std::min(wA, wB); }
+        else if (op == OP_ANDNOT) { ub += nA; bound += wA; }
+        else { ub += nA + nB; bound += wA + wB; }
+    }
+    pair0[npairs] = NU;
+    if (ub >= 0xFFFFFFF0ull) { set_err("batch too large: %llu candidate containers", (unsigned long long)ub); throw (int)RHIP_ERR_ARG; }
+    P.NU = NU;
+    P.S = NU + 1;
+    P.ub_match = ub_match;
+    P.ub_cand = cardmode ? 0 : ub;
+    P.arena_bound = cardmode ? 0 : bound;
+    // which classes can occur at all (pool-level type census): a class that cannot is not launched
+    auto has = [](const rhip_pool_t* X, int t) { return X->census[t] != 0; };
+    const bool aB = has(A, 0), aA = has(A, 1), aR = has(A, 2), bB = has(B, 0), bA = has(B, 1), bR = has(B, 2);
+    P.may_bb = aB && bB;
+    P.may_runs = aR || bR;  // interval class and the general image class
+    if (cardmode || op == OP_AND) {
+        P.may_filt = (aA && (bA || bB)) || (bA && (aA || aB));
+        P.may_wave = false;
+        P.may_copy = false;
+    } else if (op == OP_ANDNOT) {
+        P.may_filt = aA && (bA || bB);
+        P.may_wave = aB && bA;
+        P.may_copy = true;
+    } else {
+        P.may_filt = false;
+        P.may_wave = (aA && (bA || bB)) || (aB && bA);
+        P.may_copy = true;
+    }
+    // ---- device scratch
+    const size_t S = P.S;
+    P.sc.layout(N_SEC * S, P.ub_cand);
+    c->plan_in.ensure(stage_bytes + 16);
+    c->cand.ensure(4 * (N_SEC * S + 8));
+    c->cand_start.ensure(8 * (N_SEC * S + 8));
+    c->match.ensure(4 * 256 * (NU + 1));
+    c->misc.ensure(8 * P.sc.n_words + 64);
+    P.words = c->misc.as<u64>();
+    c->q[CLS_BB].ensure(sizeof(BBItem) * (ub_match + 1));
+    c->q[CLS_GEN].ensure(sizeof(GenItem) * (ub_match + 1));
+    c->q[CLS_FILT].ensure(sizeof(FatItem) * (ub_match + 1));
+    c->q[CLS_WAVE].ensure(sizeof(FatItem) * (ub_match + 1));
+    c->q[CLS_RUNS].ensure(sizeof(GenItem) * (ub_match + 1));
+    c->q[CLS_RETRY].ensure(sizeof(GenItem) * (ub_match + 1));
+    c->q[CLS_COPY].ensure(sizeof(CopyItem) * (P.ub_cand + 1));
+    if (cardmode) c->pair_acc.ensure(8 * (npairs + 1));
+    char* dp = (char*)c->plan_in.p;
+    P.d_pair0 = (u64*)(dp + o_pair0);
+    P.d_lhs = (uint32_t*)(dp + o_lhs);
+    P.d_rhs = (uint32_t*)(dp + o_rhs);
+    P.d_upair = (uint32_t*)(dp + o_upair);
+    P.d_utile = (uint32_t*)(dp + o_utile);
+    HIPCHK(hipMemcpyAsync(dp, hs, stage_bytes, hipMemcpyHostToDevice, s));
+    PoolView VA = A->view(), VB = B->view();
+    UnitView UV{P.d_upair, P.d_utile, P.d_pair0, (uint32_t)NU, (uint32_t)npairs};
+    PlanZero Z{P.words, (uint32_t)P.sc.n_words, cardmode ? c->pair_acc.as<u64>() : nullptr};
+    const size_t zero_threads = std::max<size_t>(P.sc.n_words, cardmode ? npairs : 0);
+    unsigned gp = (unsigned)std::max<size_t>(1, (std::max<size_t>(NU * 64, std::min<size_t>(zero_threads, 1 << 16)) + 255) / 256);
+    hipLaunchKernelGGL(k_count, dim3(gp), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, op, cardmode,
+                       c->cand.as<uint32_t>(), c->match.as<uint32_t>(), Z);
+    const u64 n_scan = (u64)N_SEC * S;
+    hipLaunchKernelGGL(k_scan, dim3((unsigned)((n_scan + SCAN_TILE - 1) / SCAN_TILE)), dim3(256), 0, s,
+                       c->cand.as<uint32_t>(), c->cand_start.as<u64>(), n_scan, P.scan_lb(), P.ranges(), (u64)S);
+    EmitQueues Q{c->q[CLS_BB].as<BBItem>(), c->q[CLS_GEN].as<GenItem>(), c->q[CLS_COPY].as<CopyItem>(),
+                 c->q[CLS_FILT].as<FatItem>(), c->q[CLS_WAVE].as<FatItem>(), c->q[CLS_RUNS].as<GenItem>()};
+    if (NU)
+        hipLaunchKernelGGL(k_emit, dim3((unsigned)((NU * 64 + 255) / 256)), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV,
+                           op, cardmode, c->cand_start.as<u64>(), c->match.as<uint32_t>(), CO, Q);
+    return P;
+}
+
 // The class kernels of one batch are independent of each other (disjoint work queues, disjoint result slots;
 // pair_acc and the retry counter are only touched with atomics), except that the retry pass of k_genw consumes what
-// k_bb and k_runs re-queue.  When more than one class has work they are forked onto auxiliary streams after
-// planning and joined before compaction, so the latency-bound wave-per-pair kernels overlap each other and the
+// k_bb and k_runs re-queue.  When more than one class can have work they are forked onto auxiliary streams after
+// planning and joined before the tail, so the latency-bound wave-per-pair kernels overlap each other and the
 // bandwidth-bound copies:
 //     main : k_bb ----------------------> [wait k_runs] k_genw(retry) -> [join] ...
 //     aux0 : k_runs
 //     aux1 : k_filter      aux2 : k_wave      aux3 : k_genw(general), k_copy
-// A batch with a single class (the bitset-only C2 workload) stays on the main stream with no events at all.
-void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, const OutView& O,
-                 const PlanResult& R, int cardmode) {
+// Item counts live on the device (`ranges`); grids are sized from the host's upper bounds and a class the operand
+// pools cannot produce (type census) is not launched at all.  A bitset-only batch (C2) stays on the main stream.
+void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, const OutView& O, const Plan& P,
+                 int cardmode) {
     hipStream_t s = c->stream;
-    const u64* ranges = (const u64*)((char*)c->misc.p + MISC_RANGES_OFF);
-    uint32_t* retry_count = (uint32_t*)((char*)c->misc.p + MISC_RETRY_OFF);
-    c->q[CLS_RETRY].ensure(sizeof(GenItem) * (R.n_bb + R.n_runs + 1));
-    const bool has_wave = R.n_wave && !cardmode, has_copy = R.n_copy && !cardmode;
-    const int n_classes = (R.n_bb != 0) + (R.n_runs != 0) + (R.n_filt != 0) + (has_wave ? 1 : 0) + (R.n_gen != 0) +
-                          (has_copy ? 1 : 0);
+    const u64* ranges = P.ranges();
+    uint32_t* retry_count = P.retry_count();
+    const uint64_t nm = P.ub_match;
+    const bool has_bb = P.may_bb && nm, has_runs = P.may_runs && nm, has_filt = P.may_filt && nm;
+    const bool has_wave = P.may_wave && nm && !cardmode, has_copy = P.may_copy && P.ub_cand && !cardmode;
+    const int n_classes = (has_bb ? 1 : 0) + (has_runs ? 2 : 0) + (has_filt ? 1 : 0) + (has_wave ? 1 : 0) + (has_copy ? 1 : 0);
     const bool fork = c->overlap && n_classes > 1;
     bool used[rhip_ctx_s::N_AUX] = {false, false, false, false};
     auto on = [&](int a) -> hipStream_t {
@@ -861,50 +940,48 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
     };
     if (fork) HIPCHK(hipEventRecord(c->ev_fork, s));
     // largest, latency-bound kernels first so that they get the machine's first workgroup slots
-    if (R.n_filt) {
-        unsigned grid = persistent_grid(R.n_filt, 4, 256 * 4);
+    if (has_filt) {
+        unsigned grid = persistent_grid(nm, 4, 256 * 4);
         hipLaunchKernelGGL(k_filter, dim3(grid), dim3(256), 0, on(1), VA.arena, VB.arena, O, c->q[CLS_FILT].as<FatItem>(),
                            ranges + 2 * SEC_FILT, op, cardmode, c->pair_acc.as<u64>());
     }
     if (has_wave) {
-        unsigned grid = persistent_grid(R.n_wave, 4, 256 * 4);
+        unsigned grid = persistent_grid(nm, 4, 256 * 4);
         hipLaunchKernelGGL(k_wave, dim3(grid), dim3(256), 0, on(2), VA.arena, VB.arena, O, c->q[CLS_WAVE].as<FatItem>(),
                            ranges + 2 * SEC_WAVE, op);
     }
-    if (R.n_runs) {
-        unsigned grid = persistent_grid(R.n_runs, 4, 256 * 4);
+    if (has_runs) {
+        unsigned grid = persistent_grid(nm, 4, 256 * 4);
         hipStream_t sr = on(0);
         hipLaunchKernelGGL(k_runs, dim3(grid), dim3(256), 0, sr, VA.arena, VB.arena, O, c->q[CLS_RUNS].as<GenItem>(),
                            ranges + 2 * SEC_RUNS, op, cardmode, c->pair_acc.as<u64>(), c->q[CLS_RETRY].as<GenItem>(),
                            retry_count);
         if (fork) HIPCHK(hipEventRecord(c->ev_runs, sr));
-    }
-    if (R.n_gen) {
-        unsigned grid = persistent_grid(R.n_gen, 4, 256 * 2);  // 248 VGPRs: 2 workgroups resident per CU
-        hipLaunchKernelGGL(k_genw, dim3(grid), dim3(256), 0, on(3), VA.arena, VB.arena, O, c->q[CLS_GEN].as<GenItem>(),
+        unsigned g2 = persistent_grid(nm, 4, 256 * 2);  // 248 VGPRs: 2 workgroups resident per CU
+        hipLaunchKernelGGL(k_genw, dim3(g2), dim3(256), 0, on(3), VA.arena, VB.arena, O, c->q[CLS_GEN].as<GenItem>(),
                            ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, cardmode, c->pair_acc.as<u64>());
     }
     if (has_copy) {
-        unsigned grid = persistent_grid(R.n_copy, 4, 256 * 8);
-        hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, on(3), VA, VB, O, c->q[CLS_COPY].as<Item>(),
+        unsigned grid = persistent_grid(P.ub_cand, 4, 256 * 8);
+        hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, on(3), VA.arena, VB.arena, O, c->q[CLS_COPY].as<CopyItem>(),
                            ranges + 2 * SEC_COPY);
     }
-    if (R.n_bb) {
-        unsigned grid = persistent_grid(R.n_bb, 4, 256 * 32);
+    if (has_bb) {
+        unsigned grid = persistent_grid(nm, 4, 256 * 32);
         if (c->timing) HIPCHK(hipEventRecord(c->ev[2], s));
         switch (op) {
-            case OP_AND: launch_bb<OP_AND>(c, grid, VA, VB, O, cardmode); break;
-            case OP_OR: launch_bb<OP_OR>(c, grid, VA, VB, O, cardmode); break;
-            case OP_XOR: launch_bb<OP_XOR>(c, grid, VA, VB, O, cardmode); break;
-            default: launch_bb<OP_ANDNOT>(c, grid, VA, VB, O, cardmode); break;
+            case OP_AND: launch_bb<OP_AND>(c, grid, VA, VB, O, P, cardmode); break;
+            case OP_OR: launch_bb<OP_OR>(c, grid, VA, VB, O, P, cardmode); break;
+            case OP_XOR: launch_bb<OP_XOR>(c, grid, VA, VB, O, P, cardmode); break;
+            default: launch_bb<OP_ANDNOT>(c, grid, VA, VB, O, P, cardmode); break;
         }
         if (c->timing) HIPCHK(hipEventRecord(c->ev[3], s));
     }
-    if (!cardmode && ((R.n_bb && op != OP_OR) || R.n_runs)) {
+    if (!cardmode && ((has_bb && op != OP_OR) || has_runs)) {
         // results that need the LDS image path after all: bitset x bitset results that must become
         // arrays (card <= 4096), interval results that must become bitsets
-        if (fork && R.n_runs) HIPCHK(hipStreamWaitEvent(s, c->ev_runs, 0));
-        unsigned g2 = persistent_grid(R.n_bb + R.n_runs, 4, 256 * 2);  // 248 VGPRs: 2 workgroups resident per CU
+        if (fork && has_runs) HIPCHK(hipStreamWaitEvent(s, c->ev_runs, 0));
+        unsigned g2 = persistent_grid(nm, 4, 256 * 2);
         hipLaunchKernelGGL(k_genw, dim3(g2), dim3(256), 0, s, VA.arena, VB.arena, O, c->q[CLS_RETRY].as<GenItem>(),
                            (const u64*)nullptr, retry_count, op, 0, c->pair_acc.as<u64>());
     }
@@ -916,24 +993,31 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
             }
 }
 
-void finish_stats(rhip_ctx_t* c, const PlanResult* R) {
+// many-way / flip paths: their statistics live at a fixed offset of ctx->misc (cleared by the caller)
+constexpr size_t MISC_STATS_OFF = 192;
+void finish_stats(rhip_ctx_t* c, const Stats* dstats, Stats* out, bool had_bb);
+void finish_stats_misc(rhip_ctx_t* c) { finish_stats(c, (const Stats*)((char*)c->misc.p + MISC_STATS_OFF), nullptr, false); }
+
+// the ONE host synchronisation of a call: statistics (and whatever the caller queued before) come back
+void finish_stats(rhip_ctx_t* c, const Stats* dstats, Stats* out, bool had_bb) {
     hipStream_t s = c->stream;
-    Stats st;
-    HIPCHK(hipMemcpyAsync(c->h_pinned, (char*)c->misc.p + MISC_STATS_OFF, sizeof(Stats), hipMemcpyDeviceToHost, s));
+    if (dstats) HIPCHK(hipMemcpyAsync(c->h_pinned, dstats, sizeof(Stats), hipMemcpyDeviceToHost, s));
     if (c->timing) HIPCHK(hipEventRecord(c->ev[1], s));
     HIPCHK(hipStreamSynchronize(s));
-    memcpy(&st, c->h_pinned, sizeof(Stats));
-    c->stats.matched_pairs = R ? R->n_bb + R->n_gen + R->n_filt + R->n_wave + R->n_runs : 0;
-    c->stats.passthrough = R ? R->n_copy : 0;
+    Stats st{};
+    if (dstats) memcpy(&st, c->h_pinned, sizeof(Stats));
+    if (out) *out = st;
+    c->stats.matched_pairs = st.matched_pairs;
+    c->stats.passthrough = st.passthrough;
     c->stats.bytes_in = st.bytes_in;
     c->stats.bytes_out = st.bytes_out;
-    c->stats.n_bitset_pairs = R ? R->n_bb : 0;
+    c->stats.n_bitset_pairs = st.n_bb;
     c->stats.result_containers = st.result_containers;
     c->stats.ms_bitset_kernel = 0.f;
     c->stats.ms_total = 0.f;
     if (c->timing) {
         (void)hipEventElapsedTime(&c->stats.ms_total, c->ev[0], c->ev[1]);
-        if (R && R->n_bb) (void)hipEventElapsedTime(&c->stats.ms_bitset_kernel, c->ev[2], c->ev[3]);
+        if (had_bb && st.n_bb) (void)hipEventElapsedTime(&c->stats.ms_bitset_kernel, c->ev[2], c->ev[3]);
     }
 }
 }  // namespace
@@ -954,8 +1038,20 @@ extern "C" rhip_pool_t* rhip_pairwise(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A
         }
         hipStream_t s = c->stream;
         if (c->timing) HIPCHK(hipEventRecord(c->ev[0], s));
-        OutView O;
-        PlanResult P = plan(c, op, A, B, npairs, lhs, rhs, 0, O);
+        // upper bounds first (host only), so that every buffer exists before the first launch
+        fetch_bounds(A);
+        fetch_bounds(B);
+        uint64_t ub = 0;
+        for (size_t i = 0; i < npairs; ++i) {
+            const uint64_t nA = A->h_bm_start[lhs[i] + 1] - A->h_bm_start[lhs[i]];
+            const uint64_t nB = B->h_bm_start[rhs[i] + 1] - B->h_bm_start[rhs[i]];
+            ub += op == OP_AND ? std::min(nA, nB) : op == OP_ANDNOT ? nA : nA + nB;
+        }
+        if (ub >= 0xFFFFFFF0ull) { set_err("batch too large: %llu candidate containers", (unsigned long long)ub); throw (int)RHIP_ERR_ARG; }
+        c->o_key.ensure(8 * (ub + 1)); c->o_meta.ensure(8 * (ub + 1)); c->o_off.ensure(8 * (ub + 2));
+        c->o_pair.ensure(4 * (ub + 2));
+        CandOut CO{c->o_key.as<u64>(), c->o_off.as<u64>(), c->o_pair.as<uint32_t>()};
+        Plan P = plan(c, op, A, B, npairs, lhs, rhs, 0, CO);
         R = reuse ? reuse : new rhip_pool_s();
         reuse = nullptr;
         R->ctx = c;
@@ -963,31 +1059,25 @@ extern "C" rhip_pool_t* rhip_pairwise(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A
         R->is64 = A->is64;
         R->host_dir = false;
         R->host_bm = false;
+        R->host_w = false;
         R->h_cards.clear();
-        ensure_dir(R, (uint32_t)npairs, P.total_cand);
-        R->arena.ensure(P.total_bytes + 64);
-        R->arena_used = P.total_bytes + 64;
+        ensure_dir(R, (uint32_t)npairs, P.ub_cand);
+        R->arena.ensure(P.arena_bound + 64);
+        OutView O{};
+        O.key = CO.key; O.meta = c->o_meta.as<u64>(); O.off = CO.off; O.slot = nullptr;
         O.arena = R->arena.as<uint8_t>();
         PoolView VA = A->view(), VB = B->view();
         run_kernels(c, op, VA, VB, O, P, 0);
-        // drop empty results, build the result directory
-        uint64_t n = P.total_cand;
-        c->flag.ensure(4 * (n + 2));
-        c->newidx.ensure(8 * (n + 2));
-        if (n) hipLaunchKernelGGL(k_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, O.meta, (u64)n,
-                                  c->flag.as<uint32_t>());
-        exscan(c, c->flag.as<uint32_t>(), c->newidx.as<u64>(), n);
+        // drop empty results, build the result directory, totals
         DirOut D{R->bm_start.as<u64>(), R->key.as<u64>(), R->type.as<uint8_t>(), R->card.as<uint32_t>(),
                  R->nruns.as<uint32_t>(), R->off.as<u64>()};
-        Stats* st = (Stats*)((char*)c->misc.p + MISC_STATS_OFF);
-        if (n) hipLaunchKernelGGL(k_compact, dim3((unsigned)std::min<uint64_t>((n + 4095) / 4096, 1024)), dim3(1024), 0, s,
-                                  O, (u64)n, c->newidx.as<u64>(), D, st);
-        hipLaunchKernelGGL(k_bm_start, dim3((unsigned)((npairs + 1 + 255) / 256)), dim3(256), 0, s,
-                           c->cand_start.as<u64>(), c->u_pair0.as<u64>(), (uint32_t)npairs, c->newidx.as<u64>(),
-                           R->bm_start.as<u64>());
-        HIPCHK(hipMemcpyAsync((char*)c->h_pinned + 512, c->newidx.as<u64>() + n, 8, hipMemcpyDeviceToHost, s));
-        finish_stats(c, &P);
-        memcpy(&R->n_cont, (char*)c->h_pinned + 512, 8);
+        hipLaunchKernelGGL(k_tail, dim3((unsigned)std::max<uint64_t>(1, (P.ub_cand + TAIL_TILE - 1) / TAIL_TILE)), dim3(256), 0,
+                           s, P.ranges(), CO, O.meta, D, (uint32_t)npairs, P.tail_lb(), P.stats());
+        Stats st;
+        finish_stats(c, P.stats(), &st, P.may_bb);
+        R->n_cont = st.result_containers;
+        R->arena_used = st.slot_bytes + 64;
+        for (int t = 0; t < 3; ++t) R->census[t] = st.n_type[t] ? 1 : 0;
         return R;
     } catch (int e) {
         last_status() = e;
@@ -1015,14 +1105,14 @@ extern "C" int rhip_pairwise_cardinality(rhip_ctx_t* c, rhip_op op_, rhip_pool_t
             if ((e = rhip_pool_cardinalities(B, cB.data())) != 0) throw e;
         }
         if (c->timing) HIPCHK(hipEventRecord(c->ev[0], s));
-        c->pair_acc.ensure(8 * (npairs + 1));
-        HIPCHK(hipMemsetAsync(c->pair_acc.p, 0, 8 * (npairs + 1), s));
-        OutView O;
-        PlanResult P = plan(c, OP_AND, A, B, npairs, lhs, rhs, 1, O);
+        CandOut CO{nullptr, nullptr, nullptr};
+        Plan P = plan(c, OP_AND, A, B, npairs, lhs, rhs, 1, CO);
+        OutView O{};
         PoolView VA = A->view(), VB = B->view();
         run_kernels(c, OP_AND, VA, VB, O, P, 1);
-        HIPCHK(hipMemcpyAsync(out, c->pair_acc.p, 8 * npairs, hipMemcpyDeviceToHost, s));
-        finish_stats(c, &P);
+        hipLaunchKernelGGL(k_card_stats, dim3(1), dim3(64), 0, s, P.ranges(), P.stats());
+        if (npairs) HIPCHK(hipMemcpyAsync(out, c->pair_acc.p, 8 * npairs, hipMemcpyDeviceToHost, s));
+        finish_stats(c, P.stats(), nullptr, P.may_bb);
         for (size_t i = 0; i < npairs; ++i) {
             uint64_t in = out[i];
             switch (op) {

@@ -1,39 +1,122 @@
-// rhip_plan.h -- planning (key merge -> typed work items) and result-directory compaction kernels
+// rhip_plan.h -- planning (key merge -> typed work items), the single-pass prefix scan that places them, and the
+// fused result-directory compaction of the batched pairwise pipeline
+//
+// One rhip_pairwise call is FIVE dependent launches and one host synchronisation at the very end:
+//   k_count   per unit (a tile of <= 256 directory entries of one side of one pair): matched / per-class counts,
+//             result-slot bytes, algorithmic input bytes; remembers every key's match position; zeroes the scan /
+//             statistics scratch of the call
+//   k_scan    ONE decoupled look-back exclusive scan over the 10 concatenated count sections
+//   k_emit    candidates in merged key order, slot offsets, work items at deterministic queue positions
+//   (class kernels: k_bb / k_filter / k_wave / k_runs / k_genw / k_copy, concurrently on auxiliary streams)
+//   k_tail    drop empty results + build the result directory + per-bitmap starts + statistics, one look-back pass
+// Nothing is read back in between: every buffer is sized from host-side upper bounds (container counts and
+// per-bitmap payload bounds mirrored on the host), every kernel takes its item count from device memory.
 #pragma once
 #include "rhip_common.h"
 
-// ------------------------------------------------------------------ planning
-// Four lower_bound searches per lane issued together (independent dependent-load chains).
-__device__ __forceinline__ void lower_bound4(const u64* __restrict__ key, u64 lo0, u64 hi0, const u64 k[4],
-                                             const bool act[4], u64 out[4]) {
-    u64 lo[4], hi[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { lo[t] = lo0; hi[t] = act[t] ? hi0 : lo0; }
-    bool more = true;
-    while (more) {
-        more = false;
-        u64 mid[4], kv[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { mid[t] = (lo[t] + hi[t]) >> 1; kv[t] = (lo[t] < hi[t]) ? key[mid[t]] : 0; }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (lo[t] < hi[t]) {
-                if (kv[t] < k[t]) lo[t] = mid[t] + 1;
-                else hi[t] = mid[t];
-                more |= lo[t] < hi[t];
-            }
-        }
+// ------------------------------------------------------------------ decoupled look-back (single-pass scan)
+// status word of a tile: bits 63..62 = state (0 not ready, 1 tile aggregate, 2 inclusive prefix), bits 61..0 = value
+#define LB_AGG (1ull << 62)
+#define LB_PREFIX (2ull << 62)
+#define LB_VAL(x) ((x) & ((1ull << 62) - 1))
+struct LbState {
+    u64* status;        // [n_tiles], zero before the kernel starts
+    uint32_t* ticket;   // dynamic tile numbering: tiles are numbered in the order their blocks START, so a tile only
+                        // ever waits for tiles whose blocks are already running (no dependence on dispatch order)
+};
+__device__ __forceinline__ u64 lb_load(const u64* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+__device__ __forceinline__ void lb_store(u64* p, u64 v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+// Called by ONE thread of the block with the block's aggregate; returns the exclusive prefix of the tile.
+__device__ __forceinline__ u64 lb_exclusive_prefix(u64* status, uint32_t tile, u64 aggregate) {
+    if (tile == 0) {
+        lb_store(&status[0], LB_PREFIX | aggregate);
+        return 0;
     }
+    lb_store(&status[tile], LB_AGG | aggregate);
+    u64 run = 0;
+    for (uint32_t t = tile; t-- > 0;) {
+        u64 s;
+        do { s = lb_load(&status[t]); } while ((s >> 62) == 0);
+        run += LB_VAL(s);
+        if ((s >> 62) == 2) break;
+    }
+    lb_store(&status[tile], LB_PREFIX | (run + aggregate));
+    return run;
+}
+__device__ __forceinline__ u64 wave_incl_scan64(u64 v) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) out[t] = lo[t];
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t lo = __shfl_up((uint32_t)v, o), hi = __shfl_up((uint32_t)(v >> 32), o);
+        if (lane_id() >= (uint32_t)o) v += (u64)lo | ((u64)hi << 32);
+    }
+    return v;
+}
+// exclusive prefix of v over the 256 threads of the block (u64), *total = block sum; sm: 4 u64 of shared memory
+__device__ __forceinline__ u64 blk_exscan64(u64 v, u64* sm, u64* total) {
+    const u64 inc = wave_incl_scan64(v);
+    __syncthreads();
+    if (lane_id() == 63) sm[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    u64 off = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; ++w) {
+        const u64 s = sm[w];
+        if (w < (threadIdx.x >> 6)) off += s;
+        tot += s;
+    }
+    *total = tot;
+    return off + inc - v;
 }
 
+constexpr uint32_t SCAN_TILE = 2048;  // elements per block: 256 threads x 8
+// out[i] = sum_{j<i} in[j], i in [0, n).  `ranges` (may be null): for every section k of `sec_len` elements,
+// ranges[2k] = out[k * sec_len] and ranges[2k+1] = out[k * sec_len + sec_len - 1] (begin / end of the section when its
+// last element is a zero sentinel).
+__global__ __launch_bounds__(256) void k_scan(const uint32_t* __restrict__ in, u64* __restrict__ out, u64 n, LbState lb,
+                                              u64* __restrict__ ranges, u64 sec_len) {
+    __shared__ u64 sm[4];
+    __shared__ uint32_t s_tile;
+    __shared__ u64 s_prefix;
+    if (threadIdx.x == 0) s_tile = atomicAdd(lb.ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const u64 base = (u64)tile * SCAN_TILE + 8ull * threadIdx.x;
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = base + k < n ? in[base + k] : 0u;
+    u64 mine = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mine += v[k];
+    u64 total;
+    u64 ex = blk_exscan64(mine, sm, &total);
+    if (threadIdx.x == 0) s_prefix = lb_exclusive_prefix(lb.status, tile, total);
+    __syncthreads();
+    ex += s_prefix;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const u64 i = base + k;
+        if (i < n) {
+            out[i] = ex;
+            if (ranges) {
+                const u64 sec = i / sec_len, r = i - sec * sec_len;
+                if (r == 0) ranges[2 * sec] = ex;
+                if (r == sec_len - 1) ranges[2 * sec + 1] = ex;
+            }
+        }
+        ex += v[k];
+    }
+}
+
+// ------------------------------------------------------------------ planning
 // Planning works on UNITS: one unit = one tile of up to 256 consecutive directory entries of the
 // left bitmap of a pair ("A-tile"), or -- for OR/XOR, whose result also carries the right bitmap's
 // unmatched containers -- of the right bitmap ("B-tile").  One wave per unit, so a batch of 250 pairs
 // of 4096-container bitmaps plans on 4000 waves instead of 250.
-// Count arrays (and their exclusive scan) have N_SEC sections of n_units+1 entries:
-enum { SEC_CAND = 0, SEC_M = 1, SEC_BB = 2, SEC_GEN = 3, SEC_COPY = 4, SEC_FILT = 5, SEC_WAVE = 6, SEC_RUNS = 7, N_SEC = 8 };
+// Count arrays (and their exclusive scan) have N_SEC sections of n_units+1 entries (the last one a zero sentinel):
+enum { SEC_CAND = 0, SEC_M = 1, SEC_BB = 2, SEC_GEN = 3, SEC_COPY = 4, SEC_FILT = 5, SEC_WAVE = 6, SEC_RUNS = 7,
+       SEC_SLOT = 8,   // result-slot size of the unit's candidates, in 16-byte units
+       SEC_BYTES = 9,  // algorithmic input bytes of the unit (payload of matched operands and pass-through containers)
+       N_SEC = 10 };
 // work class of a matched container pair
 // ia / ib = number of intervals of the operand when it is read as an interval list (runs: n_runs, arrays: card)
 __device__ __forceinline__ int classify(int op, int cardmode, uint8_t ta, uint8_t tb, uint32_t ia, uint32_t ib) {
@@ -60,13 +143,55 @@ struct UnitView {
     const uint32_t* tile;   // [U] tile index inside its side; UNIT_B flag marks a B-tile
     const u64* pair_unit0;  // [npairs+1] first unit of each pair
     uint32_t n_units;
+    uint32_t n_pairs;
+};
+struct PlanZero {   // scratch the first kernel of a call clears for the later ones
+    u64* words;     // scan states, tickets, retry counter, statistics: one contiguous region
+    uint32_t n_words;
+    u64* pair_acc;  // cardinality mode: per-pair accumulators (n_pairs entries), else null
 };
 
-// One wave per unit: contributions of the tile to every section.
+// first index in [lo,hi) with key[idx] >= k, four searches per lane issued together (independent load chains)
+__device__ __forceinline__ void lower_bound4(const u64* __restrict__ key, u64 lo0, u64 hi0, const u64 k[4],
+                                             const bool act[4], u64 out[4]) {
+    u64 lo[4], hi[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { lo[t] = lo0; hi[t] = act[t] ? hi0 : lo0; }
+    bool more = true;
+    while (more) {
+        more = false;
+        u64 mid[4], kv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { mid[t] = (lo[t] + hi[t]) >> 1; kv[t] = (lo[t] < hi[t]) ? key[mid[t]] : 0; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (lo[t] < hi[t]) {
+                if (kv[t] < k[t]) lo[t] = mid[t] + 1;
+                else hi[t] = mid[t];
+                more |= lo[t] < hi[t];
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) out[t] = lo[t];
+}
+
+// match[] entry of a directory element: position of its key in the other side's range (lower bound, relative to the
+// range start) and whether the key is present there
+#define MATCH_FOUND 0x80000000u
+
+// One wave per unit: contributions of the tile to every section; the match positions are kept for k_emit.
 __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uint32_t* __restrict__ lhs,
                                                const uint32_t* __restrict__ rhs, UnitView U, int op, int cardmode,
-                                               uint32_t* __restrict__ counts) {
-    const uint32_t u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+                                               uint32_t* __restrict__ counts, uint32_t* __restrict__ match, PlanZero Z) {
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 nthreads = (u64)gridDim.x * blockDim.x;
+    const size_t S = (size_t)U.n_units + 1;
+    for (u64 i = gid; i < Z.n_words; i += nthreads) Z.words[i] = 0;
+    if (Z.pair_acc)
+        for (u64 i = gid; i < U.n_pairs; i += nthreads) Z.pair_acc[i] = 0;
+    if (gid < N_SEC) counts[gid * S + U.n_units] = 0;  // section sentinels
+    const uint32_t u = (uint32_t)(gid >> 6);
     if (u >= U.n_units) return;
     const uint32_t lane = lane_id();
     const uint32_t p = U.pair[u];
@@ -88,16 +213,29 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         k[t] = act[t] ? SV.key[s0 + 64 * t + lane] : 0;
     }
     lower_bound4(LV.key, l0, l1, k, act, j);
-    uint32_t matched = 0, nbb = 0, nfilt = 0, nwave = 0, nruns_cls = 0;
+    uint32_t matched = 0, nbb = 0, nfilt = 0, nwave = 0, nruns_cls = 0, slot16 = 0, bytes = 0;
+    const bool keep_unmatched = bside || !(cardmode || op == OP_AND);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const bool found = act[t] && j[t] < l1 && LV.key[j[t]] == k[t];
+        if (act[t]) match[(size_t)u * 256 + 64 * t + lane] = (uint32_t)(j[t] - l0) | (found ? MATCH_FOUND : 0u);
         int cls = -1;
-        if (found && !bside) {
-            const u64 ai = s0 + 64 * t + lane;
-            const uint8_t ta = SV.type[ai], tb = LV.type[j[t]];
-            cls = classify(op, cardmode, ta, tb, ta == T_RUN ? SV.nruns[ai] : SV.card[ai],
-                           tb == T_RUN ? LV.nruns[j[t]] : LV.card[j[t]]);
+        if (act[t] && (bside ? !found : (found || keep_unmatched))) {
+            const u64 si = s0 + 64 * t + lane;
+            const uint8_t ts = SV.type[si];
+            const uint32_t cs = SV.card[si], ns = SV.nruns[si];
+            const uint32_t ps = payload_bytes(ts, cs, ns);
+            bytes += ps;
+            if (found) {  // A-tile, matched
+                const uint8_t tl = LV.type[j[t]];
+                const uint32_t cl = LV.card[j[t]], nl = LV.nruns[j[t]];
+                bytes += payload_bytes(tl, cl, nl);
+                cls = classify(op, cardmode, ts, tl, ts == T_RUN ? ns : cs, tl == T_RUN ? nl : cl);
+                if (!cardmode) slot16 += matched_slot(op, cs, cl) >> 4;
+            } else if (!cardmode) {
+                const uint32_t sl = align16(ps) >> 4;
+                slot16 += sl ? sl : 1u;
+            }
         }
         matched += (uint32_t)__popcll(__ballot(found));
         nbb += (uint32_t)__popcll(__ballot(cls == CLS_BB));
@@ -105,9 +243,10 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         nwave += (uint32_t)__popcll(__ballot(cls == CLS_WAVE));
         nruns_cls += (uint32_t)__popcll(__ballot(cls == CLS_RUNS));
     }
+    slot16 = wave_sum(slot16);
+    bytes = wave_sum(bytes);
     if (lane == 0) {
         const uint32_t n = (uint32_t)(s1 - s0);
-        const size_t S = (size_t)U.n_units + 1;
         uint32_t ncopy;
         if (bside) ncopy = n - matched;                              // OR/XOR only
         else ncopy = (cardmode || op == OP_AND) ? 0u : n - matched;  // A-only containers pass through
@@ -119,6 +258,8 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         counts[SEC_FILT * S + u] = nfilt;
         counts[SEC_WAVE * S + u] = nwave;
         counts[SEC_COPY * S + u] = ncopy;
+        counts[SEC_SLOT * S + u] = slot16;
+        counts[SEC_BYTES * S + u] = bytes;
     }
 }
 
@@ -128,18 +269,25 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
 //   matched / A-only element i (key k):  i + |{B keys < k}| - |{matched keys < k}|
 //   B-only element j (key k)          :  j + |{A keys < k}| - |{matched keys < k}|
 // with |{matched keys < k}| = (matched count of the pair's earlier tiles, from the scan) + a ballot rank.
+// Result slots are laid out in unit order (A-tiles of a pair, then its B-tiles) and, inside a unit, in lane order:
+// offset = 16 x (scanned slot units before this unit + wave prefix inside it).  A bitmap's slots are contiguous.
 struct EmitQueues {
-    BBItem* bb;   // section SEC_BB
-    GenItem* gen; // section SEC_GEN
-    Item* copy;   // section SEC_COPY
+    BBItem* bb;     // section SEC_BB
+    GenItem* gen;   // section SEC_GEN
+    CopyItem* copy; // section SEC_COPY
     FatItem* filt;  // section SEC_FILT
     FatItem* wave;  // section SEC_WAVE
     GenItem* runs;  // section SEC_RUNS
 };
+struct CandOut {     // candidate (pre-compaction) result directory
+    u64* key;        // [cand]
+    u64* off;        // [cand] byte offset of the slot in the result arena
+    uint32_t* pair;  // [cand] result bitmap (pair index) of the candidate
+};
 __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint32_t* __restrict__ lhs,
                                               const uint32_t* __restrict__ rhs, UnitView U, int op, int cardmode,
-                                              const u64* __restrict__ starts, OutView O, EmitQueues Q,
-                                              u64* __restrict__ unit_bytes) {
+                                              const u64* __restrict__ starts, const uint32_t* __restrict__ match,
+                                              CandOut O, EmitQueues Q) {
     const uint32_t u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (u >= U.n_units) return;
     const uint32_t lane = lane_id();
@@ -157,49 +305,52 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
     u64 qfilt = starts[SEC_FILT * S + u] - starts[SEC_FILT * S];
     u64 qwave = starts[SEC_WAVE * S + u] - starts[SEC_WAVE * S];
     u64 qruns = starts[SEC_RUNS * S + u] - starts[SEC_RUNS * S];
-    u64 bytes_in = 0;
-    u64 k[4], j[4];
-    bool act[4];
+    u64 slot_run = 16ull * (starts[SEC_SLOT * S + u] - starts[SEC_SLOT * S]);  // arena offset of the unit's first slot
     if (!bside) {
         const u64 s0 = a0 + tile * 256;
         uint32_t mbefore = (uint32_t)(starts[SEC_M * S + u] - starts[SEC_M * S + u0]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            act[t] = s0 + 64 * t + lane < a1 && 64 * t + lane < 256;
-            k[t] = act[t] ? A.key[s0 + 64 * t + lane] : 0;
-        }
-        lower_bound4(B.key, b0, b1, k, act, j);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
             const u64 ai = s0 + 64 * t + lane;
-            const bool found = act[t] && j[t] < b1 && B.key[j[t]] == k[t];
+            const bool act = ai < a1;
+            const uint32_t mt = act ? match[(size_t)u * 256 + 64 * t + lane] : 0u;
+            const bool found = (mt & MATCH_FOUND) != 0;
+            const uint32_t lbcount = mt & ~MATCH_FOUND;
+            const u64 bj = b0 + lbcount;
             const u64 fm = __ballot(found);
             const uint32_t mb = mbefore + mbcnt(fm);
             mbefore += (uint32_t)__popcll(fm);
-            const bool emit = act[t] && (found || (!cardmode && op != OP_AND));
+            const bool emit = act && (found || (!cardmode && op != OP_AND));
             uint8_t ta = 0, tb = 0;
-            uint32_t ca = 0, cb = 0, pa = 0, pos = 0, nra = 0, nrb = 0;
+            uint32_t ca = 0, cb = 0, pa = 0, pos = 0, nra = 0, nrb = 0, sl = 0;
+            u64 key = 0;
             if (emit) {
-                const uint32_t ilocal = (uint32_t)(ai - a0), lbcount = (uint32_t)(j[t] - b0);
+                const uint32_t ilocal = (uint32_t)(ai - a0);
                 if (op == OP_AND || cardmode) pos = mb;
                 else if (op == OP_ANDNOT) pos = ilocal;
                 else pos = ilocal + lbcount - mb;
+                key = A.key[ai];
                 ta = A.type[ai];
                 ca = A.card[ai];
                 nra = A.nruns[ai];
                 pa = payload_bytes(ta, ca, nra);
-                bytes_in += pa;
                 if (found) {
-                    tb = B.type[j[t]];
-                    cb = B.card[j[t]];
-                    nrb = B.nruns[j[t]];
-                    bytes_in += payload_bytes(tb, cb, nrb);
+                    tb = B.type[bj];
+                    cb = B.card[bj];
+                    nrb = B.nruns[bj];
                 }
                 if (!cardmode) {
-                    O.key[base + pos] = k[t];
-                    uint32_t sl = found ? matched_slot(op, ca, cb) : align16(pa);
-                    O.slot[base + pos] = sl < 16u ? 16u : sl;
+                    sl = found ? matched_slot(op, ca, cb) : align16(pa);
+                    sl = sl < 16u ? 16u : sl;
                 }
+            }
+            const uint32_t inc = wave_incl_scan(sl);
+            const u64 offo = slot_run + inc - sl;
+            slot_run += __shfl(inc, 63);
+            if (emit && !cardmode) {
+                O.key[base + pos] = key;
+                O.off[base + pos] = offo;
+                O.pair[base + pos] = p;
             }
             const uint32_t outidx = cardmode ? p : (uint32_t)(base + pos);
             const int cls = (emit && found) ? classify(op, cardmode, ta, tb, ta == T_RUN ? nra : ca, tb == T_RUN ? nrb : cb) : -1;
@@ -213,26 +364,30 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
             const u64 mwv = __ballot(iswave), mrn = __ballot(isruns);
             if (isbb) {
                 BBItem it;
-                it.offa = A.off[ai]; it.offb = B.off[j[t]];
-                it.a = (uint32_t)ai; it.b = (uint32_t)j[t]; it.out = outidx; it.pad = 0;
+                it.offa = A.off[ai]; it.offb = B.off[bj]; it.offo = offo; it.out = outidx; it.pad = 0;
                 Q.bb[qbb + mbcnt(mbb)] = it;
             }
             if (isgen || isruns) {
                 GenItem it;
-                it.offa = A.off[ai]; it.offb = B.off[j[t]];
+                it.offa = A.off[ai]; it.offb = B.off[bj];
                 it.out = outidx; it.ca = ca; it.cb = cb; it.types = (uint32_t)ta | ((uint32_t)tb << 8);
-                it.nra = nra; it.nrb = nrb; it.pad0 = 0; it.pad1 = 0;
+                it.nra = nra; it.nrb = nrb; it.offo = offo;
                 if (isgen) Q.gen[qgen + mbcnt(mgen)] = it;
                 else Q.runs[qruns + mbcnt(mrn)] = it;
             }
             if (isfilt || iswave) {
                 FatItem it;
-                it.offa = A.off[ai]; it.offb = B.off[j[t]];
+                it.offa = A.off[ai]; it.offb = B.off[bj]; it.offo = offo;
                 it.out = outidx; it.ca = ca; it.cb = cb; it.types = (uint32_t)ta | ((uint32_t)tb << 8);
                 if (isfilt) Q.filt[qfilt + mbcnt(mfl)] = it;
                 else Q.wave[qwave + mbcnt(mwv)] = it;
             }
-            if (iscopy) Q.copy[qcopy + mbcnt(mcp)] = Item{(uint32_t)ai, NONE32, outidx};
+            if (iscopy) {
+                CopyItem it;
+                it.src = A.off[ai]; it.offo = offo; it.meta = pack_meta(ta, ca, nra);
+                it.out = outidx; it.n16 = (pa + 15u) >> 4;
+                Q.copy[qcopy + mbcnt(mcp)] = it;
+            }
             qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv); qruns += __popcll(mrn);
         }
     } else {
@@ -241,34 +396,147 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
         uint32_t mbefore = (uint32_t)(starts[SEC_M * S + u] - starts[SEC_M * S + u0 + nAt]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            act[t] = s0 + 64 * t + lane < b1;
-            k[t] = act[t] ? B.key[s0 + 64 * t + lane] : 0;
-        }
-        lower_bound4(A.key, a0, a1, k, act, j);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
             const u64 bi = s0 + 64 * t + lane;
-            const bool found = act[t] && j[t] < a1 && A.key[j[t]] == k[t];
+            const bool act = bi < b1;
+            const uint32_t mt = act ? match[(size_t)u * 256 + 64 * t + lane] : 0u;
+            const bool found = (mt & MATCH_FOUND) != 0;
             const u64 fm = __ballot(found);
             const uint32_t mb = mbefore + mbcnt(fm);
             mbefore += (uint32_t)__popcll(fm);
-            const bool emit = act[t] && !found;
+            const bool emit = act && !found;
             const u64 mcp = __ballot(emit);
+            uint32_t sl = 0, pb = 0, cb = 0, nrb = 0;
+            uint8_t tb = 0;
             if (emit) {
-                const uint32_t pos = (uint32_t)(bi - b0) + (uint32_t)(j[t] - a0) - mb;
-                const uint32_t pb = payload_bytes(B.type[bi], B.card[bi], B.nruns[bi]);
-                O.key[base + pos] = k[t];
-                O.slot[base + pos] = align16(pb) < 16u ? 16u : align16(pb);
-                bytes_in += pb;
-                Q.copy[qcopy + mbcnt(mcp)] = Item{NONE32, (uint32_t)bi, (uint32_t)(base + pos)};
+                tb = B.type[bi]; cb = B.card[bi]; nrb = B.nruns[bi];
+                pb = payload_bytes(tb, cb, nrb);
+                sl = align16(pb) < 16u ? 16u : align16(pb);
+            }
+            const uint32_t inc = wave_incl_scan(sl);
+            const u64 offo = slot_run + inc - sl;
+            slot_run += __shfl(inc, 63);
+            if (emit) {
+                const uint32_t pos = (uint32_t)(bi - b0) + (mt & ~MATCH_FOUND) - mb;
+                O.key[base + pos] = B.key[bi];
+                O.off[base + pos] = offo;
+                O.pair[base + pos] = p;
+                CopyItem it;
+                it.src = B.off[bi] | COPY_FROM_B; it.offo = offo; it.meta = pack_meta(tb, cb, nrb);
+                it.out = (uint32_t)(base + pos); it.n16 = (pb + 15u) >> 4;
+                Q.copy[qcopy + mbcnt(mcp)] = it;
             }
             qcopy += __popcll(mcp);
         }
     }
-    bytes_in = wave_sum64(bytes_in);
-    if (lane == 0) unit_bytes[u] = bytes_in;  // summed by k_sum_u64 (no contended atomics)
 }
 
+// ------------------------------------------------------------------ fused tail: compaction + directory + statistics
+struct DirOut {
+    u64* bm_start;
+    u64* key;
+    uint8_t* type;
+    uint32_t* card;
+    uint32_t* nruns;
+    u64* off;
+};
+// One look-back pass over the candidates: keep = non-empty result (class kernels wrote meta), prefix -> position in
+// the result directory.  A thread that sees the first candidate of a result bitmap (or a gap of bitmaps with no
+// candidates) writes the bitmap starts; the block holding the last candidate finishes them and the totals.
+// n_cand is read from `ranges` (device), the launch is sized by the host's upper bound.
+constexpr uint32_t TAIL_TILE = 1024;  // candidates per block: 256 threads x 4
+__global__ __launch_bounds__(256) void k_tail(const u64* __restrict__ ranges, CandOut C, const u64* __restrict__ meta,
+                                              DirOut R, uint32_t n_pairs, LbState lb, Stats* __restrict__ stats) {
+    __shared__ u64 sm[4];
+    __shared__ uint32_t s_tile;
+    __shared__ u64 s_prefix;
+    __shared__ u64 s_bytes[4];
+    __shared__ uint32_t s_types[4][3];
+    const u64 n = ranges[2 * SEC_CAND + 1] - ranges[2 * SEC_CAND];
+    if (threadIdx.x == 0) s_tile = atomicAdd(lb.ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const u64 n_tiles = n ? (n + TAIL_TILE - 1) / TAIL_TILE : 1;
+    if (tile >= n_tiles) return;
+    const u64 base = (u64)tile * TAIL_TILE + 4ull * threadIdx.x;
+    u64 m[4];
+    uint32_t keep = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        m[k] = base + k < n ? meta[base + k] : 0;
+        keep += meta_card(m[k]) ? 1u : 0u;
+    }
+    u64 total;
+    u64 ex = blk_exscan64(keep, sm, &total);
+    if (threadIdx.x == 0) s_prefix = lb_exclusive_prefix(lb.status, tile, total);
+    __syncthreads();
+    ex += s_prefix;
+    u64 bytes = 0;
+    uint32_t nty[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u64 i = base + k;
+        if (i < n) {
+            // result bitmaps starting at candidate i: every pair in (pair of candidate i-1, pair of candidate i]
+            const uint32_t pi = C.pair[i];
+            const uint32_t pprev = i ? C.pair[i - 1] + 1u : 0u;
+            for (uint32_t q = pprev; q <= pi; ++q) R.bm_start[q] = ex;
+            if (meta_card(m[k])) {
+                const uint32_t ty = meta_type(m[k]);
+                R.key[ex] = C.key[i];
+                R.type[ex] = (uint8_t)ty;
+                R.card[ex] = meta_card(m[k]);
+                R.nruns[ex] = meta_nruns(m[k]);
+                R.off[ex] = C.off[i];
+                bytes += payload_bytes((uint8_t)ty, meta_card(m[k]), meta_nruns(m[k]));
+                nty[ty - 1]++;
+                ++ex;
+            }
+        }
+    }
+    bytes = wave_sum64(bytes);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) nty[t] = wave_sum(nty[t]);
+    if (lane_id() == 0) {
+        s_bytes[threadIdx.x >> 6] = bytes;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) s_types[threadIdx.x >> 6][t] = nty[t];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 b = 0;
+        uint32_t ty[3] = {0, 0, 0};
+        for (int w = 0; w < 4; ++w) {
+            b += s_bytes[w];
+            for (int t = 0; t < 3; ++t) ty[t] += s_types[w][t];
+        }
+        if (b) atomicAdd(&stats->bytes_out, b);
+        for (int t = 0; t < 3; ++t)
+            if (ty[t]) atomicAdd(&stats->n_type[t], (u64)ty[t]);
+        if (tile == n_tiles - 1) {
+            // the last tile closes the directory: bitmaps after the last candidate are empty
+            const u64 kept = s_prefix + total;
+            const uint32_t plast = n ? C.pair[n - 1] + 1u : 0u;
+            for (uint32_t q = plast; q <= n_pairs; ++q) R.bm_start[q] = kept;
+            stats->result_containers = kept;
+            stats->n_cand = n;
+            stats->matched_pairs = ranges[2 * SEC_M + 1] - ranges[2 * SEC_M];
+            stats->passthrough = ranges[2 * SEC_COPY + 1] - ranges[2 * SEC_COPY];
+            stats->n_bb = ranges[2 * SEC_BB + 1] - ranges[2 * SEC_BB];
+            stats->bytes_in = ranges[2 * SEC_BYTES + 1] - ranges[2 * SEC_BYTES];
+            stats->slot_bytes = 16ull * (ranges[2 * SEC_SLOT + 1] - ranges[2 * SEC_SLOT]);
+        }
+    }
+}
+// cardinality mode has no tail: the same statistics from the section totals
+__global__ void k_card_stats(const u64* __restrict__ ranges, Stats* __restrict__ stats) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        stats->matched_pairs = ranges[2 * SEC_M + 1] - ranges[2 * SEC_M];
+        stats->n_bb = ranges[2 * SEC_BB + 1] - ranges[2 * SEC_BB];
+        stats->bytes_in = ranges[2 * SEC_BYTES + 1] - ranges[2 * SEC_BYTES];
+    }
+}
+
+// ------------------------------------------------------------------ directory compaction (flip / many-way paths)
 __global__ __launch_bounds__(1024) void k_sum_u64(const u64* __restrict__ v, u64 n, u64* __restrict__ out) {
     __shared__ u64 sb[16];
     u64 s = 0;
@@ -282,21 +550,10 @@ __global__ __launch_bounds__(1024) void k_sum_u64(const u64* __restrict__ v, u64
         *out = t;
     }
 }
-
-
-// ------------------------------------------------------------------ directory compaction
 __global__ void k_flags(const u64* __restrict__ meta, u64 n, uint32_t* __restrict__ flag) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flag[i] = meta_card(meta[i]) ? 1u : 0u;
 }
-struct DirOut {
-    u64* bm_start;
-    u64* key;
-    uint8_t* type;
-    uint32_t* card;
-    uint32_t* nruns;
-    u64* off;
-};
 // grid-stride, 1024 threads per block: one pair of atomics per block for the statistics
 __global__ __launch_bounds__(1024) void k_compact(OutView O, u64 n, const u64* __restrict__ newidx, DirOut R,
                                                   Stats* stats) {
@@ -334,7 +591,11 @@ __global__ void k_bm_start(const u64* __restrict__ cand_start, const u64* __rest
     if (p <= npairs) bm_start[p] = newidx[cand_start[pair_unit0[p]]];
 }
 
-// per-bitmap cardinality = sum of container cardinalities (roaring.c:1436-1443); wave per bitmap
+// ------------------------------------------------------------------ per-bitmap host mirrors
+// wave per bitmap: cardinality (roaring.c:1436-1443), the payload bound W used to size result arenas without a
+// device round trip, and which container types occur
+//   W = sum over containers of max(align16(payload), min(8192, align16(2 * card)))
+// (an AND / ANDNOT result slot of a matched pair is <= W(a-side container); an OR / XOR slot <= the sum of both).
 __global__ __launch_bounds__(256) void k_bitmap_cards(PoolView P, uint32_t nbm, u64* __restrict__ out) {
     uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (b >= nbm) return;
@@ -342,6 +603,33 @@ __global__ __launch_bounds__(256) void k_bitmap_cards(PoolView P, uint32_t nbm, 
     for (u64 i = P.bm_start[b] + lane_id(); i < P.bm_start[b + 1]; i += 64) s += P.card[i];
     s = wave_sum64(s);
     if (lane_id() == 0) out[b] = s;
+}
+__device__ __forceinline__ uint32_t slot_bound(uint8_t type, uint32_t card, uint32_t nruns) {
+    const uint32_t p = align16(payload_bytes(type, card, nruns));
+    uint32_t c = align16(2u * card);
+    c = c > 8192u ? 8192u : c;
+    const uint32_t w = p > c ? p : c;
+    return w < 16u ? 16u : w;
+}
+__global__ __launch_bounds__(256) void k_bitmap_bounds(PoolView P, uint32_t nbm, u64* __restrict__ wout,
+                                                       uint32_t* __restrict__ census /* [3] bitset, array, run */) {
+    uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (b >= nbm) return;
+    u64 s = 0;
+    uint32_t seen = 0;
+    for (u64 i = P.bm_start[b] + lane_id(); i < P.bm_start[b + 1]; i += 64) {
+        const uint8_t t = P.type[i];
+        s += slot_bound(t, P.card[i], P.nruns[i]);
+        seen |= 1u << (t - 1);
+    }
+    s = wave_sum64(s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) seen |= __shfl_xor(seen, o);
+    if (lane_id() == 0) {
+        wout[b] = s;
+        for (int t = 0; t < 3; ++t)
+            if ((seen >> t) & 1u) census[t] = 1u;  // benign race: every writer stores the same value
+    }
 }
 __global__ __launch_bounds__(256) void k_payload_stats(const uint8_t* type, const uint32_t* card,
                                                        const uint32_t* nruns, u64 n, u64* out /*[4]*/) {

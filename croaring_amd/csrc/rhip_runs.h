@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_runs(const uint8_t* __restrict__ arenaA
             __builtin_amdgcn_wave_barrier();
             continue;
         }
-        uint8_t* outp = O.arena + O.off[t.out];
+        uint8_t* outp = O.arena + t.offo;
         if (rc && ty == T_RUN) {
             uint32_t* __restrict__ o32 = (uint32_t*)outp;
             for (uint32_t k = lane; k < rn; k += 64)
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void k_genw(const uint8_t* __restrict__ arenaA
         const bool fulla = ta == T_RUN && t.ca == 65536u, fullb = tb == T_RUN && t.cb == 65536u;
         int ty = T_ARRAY;
         if (rc) ty = decide_type(op, (int)ta, (int)tb, t.ca, t.cb, fulla, fullb, rc, rn);
-        uint8_t* outp = O.arena + O.off[t.out];
+        uint8_t* outp = O.arena + t.offo;
         uint32_t* img = ia;
 #include "rhip_wemit.inc"
         if (lane == 0) O.meta[t.out] = pack_meta(ty, rc, (ty == T_RUN) ? rn : 0u);
