@@ -2,14 +2,128 @@
 #pragma once
 #include "rhip_common.h"
 
-// ------------------------------------------------------------------ array filter (K8, K9, K12)
-// One WAVE per container pair, no workgroup barriers: the array operand Y is streamed 64 values at
-// a time, each lane tests its value for membership in X and survivors are compacted with a ballot +
-// mbcnt prefix.  X = bitset: one gathered dword test per value (array_bitset_container_intersection
-// / _andnot, mixed_intersection.c:19-46, mixed_andnot.c:24-39).  X = array: X is first scattered into
-// a wave-private 8 KiB LDS bitset (ds_or_b32), replacing the SIMD merge / galloping intersections of
-// array_util.c:385-459, 801-906 (intersect_vector16, intersect_skewed_uint16) and difference_uint16.
+// ------------------------------------------------------------------ short array probes (K9, K12 for short arrays)
+// and / andnot / and_cardinality where the streamed array Y has at most PROBE_MAX values (two per lane): membership
+// of every value is decided straight from global / L2 -- one gathered dword when X is a bitset, a two-level search
+// when X is a sorted array: lane k first holds the pivot X[k * step] (step = ceil(nx / 64)), each lane locates its
+// pivot interval with six register shuffles, then at most log2(step) <= 6 dependent probes inside the interval.
+// No LDS, few registers: full wave occupancy, which is what hides the probe latency.  This is the GPU form of the
+// reference's galloping intersection for skewed cardinalities (intersect_skewed_uint16 / advanceUntil,
+// src/array_util.c:801-906, gate src/containers/array.c:293-310) and of array_bitset_container_intersection /
+// array_bitset_container_andnot (mixed_intersection.c:19-46, mixed_andnot.c:24-39) for short arrays.
 // The result is always an array (containers.h:741-746, 1799-1803).
+__device__ __forceinline__ bool probe_sorted(const uint16_t* __restrict__ x16, uint32_t nx, uint32_t step, uint32_t piv,
+                                             uint32_t v) {
+    // pos = number of pivots <= v (pivot k sits in lane k; lanes past the last pivot hold 0xFFFFFFFF)
+    uint32_t pos = 0;
+#pragma unroll
+    for (uint32_t b = 32; b >= 1; b >>= 1) {
+        const uint32_t pv = __shfl(piv, (int)(pos + b - 1));
+        if (pv <= v) pos += b;
+    }
+    {
+        const uint32_t pv = __shfl(piv, 63);
+        if (pos == 63u && pv <= v) pos = 64u;
+    }
+    const uint32_t k = pos ? pos - 1u : 0u;
+    uint32_t last = __shfl(piv, (int)k);      // X[idx], idx = largest index known to hold a value <= v
+    uint32_t idx = k * step;
+    const uint32_t end = (idx + step < nx) ? idx + step : nx;
+    for (uint32_t b = 32; b >= 1; b >>= 1) {   // uniform trip count; intervals hold at most 64 values
+        if (b < step) {
+            const uint32_t c = idx + b;
+            if (pos && c < end) {
+                const uint32_t xv = x16[c];
+                if (xv <= v) { idx = c; last = xv; }
+            }
+        }
+    }
+    return pos != 0u && last == v;
+}
+__global__ __launch_bounds__(256) void k_probe(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                               OutView O, const FatItem* __restrict__ q,
+                                               const u64* __restrict__ qrange, int op, int cardmode, u64* pair_acc) {
+    const uint32_t lane = lane_id();
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
+    uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    FatItem tnext;
+    if (w < n) tnext = q[w];
+    for (; w < n; w += nwaves) {
+        const FatItem t = tnext;
+        if (w + nwaves < n) tnext = q[w + nwaves];
+        const uint8_t ta = (uint8_t)(t.types & 0xFF), tb = (uint8_t)(t.types >> 8);
+        bool y_is_a = true;
+        if (op == OP_AND) y_is_a = (ta == T_ARRAY) && (tb != T_ARRAY || t.ca <= t.cb);
+        const uint8_t* yp = y_is_a ? arenaA + t.offa : arenaB + t.offb;
+        const uint8_t* xp = y_is_a ? arenaB + t.offb : arenaA + t.offa;
+        const uint32_t ny = y_is_a ? t.ca : t.cb, nx = y_is_a ? t.cb : t.ca;
+        const bool x_bitset = (y_is_a ? tb : ta) == T_BITSET;
+        const bool keep_present = op == OP_AND;
+        const uint16_t* __restrict__ y16 = (const uint16_t*)yp;
+        const uint32_t v0 = lane < ny ? y16[lane] : 0u;
+        const uint32_t v1 = 64u + lane < ny ? y16[64u + lane] : 0u;
+        bool p0, p1;
+        if (x_bitset) {
+            const uint32_t* __restrict__ xw = (const uint32_t*)xp;
+            const uint32_t w0 = xw[v0 >> 5], w1 = xw[v1 >> 5];
+            p0 = (w0 >> (v0 & 31)) & 1u;
+            p1 = (w1 >> (v1 & 31)) & 1u;
+        } else {
+            const uint16_t* __restrict__ x16 = (const uint16_t*)xp;
+            const uint32_t step = (nx + 63u) >> 6;
+            const uint32_t pi = lane * step;
+            const uint32_t piv = pi < nx ? (uint32_t)x16[pi] : 0xFFFFFFFFu;
+            p0 = probe_sorted(x16, nx, step, piv, v0);
+            p1 = ny > 64u ? probe_sorted(x16, nx, step, piv, v1) : false;
+        }
+        const bool k0 = lane < ny && p0 == keep_present;
+        const bool k1 = 64u + lane < ny && p1 == keep_present;
+        const u64 m0 = __ballot(k0), m1 = __ballot(k1);
+        const uint32_t n0 = (uint32_t)__popcll(m0), run = n0 + (uint32_t)__popcll(m1);
+        if (cardmode) {
+            if (lane == 0 && run) atomicAdd(&pair_acc[t.out], (u64)run);
+        } else {
+            uint16_t* __restrict__ out = (uint16_t*)(O.arena + t.offo);
+            if (k0) out[mbcnt(m0)] = (uint16_t)v0;
+            if (k1) out[n0 + mbcnt(m1)] = (uint16_t)v1;
+            if (lane == 0) O.meta[t.out] = pack_meta(T_ARRAY, run, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void wave_scatter_or(uint32_t* img, const uint4* __restrict__ x4, uint32_t nx, uint32_t lane) {
+    const uint32_t nfull = nx >> 3;   // whole 8-value groups: no per-value bound checks
+    for (uint32_t i = lane; i < nfull; i += 64) {
+        const uint4 q4 = x4[i];
+        const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+            atomicOr(&img[v >> 5], 1u << (v & 31));
+        }
+    }
+    if ((nx & 7u) && lane == (nfull & 63u)) {  // the ragged tail group, one lane
+        const uint4 q4 = x4[nfull];
+        const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            if (h < (int)(nx & 7u)) {
+                const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                atomicOr(&img[v >> 5], 1u << (v & 31));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ array filter (K8, K12)
+// One WAVE per container pair, no workgroup barriers: the membership side X is brought into a wave-private 8 KiB LDS
+// bitset -- a bitset container by 8 coalesced 16-byte loads per lane, an array by zero + ds_or_b32 scatter -- then the
+// array operand Y is streamed 512 values per step (16 B/lane), each lane tests its values against the image and
+// survivors are compacted with a wave prefix sum.  Replaces intersect_vector16 / difference_uint16
+// (array_util.c:385-459) and array_bitset_container_intersection / _andnot (mixed_intersection.c:19-46,
+// mixed_andnot.c:24-39); short streamed arrays take k_probe instead.  The result is always an array
+// (containers.h:741-746, 1799-1803).
 __global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                                 OutView O, const FatItem* __restrict__ q,
                                                 const u64* __restrict__ qrange, int op, int cardmode,
@@ -37,29 +151,24 @@ __global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ aren
         const uint32_t ny = y_is_a ? ca : cb, nx = y_is_a ? cb : ca;
         const bool x_bitset = (y_is_a ? tb : ta) == T_BITSET;
         const bool keep_present = op == OP_AND;
-        const uint32_t* __restrict__ xw = (const uint32_t*)xp;
         const uint4* __restrict__ y4 = (const uint4*)yp;
+        const uint4* __restrict__ x4 = (const uint4*)xp;  // 8 values per lane per step (slots are 16-byte padded)
         uint4 yfirst = make_uint4(0, 0, 0, 0);
-        if (8 * lane < ny) yfirst = y4[lane];  // first 512 values of Y: in flight during the X scatter
-        if (!x_bitset) {
+        if (8 * lane < ny) yfirst = y4[lane];  // first 512 values of Y: in flight while X is staged
+        if (x_bitset) {
+            uint4 xv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xv[i] = x4[i * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ((uint4*)img)[i * 64 + lane] = xv[i];
+        } else {
             const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 8; ++i) ((uint4*)img)[i * 64 + lane] = z;
             __builtin_amdgcn_wave_barrier();  // every lane's slice is zero before any lane scatters into it
-            const uint4* __restrict__ x4 = (const uint4*)xp;  // 8 values per lane per step (slots are 16-byte padded)
-            for (uint32_t i = lane; 8 * i < nx; i += 64) {
-                const uint4 q4 = x4[i];
-                const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
-#pragma unroll
-                for (int h = 0; h < 8; ++h) {
-                    if (8 * i + h < nx) {
-                        const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
-                        atomicOr(&img[v >> 5], 1u << (v & 31));
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
+            wave_scatter_or(img, x4, nx, lane);
         }
+        __builtin_amdgcn_wave_barrier();
         PH(1);
         uint16_t* __restrict__ out = cardmode ? nullptr : (uint16_t*)(O.arena + t.offo);
         uint32_t run = 0;
@@ -68,16 +177,17 @@ __global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ aren
             uint4 q4 = yfirst;
             if (base) q4 = (i0 < ny) ? y4[(base >> 3) + lane] : make_uint4(0, 0, 0, 0);
             const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
+            const uint32_t nval = i0 < ny ? (ny - i0 < 8u ? ny - i0 : 8u) : 0u;  // values this lane holds
             uint32_t vals[8];
             uint32_t keepmask = 0;
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
                 const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
                 vals[h] = v;
-                const uint32_t word = x_bitset ? xw[v >> 5] : img[v >> 5];
-                const bool present = (word >> (v & 31)) & 1u;
-                if (i0 + h < ny && present == keep_present) keepmask |= 1u << h;
+                const uint32_t present = (img[v >> 5] >> (v & 31)) & 1u;
+                keepmask |= (present == (uint32_t)keep_present ? 1u : 0u) << h;
             }
+            keepmask &= (1u << nval) - 1u;
             const uint32_t cnt = __popc(keepmask);
             const uint32_t inc = wave_incl_scan(cnt);
             if (!cardmode) {
@@ -107,8 +217,9 @@ __global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ aren
 // returning LDS atomics (ds_or_rtn / ds_xor_rtn / ds_and_rtn) whose old values give the cardinality
 // delta -- bitset_set_list_withcard / bitset_flip_list_withcard / bitset_clear_list
 // (bitset_util.c:978-1141) without their serial dependence.  The result is typed by the reference's
-// rules and either streamed out as a bitset or extracted as a sorted array (lane owns 32 consecutive
-// words; wave prefix sum of popcounts).  No workgroup barrier anywhere.
+// rules and either streamed out as a bitset or extracted as a sorted array: words are owned strided
+// (balanced under clustering), a two-level popcount prefix gives every word its output position, values are
+// compacted into the (by then dead) image and leave with coalesced 16-byte stores.  No workgroup barrier anywhere.
 __global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                               OutView O, const FatItem* __restrict__ q,
                                               const u64* __restrict__ qrange, int op) {
@@ -117,9 +228,13 @@ __global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA
     uint32_t* img = img_all[threadIdx.x >> 6];
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
+    uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    FatItem tnext;
+    if (w < n) tnext = q[w];
     PH_BEGIN();
-    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
-        const FatItem t = q[w];
+    for (; w < n; w += nwaves) {
+        const FatItem t = tnext;
+        if (w + nwaves < n) tnext = q[w + nwaves];  // next work item in flight while this one is processed
         const uint8_t ta = (uint8_t)(t.types & 0xFF), tb = (uint8_t)(t.types >> 8);
         const uint32_t ca = t.ca, cb = t.cb;
         PH(0);
@@ -130,54 +245,46 @@ __global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA
         const uint8_t tx = x_is_a ? ta : tb;
         const uint32_t cx = x_is_a ? ca : cb, cy = x_is_a ? cb : ca;
         const uint8_t* xp = x_is_a ? arenaA + t.offa : arenaB + t.offb;
-        const uint32_t* __restrict__ y2 = (const uint32_t*)(x_is_a ? arenaB + t.offb : arenaA + t.offa);
+        const uint4* __restrict__ y4 = (const uint4*)(x_is_a ? arenaB + t.offb : arenaA + t.offa);
+        uint4 yfirst = make_uint4(0, 0, 0, 0);
+        if (8 * lane < cy) yfirst = y4[lane];  // first 512 values of Y: in flight while X is staged
         if (tx == T_BITSET) {
             const uint4* __restrict__ g = (const uint4*)xp;
+            uint4 xv[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ((uint4*)img)[i * 64 + lane] = g[i * 64 + lane];
+            for (int i = 0; i < 8; ++i) xv[i] = g[i * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ((uint4*)img)[i * 64 + lane] = xv[i];
         } else {
             const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 8; ++i) ((uint4*)img)[i * 64 + lane] = z;
             __builtin_amdgcn_wave_barrier();
-            const uint4* __restrict__ x4 = (const uint4*)xp;
-            for (uint32_t i = lane; 8 * i < cx; i += 64) {
-                const uint4 q4 = x4[i];
-                const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
-#pragma unroll
-                for (int h = 0; h < 8; ++h) {
-                    if (8 * i + h < cx) {
-                        const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
-                        atomicOr(&img[v >> 5], 1u << (v & 31));
-                    }
-                }
-            }
+            wave_scatter_or(img, (const uint4*)xp, cx, lane);
         }
         __builtin_amdgcn_wave_barrier();  // X is complete in the image before Y is applied (xor / clear are order-sensitive)
         PH(1);
         int delta = 0;
-        {
-            const uint4* __restrict__ y4 = (const uint4*)y2;
-            for (uint32_t i = lane; 8 * i < cy; i += 64) {
-                const uint4 q4 = y4[i];
-                const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
-                uint32_t old[8], bit[8];
+        for (uint32_t i = lane; 8 * i < cy; i += 64) {
+            const uint4 q4 = i == lane ? yfirst : y4[i];
+            const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
+            const uint32_t nval = cy - 8 * i < 8u ? cy - 8 * i : 8u;
+            uint32_t old[8], bit[8];
 #pragma unroll
-                for (int h = 0; h < 8; ++h) {
-                    const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
-                    bit[h] = (8 * i + h < cy) ? (1u << (v & 31)) : 0u;
-                    if (op == OP_OR) old[h] = atomicOr(&img[v >> 5], bit[h]);
-                    else if (op == OP_XOR) old[h] = atomicXor(&img[v >> 5], bit[h]);
-                    else old[h] = atomicAnd(&img[v >> 5], ~bit[h]);
-                }
+            for (int h = 0; h < 8; ++h) {
+                const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                bit[h] = ((uint32_t)h < nval) ? (1u << (v & 31)) : 0u;
+                if (op == OP_OR) old[h] = atomicOr(&img[v >> 5], bit[h]);
+                else if (op == OP_XOR) old[h] = atomicXor(&img[v >> 5], bit[h]);
+                else old[h] = atomicAnd(&img[v >> 5], ~bit[h]);
+            }
 #pragma unroll
-                for (int h = 0; h < 8; ++h) {
-                    if (bit[h]) {
-                        const bool was = (old[h] & bit[h]) != 0;
-                        if (op == OP_OR) delta += was ? 0 : 1;
-                        else if (op == OP_XOR) delta += was ? -1 : 1;
-                        else delta -= was ? 1 : 0;
-                    }
+            for (int h = 0; h < 8; ++h) {
+                if (bit[h]) {
+                    const bool was = (old[h] & bit[h]) != 0;
+                    if (op == OP_OR) delta += was ? 0 : 1;
+                    else if (op == OP_XOR) delta += was ? -1 : 1;
+                    else delta -= was ? 1 : 0;
                 }
             }
         }
@@ -192,14 +299,18 @@ __global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA
         PH(3);
         if (rc && ty == T_BITSET) {
             uint4* __restrict__ po = (uint4*)outp;
+            uint4 xv[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) po[i * 64 + lane] = ((const uint4*)img)[i * 64 + lane];
+            for (int i = 0; i < 8; ++i) xv[i] = ((const uint4*)img)[i * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) po[i * 64 + lane] = xv[i];
         } else if (rc) {
             // Balanced extraction.  Words are owned strided (lane l: words 64 r + l), so clustered values
             // spread over all lanes; the output position of each word comes from a two-level prefix:
             // per-word popcounts -> LDS, each lane prefix-sums 32 CONSECUTIVE counts, one wave scan of the
-            // lane totals, word bases back to LDS.  The image is dead once the words are in registers,
-            // so its first 4 KiB hold the u16 count/base table.
+            // lane totals, word bases back to LDS and from there into registers.  The image is dead once the
+            // words are in registers: first its lower half holds the u16 count/base table, then all of it is the
+            // staging buffer the sorted values are compacted into (rc <= 4096 values = 8 KiB).
             uint32_t wv[32];
 #pragma unroll
             for (int r = 0; r < 32; ++r) wv[r] = img[64 * r + lane];
@@ -233,17 +344,25 @@ __global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA
             }
             __builtin_amdgcn_wave_barrier();
             PH(4);
-            uint16_t* __restrict__ o16 = (uint16_t*)outp;
+            uint16_t pos16[32];
+#pragma unroll
+            for (int r = 0; r < 32; ++r) pos16[r] = tab[64 * r + lane];
+            __builtin_amdgcn_wave_barrier();  // every base is in registers: the table may be overwritten
+            uint16_t* st16 = (uint16_t*)img;
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
                 uint32_t x = wv[r];
-                uint32_t pos = tab[64 * r + lane];
+                uint32_t pos = pos16[r];
                 const uint32_t vbase = (64u * r + lane) * 32u;
                 while (x) {
-                    o16[pos++] = (uint16_t)(vbase + (__ffs((int)x) - 1));
+                    st16[pos++] = (uint16_t)(vbase + (__ffs((int)x) - 1));
                     x &= x - 1;
                 }
             }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t n16 = (2u * rc + 15u) >> 4;
+            uint4* __restrict__ po = (uint4*)outp;
+            for (uint32_t i = lane; i < n16; i += 64) po[i] = ((const uint4*)img)[i];
         }
         PH(5);
         if (lane == 0) O.meta[t.out] = pack_meta(ty, rc, 0);

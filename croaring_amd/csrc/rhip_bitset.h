@@ -53,6 +53,15 @@ __global__ __launch_bounds__(256) void k_bb(const uint8_t* __restrict__ arenaA, 
             va[i] = vop<OP>(va[i], vb[i]);
             cnt += vpopc(va[i]);
         }
+        // The result words leave as soon as they exist: whenever the slot can hold a bitset (8192 bytes: always for
+        // OR; for and / xor / andnot unless the operands are too sparse for a result above 4096 values) the eight
+        // stores are issued BEFORE the cardinality reduction resolves, so they overlap it.  If the result then turns
+        // out to be an array (card <= 4096) the retry pass rewrites the slot; a smaller slot can never need a bitset.
+        if (!cardmode && (OP == OP_OR || t.slot >= 8192u)) {
+            u32x4* __restrict__ po = (u32x4*)(O.arena + t.offo);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) __builtin_nontemporal_store(va[i], po + i * 64 + lane);
+        }
         const uint32_t card = wave_sum(cnt);
         if (cardmode) {
             if (lane == 0 && card) atomicAdd(&pair_acc[t.out], (u64)card);
@@ -62,9 +71,6 @@ __global__ __launch_bounds__(256) void k_bb(const uint8_t* __restrict__ arenaA, 
         // bitset iff card > 4096 (mixed_intersection.c:305-325, mixed_xor.c:260-273,
         // mixed_andnot.c:482-497)
         if (OP == OP_OR || card > 4096u) {
-            u32x4* __restrict__ po = (u32x4*)(O.arena + t.offo);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) __builtin_nontemporal_store(va[i], po + i * 64 + lane);
             if (lane == 0) O.meta[t.out] = pack_meta(T_BITSET, card, 0);
         } else if (card == 0) {
             if (lane == 0) O.meta[t.out] = pack_meta(T_ARRAY, 0, 0);

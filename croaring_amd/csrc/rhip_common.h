@@ -8,8 +8,9 @@ typedef unsigned long long u64;
 
 enum { T_BITSET = 1, T_ARRAY = 2, T_RUN = 3 };
 enum { OP_AND = 0, OP_OR = 1, OP_XOR = 2, OP_ANDNOT = 3 };
-enum { CLS_BB = 0, CLS_GEN = 1, CLS_COPY = 2, CLS_RETRY = 3, CLS_FILT = 4, CLS_WAVE = 5, CLS_RUNS = 6, N_CLS = 7 };
-#define RUNS_MAX_INTERVALS 256u  // per operand, for the interval kernel (k_runs)
+enum { CLS_BB = 0, CLS_GEN = 1, CLS_COPY = 2, CLS_RETRY = 3, CLS_FILT = 4, CLS_WAVE = 5, CLS_RUNS = 6, CLS_PROBE = 7, N_CLS = 8 };
+#define PROBE_MAX 128u  // streamed array of a k_probe item: at most two values per lane
+#define RUNS_MAX_INTERVALS 255u  // per operand, for the interval kernel (k_runs); 255 keeps its LDS at 4 x 8 KiB - 64 B
 #define NONE32 0xFFFFFFFFu
 
 struct PoolView {
@@ -62,7 +63,8 @@ struct __attribute__((aligned(16))) GenItem {  // general pair item (any type pa
 };
 struct __attribute__((aligned(16))) BBItem {  // bitset x bitset work item
     u64 offa, offb, offo;
-    uint32_t out, pad;
+    uint32_t out;
+    uint32_t slot;  // bytes of the result slot: 8192 whenever the result can be a bitset at all
 };
 
 struct Stats {  // device-side counters of one call, see rhip_stats_t

@@ -134,7 +134,7 @@ struct rhip_ctx_s {
     bool timing = false;
     hipEvent_t ev[4]{};
     // independent class kernels of one batch run concurrently: fork after planning, join before compaction
-    static constexpr int N_AUX = 4;
+    static constexpr int N_AUX = 3;
     hipStream_t aux[N_AUX]{};
     hipEvent_t ev_fork = nullptr, ev_join[N_AUX]{}, ev_runs = nullptr;
     bool overlap = true;
@@ -169,6 +169,7 @@ struct rhip_pool_s {
     std::vector<uint32_t> h_card, h_nruns;
     std::vector<uint64_t> h_cards;  // per-bitmap cardinalities cache
     std::vector<uint64_t> h_w;      // per-bitmap result-slot bound (k_bitmap_bounds), see fetch_bounds
+    std::vector<uint32_t> h_n;      // per-bitmap container count
     bool host_w = false;
     int8_t census[3] = {1, 1, 1};   // does the pool hold bitset / array / run containers (1 until known otherwise)
     PoolView view() const {
@@ -732,6 +733,8 @@ static void fetch_bounds(rhip_pool_t* P) {
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     for (int t = 0; t < 3; ++t) P->census[t] = census[t] ? 1 : 0;
+    P->h_n.resize((size_t)P->n_bitmaps);
+    for (uint32_t b = 0; b < P->n_bitmaps; ++b) P->h_n[b] = (uint32_t)(P->h_bm_start[b + 1] - P->h_bm_start[b]);
     P->host_w = true;
 }
 
@@ -745,7 +748,7 @@ struct PlanScratch {
         size_t w = 0;
         w_scan_status = w; w += n_scan_tiles;
         w_tail_status = w; w += n_tail_tiles;
-        w_tickets = w; w += 2;
+        w_tickets = w; w += 3;
         w_retry = w; w += 1;
         w_ranges = w; w += 2 * N_SEC;
         w_stats = w; w += (sizeof(Stats) + 7) / 8;
@@ -762,11 +765,13 @@ struct Plan {
     uint32_t *d_lhs = nullptr, *d_rhs = nullptr, *d_upair = nullptr, *d_utile = nullptr;
     u64* d_pair0 = nullptr;
     u64* words = nullptr;
+    CandOut CO{nullptr, nullptr, nullptr};
     u64* ranges() const { return words + sc.w_ranges; }
     uint32_t* retry_count() const { return (uint32_t*)(words + sc.w_retry); }
     Stats* stats() const { return (Stats*)(words + sc.w_stats); }
     LbState scan_lb() const { return LbState{words + sc.w_scan_status, (uint32_t*)(words + sc.w_tickets)}; }
     LbState tail_lb() const { return LbState{words + sc.w_tail_status, (uint32_t*)(words + sc.w_tickets + 1)}; }
+    uint32_t* tail_done() const { return (uint32_t*)(words + sc.w_tickets + 2); }
 };
 
 void check_pair_args(rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs, const uint32_t* rhs) {
@@ -775,11 +780,7 @@ void check_pair_args(rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32
     if (A->is64 != B->is64) { set_err("mixing 32-bit and 64-bit pools"); throw (int)RHIP_ERR_ARG; }
     if (A->ctx->device != B->ctx->device) { set_err("operand pools live on different devices"); throw (int)RHIP_ERR_ARG; }
     if (npairs >= 0x3FFFFFF0ull) { set_err("too many pairs"); throw (int)RHIP_ERR_ARG; }
-    for (size_t i = 0; i < npairs; ++i)
-        if (lhs[i] >= A->n_bitmaps || rhs[i] >= B->n_bitmaps) {
-            set_err("pair %zu: bitmap index out of range", i);
-            throw (int)RHIP_ERR_ARG;
-        }
+    // (the bitmap indices themselves are range-checked by the planning pass that reads them anyway)
 }
 
 template <int OP>
@@ -800,21 +801,37 @@ unsigned persistent_grid(uint64_t n_items, unsigned items_per_block, unsigned ma
 // batch description, then k_count -> k_scan -> k_emit.  On return the class queues are filled at deterministic
 // positions and `ranges` (device) holds every section's [begin, end).
 Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs,
-          const uint32_t* rhs, int cardmode, const CandOut& CO) {
+          const uint32_t* rhs, int cardmode) {
     hipStream_t s = c->stream;
     Plan P;
     P.npairs = npairs;
     fetch_bounds(A);
     fetch_bounds(B);
     const bool btiles = !cardmode && (op == OP_OR || op == OP_XOR);
-    // ---- units + upper bounds from the directory mirrors
+    const int bmode = (cardmode || op == OP_AND) ? 0 : (op == OP_ANDNOT ? 1 : 2);
+    // ---- pass 1 over the pair list: range check, units and every upper bound (directory mirrors only)
     size_t NU = 0;
-    for (size_t i = 0; i < npairs; ++i) {
-        const uint64_t nA = A->h_bm_start[lhs[i] + 1] - A->h_bm_start[lhs[i]];
-        const uint64_t nB = B->h_bm_start[rhs[i] + 1] - B->h_bm_start[rhs[i]];
-        NU += (nA + 255) / 256 + (btiles ? (nB + 255) / 256 : 0);
+    uint64_t ub_match = 0, ub = 0, bound = 0;
+    {
+        const uint32_t* nAv = A->h_n.data();
+        const uint32_t* nBv = B->h_n.data();
+        const uint64_t* wAv = A->h_w.data();
+        const uint64_t* wBv = B->h_w.data();
+        const uint32_t nbmA = A->n_bitmaps, nbmB = B->n_bitmaps;
+        for (size_t i = 0; i < npairs; ++i) {
+            const uint32_t l = lhs[i], r = rhs[i];
+            if (l >= nbmA || r >= nbmB) { set_err("pair %zu: bitmap index out of range", i); throw (int)RHIP_ERR_ARG; }
+            const uint64_t nA = nAv[l], nB = nBv[r], wA = wAv[l], wB = wBv[r];
+            NU += (nA + 255) / 256 + (btiles ? (nB + 255) / 256 : 0);
+            const uint64_t mn = nA < nB ? nA : nB;
+            ub_match += mn;
+            if (bmode == 0) { ub += mn; bound += wA < wB ? wA : wB; }
+            else if (bmode == 1) { ub += nA; bound += wA; }
+            else { ub += nA + nB; bound += wA + wB; }
+        }
     }
     if (NU >= 0x7FFFFFF0ull) { set_err("batch too large: %zu planning units", NU); throw (int)RHIP_ERR_ARG; }
+    if (ub >= 0xFFFFFFF0ull) { set_err("batch too large: %llu candidate containers", (unsigned long long)ub); throw (int)RHIP_ERR_ARG; }
     // staging layout (host pinned == device): pair0[npairs+1] u64 | lhs | rhs | upair | utile (u32 each)
     const size_t o_pair0 = 0, o_lhs = 8 * (npairs + 1), o_rhs = o_lhs + 4 * npairs, o_upair = o_rhs + 4 * npairs,
                  o_utile = o_upair + 4 * NU, stage_bytes = o_utile + 4 * NU;
@@ -827,23 +844,18 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
         memcpy(hs + o_lhs, lhs, 4 * npairs);
         memcpy(hs + o_rhs, rhs, 4 * npairs);
     }
-    uint64_t ub_match = 0, ub = 0, bound = 0;
-    size_t u = 0;
-    for (size_t i = 0; i < npairs; ++i) {
-        const uint64_t nA = A->h_bm_start[lhs[i] + 1] - A->h_bm_start[lhs[i]];
-        const uint64_t nB = B->h_bm_start[rhs[i] + 1] - B->h_bm_start[rhs[i]];
-        const uint64_t wA = A->h_w[lhs[i]], wB = B->h_w[rhs[i]];
-        pair0[i] = u;
-        for (uint64_t t = 0; t < (nA + 255) / 256; ++t) { upair[u] = (uint32_t)i; utile[u] = (uint32_t)t; ++u; }
-        if (btiles)
-            for (uint64_t t = 0; t < (nB + 255) / 256; ++t) { upair[u] = (uint32_t)i; utile[u] = (uint32_t)t | UNIT_B; ++u; }
-        ub_match += std::min(nA, nB);
-        if (cardmode || op == OP_AND) { ub += std::min(nA, nB); bound += std::min(wA, wB); }
-        else if (op == OP_ANDNOT) { ub += nA; bound += wA; }
-        else { ub += nA + nB; bound += wA + wB; }
+    {   // ---- pass 2: the units
+        const uint32_t* nAv = A->h_n.data();
+        const uint32_t* nBv = B->h_n.data();
+        size_t u = 0;
+        for (size_t i = 0; i < npairs; ++i) {
+            const uint32_t tA = (nAv[lhs[i]] + 255u) >> 8, tB = btiles ? (nBv[rhs[i]] + 255u) >> 8 : 0u;
+            pair0[i] = u;
+            for (uint32_t t = 0; t < tA; ++t) { upair[u] = (uint32_t)i; utile[u] = t; ++u; }
+            for (uint32_t t = 0; t < tB; ++t) { upair[u] = (uint32_t)i; utile[u] = t | UNIT_B; ++u; }
+        }
+        pair0[npairs] = NU;
     }
-    pair0[npairs] = NU;
-    if (ub >= 0xFFFFFFF0ull) { set_err("batch too large: %llu candidate containers", (unsigned long long)ub); throw (int)RHIP_ERR_ARG; }
     P.NU = NU;
     P.S = NU + 1;
     P.ub_match = ub_match;
@@ -882,8 +894,14 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     c->q[CLS_WAVE].ensure(sizeof(FatItem) * (ub_match + 1));
     c->q[CLS_RUNS].ensure(sizeof(GenItem) * (ub_match + 1));
     c->q[CLS_RETRY].ensure(sizeof(GenItem) * (ub_match + 1));
+    c->q[CLS_PROBE].ensure(sizeof(FatItem) * (ub_match + 1));
     c->q[CLS_COPY].ensure(sizeof(CopyItem) * (P.ub_cand + 1));
     if (cardmode) c->pair_acc.ensure(8 * (npairs + 1));
+    if (!cardmode) {
+        c->o_key.ensure(8 * (ub + 1)); c->o_meta.ensure(8 * (ub + 1)); c->o_off.ensure(8 * (ub + 2));
+        c->o_pair.ensure(4 * (ub + 2));
+        P.CO = CandOut{c->o_key.as<u64>(), c->o_off.as<u64>(), c->o_pair.as<uint32_t>()};
+    }
     char* dp = (char*)c->plan_in.p;
     P.d_pair0 = (u64*)(dp + o_pair0);
     P.d_lhs = (uint32_t*)(dp + o_lhs);
@@ -902,23 +920,33 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     hipLaunchKernelGGL(k_scan, dim3((unsigned)((n_scan + SCAN_TILE - 1) / SCAN_TILE)), dim3(256), 0, s,
                        c->cand.as<uint32_t>(), c->cand_start.as<u64>(), n_scan, P.scan_lb(), P.ranges(), (u64)S);
     EmitQueues Q{c->q[CLS_BB].as<BBItem>(), c->q[CLS_GEN].as<GenItem>(), c->q[CLS_COPY].as<CopyItem>(),
-                 c->q[CLS_FILT].as<FatItem>(), c->q[CLS_WAVE].as<FatItem>(), c->q[CLS_RUNS].as<GenItem>()};
+                 c->q[CLS_FILT].as<FatItem>(), c->q[CLS_WAVE].as<FatItem>(), c->q[CLS_RUNS].as<GenItem>(),
+                 c->q[CLS_PROBE].as<FatItem>()};
     if (NU)
         hipLaunchKernelGGL(k_emit, dim3((unsigned)((NU * 64 + 255) / 256)), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV,
-                           op, cardmode, c->cand_start.as<u64>(), c->match.as<uint32_t>(), CO, Q);
+                           op, cardmode, c->cand_start.as<u64>(), c->match.as<uint32_t>(), P.CO, Q);
     return P;
 }
 
 // The class kernels of one batch are independent of each other (disjoint work queues, disjoint result slots;
 // pair_acc and the retry counter are only touched with atomics), except that the retry pass of k_genw consumes what
 // k_bb and k_runs re-queue.  When more than one class can have work they are forked onto auxiliary streams after
-// planning and joined before the tail, so the latency-bound wave-per-pair kernels overlap each other and the
-// bandwidth-bound copies:
-//     main : k_bb ----------------------> [wait k_runs] k_genw(retry) -> [join] ...
-//     aux0 : k_runs
-//     aux1 : k_filter      aux2 : k_wave      aux3 : k_genw(general), k_copy
+// planning and joined before the tail -- four streams in all, one per hardware queue of the device (more streams
+// would share a queue and serialise again):
+//     main : k_bb --------------------------> [wait k_runs] k_genw(retry) -> [join] k_tail
+//     aux0 : k_runs -> k_genw(general) -> k_copy   few items, long dependent chains; then the pass-through copies
+//     aux1 : k_filter -> k_probe                   and / andnot / cardinality with an array operand
+//     aux2 : k_wave                                or / xor / bitset \ array
 // Item counts live on the device (`ranges`); grids are sized from the host's upper bounds and a class the operand
-// pools cannot produce (type census) is not launched at all.  A bitset-only batch (C2) stays on the main stream.
+// pools cannot produce (type census) is not launched at all.  Except for k_bb the grids are NOT persistent: a wave
+// takes at most ITEMS_PER_WAVE items and its block retires, so the workgroup dispatcher can interleave the blocks of
+// all four queues as slots free up instead of letting the first kernel's long-lived blocks hold every LDS slot.
+// A bitset-only batch (C2) stays on the main stream.
+constexpr unsigned ITEMS_PER_WAVE = 4;
+unsigned bounded_grid(uint64_t ub_items, unsigned max_blocks = 1u << 16) {
+    const uint64_t need = (ub_items + 4 * ITEMS_PER_WAVE - 1) / (4 * ITEMS_PER_WAVE);
+    return (unsigned)std::min<uint64_t>(std::max<uint64_t>(need, 1), max_blocks);
+}
 void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, const OutView& O, const Plan& P,
                  int cardmode) {
     hipStream_t s = c->stream;
@@ -927,9 +955,9 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
     const uint64_t nm = P.ub_match;
     const bool has_bb = P.may_bb && nm, has_runs = P.may_runs && nm, has_filt = P.may_filt && nm;
     const bool has_wave = P.may_wave && nm && !cardmode, has_copy = P.may_copy && P.ub_cand && !cardmode;
-    const int n_classes = (has_bb ? 1 : 0) + (has_runs ? 2 : 0) + (has_filt ? 1 : 0) + (has_wave ? 1 : 0) + (has_copy ? 1 : 0);
+    const int n_classes = (has_bb ? 1 : 0) + (has_runs ? 2 : 0) + (has_filt ? 2 : 0) + (has_wave ? 1 : 0) + (has_copy ? 1 : 0);
     const bool fork = c->overlap && n_classes > 1;
-    bool used[rhip_ctx_s::N_AUX] = {false, false, false, false};
+    bool used[rhip_ctx_s::N_AUX] = {false, false, false};
     auto on = [&](int a) -> hipStream_t {
         if (!fork) return s;
         if (!used[a]) {
@@ -939,33 +967,31 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
         return c->aux[a];
     };
     if (fork) HIPCHK(hipEventRecord(c->ev_fork, s));
-    // largest, latency-bound kernels first so that they get the machine's first workgroup slots
-    if (has_filt) {
-        unsigned grid = persistent_grid(nm, 4, 256 * 4);
-        hipLaunchKernelGGL(k_filter, dim3(grid), dim3(256), 0, on(1), VA.arena, VB.arena, O, c->q[CLS_FILT].as<FatItem>(),
-                           ranges + 2 * SEC_FILT, op, cardmode, c->pair_acc.as<u64>());
-    }
-    if (has_wave) {
-        unsigned grid = persistent_grid(nm, 4, 256 * 4);
-        hipLaunchKernelGGL(k_wave, dim3(grid), dim3(256), 0, on(2), VA.arena, VB.arena, O, c->q[CLS_WAVE].as<FatItem>(),
-                           ranges + 2 * SEC_WAVE, op);
-    }
     if (has_runs) {
-        unsigned grid = persistent_grid(nm, 4, 256 * 4);
         hipStream_t sr = on(0);
-        hipLaunchKernelGGL(k_runs, dim3(grid), dim3(256), 0, sr, VA.arena, VB.arena, O, c->q[CLS_RUNS].as<GenItem>(),
-                           ranges + 2 * SEC_RUNS, op, cardmode, c->pair_acc.as<u64>(), c->q[CLS_RETRY].as<GenItem>(),
-                           retry_count);
+        // the two small classes: few items as a rule, so few blocks (an empty block of a 32 KiB-LDS kernel still
+        // queues for a slot); many items (run-dominant data) simply loop
+        hipLaunchKernelGGL(k_runs, dim3(bounded_grid(nm, 2048)), dim3(256), 0, sr, VA.arena, VB.arena, O,
+                           c->q[CLS_RUNS].as<GenItem>(), ranges + 2 * SEC_RUNS, op, cardmode, c->pair_acc.as<u64>(),
+                           c->q[CLS_RETRY].as<GenItem>(), retry_count);
         if (fork) HIPCHK(hipEventRecord(c->ev_runs, sr));
-        unsigned g2 = persistent_grid(nm, 4, 256 * 2);  // 248 VGPRs: 2 workgroups resident per CU
-        hipLaunchKernelGGL(k_genw, dim3(g2), dim3(256), 0, on(3), VA.arena, VB.arena, O, c->q[CLS_GEN].as<GenItem>(),
-                           ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, cardmode, c->pair_acc.as<u64>());
+        hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 1024)), dim3(256), 0, sr, VA.arena, VB.arena, O,
+                           c->q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, cardmode,
+                           c->pair_acc.as<u64>());
     }
-    if (has_copy) {
-        unsigned grid = persistent_grid(P.ub_cand, 4, 256 * 8);
-        hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, on(3), VA.arena, VB.arena, O, c->q[CLS_COPY].as<CopyItem>(),
-                           ranges + 2 * SEC_COPY);
+    if (has_filt) {
+        hipLaunchKernelGGL(k_filter, dim3(bounded_grid(nm)), dim3(256), 0, on(1), VA.arena, VB.arena, O,
+                           c->q[CLS_FILT].as<FatItem>(), ranges + 2 * SEC_FILT, op, cardmode, c->pair_acc.as<u64>());
+        // short streamed arrays: no LDS, 8 waves per SIMD
+        hipLaunchKernelGGL(k_probe, dim3(bounded_grid(nm)), dim3(256), 0, on(1), VA.arena, VB.arena, O,
+                           c->q[CLS_PROBE].as<FatItem>(), ranges + 2 * SEC_PROBE, op, cardmode, c->pair_acc.as<u64>());
     }
+    if (has_wave)
+        hipLaunchKernelGGL(k_wave, dim3(bounded_grid(nm)), dim3(256), 0, on(2), VA.arena, VB.arena, O,
+                           c->q[CLS_WAVE].as<FatItem>(), ranges + 2 * SEC_WAVE, op);
+    if (has_copy)
+        hipLaunchKernelGGL(k_copy, dim3(bounded_grid(P.ub_cand)), dim3(256), 0, on(has_wave ? 0 : 2), VA.arena, VB.arena, O,
+                           c->q[CLS_COPY].as<CopyItem>(), ranges + 2 * SEC_COPY);
     if (has_bb) {
         unsigned grid = persistent_grid(nm, 4, 256 * 32);
         if (c->timing) HIPCHK(hipEventRecord(c->ev[2], s));
@@ -981,9 +1007,8 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
         // results that need the LDS image path after all: bitset x bitset results that must become
         // arrays (card <= 4096), interval results that must become bitsets
         if (fork && has_runs) HIPCHK(hipStreamWaitEvent(s, c->ev_runs, 0));
-        unsigned g2 = persistent_grid(nm, 4, 256 * 2);
-        hipLaunchKernelGGL(k_genw, dim3(g2), dim3(256), 0, s, VA.arena, VB.arena, O, c->q[CLS_RETRY].as<GenItem>(),
-                           (const u64*)nullptr, retry_count, op, 0, c->pair_acc.as<u64>());
+        hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 1024)), dim3(256), 0, s, VA.arena, VB.arena, O,
+                           c->q[CLS_RETRY].as<GenItem>(), (const u64*)nullptr, retry_count, op, 0, c->pair_acc.as<u64>());
     }
     if (fork)
         for (int a = 0; a < rhip_ctx_s::N_AUX; ++a)
@@ -1001,11 +1026,12 @@ void finish_stats_misc(rhip_ctx_t* c) { finish_stats(c, (const Stats*)((char*)c-
 // the ONE host synchronisation of a call: statistics (and whatever the caller queued before) come back
 void finish_stats(rhip_ctx_t* c, const Stats* dstats, Stats* out, bool had_bb) {
     hipStream_t s = c->stream;
+    // dstats == nullptr: the last kernel of the call already wrote the totals into the pinned area
     if (dstats) HIPCHK(hipMemcpyAsync(c->h_pinned, dstats, sizeof(Stats), hipMemcpyDeviceToHost, s));
     if (c->timing) HIPCHK(hipEventRecord(c->ev[1], s));
     HIPCHK(hipStreamSynchronize(s));
     Stats st{};
-    if (dstats) memcpy(&st, c->h_pinned, sizeof(Stats));
+    memcpy(&st, c->h_pinned, sizeof(Stats));
     if (out) *out = st;
     c->stats.matched_pairs = st.matched_pairs;
     c->stats.passthrough = st.passthrough;
@@ -1038,20 +1064,8 @@ extern "C" rhip_pool_t* rhip_pairwise(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A
         }
         hipStream_t s = c->stream;
         if (c->timing) HIPCHK(hipEventRecord(c->ev[0], s));
-        // upper bounds first (host only), so that every buffer exists before the first launch
-        fetch_bounds(A);
-        fetch_bounds(B);
-        uint64_t ub = 0;
-        for (size_t i = 0; i < npairs; ++i) {
-            const uint64_t nA = A->h_bm_start[lhs[i] + 1] - A->h_bm_start[lhs[i]];
-            const uint64_t nB = B->h_bm_start[rhs[i] + 1] - B->h_bm_start[rhs[i]];
-            ub += op == OP_AND ? std::min(nA, nB) : op == OP_ANDNOT ? nA : nA + nB;
-        }
-        if (ub >= 0xFFFFFFF0ull) { set_err("batch too large: %llu candidate containers", (unsigned long long)ub); throw (int)RHIP_ERR_ARG; }
-        c->o_key.ensure(8 * (ub + 1)); c->o_meta.ensure(8 * (ub + 1)); c->o_off.ensure(8 * (ub + 2));
-        c->o_pair.ensure(4 * (ub + 2));
-        CandOut CO{c->o_key.as<u64>(), c->o_off.as<u64>(), c->o_pair.as<uint32_t>()};
-        Plan P = plan(c, op, A, B, npairs, lhs, rhs, 0, CO);
+        Plan P = plan(c, op, A, B, npairs, lhs, rhs, 0);
+        const CandOut& CO = P.CO;
         R = reuse ? reuse : new rhip_pool_s();
         reuse = nullptr;
         R->ctx = c;
@@ -1072,9 +1086,10 @@ extern "C" rhip_pool_t* rhip_pairwise(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A
         DirOut D{R->bm_start.as<u64>(), R->key.as<u64>(), R->type.as<uint8_t>(), R->card.as<uint32_t>(),
                  R->nruns.as<uint32_t>(), R->off.as<u64>()};
         hipLaunchKernelGGL(k_tail, dim3((unsigned)std::max<uint64_t>(1, (P.ub_cand + TAIL_TILE - 1) / TAIL_TILE)), dim3(256), 0,
-                           s, P.ranges(), CO, O.meta, D, (uint32_t)npairs, P.tail_lb(), P.stats());
+                           s, P.ranges(), CO, O.meta, D, (uint32_t)npairs, P.tail_lb(), P.stats(), P.tail_done(),
+                           (Stats*)c->h_pinned);
         Stats st;
-        finish_stats(c, P.stats(), &st, P.may_bb);
+        finish_stats(c, nullptr, &st, P.may_bb);
         R->n_cont = st.result_containers;
         R->arena_used = st.slot_bytes + 64;
         for (int t = 0; t < 3; ++t) R->census[t] = st.n_type[t] ? 1 : 0;
@@ -1105,14 +1120,13 @@ extern "C" int rhip_pairwise_cardinality(rhip_ctx_t* c, rhip_op op_, rhip_pool_t
             if ((e = rhip_pool_cardinalities(B, cB.data())) != 0) throw e;
         }
         if (c->timing) HIPCHK(hipEventRecord(c->ev[0], s));
-        CandOut CO{nullptr, nullptr, nullptr};
-        Plan P = plan(c, OP_AND, A, B, npairs, lhs, rhs, 1, CO);
+        Plan P = plan(c, OP_AND, A, B, npairs, lhs, rhs, 1);
         OutView O{};
         PoolView VA = A->view(), VB = B->view();
         run_kernels(c, OP_AND, VA, VB, O, P, 1);
-        hipLaunchKernelGGL(k_card_stats, dim3(1), dim3(64), 0, s, P.ranges(), P.stats());
+        hipLaunchKernelGGL(k_card_stats, dim3(1), dim3(64), 0, s, P.ranges(), (Stats*)c->h_pinned);
         if (npairs) HIPCHK(hipMemcpyAsync(out, c->pair_acc.p, 8 * npairs, hipMemcpyDeviceToHost, s));
-        finish_stats(c, P.stats(), nullptr, P.may_bb);
+        finish_stats(c, nullptr, nullptr, P.may_bb);
         for (size_t i = 0; i < npairs; ++i) {
             uint64_t in = out[i];
             switch (op) {

@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256) void k_scan(const uint32_t* __restrict__ in, u
 enum { SEC_CAND = 0, SEC_M = 1, SEC_BB = 2, SEC_GEN = 3, SEC_COPY = 4, SEC_FILT = 5, SEC_WAVE = 6, SEC_RUNS = 7,
        SEC_SLOT = 8,   // result-slot size of the unit's candidates, in 16-byte units
        SEC_BYTES = 9,  // algorithmic input bytes of the unit (payload of matched operands and pass-through containers)
-       N_SEC = 10 };
+       SEC_PROBE = 10,
+       N_SEC = 11 };
 // work class of a matched container pair
 // ia / ib = number of intervals of the operand when it is read as an interval list (runs: n_runs, arrays: card)
 __device__ __forceinline__ int classify(int op, int cardmode, uint8_t ta, uint8_t tb, uint32_t ia, uint32_t ib) {
@@ -125,11 +126,15 @@ __device__ __forceinline__ int classify(int op, int cardmode, uint8_t ta, uint8_
     if ((ta == T_RUN || tb == T_RUN) && ta != T_BITSET && tb != T_BITSET && ia <= RUNS_MAX_INTERVALS &&
         ib <= RUNS_MAX_INTERVALS)
         return CLS_RUNS;
-    // array filtered by membership in an array / bitset: and (either order), array \ x
+    // array filtered by membership in an array / bitset: and (either order), array \ x; a short streamed array
+    // (the smaller one when both are arrays) probes global memory directly, a long one goes through the LDS image
     if (cardmode || op == OP_AND) {
-        if ((ta == T_ARRAY && tb != T_RUN) || (tb == T_ARRAY && ta != T_RUN)) return CLS_FILT;
+        if ((ta == T_ARRAY && tb != T_RUN) || (tb == T_ARRAY && ta != T_RUN)) {
+            const uint32_t ny = (ta == T_ARRAY && tb == T_ARRAY) ? (ia < ib ? ia : ib) : (ta == T_ARRAY ? ia : ib);
+            return ny <= PROBE_MAX ? CLS_PROBE : CLS_FILT;
+        }
     } else if (op == OP_ANDNOT) {
-        if (ta == T_ARRAY && tb != T_RUN) return CLS_FILT;
+        if (ta == T_ARRAY && tb != T_RUN) return ia <= PROBE_MAX ? CLS_PROBE : CLS_FILT;
         if (ta == T_BITSET && tb == T_ARRAY) return CLS_WAVE;  // bitset \ array: clear-list in LDS
     } else {
         if (ta != T_RUN && tb != T_RUN) return CLS_WAVE;       // or / xor with an array operand
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         k[t] = act[t] ? SV.key[s0 + 64 * t + lane] : 0;
     }
     lower_bound4(LV.key, l0, l1, k, act, j);
-    uint32_t matched = 0, nbb = 0, nfilt = 0, nwave = 0, nruns_cls = 0, slot16 = 0, bytes = 0;
+    uint32_t matched = 0, nbb = 0, nfilt = 0, nwave = 0, nruns_cls = 0, nprobe = 0, slot16 = 0, bytes = 0;
     const bool keep_unmatched = bside || !(cardmode || op == OP_AND);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -242,6 +247,7 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         nfilt += (uint32_t)__popcll(__ballot(cls == CLS_FILT));
         nwave += (uint32_t)__popcll(__ballot(cls == CLS_WAVE));
         nruns_cls += (uint32_t)__popcll(__ballot(cls == CLS_RUNS));
+        nprobe += (uint32_t)__popcll(__ballot(cls == CLS_PROBE));
     }
     slot16 = wave_sum(slot16);
     bytes = wave_sum(bytes);
@@ -253,7 +259,8 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         counts[SEC_CAND * S + u] = bside ? ncopy : matched + ncopy;
         counts[SEC_M * S + u] = matched;
         counts[SEC_BB * S + u] = nbb;
-        counts[SEC_GEN * S + u] = bside ? 0u : matched - nbb - nfilt - nwave - nruns_cls;
+        counts[SEC_GEN * S + u] = bside ? 0u : matched - nbb - nfilt - nwave - nruns_cls - nprobe;
+        counts[SEC_PROBE * S + u] = nprobe;
         counts[SEC_RUNS * S + u] = nruns_cls;
         counts[SEC_FILT * S + u] = nfilt;
         counts[SEC_WAVE * S + u] = nwave;
@@ -278,6 +285,7 @@ struct EmitQueues {
     FatItem* filt;  // section SEC_FILT
     FatItem* wave;  // section SEC_WAVE
     GenItem* runs;  // section SEC_RUNS
+    FatItem* probe; // section SEC_PROBE
 };
 struct CandOut {     // candidate (pre-compaction) result directory
     u64* key;        // [cand]
@@ -305,6 +313,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
     u64 qfilt = starts[SEC_FILT * S + u] - starts[SEC_FILT * S];
     u64 qwave = starts[SEC_WAVE * S + u] - starts[SEC_WAVE * S];
     u64 qruns = starts[SEC_RUNS * S + u] - starts[SEC_RUNS * S];
+    u64 qprobe = starts[SEC_PROBE * S + u] - starts[SEC_PROBE * S];
     u64 slot_run = 16ull * (starts[SEC_SLOT * S + u] - starts[SEC_SLOT * S]);  // arena offset of the unit's first slot
     if (!bside) {
         const u64 s0 = a0 + tile * 256;
@@ -359,12 +368,13 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
             const bool isfilt = cls == CLS_FILT;
             const bool iswave = cls == CLS_WAVE;
             const bool isruns = cls == CLS_RUNS;
+            const bool isprobe = cls == CLS_PROBE;
             const bool iscopy = emit && !found;
             const u64 mbb = __ballot(isbb), mgen = __ballot(isgen), mcp = __ballot(iscopy), mfl = __ballot(isfilt);
-            const u64 mwv = __ballot(iswave), mrn = __ballot(isruns);
+            const u64 mwv = __ballot(iswave), mrn = __ballot(isruns), mpr = __ballot(isprobe);
             if (isbb) {
                 BBItem it;
-                it.offa = A.off[ai]; it.offb = B.off[bj]; it.offo = offo; it.out = outidx; it.pad = 0;
+                it.offa = A.off[ai]; it.offb = B.off[bj]; it.offo = offo; it.out = outidx; it.slot = sl;
                 Q.bb[qbb + mbcnt(mbb)] = it;
             }
             if (isgen || isruns) {
@@ -375,12 +385,14 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 if (isgen) Q.gen[qgen + mbcnt(mgen)] = it;
                 else Q.runs[qruns + mbcnt(mrn)] = it;
             }
-            if (isfilt || iswave) {
+            if (isfilt || iswave || isprobe) {
                 FatItem it;
                 it.offa = A.off[ai]; it.offb = B.off[bj]; it.offo = offo;
                 it.out = outidx; it.ca = ca; it.cb = cb; it.types = (uint32_t)ta | ((uint32_t)tb << 8);
+                it.pad0 = 0; it.pad1 = 0;
                 if (isfilt) Q.filt[qfilt + mbcnt(mfl)] = it;
-                else Q.wave[qwave + mbcnt(mwv)] = it;
+                else if (iswave) Q.wave[qwave + mbcnt(mwv)] = it;
+                else Q.probe[qprobe + mbcnt(mpr)] = it;
             }
             if (iscopy) {
                 CopyItem it;
@@ -388,7 +400,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 it.out = outidx; it.n16 = (pa + 15u) >> 4;
                 Q.copy[qcopy + mbcnt(mcp)] = it;
             }
-            qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv); qruns += __popcll(mrn);
+            qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv); qruns += __popcll(mrn); qprobe += __popcll(mpr);
         }
     } else {
         const u64 nAt = (a1 - a0 + 255) / 256;
@@ -445,7 +457,8 @@ struct DirOut {
 // n_cand is read from `ranges` (device), the launch is sized by the host's upper bound.
 constexpr uint32_t TAIL_TILE = 1024;  // candidates per block: 256 threads x 4
 __global__ __launch_bounds__(256) void k_tail(const u64* __restrict__ ranges, CandOut C, const u64* __restrict__ meta,
-                                              DirOut R, uint32_t n_pairs, LbState lb, Stats* __restrict__ stats) {
+                                              DirOut R, uint32_t n_pairs, LbState lb, Stats* __restrict__ stats,
+                                              uint32_t* __restrict__ done, Stats* __restrict__ host_stats) {
     __shared__ u64 sm[4];
     __shared__ uint32_t s_tile;
     __shared__ u64 s_prefix;
@@ -525,14 +538,24 @@ __global__ __launch_bounds__(256) void k_tail(const u64* __restrict__ ranges, Ca
             stats->bytes_in = ranges[2 * SEC_BYTES + 1] - ranges[2 * SEC_BYTES];
             stats->slot_bytes = 16ull * (ranges[2 * SEC_SLOT + 1] - ranges[2 * SEC_SLOT]);
         }
+        // the block that finishes last hands the totals to the host (pinned memory): no copy kernel after the tail
+        __threadfence();
+        if (atomicAdd(done, 1u) == (uint32_t)(n_tiles - 1)) {
+            __threadfence();
+            const volatile u64* sv = (const volatile u64*)stats;
+            u64* hv = (u64*)host_stats;
+            for (uint32_t k = 0; k < sizeof(Stats) / 8; ++k) hv[k] = sv[k];
+        }
     }
 }
 // cardinality mode has no tail: the same statistics from the section totals
-__global__ void k_card_stats(const u64* __restrict__ ranges, Stats* __restrict__ stats) {
+__global__ void k_card_stats(const u64* __restrict__ ranges, Stats* __restrict__ host_stats) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        stats->matched_pairs = ranges[2 * SEC_M + 1] - ranges[2 * SEC_M];
-        stats->n_bb = ranges[2 * SEC_BB + 1] - ranges[2 * SEC_BB];
-        stats->bytes_in = ranges[2 * SEC_BYTES + 1] - ranges[2 * SEC_BYTES];
+        Stats st = {};
+        st.matched_pairs = ranges[2 * SEC_M + 1] - ranges[2 * SEC_M];
+        st.n_bb = ranges[2 * SEC_BB + 1] - ranges[2 * SEC_BB];
+        st.bytes_in = ranges[2 * SEC_BYTES + 1] - ranges[2 * SEC_BYTES];
+        *host_stats = st;
     }
 }
 

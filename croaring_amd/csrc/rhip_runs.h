@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_runs(const uint8_t* __restrict__ arenaA
     constexpr uint32_t NB = 2 * RUNS_MAX_INTERVALS;  // max boundaries per list
     // per wave (~8 KiB): both operand lists staged in LDS (every binary-search probe is an LDS read), the
     // start/end prefix tables of both lists (bit 15 = flag), result starts / ends
-    __shared__ __attribute__((aligned(16))) uint8_t lists_all[4][2][4 * RUNS_MAX_INTERVALS];
+    __shared__ __attribute__((aligned(16))) uint8_t lists_all[4][2][1024];  // 4 * RUNS_MAX_INTERVALS, padded to 16 bytes
     __shared__ uint16_t lds_all[4][4 * (NB + 1) + 2 * NB];
     const uint32_t lane = lane_id();
     uint16_t* base = lds_all[threadIdx.x >> 6];

@@ -1,0 +1,13 @@
+"""Print the kernel timeline of the last batch of each rocprofv3 kernel trace under gpurun_out/prof_r2/<name>."""
+import csv, glob, sys
+for name in sys.argv[1:]:
+    f = glob.glob(f'gpurun_out/prof_r2/{name}/*kernel_trace.csv')[0]
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
+    idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('k_count')]
+    i0, i1 = idx[-2], idx[-1]
+    t0 = int(rows[i0]['Start_Timestamp'])
+    print('==', name)
+    for r in rows[i0:i1]:
+        s = int(r['Start_Timestamp']) - t0; e = int(r['End_Timestamp']) - t0
+        print(f"  {r['Kernel_Name'][:34]:34s} start {s/1e3:8.1f} end {e/1e3:8.1f} dur {(e-s)/1e3:7.1f} us")
+    print('  batch period', (int(rows[i1]['Start_Timestamp']) - t0) / 1e3, 'us')

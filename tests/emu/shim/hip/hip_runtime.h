@@ -194,6 +194,7 @@ static inline unsigned mbcnt(unsigned mask, unsigned add, int hi) {
 
 #define HIPEMU_SITE ((int)(__LINE__ * 131 + sizeof(__FILE__)))
 #define __syncthreads() hipemu::block_sync()
+#define __threadfence() ((void)0)  /* blocks of the emulator run one after another: every write is visible */
 #define __shfl(v, src, ...) hipemu::shfl(HIPEMU_SITE, (v), (src))
 #define __shfl_up(v, d, ...) hipemu::shfl_up(HIPEMU_SITE, (v), (d))
 #define __shfl_down(v, d, ...) hipemu::shfl_down(HIPEMU_SITE, (v), (d))

@@ -188,3 +188,7 @@ def test_emu_sharded_many_partials_and_finalize(emu, oracle, op):
             p.free()
     for h in hs + [want]:
         oracle.free(h)
+
+
+def test_emu_array_filter_probe_boundaries(emu, oracle):
+    G.test_array_filter_probe_boundaries(emu, oracle)

@@ -437,3 +437,49 @@ def test_array_array_union_boundaries(engine, oracle):
                 oracle.free(oo)
     for h in hs:
         oracle.free(h)
+
+
+def test_array_filter_probe_boundaries(engine, oracle):
+    """and / andnot / and_cardinality with an array operand around every boundary of the two filter kernels: streamed
+    side of 1 .. 129 values (k_probe holds at most 128: one or two per lane), probed arrays whose pivot step changes
+    (64 / 65 / 128 / 129 / 4096 values), a bitset partner, values at both ends of the u16 range, hits at pivots and
+    between them, identical and disjoint operands; both operand orders."""
+    rng = np.random.default_rng(99)
+    small = [1, 2, 31, 63, 64, 65, 100, 127, 128, 129, 200]
+    large = [1, 5, 63, 64, 65, 127, 128, 129, 640, 1000, 4095, 4096]
+    cases = []
+    for ny in small:
+        for nx in large:
+            univ = np.sort(rng.choice(65536, min(65536, max(ny, nx) * int(rng.choice([1, 2, 8])) + 8), replace=False))
+            x = np.sort(rng.choice(univ, nx, replace=False))
+            y = np.sort(rng.choice(univ, ny, replace=False))
+            if rng.random() < 0.3:
+                y = np.unique(np.concatenate([y[: max(1, ny // 2)], x[:: max(1, nx // max(1, ny // 2))][: ny // 2 + 1]]))[:ny]
+            if rng.random() < 0.25:
+                x = np.unique(np.concatenate([x, [0, 65535]]))[-nx:] if nx > 2 else x
+                y = np.unique(np.concatenate([y, [0, 65535]]))
+            cases.append((y, x))
+        dense = np.flatnonzero(rng.random(65536) < 0.3)
+        cases.append((np.sort(rng.choice(65536, ny, replace=False)), dense))           # array x bitset
+        cases.append((np.sort(rng.choice(dense, ny, replace=False)), dense))           # all hits
+    ident = np.sort(rng.choice(65536, 128, replace=False))
+    cases += [(ident, ident), (ident[:64], ident), (ident, ident[64:]), (np.arange(100), np.arange(100, 1000))]
+    hs = []
+    for a, b in cases:
+        hs.append(oracle.from_sorted(np.asarray(a, np.uint32) + (3 << 16), run_optimize=False))
+        hs.append(oracle.from_sorted(np.asarray(b, np.uint32) + (3 << 16), run_optimize=False))
+    bufs = [oracle.serialize(h) for h in hs]
+    pool = engine.pool_from_serialized(bufs)
+    n = len(cases)
+    lhs, rhs = np.arange(n, dtype=np.uint32) * 2, np.arange(n, dtype=np.uint32) * 2 + 1
+    for op in ("and", "andnot"):
+        for l, r in ((lhs, rhs), (rhs, lhs)):
+            res = engine.pairwise(op, pool, l, pool, r)
+            cards = engine.pairwise_cardinality(op, pool, l, pool, r)
+            for k in range(n):
+                oo = oracle.op(op, hs[l[k]], hs[r[k]])
+                assert res.serialize(k) == oracle.serialize(oo), (op, k, len(cases[k][0]), len(cases[k][1]))
+                assert cards[k] == oracle.cardinality(oo), (op, k)
+                oracle.free(oo)
+    for h in hs:
+        oracle.free(h)
