@@ -87,6 +87,75 @@ __global__ __launch_bounds__(256) void k_bb(const uint8_t* __restrict__ arenaA, 
     }
 }
 
+// ------------------------------------------------------------------ bitset x bitset -> (mostly) array
+// and / andnot of two bitsets whose result is expected to hold at most 4096 values (three quarters of the bitset pairs
+// of weather_sept_85 under and): one wave per pair reads both operands once, and writes the result in whichever form
+// the reference's rule picks (card <= 4096 -> array via bitset extraction, mixed_intersection.c:305-325,
+// mixed_andnot.c:482-497; else the bitset, straight from registers) -- no second pass over the operands.
+// Lane l holds the 16-byte groups i * 64 + l (i = 0..7): segment i covers values [8192 i, 8192 i + 8192), so the
+// sorted output is segment by segment, inside a segment lane by lane (wave prefix of popcounts), inside a lane bit by
+// bit; values are compacted into a wave-private 8 KiB LDS buffer and leave with coalesced 16-byte stores.
+template <int OP>
+__global__ __launch_bounds__(256) void k_bba(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                             OutView O, const BBItem* __restrict__ q, const u64* __restrict__ qrange) {
+    __shared__ __attribute__((aligned(16))) uint16_t stage_all[4][4096];
+    const uint32_t lane = lane_id();
+    uint16_t* st16 = stage_all[threadIdx.x >> 6];
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
+    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
+        const BBItem t = q[w];
+        const u32x4* __restrict__ pa = (const u32x4*)(arenaA + t.offa);
+        const u32x4* __restrict__ pb = (const u32x4*)(arenaB + t.offb);
+        u32x4 va[8], vb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) va[i] = pa[i * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vb[i] = pb[i * 64 + lane];
+        uint32_t cnt[8], tot = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            va[i] = vop<OP>(va[i], vb[i]);
+            cnt[i] = vpopc(va[i]);
+            tot += cnt[i];
+        }
+        const uint32_t card = wave_sum(tot);
+        uint8_t* outp = O.arena + t.offo;
+        if (card > 4096u) {
+            u32x4* __restrict__ po = (u32x4*)outp;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) po[i * 64 + lane] = va[i];
+            if (lane == 0) O.meta[t.out] = pack_meta(T_BITSET, card, 0);
+            continue;
+        }
+        if (card) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t inc = wave_incl_scan(cnt[i]);
+                uint32_t pos = run + inc - cnt[i];
+                run += __shfl(inc, 63);
+                const uint32_t wd[4] = {va[i].x, va[i].y, va[i].z, va[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t x = wd[j];
+                    const uint32_t vbase = (4u * (i * 64 + lane) + j) * 32u;
+                    while (x) {
+                        st16[pos++] = (uint16_t)(vbase + (__ffs((int)x) - 1));
+                        x &= x - 1;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t n16 = (2u * card + 15u) >> 4;
+            uint4* __restrict__ po = (uint4*)outp;
+            for (uint32_t i = lane; i < n16; i += 64) po[i] = ((const uint4*)st16)[i];
+        }
+        if (lane == 0) O.meta[t.out] = pack_meta(T_ARRAY, card, 0);
+        __builtin_amdgcn_wave_barrier();  // the staging buffer is reused by the next item
+    }
+}
+
 // ------------------------------------------------------------------ pass-through copy
 // One wave per container while the queue is long; the item says where from, where to, how much -- no directory loads.
 __global__ __launch_bounds__(256) void k_copy(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,

@@ -895,6 +895,7 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     c->q[CLS_RUNS].ensure(sizeof(GenItem) * (ub_match + 1));
     c->q[CLS_RETRY].ensure(sizeof(GenItem) * (ub_match + 1));
     c->q[CLS_PROBE].ensure(sizeof(FatItem) * (ub_match + 1));
+    c->q[CLS_BBA].ensure(sizeof(BBItem) * (ub_match + 1));
     c->q[CLS_COPY].ensure(sizeof(CopyItem) * (P.ub_cand + 1));
     if (cardmode) c->pair_acc.ensure(8 * (npairs + 1));
     if (!cardmode) {
@@ -921,7 +922,7 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
                        c->cand.as<uint32_t>(), c->cand_start.as<u64>(), n_scan, P.scan_lb(), P.ranges(), (u64)S);
     EmitQueues Q{c->q[CLS_BB].as<BBItem>(), c->q[CLS_GEN].as<GenItem>(), c->q[CLS_COPY].as<CopyItem>(),
                  c->q[CLS_FILT].as<FatItem>(), c->q[CLS_WAVE].as<FatItem>(), c->q[CLS_RUNS].as<GenItem>(),
-                 c->q[CLS_PROBE].as<FatItem>()};
+                 c->q[CLS_PROBE].as<FatItem>(), c->q[CLS_BBA].as<BBItem>()};
     if (NU)
         hipLaunchKernelGGL(k_emit, dim3((unsigned)((NU * 64 + 255) / 256)), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV,
                            op, cardmode, c->cand_start.as<u64>(), c->match.as<uint32_t>(), P.CO, Q);
@@ -931,17 +932,21 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
 // The class kernels of one batch are independent of each other (disjoint work queues, disjoint result slots;
 // pair_acc and the retry counter are only touched with atomics), except that the retry pass of k_genw consumes what
 // k_bb and k_runs re-queue.  When more than one class can have work they are forked onto auxiliary streams after
-// planning and joined before the tail -- four streams in all, one per hardware queue of the device (more streams
-// would share a queue and serialise again):
-//     main : k_bb --------------------------> [wait k_runs] k_genw(retry) -> [join] k_tail
-//     aux0 : k_runs -> k_genw(general) -> k_copy   few items, long dependent chains; then the pass-through copies
-//     aux1 : k_filter -> k_probe                   and / andnot / cardinality with an array operand
-//     aux2 : k_wave                                or / xor / bitset \ array
+// planning and joined before the tail -- four streams in all, one per hardware queue of the device (a fifth
+// stream shares a queue with another and serialises behind it):
+//     main : k_bb -> [ev_bb] -> k_probe -> k_bba -> k_copy -> [join] -> k_tail      streaming / light classes
+//     aux0 : k_runs -> k_genw(general) -> [wait ev_bb] -> k_genw(retry)              few items, heavy waves
+//     aux1 : k_filter                                                                and / andnot / cardinality
+//     aux2 : k_wave                                                                  or / xor / bitset \ array
+// Schedules that were measured and dropped (profiles/r02_schedule_notes.md): persistent grids for every class (the
+// first kernel's long-lived blocks hold every LDS slot and the others start when it ends); the few-item classes
+// alone before the fork (their 15-75 us then add to every batch); stream priority for aux0 (no effect: a 248-VGPR
+// k_genw workgroup that does not fit is skipped for a k_filter workgroup that does, whatever the priority).
+// k_genw therefore still finishes late next to a machine-filling k_filter / k_wave, but off the critical path.
 // Item counts live on the device (`ranges`); grids are sized from the host's upper bounds and a class the operand
 // pools cannot produce (type census) is not launched at all.  Except for k_bb the grids are NOT persistent: a wave
 // takes at most ITEMS_PER_WAVE items and its block retires, so the workgroup dispatcher can interleave the blocks of
-// all four queues as slots free up instead of letting the first kernel's long-lived blocks hold every LDS slot.
-// A bitset-only batch (C2) stays on the main stream.
+// all four queues as slots free up.  A bitset-only batch (C2) stays on the main stream.
 constexpr unsigned ITEMS_PER_WAVE = 4;
 unsigned bounded_grid(uint64_t ub_items, unsigned max_blocks = 1u << 16) {
     const uint64_t need = (ub_items + 4 * ITEMS_PER_WAVE - 1) / (4 * ITEMS_PER_WAVE);
@@ -955,8 +960,9 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
     const uint64_t nm = P.ub_match;
     const bool has_bb = P.may_bb && nm, has_runs = P.may_runs && nm, has_filt = P.may_filt && nm;
     const bool has_wave = P.may_wave && nm && !cardmode, has_copy = P.may_copy && P.ub_cand && !cardmode;
-    const int n_classes = (has_bb ? 1 : 0) + (has_runs ? 2 : 0) + (has_filt ? 2 : 0) + (has_wave ? 1 : 0) + (has_copy ? 1 : 0);
-    const bool fork = c->overlap && n_classes > 1;
+    const bool has_bba = has_bb && !cardmode && (op == OP_AND || op == OP_ANDNOT);
+    const bool has_retry = !cardmode && ((has_bb && op != OP_OR) || has_runs);
+    const bool fork = c->overlap && (has_runs || has_filt || has_wave);
     bool used[rhip_ctx_s::N_AUX] = {false, false, false};
     auto on = [&](int a) -> hipStream_t {
         if (!fork) return s;
@@ -968,30 +974,21 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
     };
     if (fork) HIPCHK(hipEventRecord(c->ev_fork, s));
     if (has_runs) {
-        hipStream_t sr = on(0);
         // the two small classes: few items as a rule, so few blocks (an empty block of a 32 KiB-LDS kernel still
         // queues for a slot); many items (run-dominant data) simply loop
-        hipLaunchKernelGGL(k_runs, dim3(bounded_grid(nm, 2048)), dim3(256), 0, sr, VA.arena, VB.arena, O,
+        hipLaunchKernelGGL(k_runs, dim3(bounded_grid(nm, 2048)), dim3(256), 0, on(0), VA.arena, VB.arena, O,
                            c->q[CLS_RUNS].as<GenItem>(), ranges + 2 * SEC_RUNS, op, cardmode, c->pair_acc.as<u64>(),
                            c->q[CLS_RETRY].as<GenItem>(), retry_count);
-        if (fork) HIPCHK(hipEventRecord(c->ev_runs, sr));
-        hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 1024)), dim3(256), 0, sr, VA.arena, VB.arena, O,
+        hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 512)), dim3(256), 0, on(0), VA.arena, VB.arena, O,
                            c->q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, cardmode,
                            c->pair_acc.as<u64>());
     }
-    if (has_filt) {
+    if (has_filt)
         hipLaunchKernelGGL(k_filter, dim3(bounded_grid(nm)), dim3(256), 0, on(1), VA.arena, VB.arena, O,
                            c->q[CLS_FILT].as<FatItem>(), ranges + 2 * SEC_FILT, op, cardmode, c->pair_acc.as<u64>());
-        // short streamed arrays: no LDS, 8 waves per SIMD
-        hipLaunchKernelGGL(k_probe, dim3(bounded_grid(nm)), dim3(256), 0, on(1), VA.arena, VB.arena, O,
-                           c->q[CLS_PROBE].as<FatItem>(), ranges + 2 * SEC_PROBE, op, cardmode, c->pair_acc.as<u64>());
-    }
     if (has_wave)
         hipLaunchKernelGGL(k_wave, dim3(bounded_grid(nm)), dim3(256), 0, on(2), VA.arena, VB.arena, O,
                            c->q[CLS_WAVE].as<FatItem>(), ranges + 2 * SEC_WAVE, op);
-    if (has_copy)
-        hipLaunchKernelGGL(k_copy, dim3(bounded_grid(P.ub_cand)), dim3(256), 0, on(has_wave ? 0 : 2), VA.arena, VB.arena, O,
-                           c->q[CLS_COPY].as<CopyItem>(), ranges + 2 * SEC_COPY);
     if (has_bb) {
         unsigned grid = persistent_grid(nm, 4, 256 * 32);
         if (c->timing) HIPCHK(hipEventRecord(c->ev[2], s));
@@ -1002,14 +999,30 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
             default: launch_bb<OP_ANDNOT>(c, grid, VA, VB, O, P, cardmode); break;
         }
         if (c->timing) HIPCHK(hipEventRecord(c->ev[3], s));
+        if (fork && has_retry && has_runs) HIPCHK(hipEventRecord(c->ev_runs, s));  // "k_bb done" for the retry pass on aux0
     }
-    if (!cardmode && ((has_bb && op != OP_OR) || has_runs)) {
+    if (has_retry) {
         // results that need the LDS image path after all: bitset x bitset results that must become
         // arrays (card <= 4096), interval results that must become bitsets
-        if (fork && has_runs) HIPCHK(hipStreamWaitEvent(s, c->ev_runs, 0));
-        hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 1024)), dim3(256), 0, s, VA.arena, VB.arena, O,
+        hipStream_t sr = has_runs ? on(0) : s;
+        if (fork && has_runs && has_bb) HIPCHK(hipStreamWaitEvent(sr, c->ev_runs, 0));
+        hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 512)), dim3(256), 0, sr, VA.arena, VB.arena, O,
                            c->q[CLS_RETRY].as<GenItem>(), (const u64*)nullptr, retry_count, op, 0, c->pair_acc.as<u64>());
     }
+    if (has_filt)  // short streamed arrays: no LDS, 8 waves per SIMD -- co-resides with the LDS-bound kernels
+        hipLaunchKernelGGL(k_probe, dim3(bounded_grid(nm)), dim3(256), 0, s, VA.arena, VB.arena, O,
+                           c->q[CLS_PROBE].as<FatItem>(), ranges + 2 * SEC_PROBE, op, cardmode, c->pair_acc.as<u64>());
+    if (has_bba) {  // bitset pairs expected to give arrays
+        if (op == OP_AND)
+            hipLaunchKernelGGL(k_bba<OP_AND>, dim3(bounded_grid(nm)), dim3(256), 0, s, VA.arena, VB.arena, O,
+                               c->q[CLS_BBA].as<BBItem>(), ranges + 2 * SEC_BBA);
+        else
+            hipLaunchKernelGGL(k_bba<OP_ANDNOT>, dim3(bounded_grid(nm)), dim3(256), 0, s, VA.arena, VB.arena, O,
+                               c->q[CLS_BBA].as<BBItem>(), ranges + 2 * SEC_BBA);
+    }
+    if (has_copy)
+        hipLaunchKernelGGL(k_copy, dim3(bounded_grid(P.ub_cand)), dim3(256), 0, s, VA.arena, VB.arena, O,
+                           c->q[CLS_COPY].as<CopyItem>(), ranges + 2 * SEC_COPY);
     if (fork)
         for (int a = 0; a < rhip_ctx_s::N_AUX; ++a)
             if (used[a]) {

@@ -117,11 +117,19 @@ enum { SEC_CAND = 0, SEC_M = 1, SEC_BB = 2, SEC_GEN = 3, SEC_COPY = 4, SEC_FILT 
        SEC_SLOT = 8,   // result-slot size of the unit's candidates, in 16-byte units
        SEC_BYTES = 9,  // algorithmic input bytes of the unit (payload of matched operands and pass-through containers)
        SEC_PROBE = 10,
-       N_SEC = 11 };
+       SEC_BBA = 11,
+       N_SEC = 12 };
 // work class of a matched container pair
 // ia / ib = number of intervals of the operand when it is read as an interval list (runs: n_runs, arrays: card)
 __device__ __forceinline__ int classify(int op, int cardmode, uint8_t ta, uint8_t tb, uint32_t ia, uint32_t ib) {
-    if (ta == T_BITSET && tb == T_BITSET) return CLS_BB;
+    if (ta == T_BITSET && tb == T_BITSET) {
+        // Two bitsets whose and / andnot is EXPECTED (cardinalities, independence) to fall to <= 4096 values take
+        // the kernel that can emit an array straight away; everything else streams through k_bb, which re-queues
+        // the odd array result.  Either kernel is correct for either outcome: this only picks the cheaper one.
+        if (!cardmode && op == OP_AND && (u64)ia * ib <= 4096ull * 65536ull) return CLS_BBA;
+        if (!cardmode && op == OP_ANDNOT && (u64)ia * (65536u - ib) <= 4096ull * 65536ull) return CLS_BBA;
+        return CLS_BB;
+    }
     // interval algebra in O(n log n) when a run container meets a run / a short array
     if ((ta == T_RUN || tb == T_RUN) && ta != T_BITSET && tb != T_BITSET && ia <= RUNS_MAX_INTERVALS &&
         ib <= RUNS_MAX_INTERVALS)
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         k[t] = act[t] ? SV.key[s0 + 64 * t + lane] : 0;
     }
     lower_bound4(LV.key, l0, l1, k, act, j);
-    uint32_t matched = 0, nbb = 0, nfilt = 0, nwave = 0, nruns_cls = 0, nprobe = 0, slot16 = 0, bytes = 0;
+    uint32_t matched = 0, nbb = 0, nfilt = 0, nwave = 0, nruns_cls = 0, nprobe = 0, nbba = 0, slot16 = 0, bytes = 0;
     const bool keep_unmatched = bside || !(cardmode || op == OP_AND);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -248,6 +256,7 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         nwave += (uint32_t)__popcll(__ballot(cls == CLS_WAVE));
         nruns_cls += (uint32_t)__popcll(__ballot(cls == CLS_RUNS));
         nprobe += (uint32_t)__popcll(__ballot(cls == CLS_PROBE));
+        nbba += (uint32_t)__popcll(__ballot(cls == CLS_BBA));
     }
     slot16 = wave_sum(slot16);
     bytes = wave_sum(bytes);
@@ -259,8 +268,9 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         counts[SEC_CAND * S + u] = bside ? ncopy : matched + ncopy;
         counts[SEC_M * S + u] = matched;
         counts[SEC_BB * S + u] = nbb;
-        counts[SEC_GEN * S + u] = bside ? 0u : matched - nbb - nfilt - nwave - nruns_cls - nprobe;
+        counts[SEC_GEN * S + u] = bside ? 0u : matched - nbb - nfilt - nwave - nruns_cls - nprobe - nbba;
         counts[SEC_PROBE * S + u] = nprobe;
+        counts[SEC_BBA * S + u] = nbba;
         counts[SEC_RUNS * S + u] = nruns_cls;
         counts[SEC_FILT * S + u] = nfilt;
         counts[SEC_WAVE * S + u] = nwave;
@@ -286,6 +296,7 @@ struct EmitQueues {
     FatItem* wave;  // section SEC_WAVE
     GenItem* runs;  // section SEC_RUNS
     FatItem* probe; // section SEC_PROBE
+    BBItem* bba;    // section SEC_BBA
 };
 struct CandOut {     // candidate (pre-compaction) result directory
     u64* key;        // [cand]
@@ -314,6 +325,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
     u64 qwave = starts[SEC_WAVE * S + u] - starts[SEC_WAVE * S];
     u64 qruns = starts[SEC_RUNS * S + u] - starts[SEC_RUNS * S];
     u64 qprobe = starts[SEC_PROBE * S + u] - starts[SEC_PROBE * S];
+    u64 qbba = starts[SEC_BBA * S + u] - starts[SEC_BBA * S];
     u64 slot_run = 16ull * (starts[SEC_SLOT * S + u] - starts[SEC_SLOT * S]);  // arena offset of the unit's first slot
     if (!bside) {
         const u64 s0 = a0 + tile * 256;
@@ -364,6 +376,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
             const uint32_t outidx = cardmode ? p : (uint32_t)(base + pos);
             const int cls = (emit && found) ? classify(op, cardmode, ta, tb, ta == T_RUN ? nra : ca, tb == T_RUN ? nrb : cb) : -1;
             const bool isbb = cls == CLS_BB;
+            const bool isbba = cls == CLS_BBA;
             const bool isgen = cls == CLS_GEN;
             const bool isfilt = cls == CLS_FILT;
             const bool iswave = cls == CLS_WAVE;
@@ -371,11 +384,12 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
             const bool isprobe = cls == CLS_PROBE;
             const bool iscopy = emit && !found;
             const u64 mbb = __ballot(isbb), mgen = __ballot(isgen), mcp = __ballot(iscopy), mfl = __ballot(isfilt);
-            const u64 mwv = __ballot(iswave), mrn = __ballot(isruns), mpr = __ballot(isprobe);
-            if (isbb) {
+            const u64 mwv = __ballot(iswave), mrn = __ballot(isruns), mpr = __ballot(isprobe), mba = __ballot(isbba);
+            if (isbb || isbba) {
                 BBItem it;
                 it.offa = A.off[ai]; it.offb = B.off[bj]; it.offo = offo; it.out = outidx; it.slot = sl;
-                Q.bb[qbb + mbcnt(mbb)] = it;
+                if (isbb) Q.bb[qbb + mbcnt(mbb)] = it;
+                else Q.bba[qbba + mbcnt(mba)] = it;
             }
             if (isgen || isruns) {
                 GenItem it;
@@ -400,7 +414,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 it.out = outidx; it.n16 = (pa + 15u) >> 4;
                 Q.copy[qcopy + mbcnt(mcp)] = it;
             }
-            qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv); qruns += __popcll(mrn); qprobe += __popcll(mpr);
+            qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv); qruns += __popcll(mrn); qprobe += __popcll(mpr); qbba += __popcll(mba);
         }
     } else {
         const u64 nAt = (a1 - a0 + 255) / 256;
@@ -455,7 +469,8 @@ struct DirOut {
 // the result directory.  A thread that sees the first candidate of a result bitmap (or a gap of bitmaps with no
 // candidates) writes the bitmap starts; the block holding the last candidate finishes them and the totals.
 // n_cand is read from `ranges` (device), the launch is sized by the host's upper bound.
-constexpr uint32_t TAIL_TILE = 1024;  // candidates per block: 256 threads x 4
+constexpr uint32_t TAIL_PER_THREAD = 8;
+constexpr uint32_t TAIL_TILE = 256 * TAIL_PER_THREAD;  // candidates per block
 __global__ __launch_bounds__(256) void k_tail(const u64* __restrict__ ranges, CandOut C, const u64* __restrict__ meta,
                                               DirOut R, uint32_t n_pairs, LbState lb, Stats* __restrict__ stats,
                                               uint32_t* __restrict__ done, Stats* __restrict__ host_stats) {
@@ -470,11 +485,11 @@ __global__ __launch_bounds__(256) void k_tail(const u64* __restrict__ ranges, Ca
     const uint32_t tile = s_tile;
     const u64 n_tiles = n ? (n + TAIL_TILE - 1) / TAIL_TILE : 1;
     if (tile >= n_tiles) return;
-    const u64 base = (u64)tile * TAIL_TILE + 4ull * threadIdx.x;
-    u64 m[4];
+    const u64 base = (u64)tile * TAIL_TILE + (u64)TAIL_PER_THREAD * threadIdx.x;
+    u64 m[TAIL_PER_THREAD];
     uint32_t keep = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < (int)TAIL_PER_THREAD; ++k) {
         m[k] = base + k < n ? meta[base + k] : 0;
         keep += meta_card(m[k]) ? 1u : 0u;
     }
@@ -486,7 +501,7 @@ __global__ __launch_bounds__(256) void k_tail(const u64* __restrict__ ranges, Ca
     u64 bytes = 0;
     uint32_t nty[3] = {0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < (int)TAIL_PER_THREAD; ++k) {
         const u64 i = base + k;
         if (i < n) {
             // result bitmaps starting at candidate i: every pair in (pair of candidate i-1, pair of candidate i]
@@ -534,7 +549,7 @@ __global__ __launch_bounds__(256) void k_tail(const u64* __restrict__ ranges, Ca
             stats->n_cand = n;
             stats->matched_pairs = ranges[2 * SEC_M + 1] - ranges[2 * SEC_M];
             stats->passthrough = ranges[2 * SEC_COPY + 1] - ranges[2 * SEC_COPY];
-            stats->n_bb = ranges[2 * SEC_BB + 1] - ranges[2 * SEC_BB];
+            stats->n_bb = ranges[2 * SEC_BB + 1] - ranges[2 * SEC_BB] + ranges[2 * SEC_BBA + 1] - ranges[2 * SEC_BBA];
             stats->bytes_in = ranges[2 * SEC_BYTES + 1] - ranges[2 * SEC_BYTES];
             stats->slot_bytes = 16ull * (ranges[2 * SEC_SLOT + 1] - ranges[2 * SEC_SLOT]);
         }
