@@ -192,3 +192,11 @@ def test_emu_sharded_many_partials_and_finalize(emu, oracle, op):
 
 def test_emu_array_filter_probe_boundaries(emu, oracle):
     G.test_array_filter_probe_boundaries(emu, oracle)
+
+
+def test_emu_array_array_union_boundaries(emu, oracle):
+    G.test_array_array_union_boundaries(emu, oracle)
+
+
+def test_emu_tiny_interval_pairs(emu, oracle):
+    G.test_tiny_interval_pairs(emu, oracle)

@@ -483,3 +483,47 @@ def test_array_filter_probe_boundaries(engine, oracle):
                 oracle.free(oo)
     for h in hs:
         oracle.free(h)
+
+
+def test_tiny_interval_pairs(engine, oracle):
+    """Short interval lists (the k_tiny thread-per-pair sweep and its hand-over to k_runs): run containers of 1 .. 70
+    runs and arrays of 1 .. 70 values around every classification boundary (64 / 65 intervals; array cardinality
+    31 / 32 / 33 under xor; run cardinality 32 / 33 under andnot), touching and nested intervals, both ends of the
+    u16 range, full containers; four ops + cardinalities, both operand orders."""
+    rng = np.random.default_rng(314)
+
+    def runs(k, maxlen):
+        cuts = np.sort(rng.choice(65536, 2 * k, replace=False))
+        parts = [np.arange(cuts[2 * i], min(cuts[2 * i + 1], cuts[2 * i] + maxlen) + 1) for i in range(k)]
+        return np.unique(np.concatenate(parts))
+
+    shapes = []
+    for k in (1, 2, 3, 8, 16, 31, 32, 33, 63, 64, 65, 70):
+        shapes.append(("run", runs(k, 400)))
+        shapes.append(("run", runs(k, 2)))
+        shapes.append(("arr", np.sort(rng.choice(65536, k, replace=False))))
+        shapes.append(("arr", np.sort(rng.choice(2000, k, replace=False)) + 30000))
+    shapes += [("run", np.arange(65536)), ("run", np.arange(0, 33)), ("run", np.arange(0, 32)),
+               ("run", np.concatenate([np.arange(0, 10), np.arange(65500, 65536)])),
+               ("arr", np.array([0, 65535])), ("arr", np.array([9, 10, 65499, 65500])),
+               ("run", np.concatenate([np.arange(100, 200), np.arange(201, 300), np.arange(301, 5000)]))]
+    hs = [oracle.from_sorted(np.asarray(v, np.uint32) + (9 << 16), run_optimize=(kind == "run")) for kind, v in shapes]
+    bufs = [oracle.serialize(h) for h in hs]
+    pool = engine.pool_from_serialized(bufs)
+    n = len(hs)
+    lhs, rhs = np.meshgrid(np.arange(n, dtype=np.uint32), np.arange(n, dtype=np.uint32))
+    lhs, rhs = lhs.ravel().copy(), rhs.ravel().copy()
+    for op in OPS:
+        res = engine.pairwise(op, pool, lhs, pool, rhs)
+        cards = engine.pairwise_cardinality(op, pool, lhs, pool, rhs)
+        blob, offs = res.serialize_many()
+        raw = blob.tobytes()
+        bad = []
+        for k in range(lhs.size):
+            oo = oracle.op(op, hs[lhs[k]], hs[rhs[k]])
+            if raw[int(offs[k]):int(offs[k + 1])] != oracle.serialize(oo) or cards[k] != oracle.cardinality(oo):
+                bad.append((int(lhs[k]), int(rhs[k])))
+            oracle.free(oo)
+        assert not bad, f"{op}: {len(bad)} mismatching pairs, first {bad[:6]}"
+    for h in hs:
+        oracle.free(h)
