@@ -760,7 +760,7 @@ struct Plan {
     PlanScratch sc;
     size_t npairs = 0, NU = 0, S = 0;
     uint64_t ub_match = 0, ub_cand = 0, arena_bound = 0;
-    bool may_bb = true, may_filt = true, may_wave = true, may_runs = true, may_copy = true, may_tiny = true;
+    bool may_bb = true, may_filt = true, may_wave = true, may_runs = true, may_copy = true;
     // device pointers
     uint32_t *d_lhs = nullptr, *d_rhs = nullptr, *d_upair = nullptr, *d_utile = nullptr;
     u64* d_pair0 = nullptr;
@@ -866,7 +866,6 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     const bool aB = has(A, 0), aA = has(A, 1), aR = has(A, 2), bB = has(B, 0), bA = has(B, 1), bR = has(B, 2);
     P.may_bb = aB && bB;
     P.may_runs = aR || bR;  // interval class and the general image class
-    P.may_tiny = aR || bR || (!cardmode && (op == OP_OR || op == OP_XOR) && aA && bA);
     if (cardmode || op == OP_AND) {
         P.may_filt = (aA && (bA || bB)) || (bA && (aA || aB));
         P.may_wave = false;
@@ -897,7 +896,6 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     c->q[CLS_RETRY].ensure(sizeof(GenItem) * (ub_match + 1));
     c->q[CLS_PROBE].ensure(sizeof(FatItem) * (ub_match + 1));
     c->q[CLS_BBA].ensure(sizeof(BBItem) * (ub_match + 1));
-    c->q[CLS_TINY].ensure(sizeof(GenItem) * (ub_match + 1));
     c->q[CLS_COPY].ensure(sizeof(CopyItem) * (P.ub_cand + 1));
     if (cardmode) c->pair_acc.ensure(8 * (npairs + 1));
     if (!cardmode) {
@@ -924,7 +922,7 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
                        c->cand.as<uint32_t>(), c->cand_start.as<u64>(), n_scan, P.scan_lb(), P.ranges(), (u64)S);
     EmitQueues Q{c->q[CLS_BB].as<BBItem>(), c->q[CLS_GEN].as<GenItem>(), c->q[CLS_COPY].as<CopyItem>(),
                  c->q[CLS_FILT].as<FatItem>(), c->q[CLS_WAVE].as<FatItem>(), c->q[CLS_RUNS].as<GenItem>(),
-                 c->q[CLS_PROBE].as<FatItem>(), c->q[CLS_BBA].as<BBItem>(), c->q[CLS_TINY].as<GenItem>()};
+                 c->q[CLS_PROBE].as<FatItem>(), c->q[CLS_BBA].as<BBItem>()};
     if (NU)
         hipLaunchKernelGGL(k_emit, dim3((unsigned)((NU * 64 + 255) / 256)), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV,
                            op, cardmode, c->cand_start.as<u64>(), c->match.as<uint32_t>(), P.CO, Q);
@@ -936,7 +934,7 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
 // k_bb and k_runs re-queue.  When more than one class can have work they are forked onto auxiliary streams after
 // planning and joined before the tail -- four streams in all, one per hardware queue of the device (a fifth
 // stream shares a queue with another and serialises behind it):
-//     main : k_bb -> k_tiny -> [ev_bb] -> k_probe -> k_bba -> k_copy -> [join] -> k_tail      streaming / light classes
+//     main : k_bb -> [ev_bb] -> k_probe -> k_bba -> k_copy -> [join] -> k_tail      streaming / light classes
 //     aux0 : k_runs -> k_genw(general) -> [wait ev_bb] -> k_genw(retry)              few items, heavy waves
 //     aux1 : k_filter                                                                and / andnot / cardinality
 //     aux2 : k_wave                                                                  or / xor / bitset \ array
@@ -963,7 +961,7 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
     const bool has_bb = P.may_bb && nm, has_runs = P.may_runs && nm, has_filt = P.may_filt && nm;
     const bool has_wave = P.may_wave && nm && !cardmode, has_copy = P.may_copy && P.ub_cand && !cardmode;
     const bool has_bba = has_bb && !cardmode && (op == OP_AND || op == OP_ANDNOT);
-    const bool has_retry = !cardmode && ((has_bb && op != OP_OR) || has_runs);  // (k_tiny never re-queues in practice)
+    const bool has_retry = !cardmode && ((has_bb && op != OP_OR) || has_runs);
     const bool fork = c->overlap && (has_runs || has_filt || has_wave);
     bool used[rhip_ctx_s::N_AUX] = {false, false, false};
     auto on = [&](int a) -> hipStream_t {
@@ -1001,18 +999,13 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
             default: launch_bb<OP_ANDNOT>(c, grid, VA, VB, O, P, cardmode); break;
         }
         if (c->timing) HIPCHK(hipEventRecord(c->ev[3], s));
+        if (fork && has_retry && has_runs) HIPCHK(hipEventRecord(c->ev_runs, s));  // "k_bb done" for the retry pass on aux0
     }
-    if (P.may_tiny && nm)  // short interval pairs, one thread each: no LDS, co-resides with anything
-        hipLaunchKernelGGL(k_tiny, dim3((unsigned)std::min<uint64_t>((nm + 255) / 256, 4096)), dim3(256), 0, s, VA.arena,
-                           VB.arena, O, c->q[CLS_TINY].as<GenItem>(), ranges + 2 * SEC_TINY, op, cardmode,
-                           c->pair_acc.as<u64>(), c->q[CLS_RETRY].as<GenItem>(), retry_count);
-    // "every producer of retry items on the main stream is done" for the retry pass on aux0
-    if (fork && has_retry && has_runs && (has_bb || (P.may_tiny && nm))) HIPCHK(hipEventRecord(c->ev_runs, s));
     if (has_retry) {
         // results that need the LDS image path after all: bitset x bitset results that must become
         // arrays (card <= 4096), interval results that must become bitsets
         hipStream_t sr = has_runs ? on(0) : s;
-        if (fork && has_runs && (has_bb || (P.may_tiny && nm))) HIPCHK(hipStreamWaitEvent(sr, c->ev_runs, 0));
+        if (fork && has_runs && has_bb) HIPCHK(hipStreamWaitEvent(sr, c->ev_runs, 0));
         hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 512)), dim3(256), 0, sr, VA.arena, VB.arena, O,
                            c->q[CLS_RETRY].as<GenItem>(), (const u64*)nullptr, retry_count, op, 0, c->pair_acc.as<u64>());
     }

@@ -118,24 +118,10 @@ enum { SEC_CAND = 0, SEC_M = 1, SEC_BB = 2, SEC_GEN = 3, SEC_COPY = 4, SEC_FILT 
        SEC_BYTES = 9,  // algorithmic input bytes of the unit (payload of matched operands and pass-through containers)
        SEC_PROBE = 10,
        SEC_BBA = 11,
-       SEC_TINY = 12,
-       N_SEC = 13 };
+       N_SEC = 12 };
 // work class of a matched container pair
 // ia / ib = number of intervals of the operand when it is read as an interval list (runs: n_runs, arrays: card)
-// ca / cb = cardinalities
-__device__ __forceinline__ int classify(int op, int cardmode, uint8_t ta, uint8_t tb, uint32_t ia, uint32_t ib,
-                                        uint32_t ca, uint32_t cb) {
-    // Two short interval lists (<= TINY_MAX runs / values each, no bitset): one THREAD sweeps the pair.  Taken for
-    // every run pair and for or / xor of two short arrays, except where the reference's typing can ask for a large
-    // array out of a short list (run \ array with a big run, xor of a run with an array of >= 32 values).
-    if (ta != T_BITSET && tb != T_BITSET && ia <= TINY_MAX && ib <= TINY_MAX) {
-        const bool any_run = ta == T_RUN || tb == T_RUN;
-        const int eff_op = cardmode ? OP_AND : op;
-        bool ok = any_run || (!cardmode && (op == OP_OR || op == OP_XOR));
-        if (eff_op == OP_ANDNOT && ta == T_RUN && tb == T_ARRAY && ca > 32u) ok = false;
-        if (eff_op == OP_XOR && any_run && (ta == T_ARRAY ? ca : (tb == T_ARRAY ? cb : 0u)) >= 32u) ok = false;
-        if (ok) return CLS_TINY;
-    }
+__device__ __forceinline__ int classify(int op, int cardmode, uint8_t ta, uint8_t tb, uint32_t ia, uint32_t ib) {
     if (ta == T_BITSET && tb == T_BITSET) {
         // Two bitsets whose and / andnot is EXPECTED (cardinalities, independence) to fall to <= 4096 values take
         // the kernel that can emit an array straight away; everything else streams through k_bb, which re-queues
@@ -240,7 +226,7 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         k[t] = act[t] ? SV.key[s0 + 64 * t + lane] : 0;
     }
     lower_bound4(LV.key, l0, l1, k, act, j);
-    uint32_t matched = 0, nbb = 0, nfilt = 0, nwave = 0, nruns_cls = 0, nprobe = 0, nbba = 0, ntiny = 0, slot16 = 0, bytes = 0;
+    uint32_t matched = 0, nbb = 0, nfilt = 0, nwave = 0, nruns_cls = 0, nprobe = 0, nbba = 0, slot16 = 0, bytes = 0;
     const bool keep_unmatched = bside || !(cardmode || op == OP_AND);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -257,7 +243,7 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
                 const uint8_t tl = LV.type[j[t]];
                 const uint32_t cl = LV.card[j[t]], nl = LV.nruns[j[t]];
                 bytes += payload_bytes(tl, cl, nl);
-                cls = classify(op, cardmode, ts, tl, ts == T_RUN ? ns : cs, tl == T_RUN ? nl : cl, cs, cl);
+                cls = classify(op, cardmode, ts, tl, ts == T_RUN ? ns : cs, tl == T_RUN ? nl : cl);
                 if (!cardmode) slot16 += matched_slot(op, cs, cl) >> 4;
             } else if (!cardmode) {
                 const uint32_t sl = align16(ps) >> 4;
@@ -271,7 +257,6 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         nruns_cls += (uint32_t)__popcll(__ballot(cls == CLS_RUNS));
         nprobe += (uint32_t)__popcll(__ballot(cls == CLS_PROBE));
         nbba += (uint32_t)__popcll(__ballot(cls == CLS_BBA));
-        ntiny += (uint32_t)__popcll(__ballot(cls == CLS_TINY));
     }
     slot16 = wave_sum(slot16);
     bytes = wave_sum(bytes);
@@ -283,10 +268,9 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         counts[SEC_CAND * S + u] = bside ? ncopy : matched + ncopy;
         counts[SEC_M * S + u] = matched;
         counts[SEC_BB * S + u] = nbb;
-        counts[SEC_GEN * S + u] = bside ? 0u : matched - nbb - nfilt - nwave - nruns_cls - nprobe - nbba - ntiny;
+        counts[SEC_GEN * S + u] = bside ? 0u : matched - nbb - nfilt - nwave - nruns_cls - nprobe - nbba;
         counts[SEC_PROBE * S + u] = nprobe;
         counts[SEC_BBA * S + u] = nbba;
-        counts[SEC_TINY * S + u] = ntiny;
         counts[SEC_RUNS * S + u] = nruns_cls;
         counts[SEC_FILT * S + u] = nfilt;
         counts[SEC_WAVE * S + u] = nwave;
@@ -313,7 +297,6 @@ struct EmitQueues {
     GenItem* runs;  // section SEC_RUNS
     FatItem* probe; // section SEC_PROBE
     BBItem* bba;    // section SEC_BBA
-    GenItem* tiny;  // section SEC_TINY
 };
 struct CandOut {     // candidate (pre-compaction) result directory
     u64* key;        // [cand]
@@ -343,7 +326,6 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
     u64 qruns = starts[SEC_RUNS * S + u] - starts[SEC_RUNS * S];
     u64 qprobe = starts[SEC_PROBE * S + u] - starts[SEC_PROBE * S];
     u64 qbba = starts[SEC_BBA * S + u] - starts[SEC_BBA * S];
-    u64 qtiny = starts[SEC_TINY * S + u] - starts[SEC_TINY * S];
     u64 slot_run = 16ull * (starts[SEC_SLOT * S + u] - starts[SEC_SLOT * S]);  // arena offset of the unit's first slot
     if (!bside) {
         const u64 s0 = a0 + tile * 256;
@@ -392,10 +374,9 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 O.pair[base + pos] = p;
             }
             const uint32_t outidx = cardmode ? p : (uint32_t)(base + pos);
-            const int cls = (emit && found) ? classify(op, cardmode, ta, tb, ta == T_RUN ? nra : ca, tb == T_RUN ? nrb : cb, ca, cb) : -1;
+            const int cls = (emit && found) ? classify(op, cardmode, ta, tb, ta == T_RUN ? nra : ca, tb == T_RUN ? nrb : cb) : -1;
             const bool isbb = cls == CLS_BB;
             const bool isbba = cls == CLS_BBA;
-            const bool istiny = cls == CLS_TINY;
             const bool isgen = cls == CLS_GEN;
             const bool isfilt = cls == CLS_FILT;
             const bool iswave = cls == CLS_WAVE;
@@ -404,21 +385,19 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
             const bool iscopy = emit && !found;
             const u64 mbb = __ballot(isbb), mgen = __ballot(isgen), mcp = __ballot(iscopy), mfl = __ballot(isfilt);
             const u64 mwv = __ballot(iswave), mrn = __ballot(isruns), mpr = __ballot(isprobe), mba = __ballot(isbba);
-            const u64 mty = __ballot(istiny);
             if (isbb || isbba) {
                 BBItem it;
                 it.offa = A.off[ai]; it.offb = B.off[bj]; it.offo = offo; it.out = outidx; it.slot = sl;
                 if (isbb) Q.bb[qbb + mbcnt(mbb)] = it;
                 else Q.bba[qbba + mbcnt(mba)] = it;
             }
-            if (isgen || isruns || istiny) {
+            if (isgen || isruns) {
                 GenItem it;
                 it.offa = A.off[ai]; it.offb = B.off[bj];
                 it.out = outidx; it.ca = ca; it.cb = cb; it.types = (uint32_t)ta | ((uint32_t)tb << 8);
                 it.nra = nra; it.nrb = nrb; it.offo = offo;
                 if (isgen) Q.gen[qgen + mbcnt(mgen)] = it;
-                else if (isruns) Q.runs[qruns + mbcnt(mrn)] = it;
-                else Q.tiny[qtiny + mbcnt(mty)] = it;
+                else Q.runs[qruns + mbcnt(mrn)] = it;
             }
             if (isfilt || iswave || isprobe) {
                 FatItem it;
@@ -435,7 +414,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 it.out = outidx; it.n16 = (pa + 15u) >> 4;
                 Q.copy[qcopy + mbcnt(mcp)] = it;
             }
-            qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv); qruns += __popcll(mrn); qprobe += __popcll(mpr); qbba += __popcll(mba); qtiny += __popcll(mty);
+            qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv); qruns += __popcll(mrn); qprobe += __popcll(mpr); qbba += __popcll(mba);
         }
     } else {
         const u64 nAt = (a1 - a0 + 255) / 256;

@@ -193,89 +193,6 @@ __global__ __launch_bounds__(256) void k_runs(const uint8_t* __restrict__ arenaA
     }
 }
 
-// ------------------------------------------------------------------ short interval pairs: one THREAD per pair
-// wikileaks-style data is run containers of a few dozen intervals at most, census-style data has many arrays of a
-// handful of values: a 64-lane wave per such pair is 95 % idle lanes and ~400 instructions of wave machinery.  Here
-// one THREAD owns a pair (64 pairs per wave): it sweeps the two sorted boundary lists (runs: s, e+1; array values
-// as unit intervals: v, v+1) with two cursors, toggling "inside A" / "inside B" at every boundary and opening /
-// closing a result run whenever op(inA, inB) changes -- the sequential interval merges of
-// run_container_{union,intersection,xor,andnot} (src/containers/run.c:231-283, 348-463, 575-633) and the array x run
-// forms (mixed_intersection.c:73-111, mixed_union.c:66-108, mixed_andnot.c:277-412, mixed_xor.c:140-173), which
-// are exactly this loop on the CPU.  The sweep yields canonical runs (touching intervals merge because the predicate
-// does not change across them).  Two sweeps: the first counts (cardinality, runs) so that the reference's typing
-// rule can be applied (decide_type), the second writes the slot in the chosen form -- runs, or values expanded into
-// an array (short by construction: classify() keeps pairs that could demand a long array away from this kernel).
-struct TinyList {
-    const uint8_t* p;
-    uint32_t n2;  // boundaries = 2 x intervals
-    bool is_run;
-    __device__ __forceinline__ uint32_t at(uint32_t j) const {
-        if (is_run) {
-            const uint32_t w = ((const uint32_t*)p)[j >> 1];
-            const uint32_t s = w & 0xFFFFu;
-            return (j & 1u) ? s + (w >> 16) + 1u : s;
-        }
-        return (uint32_t)((const uint16_t*)p)[j >> 1] + (j & 1u);
-    }
-};
-template <class F>
-__device__ __forceinline__ void tiny_sweep(const TinyList& A, const TinyList& B, int op, F&& on_run) {
-    constexpr uint32_t SENT = 0x20000u;  // past every boundary (the largest is 65536)
-    uint32_t ia = 0, ib = 0, inA = 0, inB = 0, start = 0;
-    bool f = false;
-    uint32_t pa = A.n2 ? A.at(0) : SENT, pb = B.n2 ? B.at(0) : SENT;
-    while (pa != SENT || pb != SENT) {
-        const uint32_t p = pa < pb ? pa : pb;
-        while (pa == p) { inA ^= 1u; ++ia; pa = ia < A.n2 ? A.at(ia) : SENT; }
-        while (pb == p) { inB ^= 1u; ++ib; pb = ib < B.n2 ? B.at(ib) : SENT; }
-        const bool nf = bop(op, inA, inB);
-        if (nf != f) {
-            if (nf) start = p;
-            else on_run(start, p - 1u);
-            f = nf;
-        }
-    }
-}
-__global__ __launch_bounds__(256) void k_tiny(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
-                                              OutView O, const GenItem* __restrict__ q,
-                                              const u64* __restrict__ qrange, int op, int cardmode, u64* pair_acc,
-                                              GenItem* retry_q, uint32_t* retry_count) {
-    const u64 n = qrange[1] - qrange[0];
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
-        const GenItem t = q[i];
-        const uint32_t ta = t.types & 0xFFu, tb = t.types >> 8;
-        TinyList A, B;
-        A.p = arenaA + t.offa; A.is_run = ta == T_RUN; A.n2 = 2u * (ta == T_RUN ? t.nra : t.ca);
-        B.p = arenaB + t.offb; B.is_run = tb == T_RUN; B.n2 = 2u * (tb == T_RUN ? t.nrb : t.cb);
-        uint32_t rc = 0, rn = 0;
-        tiny_sweep(A, B, op, [&](uint32_t s, uint32_t e) { rc += e - s + 1u; ++rn; });
-        if (cardmode) {
-            if (rc) atomicAdd(&pair_acc[t.out], (u64)rc);
-            continue;
-        }
-        const bool fulla = ta == T_RUN && t.ca == 65536u, fullb = tb == T_RUN && t.cb == 65536u;
-        int ty = T_ARRAY;
-        if (rc) ty = decide_type(op, (int)ta, (int)tb, t.ca, t.cb, fulla, fullb, rc, rn);
-        if (rc && ty == T_BITSET) {  // cannot happen for the pairs classify() sends here; kept for safety
-            retry_q[atomicAdd(retry_count, 1u)] = t;
-            continue;
-        }
-        uint8_t* outp = O.arena + t.offo;
-        if (rc && ty == T_RUN) {
-            uint32_t* o32 = (uint32_t*)outp;
-            uint32_t k = 0;
-            tiny_sweep(A, B, op, [&](uint32_t s, uint32_t e) { o32[k++] = s | ((e - s) << 16); });
-        } else if (rc) {
-            uint16_t* o16 = (uint16_t*)outp;
-            uint32_t k = 0;
-            tiny_sweep(A, B, op, [&](uint32_t s, uint32_t e) {
-                for (uint32_t v = s; v <= e; ++v) o16[k++] = (uint16_t)v;
-            });
-        }
-        O.meta[t.out] = pack_meta(ty, rc, (ty == T_RUN) ? rn : 0u);
-    }
-}
-
 // ------------------------------------------------------------------ wave-level general pair kernel (K5, K7, K13-K16)
 // Every type pair the specialised kernels do not take (all pairs with a run container, plus
 // bitset x bitset results that must become arrays): ONE WAVE per container pair, two wave-private
