@@ -10,8 +10,10 @@
 
 struct FlipBm {          // per bitmap, computed by the host from the directory mirror
     u64 c0, lo, hi, c1;  // source containers [c0, c1); [lo, hi) are those whose keys lie in [ks, ke]
-    uint32_t ks, nk;     // first key of the range, number of keys in it (0: nothing to flip, pure copy)
+    u64 ks;              // first key of the range (16-bit keys for 32-bit pools, 48-bit keys for 64-bit pools)
+    uint32_t nk;         // number of keys in it (0: nothing to flip, pure copy)
     uint32_t s_low, e_low;  // low 16 bits of the first / last flipped value (closed range)
+    uint32_t pad;
 };
 struct FlipWork {
     uint32_t src;    // source container (NONE32: the source has no container under this key)
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void k_flip_plan(PoolView P, const FlipBm* __r
         w.range = FLIP_COPY;
     } else {
         const uint32_t t = (uint32_t)(local - n_before);
-        key = (u64)F.ks + t;
+        key = F.ks + t;
         const u64 c = lower_bound(P.key, F.lo, F.hi, key);
         const bool present = c < F.hi && P.key[c] == key;
         const uint32_t flo = t == 0 ? F.s_low : 0u, fhi = t == F.nk - 1 ? F.e_low : 65535u;

@@ -179,7 +179,10 @@ rhip_pool_t *rhip_pool_remove_run_compression(rhip_ctx_t *ctx, rhip_pool_t *pool
  * negated on [starts[i], ends[i]) with the reference's own argument handling (start >= end, or a start beyond
  * 2^32: plain copy; both ends are truncated to 32 bits as roaring_bitmap_flip does) and its container typing
  * (container_not_range / container_not, containers.h:2009-2073; container_range_of_ones where the source has no
- * container under a key).  Returns a new pool; byte-identical portable serialization. */
+ * container under a key).  64-bit pools: roaring64_bitmap_flip (roaring64.h:525, src/roaring64.c:2007-2074) --
+ * [min, max) over the 64-bit universe, a copy when min >= max; every 48-bit key of the range gets a container
+ * (full ones where the bitmap had none), so a range may span at most 2^32 - 16 containers (RHIP_ERR_ARG beyond).
+ * Returns a new pool; byte-identical portable serialization. */
 rhip_pool_t *rhip_pool_flip(rhip_ctx_t *ctx, rhip_pool_t *pool, const uint64_t *starts, const uint64_t *ends);
 
 /* ---- many-way aggregation ------------------------------------------------ */

@@ -66,6 +66,7 @@ class Oracle:
         L.oc64_get_cardinality.restype = u64; L.oc64_get_cardinality.argtypes = [vp]
         L.oc64_or_many.restype = vp; L.oc64_or_many.argtypes = [sz, C.POINTER(vp)]
         L.oc64_free.restype = None; L.oc64_free.argtypes = [vp]
+        L.oc64_flip.restype = vp; L.oc64_flip.argtypes = [vp, u64, u64]
         self.L = L
 
     # -- 32-bit
@@ -166,6 +167,9 @@ class Oracle:
     def or_many64(self, hs):
         return self._many(self.L.oc64_or_many, hs)
 
+    def flip64(self, h, start: int, end: int):
+        return self.L.oc64_flip(h, start, end)
+
     def free64(self, h):
         self.L.oc64_free(h)
 
@@ -222,6 +226,7 @@ class Ref:
         L.roaring64_bitmap_free.restype = None; L.roaring64_bitmap_free.argtypes = [vp]
         L.roaring64_bitmap_or_inplace.restype = None; L.roaring64_bitmap_or_inplace.argtypes = [vp, vp]
         L.roaring64_bitmap_create.restype = vp; L.roaring64_bitmap_create.argtypes = []
+        L.roaring64_bitmap_flip.restype = vp; L.roaring64_bitmap_flip.argtypes = [vp, u64, u64]
         self.L = L
 
     def deserialize(self, buf: bytes):
@@ -315,6 +320,9 @@ class Ref:
 
     def cardinality64(self, h) -> int:
         return self.L.roaring64_bitmap_get_cardinality(h)
+
+    def flip64(self, h, start: int, end: int):
+        return self.L.roaring64_bitmap_flip(h, start, end)
 
     def or_many64(self, hs):
         # no C many-way API for 64-bit: left fold of or_inplace

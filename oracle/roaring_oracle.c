@@ -1319,6 +1319,35 @@ uint64_t oc64_get_cardinality(const oc_bitmap64_t *b) {
     for (int64_t i = 0; i < b->n; i++) s += oc_get_cardinality(b->bm[i]);
     return s;
 }
+/* roaring64_bitmap_flip (roaring64.c:2007-2074): [min, max) over the 64-bit universe.  Per 48-bit key of the range the
+ * reference applies container_not / container_not_range (or container_range_of_ones where the key is absent) -- the
+ * same container-level functions roaring_bitmap_flip_closed applies per 16-bit key -- so, bucket by bucket (high 32
+ * bits), the result is what oc_flip gives on the bucket's own 32-bit sub-range; buckets the bitmap lacks start empty.
+ * (oc_flip's 32-bit truncation quirk does not come into play: every sub-range lies inside [0, 2^32].) */
+oc_bitmap64_t *oc64_flip(const oc_bitmap64_t *x, uint64_t min, uint64_t max) {
+    oc_bitmap64_t *r = oc64_create();
+    if (min >= max) {
+        for (int64_t i = 0; i < x->n; i++) b64_push(r, x->high[i], oc_copy(x->bm[i]));
+        return r;
+    }
+    const uint64_t last = max - 1; /* closed */
+    const uint64_t hb0 = min >> 32, hb1 = last >> 32;
+    int64_t i = 0;
+    for (; i < x->n && x->high[i] < hb0; i++) b64_push(r, x->high[i], oc_copy(x->bm[i]));
+    for (uint64_t hb = hb0; hb <= hb1; hb++) {
+        const uint64_t lo = hb == hb0 ? (min & 0xFFFFFFFFull) : 0;
+        const uint64_t hi = hb == hb1 ? (last & 0xFFFFFFFFull) + 1 : 0x100000000ull; /* exclusive */
+        oc_bitmap_t *src = NULL, *empty = NULL;
+        if (i < x->n && x->high[i] == hb) src = x->bm[i++];
+        else src = empty = oc_create();
+        oc_bitmap_t *f = oc_flip(src, lo, hi);
+        if (empty) oc_free(empty);
+        if (f->n) b64_push(r, (uint32_t)hb, f);
+        else oc_free(f);
+    }
+    for (; i < x->n; i++) b64_push(r, x->high[i], oc_copy(x->bm[i]));
+    return r;
+}
 /* No C many-way API exists for 64-bit; reference = left fold of or. */
 oc_bitmap64_t *oc64_or_many(size_t n, const oc_bitmap64_t **x) {
     oc_bitmap64_t *ans = oc64_create();

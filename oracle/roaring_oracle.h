@@ -107,6 +107,7 @@ int oc64_run_optimize(oc_bitmap64_t *b);
 oc_bitmap64_t *oc64_op(int op, const oc_bitmap64_t *a, const oc_bitmap64_t *b);
 uint64_t oc64_get_cardinality(const oc_bitmap64_t *b);
 oc_bitmap64_t *oc64_or_many(size_t n, const oc_bitmap64_t **x);
+oc_bitmap64_t *oc64_flip(const oc_bitmap64_t *x, uint64_t min, uint64_t max); /* roaring64_bitmap_flip */
 void oc64_free(oc_bitmap64_t *b);
 
 #ifdef __cplusplus

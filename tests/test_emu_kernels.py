@@ -137,6 +137,7 @@ def test_emu_device_deserialization(emu, oracle):
 def test_emu_flip(emu, oracle):
     import test_gpu_poolops as GP
     GP.test_flip(emu, oracle)
+    GP.test_flip_64bit(emu, oracle)
 
 
 def test_emu_value_lists(emu, oracle):

@@ -556,6 +556,65 @@ def test_flip(engine, oracle):
         oracle.free(h)
 
 
+def _flip64_cases(rng):
+    """(sorted uint64 values, min, max) cases for roaring64_bitmap_flip: ranges inside one container, across
+    containers, across high-32 buckets (present and absent), empty / reversed ranges, both ends of the universe."""
+    cases = []
+    for _ in range(24):
+        nb = int(rng.integers(0, 4))
+        highs = np.sort(rng.choice(5, nb, replace=False)).astype(np.uint64)
+        parts = [(h << np.uint64(32)) | random_bitmap(rng, max_keys=4, key_space=6).astype(np.uint64) for h in highs]
+        v = np.unique(np.concatenate(parts)) if parts else np.zeros(0, np.uint64)
+        kind = int(rng.integers(0, 6))
+        hb = int(rng.integers(0, 5))
+        base = hb << 32
+        if kind == 0:    # inside one container
+            k = int(rng.integers(0, 6)); a, b = sorted(int(x) for x in rng.integers(0, 65537, 2))
+            lo, hi = base + (k << 16) + a, base + (k << 16) + b
+        elif kind == 1:  # a few containers of one bucket
+            a, b = sorted(int(x) for x in rng.integers(0, 8 << 16, 2))
+            lo, hi = base + a, base + b
+        elif kind == 2:  # across a bucket boundary, 3 containers each side
+            lo, hi = base + (1 << 32) - int(rng.integers(1, 3 << 16)), base + (1 << 32) + int(rng.integers(0, 3 << 16))
+        elif kind == 3:  # reversed / empty
+            lo, hi = base + 500, base + int(rng.integers(0, 501))
+        elif kind == 4:  # the very start of the universe
+            lo, hi = 0, int(rng.integers(1, 5 << 16))
+        else:            # whole containers exactly
+            k = int(rng.integers(0, 4)); lo, hi = base + (k << 16), base + ((k + int(rng.integers(1, 4))) << 16)
+        cases.append((v, lo, hi))
+    top = (1 << 64) - 1
+    cases.append((np.array([top - 5, top], np.uint64), top - (2 << 16), top))       # near the end of the universe
+    cases.append((np.zeros(0, np.uint64), 70000, 70001))                             # one value into an empty bitmap
+    cases.append((np.arange(0, 1 << 17, dtype=np.uint64), 0, 1 << 17))               # everything away
+    return cases
+
+
+def test_flip_64bit(engine, oracle):
+    """rhip_pool_flip on a 64-bit pool == roaring64_bitmap_flip (roaring64.c:2007-2074), byte level (the oracle's
+    oc64_flip is pinned to the real function in tests/test_oracle_vs_ref.py)."""
+    rng = np.random.default_rng(6464)
+    cases = _flip64_cases(rng)
+    hs = [oracle.from_sorted64(v, run_optimize=bool(i & 1)) for i, (v, _, _) in enumerate(cases)]
+    P = engine.pool_from_serialized64([oracle.serialize64(h) for h in hs])
+    F = engine.flip(P, [lo for _, lo, _ in cases], [hi for _, _, hi in cases])
+    assert F.is64 and len(F) == len(cases)
+    bad = []
+    for i, (h, (_, lo, hi)) in enumerate(zip(hs, cases)):
+        want = oracle.flip64(h, lo, hi)
+        if F.serialize(i) != oracle.serialize64(want):
+            bad.append((i, lo, hi))
+        oracle.free64(want)
+    assert not bad, f"{len(bad)} 64-bit flips differ, first {bad[:5]}"
+    FF = engine.flip(F, [lo for _, lo, _ in cases], [hi for _, _, hi in cases])
+    assert np.array_equal(FF.cardinalities(), P.cardinalities())
+    assert engine.pairwise_predicate("equals", FF, np.arange(len(hs)), P, np.arange(len(hs))).all()
+    with pytest.raises(Exception):  # 2^48 containers: refused, not attempted
+        engine.flip(P, [0] * len(cases), [1 << 63] * len(cases))
+    for h in hs:
+        oracle.free64(h)
+
+
 def test_device_deserialization_fuzz_64bit(engine, oracle):
     """The same differential fuzzing for roaring64 images (bucket count, high keys, nested 32-bit images)."""
     rng = np.random.default_rng(32)

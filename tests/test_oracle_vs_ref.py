@@ -156,3 +156,18 @@ def test_flip(oracle, ref):
             ref.free(fb)
         oracle.free(a)
         ref.free(b)
+
+
+def test_flip_64bit_oracle_vs_ref(oracle, ref):
+    """oc64_flip == the real roaring64_bitmap_flip, byte level, on the cases the GPU test uses."""
+    from test_gpu_poolops import _flip64_cases
+    rng = np.random.default_rng(6464)
+    for i, (v, lo, hi) in enumerate(_flip64_cases(rng)):
+        ho, hr = oracle.from_sorted64(v, run_optimize=bool(i & 1)), ref.from_sorted64(v, run_optimize=bool(i & 1))
+        assert oracle.serialize64(ho) == ref.serialize64(hr)
+        fo, fr = oracle.flip64(ho, lo, hi), ref.flip64(hr, lo, hi)
+        assert oracle.serialize64(fo) == ref.serialize64(fr), (i, lo, hi)
+        for h in (ho, fo):
+            oracle.free64(h)
+        for h in (hr, fr):
+            ref.free64(h)
