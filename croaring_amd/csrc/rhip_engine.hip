@@ -161,6 +161,7 @@ struct rhip_pool_s {
     bool is64 = false;
     DBuf bm_start, key, type, card, nruns, off, arena;
     uint64_t arena_used = 0;
+    uint64_t compact_mark = 0;  // arena_used right after the last compaction (0: never updated in place), see rhip_pairwise_inplace
     // host mirror of the directory (filled lazily for serialization); planning only needs bm_start
     bool host_dir = false;
     bool host_bm = false;

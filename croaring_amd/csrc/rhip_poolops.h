@@ -41,6 +41,34 @@ __global__ __launch_bounds__(256) void k_select_dir(const PoolView* __restrict__
     from[j].p = V.arena + V.off[c];
 }
 
+// Directory-only form for the in-place entry points: output container j takes its directory entry from its source
+// and its payload STAYS where it is -- the offset is the source's offset plus off_add[source pool] (0 for the pool
+// being updated, the append position for the freshly computed results that were copied behind its arena).
+__global__ __launch_bounds__(256) void k_splice_dir(const PoolView* __restrict__ srcs, const u64* __restrict__ off_add,
+                                                    const uint32_t* __restrict__ src_pool,
+                                                    const u64* __restrict__ src_c0,
+                                                    const u64* __restrict__ out_bm_start, uint32_t n_bitmaps, u64 n_out,
+                                                    u64* __restrict__ okey, uint8_t* __restrict__ otype,
+                                                    uint32_t* __restrict__ ocard, uint32_t* __restrict__ onruns,
+                                                    u64* __restrict__ ooff) {
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_out) return;
+    u64 lo = 0, hi = n_bitmaps;
+    while (lo + 1 < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if (out_bm_start[mid] <= j) lo = mid;
+        else hi = mid;
+    }
+    const uint32_t sp = src_pool[lo];
+    const PoolView V = srcs[sp];
+    const u64 c = src_c0[lo] + (j - out_bm_start[lo]);
+    okey[j] = V.key[c];
+    otype[j] = V.type[c];
+    ocard[j] = V.card[c];
+    onruns[j] = V.nruns[c];
+    ooff[j] = V.off[c] + off_add[sp];
+}
+
 // One wave per container: slot bytes (a multiple of 16) in 16-byte pieces, 64 lanes wide.
 __global__ __launch_bounds__(256) void k_select_copy(const SelSrc* __restrict__ from, const uint32_t* __restrict__ slot,
                                                      const u64* __restrict__ off, uint8_t* __restrict__ arena,

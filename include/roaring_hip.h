@@ -157,8 +157,10 @@ int rhip_pairwise_predicate(rhip_ctx_t *ctx, rhip_pred pred, rhip_pool_t *A, rhi
 /* roaring_bitmap_{and,or,xor,andnot}_inplace (roaring.h:280,295,326,348; src/roaring.c:812-875, 1063-1119,
  * 1200-1273, 1342-1434) for a batch, on device-resident handles: A[lhs[k]] <- op(A[lhs[k]], B[rhs[k]]), every
  * other bitmap of A unchanged; the handle A stays valid and now names the updated pool.  lhs must not repeat.
- * B may be A.  (Pools are immutable images: the update builds the new image with rhip_pool_select and swaps it
- * in, so the cost is the op plus one copy of A's payload.) */
+ * B may be A.  The results are spliced into A: their payload is appended to A's arena and only A's directory is
+ * rebuilt -- bitmaps that are not updated are not copied (cost = the op + one copy of the RESULTS).  The replaced
+ * bitmaps' old slots stay behind as garbage; once the arena has doubled since the last compaction the update goes
+ * through rhip_pool_select instead, which rewrites the pool compactly. */
 int rhip_pairwise_inplace(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *A, rhip_pool_t *B, size_t npairs,
                           const uint32_t *lhs, const uint32_t *rhs);
 

@@ -120,6 +120,7 @@ def test_emu_pool_reshaping(emu, oracle):
     GP.test_pool_select_64bit(emu, oracle)
     for op in OPS:
         GP.test_pairwise_inplace(emu, oracle, op)
+    GP.test_pairwise_inplace_chain(emu, oracle)
     for mode in ("run_optimize", "remove_run_compression"):
         GP.test_container_conversions(emu, oracle, mode)
     GP.test_pairwise_predicates(emu, oracle)

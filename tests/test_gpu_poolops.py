@@ -113,6 +113,42 @@ def test_pairwise_inplace(engine, oracle, op):
         oracle.free(h)
 
 
+def test_pairwise_inplace_chain(engine, oracle):
+    """A chain of in-place updates on one device handle -- a |= b, a &= c, a ^= b, a -= c ... on changing subsets --
+    tracked step by step by the oracle: the spliced pool (appended results, garbage left behind, periodic
+    compaction through pool_select once the arena has doubled) must stay byte-identical to the reference's
+    sequence of roaring_bitmap_*_inplace calls, untouched bitmaps included, and remain a normal operand."""
+    rng = np.random.default_rng(77)
+    hs, bufs = _mixed_pool(oracle, rng, 40)
+    hb, bufs_b = _mixed_pool(oracle, rng, 12)
+    A = engine.pool_from_serialized(bufs)
+    B = engine.pool_from_serialized(bufs_b)
+    cur = [oracle.deserialize(b) for b in bufs]
+    for step in range(14):
+        op = OPS[step % 4]
+        k = int(rng.integers(1, 25))
+        lhs = rng.choice(40, k, replace=False).astype(np.uint32)
+        rhs = rng.integers(0, 12, k).astype(np.uint32)
+        engine.pairwise_inplace(op, A, lhs, B, rhs)
+        for l, r in zip(lhs, rhs):
+            nxt = oracle.op(op, cur[l], hb[r])
+            oracle.free(cur[l])
+            cur[l] = nxt
+        if step % 3 == 2 or step == 13:
+            got = A.serialize_all()
+            bad = [i for i in range(40) if got[i] != oracle.serialize(cur[i])]
+            assert not bad, (step, op, bad[:5])
+            assert np.array_equal(A.cardinalities(), np.array([oracle.cardinality(h) for h in cur], np.uint64))
+    # the updated handle is an ordinary operand
+    res = engine.pairwise("or", A, np.arange(40, dtype=np.uint32), A, (np.arange(40, dtype=np.uint32) * 7 + 3) % 40)
+    for i in (0, 13, 39):
+        oo = oracle.op("or", cur[i], cur[(i * 7 + 3) % 40])
+        assert res.serialize(i) == oracle.serialize(oo)
+        oracle.free(oo)
+    for h in hs + hb + cur:
+        oracle.free(h)
+
+
 def _inefficient_run_bitmap():
     """One run container with 3000 runs of 10 values (12000-byte payload): valid, not run-efficient."""
     starts = np.arange(3000, dtype=np.uint32) * 20
