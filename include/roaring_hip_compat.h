@@ -82,6 +82,27 @@ roaring_bitmap_t *roaring_bitmap_lazy_xor(const roaring_bitmap_t *r1, const roar
 void roaring_bitmap_lazy_xor_inplace(roaring_bitmap_t *r1, const roaring_bitmap_t *r2);
 void roaring_bitmap_repair_after_lazy(roaring_bitmap_t *r1);
 
+/* ---- 64-bit (include/roaring/roaring64.h:423-531) -----------------------------------------------------------
+ * roaring64_bitmap_t is an ART with a private node layout, so these go through the portable format: operands are
+ * serialized with the REFERENCE's roaring64_bitmap_portable_serialize (resolved with dlsym(RTLD_DEFAULT) from the
+ * program this library is loaded into -- link the program with -rdynamic if libroaring is linked statically),
+ * results are built by its roaring64_bitmap_portable_deserialize_safe, in-place forms use roaring64_bitmap_overwrite.
+ * Results are byte-identical (portable serialization) to the reference's. */
+typedef struct roaring64_bitmap_s roaring64_bitmap_t;
+roaring64_bitmap_t *roaring64_bitmap_and(const roaring64_bitmap_t *r1, const roaring64_bitmap_t *r2);        /* roaring64.h:423 */
+roaring64_bitmap_t *roaring64_bitmap_or(const roaring64_bitmap_t *r1, const roaring64_bitmap_t *r2);         /* :468 */
+roaring64_bitmap_t *roaring64_bitmap_xor(const roaring64_bitmap_t *r1, const roaring64_bitmap_t *r2);        /* :488 */
+roaring64_bitmap_t *roaring64_bitmap_andnot(const roaring64_bitmap_t *r1, const roaring64_bitmap_t *r2);     /* :509 */
+void roaring64_bitmap_and_inplace(roaring64_bitmap_t *r1, const roaring64_bitmap_t *r2);                      /* :439 */
+void roaring64_bitmap_or_inplace(roaring64_bitmap_t *r1, const roaring64_bitmap_t *r2);                       /* :480 */
+void roaring64_bitmap_xor_inplace(roaring64_bitmap_t *r1, const roaring64_bitmap_t *r2);                      /* :501 */
+void roaring64_bitmap_andnot_inplace(roaring64_bitmap_t *r1, const roaring64_bitmap_t *r2);                   /* :522 */
+uint64_t roaring64_bitmap_and_cardinality(const roaring64_bitmap_t *r1, const roaring64_bitmap_t *r2);        /* :429 */
+uint64_t roaring64_bitmap_or_cardinality(const roaring64_bitmap_t *r1, const roaring64_bitmap_t *r2);         /* :474 */
+uint64_t roaring64_bitmap_xor_cardinality(const roaring64_bitmap_t *r1, const roaring64_bitmap_t *r2);        /* :494 */
+uint64_t roaring64_bitmap_andnot_cardinality(const roaring64_bitmap_t *r1, const roaring64_bitmap_t *r2);     /* :515 */
+roaring64_bitmap_t *roaring64_bitmap_flip(const roaring64_bitmap_t *r, uint64_t min, uint64_t max);           /* :531 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,28 @@
+# round-2 measurement pass: everything profiles/r02_* cites, from ONE box.  gpurun -- 'bash scripts/gpu_final_r2.sh'
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/final_r2
+mkdir -p $O
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; cut -c1-260 $O/bench.json
+timeout 200 python scripts/bench_c2_ops.py > $O/c2_ops.jsonl 2>/dev/null
+timeout 200 python scripts/quick_c3.py > $O/quick_c3.jsonl 2>/dev/null
+timeout 200 python scripts/quick_classes.py > $O/class_throughput.jsonl 2>/dev/null
+timeout 200 python scripts/bench_poolops.py > $O/poolops.jsonl 2>/dev/null
+# kernel-trace stats: the bench command itself (C2 only), then one realdata batch type per run
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -- python bench.py --steps 6 --warmup 2 --no-cpu --no-secondary > $O/prof_bench.log 2>&1
+for spec in w_and:and:weather_sept_85 w_or:or:weather_sept_85 w_xor:xor:weather_sept_85 w_andnot:andnot:weather_sept_85 c1_and:and:census1881 c1_or:or:census1881 wk_and:and:wikileaks-noquotes; do
+  name=${spec%%:*}; rest=${spec#*:}; op=${rest%%:*}; ds=${rest#*:}
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -o p -- python scripts/prof_weather.py $op $ds > $O/prof_$name.log 2>&1
+  grep "min ms" $O/prof_$name.log
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c4 -o p -- python scripts/prof_c4.py 100000 > $O/prof_c4.log 2>&1; tail -1 $O/prof_c4.log | cut -c1-200
+# PMC passes, each counter set in its own run, kernel-trace only (no other trace domains)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o b -- python bench.py --steps 2 --warmup 1 --rounds 1 --no-cpu --no-secondary > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o b -- python bench.py --steps 2 --warmup 1 --rounds 1 --no-cpu --no-secondary > $O/pmc_write.log 2>&1
+for op in and or; do
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pmc_w_$op -o w -- python scripts/prof_weather.py $op > $O/pmc_w_$op.log 2>&1
+done
+# raw traces are large: keep the stats and counter tables, drop the per-dispatch traces except the realdata ones (small)
+rm -f $O/prof_bench/*kernel_trace.csv $O/prof_c4/*kernel_trace.csv
+du -sh $O
+echo done

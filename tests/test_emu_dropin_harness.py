@@ -24,10 +24,11 @@ def _build():
     if not os.path.exists(build_emu.CXX):
         return
     lib = build_emu.build()
-    for b in ("toplevel_unit_emu", "cpp_random_unit_emu"):
+    for b in ("toplevel_unit_emu", "cpp_random_unit_emu", "roaring64_unit_emu"):
         exe = os.path.join(REF, b)
         if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(lib):
-            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "dropin_emu"], check=False, capture_output=True)
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "dropin_emu", "dropin64_emu"], check=False,
+                           capture_output=True)
             break
 
 
@@ -75,3 +76,20 @@ def test_reference_realdata_unit_through_the_emulator():
     assert p.returncode == 0 and "failure" not in p.stdout, (p.stdout + p.stderr)[-2000:]
     c = re.search(r"pairwise (\d+), in-place (\d+), cardinality (\d+), many-way (\d+)", p.stderr)
     assert c and int(c.group(1)) > 100000, (p.stdout + p.stderr)[-500:]
+
+
+def test_reference_roaring64_unit_on_emulated_kernels():
+    """tests/roaring64_unit.cpp, unmodified (75 tests): every roaring64_bitmap_{and,or,xor,andnot}(_inplace,
+    _cardinality) and roaring64_bitmap_flip it issues goes through the 64-bit drop-ins (portable format in, device
+    pipeline, portable format out) on the emulated kernels."""
+    exe = os.path.join(REF, "roaring64_unit_emu")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/roaring64_unit_emu not built (needs /root/reference and the emulator build)")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=dict(os.environ, RHIP_COMPAT_STATS="1"), cwd=REF)
+    tail = (p.stdout + p.stderr)[-3000:]
+    m = re.search(r"(\d+) tests, (\d+) failed", p.stdout)
+    assert m, tail
+    assert int(m.group(1)) >= 70 and int(m.group(2)) == 0 and p.returncode == 0, tail
+    c = re.search(r"compat64\] device-executed calls: pairwise (\d+), in-place (\d+), cardinality (\d+), flip (\d+)", p.stderr)
+    assert c, tail
+    assert int(c.group(1)) >= 8 and int(c.group(2)) >= 4 and int(c.group(3)) >= 4 and int(c.group(4)) >= 1, c.group(0)

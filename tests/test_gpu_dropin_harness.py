@@ -64,3 +64,23 @@ def test_reference_cpp_unit_against_dropin():
     m = re.search(r"(\d+) tests, (\d+) failed", p.stdout)
     assert m, tail
     assert int(m.group(1)) >= 60 and int(m.group(2)) == 0 and p.returncode == 0, tail
+
+
+BIN_64 = os.path.join(ROOT, "oracle", "_ref", "roaring64_unit_dropin")
+
+
+def test_reference_roaring64_unit_against_dropin():
+    """tests/roaring64_unit.cpp, unmodified (75 tests), with the 13 roaring64 hot-path symbols resolved to
+    libroaring_hip.so: the 64-bit drop-ins serialize the operands with the reference's own portable functions, run
+    the device pipeline on a 64-bit pool and rebuild the result with the reference's deserializer."""
+    if not os.path.exists(BIN_64):
+        pytest.skip("oracle/_ref/roaring64_unit_dropin not prebuilt")
+    env = dict(os.environ, RHIP_COMPAT_STATS="1")
+    p = subprocess.run([BIN_64], capture_output=True, text=True, timeout=1200, env=env)
+    tail = (p.stdout + p.stderr)[-3000:]
+    m = re.search(r"(\d+) tests, (\d+) failed", p.stdout)
+    assert m, tail
+    assert int(m.group(1)) >= 70 and int(m.group(2)) == 0 and p.returncode == 0, tail
+    c = re.search(r"compat64\] device-executed calls: pairwise (\d+), in-place (\d+), cardinality (\d+), flip (\d+)", p.stderr)
+    assert c, tail
+    assert int(c.group(1)) >= 8 and int(c.group(2)) >= 4 and int(c.group(3)) >= 4 and int(c.group(4)) >= 1, c.group(0)
