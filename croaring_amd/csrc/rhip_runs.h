@@ -3,21 +3,25 @@
 #include "rhip_common.h"
 
 // ------------------------------------------------------------------ interval kernel (K13, K14, K16)
-// run x run, array x run, run x array for all four ops, in O((nA + nB) log(nA + nB)) instead of
-// rasterising 65536 bits: one WAVE per pair, no workgroup barrier.  Replaces the sequential interval
-// merges run_container_{union,intersection,xor,andnot} (src/containers/run.c:231-283, 387-463, 348-383,
-// 575-633), array_run_container_{intersection,union,andnot,lazy_xor}, run_array_container_andnot
+// run x run, array x run, run x array for all four ops, in O(nA + nB) work instead of rasterising 65536 bits: one
+// WAVE per pair, no workgroup barrier.  Replaces the sequential interval merges
+// run_container_{union,intersection,xor,andnot} (src/containers/run.c:231-283, 387-463, 348-383, 575-633),
+// array_run_container_{intersection,union,andnot,lazy_xor}, run_array_container_andnot
 // (mixed_intersection.c:73-111, mixed_union.c:66-108, mixed_andnot.c:277-412, mixed_xor.c:140-173).
 //
 // Each operand is read as a sorted BOUNDARY list b(0) <= b(1) <= ... <= b(2n-1) = s0, e0+1, s1, e1+1, ...
-// (arrays: e = s).  Membership is a parity: x is in the operand iff |{j : b(j) <= x}| is odd.  The result
-// can only change at a boundary p of either operand; with lb/ub = lower/upper bound of p in a list,
-//   f(p-1) = op(lbA & 1, lbB & 1),   f(p) = op(ubA & 1, ubB & 1),
-// so p starts a result run iff f(p) & !f(p-1) and ends one (at p-1) iff !f(p) & f(p-1).  Lanes evaluate
-// boundaries in parallel (one binary search into the other list each); result starts and ends are ranked
-// by ballot prefix counts per list plus a prefix lookup in the other list, and the k-th start pairs with
-// the k-th end.  The run list is then typed by the reference's rules (convert_run_to_efficient_container
+// (arrays: e = s).  Membership is a parity: x is in the operand iff an odd number of its boundaries are <= x.  The
+// two lists (staged in LDS) are merged by MERGE PATH: lane l owns merged positions [l * per, (l+1) * per) and finds
+// its split (ia, ib) with one binary search along its diagonal; the state before its chunk is just (ia & 1, ib & 1).
+// It then walks its <= 16 events sequentially (two LDS reads per event), toggling inA / inB.  Only the LAST event at
+// a position is "effective" (an array's v+1 / next-v pair, or a boundary shared by both lists, toggles twice at
+// one position); a result run starts at an effective event where op(inA, inB) turns 1 and ends before one where it
+// turns 0, "turns" being relative to the previous effective event -- across lanes that is one ballot pair and a
+// count-leading-zeros.  Three walks: (1) last effective state per lane, (2) count starts / ends, (3) write them at
+// wave-scanned positions.  The run list is then typed by the reference's rules (convert_run_to_efficient_container
 // etc.) and written as runs or expanded into an array; the rare bitset result is re-queued for k_genw.
+// (Round 1 evaluated every boundary with a binary search into the other list, twice: 7 ns per pair of 100-run
+// containers; the merge walk does the same in a fraction of the LDS round trips.)
 struct IvList {
     const uint8_t* p;
     uint32_t n2;     // number of boundaries (2 x intervals)
@@ -50,19 +54,17 @@ __global__ __launch_bounds__(256) void k_runs(const uint8_t* __restrict__ arenaA
                                               OutView O, const GenItem* __restrict__ q,
                                               const u64* __restrict__ qrange, int op, int cardmode, u64* pair_acc,
                                               GenItem* retry_q, uint32_t* retry_count) {
-    constexpr uint32_t NB = 2 * RUNS_MAX_INTERVALS;  // max boundaries per list
-    // per wave (~8 KiB): both operand lists staged in LDS (every binary-search probe is an LDS read), the
-    // start/end prefix tables of both lists (bit 15 = flag), result starts / ends
+    constexpr uint32_t NB = 2 * RUNS_MAX_INTERVALS;  // max boundaries per list = max result runs
+    // per wave (~5 KiB): both operand lists staged in LDS, result run starts / ends, a prefix table for the expansion
     __shared__ __attribute__((aligned(16))) uint8_t lists_all[4][2][1024];  // 4 * RUNS_MAX_INTERVALS, padded to 16 bytes
-    __shared__ uint16_t lds_all[4][4 * (NB + 1) + 2 * NB];
+    __shared__ uint16_t lds_all[4][3 * NB + 2];
     const uint32_t lane = lane_id();
     uint16_t* base = lds_all[threadIdx.x >> 6];
     uint8_t* lsA = lists_all[threadIdx.x >> 6][0];
     uint8_t* lsB = lists_all[threadIdx.x >> 6][1];
-    uint16_t* PS[2] = {base, base + (NB + 1)};                   // start-prefix of list A / B
-    uint16_t* PE[2] = {base + 2 * (NB + 1), base + 3 * (NB + 1)};  // end-prefix of list A / B
-    uint16_t* RS = base + 4 * (NB + 1);                           // result run starts
-    uint16_t* RE = RS + NB;                                       // result run ends (inclusive)
+    uint16_t* RS = base;            // result run starts
+    uint16_t* RE = base + NB;       // result run ends (inclusive)
+    uint16_t* PL = base + 2 * NB;   // exclusive prefix of run lengths (array expansion)
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
     uint32_t wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -82,63 +84,68 @@ __global__ __launch_bounds__(256) void k_runs(const uint8_t* __restrict__ arenaA
             if (lane < nb16) ((uint4*)lsB)[lane] = ((const uint4*)(arenaB + t.offb))[lane];
             __builtin_amdgcn_wave_barrier();
         }
-        // ---- pass 1: start / end flags of every boundary, exclusive prefix counts per list
-        uint32_t tot_s[2], tot_e[2];
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            const IvList& own = L[x];
-            const IvList& oth = L[1 - x];
-            uint32_t run_s = 0, run_e = 0;
-            for (uint32_t j0 = 0; j0 < own.n2; j0 += 64) {
-                const uint32_t j = j0 + lane;
-                bool is_s = false, is_e = false;
-                if (j < own.n2) {
-                    const uint32_t p = own.at(j);
-                    const bool dup_own = j > 0 && own.at(j - 1) == p;
-                    const uint32_t lbo = oth.lower(p);
-                    const bool in_oth = lbo < oth.n2 && oth.at(lbo) == p;
-                    // a boundary present in both lists is handled once, by list A
-                    if (!dup_own && !(x == 1 && in_oth)) {
-                        const uint32_t ub_own = j + 1u + ((j + 1u < own.n2 && own.at(j + 1u) == p) ? 1u : 0u);
-                        uint32_t ub_oth = lbo;
-                        if (in_oth) ub_oth = lbo + 1u + ((lbo + 1u < oth.n2 && oth.at(lbo + 1u) == p) ? 1u : 0u);
-                        const uint32_t lbA = x == 0 ? j : lbo, ubA = x == 0 ? ub_own : ub_oth;
-                        const uint32_t lbB = x == 0 ? lbo : j, ubB = x == 0 ? ub_oth : ub_own;
-                        const bool fb = bop(op, lbA, lbB), fa = bop(op, ubA, ubB);
-                        is_s = fa && !fb;
-                        is_e = !fa && fb;
-                    }
-                }
-                const u64 ms = __ballot(is_s), me = __ballot(is_e);
-                if (j < own.n2) {
-                    PS[x][j] = (uint16_t)((run_s + mbcnt(ms)) | (is_s ? 0x8000u : 0u));
-                    PE[x][j] = (uint16_t)((run_e + mbcnt(me)) | (is_e ? 0x8000u : 0u));
-                }
-                run_s += (uint32_t)__popcll(ms);
-                run_e += (uint32_t)__popcll(me);
+        // ---- merge path: this lane's chunk of the merged boundary sequence
+        constexpr uint32_t SENT = 0x20000u;  // past every boundary (the largest is 65536)
+        const IvList& LA = L[0];
+        const IvList& LB = L[1];
+        const uint32_t nA = LA.n2, nB2 = LB.n2, E = nA + nB2;
+        const uint32_t per = (E + 63u) >> 6;
+        const uint32_t d0 = lane * per < E ? lane * per : E;
+        const uint32_t d1 = d0 + per < E ? d0 + per : E;
+        uint32_t ia0;
+        {
+            uint32_t lo = d0 > nB2 ? d0 - nB2 : 0u, hi = d0 < nA ? d0 : nA;
+            while (lo < hi) {  // A goes first on ties: A[mid] <= B[d0 - mid - 1] means more of A lies before the diagonal
+                const uint32_t mid = (lo + hi) >> 1;
+                if (LA.at(mid) <= LB.at(d0 - mid - 1u)) lo = mid + 1u;
+                else hi = mid;
             }
-            if (lane == 0) { PS[x][own.n2] = (uint16_t)run_s; PE[x][own.n2] = (uint16_t)run_e; }
-            tot_s[x] = run_s; tot_e[x] = run_e;
+            ia0 = lo;
         }
-        const uint32_t rn = tot_s[0] + tot_s[1];  // == tot_e[0] + tot_e[1]
-        __builtin_amdgcn_wave_barrier();
-        // ---- pass 2: rank flagged boundaries over both lists, scatter into RS / RE
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            const IvList& own = L[x];
-            const IvList& oth = L[1 - x];
-            for (uint32_t j0 = 0; j0 < own.n2; j0 += 64) {
-                const uint32_t j = j0 + lane;
-                if (j < own.n2) {
-                    const uint32_t fs = PS[x][j], fe = PE[x][j];
-                    if ((fs | fe) & 0x8000u) {
-                        const uint32_t p = own.at(j);
-                        const uint32_t lbo = oth.lower(p);
-                        if (fs & 0x8000u) RS[(fs & 0x7FFFu) + (PS[1 - x][lbo] & 0x7FFFu)] = (uint16_t)p;
-                        if (fe & 0x8000u) RE[(fe & 0x7FFFu) + (PE[1 - x][lbo] & 0x7FFFu)] = (uint16_t)(p - 1u);
-                    }
+        const uint32_t ib0 = d0 - ia0, steps = d1 - d0;
+        // walk the chunk; fn(p, g) is called for every EFFECTIVE event (last event at position p), g = op state after it
+        auto walk = [&](auto&& fn) {
+            uint32_t ia = ia0, ib = ib0, inA = ia0 & 1u, inB = ib0 & 1u;
+            uint32_t pa = ia < nA ? LA.at(ia) : SENT, pb = ib < nB2 ? LB.at(ib) : SENT;
+            for (uint32_t sidx = 0; sidx < steps; ++sidx) {
+                uint32_t pcur;
+                if (pa <= pb) {
+                    pcur = pa; inA ^= 1u; ++ia;
+                    pa = ia < nA ? LA.at(ia) : SENT;
+                } else {
+                    pcur = pb; inB ^= 1u; ++ib;
+                    pb = ib < nB2 ? LB.at(ib) : SENT;
                 }
+                const uint32_t pnext = pa < pb ? pa : pb;
+                if (pnext != pcur) fn(pcur, bop(op, inA, inB));
             }
+        };
+        // walk 1: does the chunk hold an effective event, and the state after its last one
+        bool has_eff = false, g_last = false;
+        walk([&](uint32_t, bool g) { has_eff = true; g_last = g; });
+        bool gprev = false;  // state after the last effective event BEFORE this chunk
+        {
+            const u64 mh = __ballot(has_eff), mg = __ballot(g_last);
+            const u64 below = mh & ((1ull << lane) - 1ull);
+            if (below) gprev = (mg >> (63 - __clzll((long long)below))) & 1ull;
+        }
+        // walk 2: result run starts / ends in this chunk
+        uint32_t ns = 0, ne = 0;
+        {
+            bool gp = gprev;
+            walk([&](uint32_t, bool g) { ns += (g && !gp) ? 1u : 0u; ne += (!g && gp) ? 1u : 0u; gp = g; });
+        }
+        const uint32_t incs = wave_incl_scan(ns), ince = wave_incl_scan(ne);
+        const uint32_t rn = __shfl(incs, 63);  // == total ends: every run that starts also ends (both states end at 0)
+        // walk 3: write them
+        {
+            uint32_t ks = incs - ns, ke = ince - ne;
+            bool gp = gprev;
+            walk([&](uint32_t pcur, bool g) {
+                if (g && !gp) RS[ks++] = (uint16_t)pcur;
+                if (!g && gp) RE[ke++] = (uint16_t)(pcur - 1u);
+                gp = g;
+            });
         }
         __builtin_amdgcn_wave_barrier();
         // ---- cardinality, typing
@@ -165,9 +172,8 @@ __global__ __launch_bounds__(256) void k_runs(const uint8_t* __restrict__ arenaA
             for (uint32_t k = lane; k < rn; k += 64)
                 o32[k] = (uint32_t)RS[k] | (((uint32_t)RE[k] - (uint32_t)RS[k]) << 16);
         } else if (rc) {
-            // expand runs into a sorted array: exclusive prefix of run lengths (reuses PS[0]), then one
+            // expand runs into a sorted array: exclusive prefix of run lengths (PL), then one
             // binary search per output value
-            uint16_t* PL = PS[0];
             uint32_t runbase = 0;
             for (uint32_t k0 = 0; k0 < rn; k0 += 64) {
                 const uint32_t k = k0 + lane;
