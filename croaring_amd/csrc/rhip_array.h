@@ -116,6 +116,156 @@ __device__ __forceinline__ void wave_scatter_or(uint32_t* img, const uint4* __re
     }
 }
 
+// ------------------------------------------------------------------ short array merged into a long one (K10, K11)
+// or / xor of two arrays when the smaller one (Y, <= USMALL_MAX values: two per lane) is short and |X| + |Y| <= 4096,
+// so that the result is an array by the reference's rule before anything is computed (mixed_union.c:162-191,
+// mixed_xor.c:196-219; half of the array pairs of weather_sept_85).  The result is X with a few values inserted
+// (and, under xor, a few removed), so it is built BY RANK instead of through a 65536-bit image:
+//   * every y finds its rank r(y) in X (number of X values below it) and whether X holds it: the two-level pivot
+//     search of k_probe, straight from global / L2;
+//   * new values (y not in X) bump a per-rank counter in LDS, values in both (xor) set a "deleted" bit per X index;
+//   * X is streamed in 16-byte groups: X[i] goes to  i - (deleted before i) + (new values with rank <= i), the two
+//     counts coming from one packed wave prefix sum over the groups plus a running count inside the group;
+//   * a new y goes to  r(y) - (deleted before r(y)) + (new values before it).
+// ~350 wave instructions for the median pair (26 x 1268 values) against ~1000 through the image kernel, whose cost
+// is the 2048-word image however few values there are.  union_vector16 / xor_vector16 (array_util.c) on the CPU.
+__device__ __forceinline__ uint32_t byte_sum(uint32_t c) {
+#ifdef RHIP_EMU
+    return (c & 0xFFu) + ((c >> 8) & 0xFFu) + ((c >> 16) & 0xFFu) + (c >> 24);
+#else
+    return __builtin_amdgcn_sad_u8(c, 0u, 0u);
+#endif
+}
+// rank of v in the sorted array x16[0..nx) (number of values < v) and whether it is present; pivots as in probe_sorted
+__device__ __forceinline__ uint32_t probe_rank(const uint16_t* __restrict__ x16, uint32_t nx, uint32_t step, uint32_t piv,
+                                               uint32_t v, bool* present) {
+    uint32_t pos = 0;
+#pragma unroll
+    for (uint32_t b = 32; b >= 1; b >>= 1) {
+        const uint32_t pv = __shfl(piv, (int)(pos + b - 1));
+        if (pv <= v) pos += b;
+    }
+    {
+        const uint32_t pv = __shfl(piv, 63);
+        if (pos == 63u && pv <= v) pos = 64u;
+    }
+    const uint32_t k = pos ? pos - 1u : 0u;
+    uint32_t last = __shfl(piv, (int)k);
+    uint32_t idx = k * step;
+    const uint32_t end = (idx + step < nx) ? idx + step : nx;
+    for (uint32_t b = 32; b >= 1; b >>= 1) {
+        if (b < step) {
+            const uint32_t c = idx + b;
+            if (pos && c < end) {
+                const uint32_t xv = x16[c];
+                if (xv <= v) { idx = c; last = xv; }
+            }
+        }
+    }
+    *present = pos != 0u && last == v;
+    return pos == 0u ? 0u : (last == v ? idx : idx + 1u);
+}
+__global__ __launch_bounds__(256) void k_usmall(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                                OutView O, const FatItem* __restrict__ q,
+                                                const u64* __restrict__ qrange, int op) {
+    // per wave: D = one byte counter per X index 0..nx (new values by rank), DEL = one bit per X index (xor: value
+    // in both), GP = deleted-before count of every 8-index group
+    constexpr uint32_t D_WORDS = 1032, DEL_WORDS = 136, GP_WORDS = 264;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[4][D_WORDS + DEL_WORDS + GP_WORDS];
+    const uint32_t lane = lane_id();
+    uint32_t* D32 = lds_all[threadIdx.x >> 6];
+    uint32_t* DEL = D32 + D_WORDS;
+    uint16_t* GP = (uint16_t*)(DEL + DEL_WORDS);
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
+    uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    FatItem tnext;
+    if (w < n) tnext = q[w];
+    for (; w < n; w += nwaves) {
+        const FatItem t = tnext;
+        if (w + nwaves < n) tnext = q[w + nwaves];
+        const bool x_is_a = t.ca >= t.cb;
+        const uint8_t* xp = x_is_a ? arenaA + t.offa : arenaB + t.offb;
+        const uint8_t* yp = x_is_a ? arenaB + t.offb : arenaA + t.offa;
+        const uint32_t nx = x_is_a ? t.ca : t.cb, ny = x_is_a ? t.cb : t.ca;
+        const uint16_t* __restrict__ x16 = (const uint16_t*)xp;
+        const uint16_t* __restrict__ y16 = (const uint16_t*)yp;
+        const uint4* __restrict__ x4 = (const uint4*)xp;
+        // loads first: the two y values of this lane, its pivot of X
+        const bool ok0 = lane < ny, ok1 = 64u + lane < ny;
+        const uint32_t v0 = ok0 ? y16[lane] : 0u, v1 = ok1 ? y16[64u + lane] : 0u;
+        const uint32_t step = (nx + 63u) >> 6;
+        const uint32_t pi = lane * step;
+        const uint32_t piv = pi < nx ? (uint32_t)x16[pi] : 0xFFFFFFFFu;
+        const uint32_t nd = 2u * ((nx + 8u) >> 3) + 2u, ndl = (nx + 32u) >> 5;  // whole 8-index groups, index nx included
+        for (uint32_t i = lane; i < nd; i += 64) D32[i] = 0u;
+        if (op == OP_XOR)
+            for (uint32_t i = lane; i < ndl; i += 64) DEL[i] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        bool pr0 = false, pr1 = false;
+        const uint32_t r0 = probe_rank(x16, nx, step, piv, v0, &pr0);
+        const uint32_t r1 = ny > 64u ? probe_rank(x16, nx, step, piv, v1, &pr1) : 0u;
+        const bool new0 = ok0 && !pr0, new1 = ok1 && !pr1;
+        const bool del0 = op == OP_XOR && ok0 && pr0, del1 = op == OP_XOR && ok1 && pr1;
+        if (new0) atomicAdd(&D32[r0 >> 2], 1u << (8u * (r0 & 3u)));
+        if (new1) atomicAdd(&D32[r1 >> 2], 1u << (8u * (r1 & 3u)));
+        if (del0) atomicOr(&DEL[r0 >> 5], 1u << (r0 & 31u));
+        if (del1) atomicOr(&DEL[r1 >> 5], 1u << (r1 & 31u));
+        const u64 m0 = __ballot(new0), m1 = __ballot(new1);
+        const uint32_t nnew0 = (uint32_t)__popcll(m0), nnew = nnew0 + (uint32_t)__popcll(m1);
+        const uint32_t ndel = (uint32_t)__popcll(__ballot(del0)) + (uint32_t)__popcll(__ballot(del1));
+        __builtin_amdgcn_wave_barrier();
+        uint16_t* __restrict__ o16 = (uint16_t*)(O.arena + t.offo);
+        // ---- X, 16 bytes (8 values) per lane and step
+        const uint32_t ngroups = (nx + 7u) >> 3;
+        uint32_t run_new = 0, run_del = 0;
+        for (uint32_t g0 = 0; g0 < ngroups; g0 += 64) {
+            const uint32_t g = g0 + lane;
+            const bool act = g < ngroups;
+            uint4 xq = make_uint4(0, 0, 0, 0);
+            uint32_t c0 = 0, c1 = 0, delb = 0;
+            if (act) {
+                xq = x4[g];
+                c0 = D32[2u * g];
+                c1 = D32[2u * g + 1u];
+                if (op == OP_XOR) delb = (DEL[g >> 2] >> (8u * (g & 3u))) & 0xFFu;
+            }
+            const uint32_t packed = (byte_sum(c0) + byte_sum(c1)) | ((uint32_t)__popc(delb) << 16);
+            const uint32_t inc = wave_incl_scan(packed);
+            const uint32_t excl = inc - packed;
+            uint32_t newc = run_new + (excl & 0xFFFFu), delc = run_del + (excl >> 16);
+            if (op == OP_XOR && act) GP[g] = (uint16_t)delc;
+            const uint32_t tot = __shfl(inc, 63);
+            run_new += tot & 0xFFFFu;
+            run_del += tot >> 16;
+            const uint32_t nval = act ? (nx - 8u * g < 8u ? nx - 8u * g : 8u) : 0u;
+            const uint32_t d[4] = {xq.x, xq.y, xq.z, xq.w};
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                if ((uint32_t)h < nval) {
+                    newc += ((h < 4 ? c0 : c1) >> (8 * (h & 3))) & 0xFFu;
+                    const uint32_t dl = (delb >> h) & 1u;
+                    if (!dl) o16[8u * g + h + newc - delc] = (uint16_t)((d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu);
+                    delc += dl;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // GP complete
+        // ---- the new values of Y
+        auto del_below = [&](uint32_t r) -> uint32_t {
+            if (op != OP_XOR) return 0u;
+            const uint32_t g = r >> 3;
+            if (g >= ngroups) return ndel;
+            const uint32_t byte = (DEL[g >> 2] >> (8u * (g & 3u))) & 0xFFu;
+            return (uint32_t)GP[g] + (uint32_t)__popc(byte & ((1u << (r & 7u)) - 1u));
+        };
+        if (new0) o16[r0 - del_below(r0) + mbcnt(m0)] = (uint16_t)v0;
+        if (new1) o16[r1 - del_below(r1) + nnew0 + mbcnt(m1)] = (uint16_t)v1;
+        if (lane == 0) O.meta[t.out] = pack_meta(T_ARRAY, nx + nnew - ndel, 0);
+        __builtin_amdgcn_wave_barrier();  // LDS is reused by the next item
+    }
+}
+
 // ------------------------------------------------------------------ array filter (K8, K12)
 // One WAVE per container pair, no workgroup barriers: the membership side X is brought into a wave-private 8 KiB LDS
 // bitset -- a bitset container by 8 coalesced 16-byte loads per lane, an array by zero + ds_or_b32 scatter -- then the

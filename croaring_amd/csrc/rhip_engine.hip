@@ -897,6 +897,7 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     c->q[CLS_RETRY].ensure(sizeof(GenItem) * (ub_match + 1));
     c->q[CLS_PROBE].ensure(sizeof(FatItem) * (ub_match + 1));
     c->q[CLS_BBA].ensure(sizeof(BBItem) * (ub_match + 1));
+    c->q[CLS_USMALL].ensure(sizeof(FatItem) * (ub_match + 1));
     c->q[CLS_COPY].ensure(sizeof(CopyItem) * (P.ub_cand + 1));
     if (cardmode) c->pair_acc.ensure(8 * (npairs + 1));
     if (!cardmode) {
@@ -923,7 +924,7 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
                        c->cand.as<uint32_t>(), c->cand_start.as<u64>(), n_scan, P.scan_lb(), P.ranges(), (u64)S);
     EmitQueues Q{c->q[CLS_BB].as<BBItem>(), c->q[CLS_GEN].as<GenItem>(), c->q[CLS_COPY].as<CopyItem>(),
                  c->q[CLS_FILT].as<FatItem>(), c->q[CLS_WAVE].as<FatItem>(), c->q[CLS_RUNS].as<GenItem>(),
-                 c->q[CLS_PROBE].as<FatItem>(), c->q[CLS_BBA].as<BBItem>()};
+                 c->q[CLS_PROBE].as<FatItem>(), c->q[CLS_BBA].as<BBItem>(), c->q[CLS_USMALL].as<FatItem>()};
     if (NU)
         hipLaunchKernelGGL(k_emit, dim3((unsigned)((NU * 64 + 255) / 256)), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV,
                            op, cardmode, c->cand_start.as<u64>(), c->match.as<uint32_t>(), P.CO, Q);
@@ -935,7 +936,7 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
 // k_bb and k_runs re-queue.  When more than one class can have work they are forked onto auxiliary streams after
 // planning and joined before the tail -- four streams in all, one per hardware queue of the device (a fifth
 // stream shares a queue with another and serialises behind it):
-//     main : k_bb -> [ev_bb] -> k_probe -> k_bba -> k_copy -> [join] -> k_tail      streaming / light classes
+//     main : k_bb -> [ev_bb] -> k_usmall | k_probe -> k_bba -> k_copy -> [join] -> k_tail      streaming / light classes
 //     aux0 : k_runs -> k_genw(general) -> [wait ev_bb] -> k_genw(retry)              few items, heavy waves
 //     aux1 : k_filter                                                                and / andnot / cardinality
 //     aux2 : k_wave                                                                  or / xor / bitset \ array
@@ -1010,6 +1011,9 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
         hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 512)), dim3(256), 0, sr, VA.arena, VB.arena, O,
                            c->q[CLS_RETRY].as<GenItem>(), (const u64*)nullptr, retry_count, op, 0, c->pair_acc.as<u64>());
     }
+    if (has_wave && op != OP_ANDNOT)  // or / xor of a short array with a long one, by rank: light, beside k_wave
+        hipLaunchKernelGGL(k_usmall, dim3(bounded_grid(nm)), dim3(256), 0, s, VA.arena, VB.arena, O,
+                           c->q[CLS_USMALL].as<FatItem>(), ranges + 2 * SEC_USMALL, op);
     if (has_filt)  // short streamed arrays: no LDS, 8 waves per SIMD -- co-resides with the LDS-bound kernels
         hipLaunchKernelGGL(k_probe, dim3(bounded_grid(nm)), dim3(256), 0, s, VA.arena, VB.arena, O,
                            c->q[CLS_PROBE].as<FatItem>(), ranges + 2 * SEC_PROBE, op, cardmode, c->pair_acc.as<u64>());

@@ -118,7 +118,8 @@ enum { SEC_CAND = 0, SEC_M = 1, SEC_BB = 2, SEC_GEN = 3, SEC_COPY = 4, SEC_FILT 
        SEC_BYTES = 9,  // algorithmic input bytes of the unit (payload of matched operands and pass-through containers)
        SEC_PROBE = 10,
        SEC_BBA = 11,
-       N_SEC = 12 };
+       SEC_USMALL = 12,
+       N_SEC = 13 };
 // work class of a matched container pair
 // ia / ib = number of intervals of the operand when it is read as an interval list (runs: n_runs, arrays: card)
 __device__ __forceinline__ int classify(int op, int cardmode, uint8_t ta, uint8_t tb, uint32_t ia, uint32_t ib) {
@@ -145,6 +146,9 @@ __device__ __forceinline__ int classify(int op, int cardmode, uint8_t ta, uint8_
         if (ta == T_ARRAY && tb != T_RUN) return ia <= PROBE_MAX ? CLS_PROBE : CLS_FILT;
         if (ta == T_BITSET && tb == T_ARRAY) return CLS_WAVE;  // bitset \ array: clear-list in LDS
     } else {
+        // or / xor of two arrays, one of them short and the sum small enough that the result is an array whatever its
+        // cardinality (mixed_union.c:162-191, mixed_xor.c:196-219): the short one is merged INTO the long one by rank
+        if (ta == T_ARRAY && tb == T_ARRAY && (ia < ib ? ia : ib) <= USMALL_MAX && ia + ib <= 4096u) return CLS_USMALL;
         if (ta != T_RUN && tb != T_RUN) return CLS_WAVE;       // or / xor with an array operand
     }
     return CLS_GEN;
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         k[t] = act[t] ? SV.key[s0 + 64 * t + lane] : 0;
     }
     lower_bound4(LV.key, l0, l1, k, act, j);
-    uint32_t matched = 0, nbb = 0, nfilt = 0, nwave = 0, nruns_cls = 0, nprobe = 0, nbba = 0, slot16 = 0, bytes = 0;
+    uint32_t matched = 0, nbb = 0, nfilt = 0, nwave = 0, nruns_cls = 0, nprobe = 0, nbba = 0, nusm = 0, slot16 = 0, bytes = 0;
     const bool keep_unmatched = bside || !(cardmode || op == OP_AND);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -257,6 +261,7 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         nruns_cls += (uint32_t)__popcll(__ballot(cls == CLS_RUNS));
         nprobe += (uint32_t)__popcll(__ballot(cls == CLS_PROBE));
         nbba += (uint32_t)__popcll(__ballot(cls == CLS_BBA));
+        nusm += (uint32_t)__popcll(__ballot(cls == CLS_USMALL));
     }
     slot16 = wave_sum(slot16);
     bytes = wave_sum(bytes);
@@ -268,9 +273,10 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         counts[SEC_CAND * S + u] = bside ? ncopy : matched + ncopy;
         counts[SEC_M * S + u] = matched;
         counts[SEC_BB * S + u] = nbb;
-        counts[SEC_GEN * S + u] = bside ? 0u : matched - nbb - nfilt - nwave - nruns_cls - nprobe - nbba;
+        counts[SEC_GEN * S + u] = bside ? 0u : matched - nbb - nfilt - nwave - nruns_cls - nprobe - nbba - nusm;
         counts[SEC_PROBE * S + u] = nprobe;
         counts[SEC_BBA * S + u] = nbba;
+        counts[SEC_USMALL * S + u] = nusm;
         counts[SEC_RUNS * S + u] = nruns_cls;
         counts[SEC_FILT * S + u] = nfilt;
         counts[SEC_WAVE * S + u] = nwave;
@@ -297,6 +303,7 @@ struct EmitQueues {
     GenItem* runs;  // section SEC_RUNS
     FatItem* probe; // section SEC_PROBE
     BBItem* bba;    // section SEC_BBA
+    FatItem* usmall; // section SEC_USMALL
 };
 struct CandOut {     // candidate (pre-compaction) result directory
     u64* key;        // [cand]
@@ -326,6 +333,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
     u64 qruns = starts[SEC_RUNS * S + u] - starts[SEC_RUNS * S];
     u64 qprobe = starts[SEC_PROBE * S + u] - starts[SEC_PROBE * S];
     u64 qbba = starts[SEC_BBA * S + u] - starts[SEC_BBA * S];
+    u64 qusm = starts[SEC_USMALL * S + u] - starts[SEC_USMALL * S];
     u64 slot_run = 16ull * (starts[SEC_SLOT * S + u] - starts[SEC_SLOT * S]);  // arena offset of the unit's first slot
     if (!bside) {
         const u64 s0 = a0 + tile * 256;
@@ -377,6 +385,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
             const int cls = (emit && found) ? classify(op, cardmode, ta, tb, ta == T_RUN ? nra : ca, tb == T_RUN ? nrb : cb) : -1;
             const bool isbb = cls == CLS_BB;
             const bool isbba = cls == CLS_BBA;
+            const bool isusm = cls == CLS_USMALL;
             const bool isgen = cls == CLS_GEN;
             const bool isfilt = cls == CLS_FILT;
             const bool iswave = cls == CLS_WAVE;
@@ -385,6 +394,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
             const bool iscopy = emit && !found;
             const u64 mbb = __ballot(isbb), mgen = __ballot(isgen), mcp = __ballot(iscopy), mfl = __ballot(isfilt);
             const u64 mwv = __ballot(iswave), mrn = __ballot(isruns), mpr = __ballot(isprobe), mba = __ballot(isbba);
+            const u64 mus = __ballot(isusm);
             if (isbb || isbba) {
                 BBItem it;
                 it.offa = A.off[ai]; it.offb = B.off[bj]; it.offo = offo; it.out = outidx; it.slot = sl;
@@ -399,14 +409,15 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 if (isgen) Q.gen[qgen + mbcnt(mgen)] = it;
                 else Q.runs[qruns + mbcnt(mrn)] = it;
             }
-            if (isfilt || iswave || isprobe) {
+            if (isfilt || iswave || isprobe || isusm) {
                 FatItem it;
                 it.offa = A.off[ai]; it.offb = B.off[bj]; it.offo = offo;
                 it.out = outidx; it.ca = ca; it.cb = cb; it.types = (uint32_t)ta | ((uint32_t)tb << 8);
                 it.pad0 = 0; it.pad1 = 0;
                 if (isfilt) Q.filt[qfilt + mbcnt(mfl)] = it;
                 else if (iswave) Q.wave[qwave + mbcnt(mwv)] = it;
-                else Q.probe[qprobe + mbcnt(mpr)] = it;
+                else if (isprobe) Q.probe[qprobe + mbcnt(mpr)] = it;
+                else Q.usmall[qusm + mbcnt(mus)] = it;
             }
             if (iscopy) {
                 CopyItem it;
@@ -414,7 +425,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 it.out = outidx; it.n16 = (pa + 15u) >> 4;
                 Q.copy[qcopy + mbcnt(mcp)] = it;
             }
-            qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv); qruns += __popcll(mrn); qprobe += __popcll(mpr); qbba += __popcll(mba);
+            qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv); qruns += __popcll(mrn); qprobe += __popcll(mpr); qbba += __popcll(mba); qusm += __popcll(mus);
         }
     } else {
         const u64 nAt = (a1 - a0 + 255) / 256;

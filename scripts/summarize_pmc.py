@@ -30,7 +30,7 @@ for k in sorted(set(F) | set(W), key=lambda k: -(sum(F.get(k, [0])) + sum(W.get(
     w = sum(W.get(k, [0])) / max(1, len(W.get(k, [1])))
     lines.append(f"| {k[:60]} | {len(F.get(k, []))} | {f:,.0f} | {2 * f * KiB:,.0f} | {w:,.0f} | {w * KiB:,.0f} |")
     out[k] = (2 * f * KiB, w * KiB)
-bb = [k for k in out if "k_bb" in k]
+bb = [k for k in out if "k_bb<" in k]
 rd = sum(out[k][0] for k in bb) / len(bb)
 wr = sum(out[k][1] for k in bb) / len(bb)
 pairs = 250 * 4096

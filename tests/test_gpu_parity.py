@@ -417,6 +417,22 @@ def test_array_array_union_boundaries(engine, oracle):
             a = np.sort(rng.choice(univ, min(ca, univ.size), replace=False))
             b = np.sort(rng.choice(univ, min(cb, univ.size), replace=False))
             cases.append((a, b))
+    # the rank-merge kernel (short array into a long one): short side 1 / 64 / 65 / 128 / 129 values, sums at 4096 /
+    # 4097, shared values (xor deletes them), short values below / above / between all long values, both ends of u16
+    for ny, nx in ((1, 1), (1, 4095), (1, 4096), (64, 900), (65, 900), (127, 1000), (128, 1000), (129, 1000), (128, 3968),
+                   (128, 3969), (100, 3996), (100, 3997), (2, 7), (128, 128), (128, 129), (40, 4000)):
+        big = np.sort(rng.choice(np.arange(300, 65000), nx, replace=False))
+        for mode in range(4):
+            if mode == 0:
+                small = np.sort(rng.choice(65536, ny, replace=False))                     # mostly new values
+            elif mode == 1:
+                small = np.sort(rng.choice(big, min(ny, nx), replace=False))              # all shared
+            elif mode == 2:
+                small = np.unique(np.concatenate([rng.choice(big, min(ny // 2 + 1, nx), replace=False),
+                                                  rng.choice(65536, ny, replace=False)]))[:ny]   # mixed
+            else:
+                small = np.unique(np.concatenate([np.arange(0, ny // 2 + 1), 65535 - np.arange(0, ny // 2 + 1)]))[:ny]
+            cases.append((np.sort(small), big))
     hs = []
     for a, b in cases:
         hs.append(oracle.from_sorted(np.asarray(a, np.uint32) + (7 << 16), run_optimize=False))
