@@ -68,34 +68,20 @@ __global__ __launch_bounds__(256) void k_runs(const uint8_t* __restrict__ arenaA
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
     uint32_t wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    // Two-deep software pipeline over the work items: the NEXT item's descriptor is requested at the top of an
-    // iteration and, once the current lists sit in LDS and the first walk is done, so are the next item's payloads
-    // (one 16-byte load per lane and list: <= 1 KiB each) -- their global-memory latency overlaps the rest of the
-    // current item instead of opening every iteration.
-    auto list16 = [](uint32_t types, int side, uint32_t nr, uint32_t c) -> uint32_t {  // payload size in 16-byte units
-        const bool run = ((side ? types >> 8 : types) & 0xFFu) == T_RUN;
-        return ((run ? 4u * nr : 2u * c) + 15u) >> 4;
-    };
     GenItem tnext;
-    uint4 pfA = make_uint4(0, 0, 0, 0), pfB = pfA;
-    if (wi < n) {
-        tnext = q[wi];
-        if (lane < list16(tnext.types, 0, tnext.nra, tnext.ca)) pfA = ((const uint4*)(arenaA + tnext.offa))[lane];
-        if (lane < list16(tnext.types, 1, tnext.nrb, tnext.cb)) pfB = ((const uint4*)(arenaB + tnext.offb))[lane];
-    }
+    if (wi < n) tnext = q[wi];
     for (; wi < n; wi += nwaves) {
         const GenItem t = tnext;
-        const bool more = wi + nwaves < n;
-        if (more) tnext = q[wi + nwaves];  // next work item in flight while this one is processed
+        if (wi + nwaves < n) tnext = q[wi + nwaves];  // next work item in flight while this one is processed
         const uint32_t ta = t.types & 0xFFu, tb = t.types >> 8;
         IvList L[2];
         L[0].p = lsA; L[0].is_run = ta == T_RUN; L[0].n2 = 2u * (ta == T_RUN ? t.nra : t.ca);
         L[1].p = lsB; L[1].is_run = tb == T_RUN; L[1].n2 = 2u * (tb == T_RUN ? t.nrb : t.cb);
-        {   // stage both payloads (<= 1 KiB each, 16-byte padded slots) from the prefetch registers
+        {   // stage both payloads (<= 1 KiB each, 16-byte padded slots): one 16-byte load per lane
             const uint32_t na16 = ((L[0].is_run ? 2u : 1u) * L[0].n2 + 15u) >> 4;
             const uint32_t nb16 = ((L[1].is_run ? 2u : 1u) * L[1].n2 + 15u) >> 4;
-            if (lane < na16) ((uint4*)lsA)[lane] = pfA;
-            if (lane < nb16) ((uint4*)lsB)[lane] = pfB;
+            if (lane < na16) ((uint4*)lsA)[lane] = ((const uint4*)(arenaA + t.offa))[lane];
+            if (lane < nb16) ((uint4*)lsB)[lane] = ((const uint4*)(arenaB + t.offb))[lane];
             __builtin_amdgcn_wave_barrier();
         }
         // ---- merge path: this lane's chunk of the merged boundary sequence
@@ -137,10 +123,6 @@ __global__ __launch_bounds__(256) void k_runs(const uint8_t* __restrict__ arenaA
         // walk 1: does the chunk hold an effective event, and the state after its last one
         bool has_eff = false, g_last = false;
         walk([&](uint32_t, bool g) { has_eff = true; g_last = g; });
-        if (more) {  // the next item's lists: in flight during walks 2-3, typing and output of this one
-            if (lane < list16(tnext.types, 0, tnext.nra, tnext.ca)) pfA = ((const uint4*)(arenaA + tnext.offa))[lane];
-            if (lane < list16(tnext.types, 1, tnext.nrb, tnext.cb)) pfB = ((const uint4*)(arenaB + tnext.offb))[lane];
-        }
         bool gprev = false;  // state after the last effective event BEFORE this chunk
         {
             const u64 mh = __ballot(has_eff), mg = __ballot(g_last);
