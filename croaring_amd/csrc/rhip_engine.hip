@@ -127,7 +127,7 @@ struct rhip_ctx_s {
     void* h_stage = nullptr;  // pinned staging of one batch description (grow-only)
     size_t h_stage_cap = 0;
     void ensure_stage(size_t n);
-    DBuf many[16];
+    DBuf many[20];
     DBuf sel[5];  // pool_select / pool_convert scratch
     void* h_pinned = nullptr;  // small pinned readback area
     rhip_stats_t stats{};

@@ -81,8 +81,12 @@ __device__ __forceinline__ uint32_t unit_group(const u64* __restrict__ ustart, u
 
 // wave per unit: sum of member cardinalities -> gcard[group]; single-member groups also
 // record their payload size (pass-through slot)
+// ... and, for the replay of roaring_bitmap_or_many's full-union typing (full_union_is_run), where the group's LAST
+// full-run member and LAST bitset member sit (position relative to the group start, +1; 0 = none): glast[2g],
+// glast[2g+1].  A key present in every bitmap of a 100 000-bitmap set has 100 000 members (BASELINE config C4's key
+// 0): finding these two positions inside the finalising workgroup cost it 0.3 ms of dependent loads.
 __global__ __launch_bounds__(256) void k_many_cardsum(PoolView P, ManyView V, const u64* __restrict__ n_units,
-                                                      u64* __restrict__ gcard) {
+                                                      u64* __restrict__ gcard, uint32_t* __restrict__ glast) {
     const u64 u = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (u >= *n_units) return;
     const uint32_t G = *V.n_groups;
@@ -90,9 +94,28 @@ __global__ __launch_bounds__(256) void k_many_cardsum(PoolView P, ManyView V, co
     const u64 m0 = V.gstart[g] + (u - V.ustart[g]) * V.ch;
     const u64 m1 = (m0 + V.ch < V.gstart[g + 1]) ? m0 + V.ch : V.gstart[g + 1];
     u64 s = 0;
-    for (u64 m = m0 + lane_id(); m < m1; m += 64) s += P.card[V.sval[m]];
+    uint32_t lrf = 0, lb = 0;
+    const u64 gs = V.gstart[g];
+    for (u64 m = m0 + lane_id(); m < m1; m += 64) {
+        const uint32_t c = V.sval[m];
+        const uint32_t cd = P.card[c];
+        const uint8_t ty = P.type[c];
+        s += cd;
+        if (ty == T_RUN && cd == 65536u) lrf = (uint32_t)(m - gs) + 1u;
+        if (ty == T_BITSET) lb = (uint32_t)(m - gs) + 1u;
+    }
     s = wave_sum64(s);
-    if (lane_id() == 0) atomicAdd(&gcard[g], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = __shfl_xor(lrf, o), b = __shfl_xor(lb, o);
+        lrf = a > lrf ? a : lrf;
+        lb = b > lb ? b : lb;
+    }
+    if (lane_id() == 0) {
+        atomicAdd(&gcard[g], s);
+        if (lrf) atomicMax(&glast[2 * (u64)g], lrf);
+        if (lb) atomicMax(&glast[2 * (u64)g + 1], lb);
+    }
 }
 
 // slot size of every group (upper bound on the canonical result payload)
@@ -246,6 +269,7 @@ struct ManyOut {
     int partial_mode;   // 1: write uncompressed chunks instead of canonical containers
     int force_typed;    // 1: single-member groups are typed by cardinality too
     int exact_or_many;  // 1: reproduce roaring_bitmap_or_many's run-vs-bitset choice for FULL containers
+    const uint32_t* glast;  // [2 G] last full-run / last bitset member of every group (k_many_cardsum)
     u64 first_lo, first_hi, second_lo, second_hi;  // container index ranges of ids[0] and ids[1]
 };
 
@@ -258,7 +282,7 @@ struct ManyOut {
 // "is the union already full after the last bitset member?" -- answered by re-accumulating that prefix.
 // Returns true for a full run, false for a (full) bitset.
 __device__ bool full_union_is_run(uint32_t* acc2, uint32_t* tmp, const PoolView& P, const ManyView& V,
-                                  const ManyOut& MO, u64 gs, u64 ge, BlockScratch* sc, ManyLists* ml) {
+                                  const ManyOut& MO, uint32_t g, u64 gs, u64 ge, BlockScratch* sc, ManyLists* ml) {
     const uint32_t c0 = V.sval[gs], c1 = V.sval[gs + 1];
     const bool first = c0 >= MO.first_lo && c0 < MO.first_hi && c1 >= MO.second_lo && c1 < MO.second_hi;
     auto isB = [&](uint32_t c) { return P.type[c] == T_BITSET; };
@@ -273,26 +297,12 @@ __device__ bool full_union_is_run(uint32_t* acc2, uint32_t* tmp, const PoolView&
         if (isB(c0) && P.card[c0] == 65536u) return false;  // known-full bitset: skipped, repair keeps a bitset
         start = gs + 1;
     }
-    // One pass over the members, 256 at a time (a key present in every bitmap of a 100 000-bitmap set has 100 000
-    // members: BASELINE config C4's key 0): any full run wins (it is never skipped: the accumulator's cardinality
-    // is unknown or below 65536 when it arrives); otherwise the LAST bitset member decides.
-    uint32_t rf = 0, lb = 0;  // lb = 1 + position of the last bitset member relative to gs (0: none)
-    for (u64 m = start + threadIdx.x; m < ge; m += 256) {
-        const uint32_t c = V.sval[m];
-        if (isRF(c)) rf = 1;
-        if (isB(c)) lb = (uint32_t)(m - gs) + 1u;
-    }
-    if (blk_sum(rf, sc->wsum)) return true;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t x = __shfl_xor(lb, o);
-        lb = x > lb ? x : lb;
-    }
-    __syncthreads();
-    if (lane_id() == 0) sc->wsum2[threadIdx.x >> 6] = lb;
-    __syncthreads();
-    lb = sc->wsum2[0];
-    for (int w2 = 1; w2 < 4; ++w2) lb = sc->wsum2[w2] > lb ? sc->wsum2[w2] : lb;
+    // Any full run among the members [start, ge) wins (it is never skipped: the accumulator's cardinality is unknown
+    // or below 65536 when it arrives); otherwise the LAST bitset member decides.  Both positions were recorded by
+    // k_many_cardsum (relative to gs, +1).
+    const uint32_t lrf = MO.glast[2 * (u64)g], lb_all = MO.glast[2 * (u64)g + 1];
+    if (lrf && gs + lrf - 1u >= start) return true;
+    const uint32_t lb = (lb_all && gs + lb_all - 1u >= start) ? lb_all : 0u;
     if (!lb) return false;
     const u64 last_b = gs + lb - 1u;
     // union of members [gs, last_b] full?
@@ -320,7 +330,7 @@ __device__ void many_finalize(uint32_t* acc, uint16_t* stage, const ManyOut& MO,
     uint32_t r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
     const uint32_t rc = blk_sum(popc4(r0) + popc4(r1), sc->wsum);
     int ty = T_ARRAY;
-    if (rc == 65536u && MO.exact_or_many && ge - gs >= 2 && full_union_is_run(acc2, tmp, P, V, MO, gs, ge, sc, ml)) {
+    if (rc == 65536u && MO.exact_or_many && ge - gs >= 2 && full_union_is_run(acc2, tmp, P, V, MO, g, gs, ge, sc, ml)) {
         if (tid == 0) {
             *(uint32_t*)(MO.O.arena + MO.O.off[g]) = 0xFFFF0000u;  // one run {value 0, length 0xFFFF}
             MO.O.meta[g] = pack_meta(T_RUN, 65536u, 1u);
