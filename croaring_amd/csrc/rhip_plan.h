@@ -26,21 +26,36 @@ struct LbState {
 };
 __device__ __forceinline__ u64 lb_load(const u64* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 __device__ __forceinline__ void lb_store(u64* p, u64 v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
-// Called by ONE thread of the block with the block's aggregate; returns the exclusive prefix of the tile.
+// Called by the 64 lanes of ONE wave of the block with the block's aggregate; returns (to every lane) the exclusive
+// prefix of the tile.  The look-back is wave-parallel: the lanes read the status of the 64 preceding tiles at once,
+// the nearest tile that already published an inclusive prefix ends the walk, the aggregates in front of it are summed
+// with one wave reduction.  (A one-thread walk cost one global round trip per preceding tile: 0.3 ms for the 1 400
+// tiles of a 2.9 M-candidate batch.)
 __device__ __forceinline__ u64 lb_exclusive_prefix(u64* status, uint32_t tile, u64 aggregate) {
+    const uint32_t lane = lane_id();
     if (tile == 0) {
-        lb_store(&status[0], LB_PREFIX | aggregate);
+        if (lane == 0) lb_store(&status[0], LB_PREFIX | aggregate);
         return 0;
     }
-    lb_store(&status[tile], LB_AGG | aggregate);
+    if (lane == 0) lb_store(&status[tile], LB_AGG | aggregate);
     u64 run = 0;
-    for (uint32_t t = tile; t-- > 0;) {
-        u64 s;
-        do { s = lb_load(&status[t]); } while ((s >> 62) == 0);
-        run += LB_VAL(s);
-        if ((s >> 62) == 2) break;
+    long long base = (long long)tile - 1;  // lane l looks at tile base - l
+    for (;;) {
+        const long long idx = base - (long long)lane;
+        const u64 s = idx >= 0 ? lb_load(&status[idx]) : LB_PREFIX;  // in front of tile 0: prefix 0
+        const u64 ready = __ballot((s >> 62) != 0), pref = __ballot((s >> 62) == 2);
+        if (pref) {
+            const uint32_t first = (uint32_t)__ffsll((long long)pref) - 1u;  // nearest published prefix
+            const u64 need = first == 63u ? ~0ull : ((1ull << (first + 1u)) - 1ull);
+            if ((ready & need) != need) continue;  // an aggregate in front of it is not there yet: look again
+            run += wave_sum64(lane <= first ? LB_VAL(s) : 0ull);
+            break;
+        }
+        if (ready != ~0ull) continue;
+        run += wave_sum64(LB_VAL(s));
+        base -= 64;
     }
-    lb_store(&status[tile], LB_PREFIX | (run + aggregate));
+    if (lane == 0) lb_store(&status[tile], LB_PREFIX | (run + aggregate));
     return run;
 }
 __device__ __forceinline__ u64 wave_incl_scan64(u64 v) {
@@ -89,7 +104,10 @@ __global__ __launch_bounds__(256) void k_scan(const uint32_t* __restrict__ in, u
     for (int k = 0; k < 8; ++k) mine += v[k];
     u64 total;
     u64 ex = blk_exscan64(mine, sm, &total);
-    if (threadIdx.x == 0) s_prefix = lb_exclusive_prefix(lb.status, tile, total);
+    if (threadIdx.x < 64) {
+        const u64 pfx = lb_exclusive_prefix(lb.status, tile, total);
+        if (threadIdx.x == 0) s_prefix = pfx;
+    }
     __syncthreads();
     ex += s_prefix;
 #pragma unroll
@@ -506,7 +524,10 @@ __global__ __launch_bounds__(256) void k_tail(const u64* __restrict__ ranges, Ca
     }
     u64 total;
     u64 ex = blk_exscan64(keep, sm, &total);
-    if (threadIdx.x == 0) s_prefix = lb_exclusive_prefix(lb.status, tile, total);
+    if (threadIdx.x < 64) {
+        const u64 pfx = lb_exclusive_prefix(lb.status, tile, total);
+        if (threadIdx.x == 0) s_prefix = pfx;
+    }
     __syncthreads();
     ex += s_prefix;
     u64 bytes = 0;

@@ -74,20 +74,18 @@ __global__ __launch_bounds__(256) void k_runs(const uint8_t* __restrict__ arenaA
         const GenItem t = tnext;
         if (wi + nwaves < n) tnext = q[wi + nwaves];  // next work item in flight while this one is processed
         const uint32_t ta = t.types & 0xFFu, tb = t.types >> 8;
-        IvList L[2];
-        L[0].p = lsA; L[0].is_run = ta == T_RUN; L[0].n2 = 2u * (ta == T_RUN ? t.nra : t.ca);
-        L[1].p = lsB; L[1].is_run = tb == T_RUN; L[1].n2 = 2u * (tb == T_RUN ? t.nrb : t.cb);
+        IvList LA, LB;
+        LA.p = lsA; LA.is_run = ta == T_RUN; LA.n2 = 2u * (ta == T_RUN ? t.nra : t.ca);
+        LB.p = lsB; LB.is_run = tb == T_RUN; LB.n2 = 2u * (tb == T_RUN ? t.nrb : t.cb);
         {   // stage both payloads (<= 1 KiB each, 16-byte padded slots): one 16-byte load per lane
-            const uint32_t na16 = ((L[0].is_run ? 2u : 1u) * L[0].n2 + 15u) >> 4;
-            const uint32_t nb16 = ((L[1].is_run ? 2u : 1u) * L[1].n2 + 15u) >> 4;
+            const uint32_t na16 = ((LA.is_run ? 2u : 1u) * LA.n2 + 15u) >> 4;
+            const uint32_t nb16 = ((LB.is_run ? 2u : 1u) * LB.n2 + 15u) >> 4;
             if (lane < na16) ((uint4*)lsA)[lane] = ((const uint4*)(arenaA + t.offa))[lane];
             if (lane < nb16) ((uint4*)lsB)[lane] = ((const uint4*)(arenaB + t.offb))[lane];
             __builtin_amdgcn_wave_barrier();
         }
         // ---- merge path: this lane's chunk of the merged boundary sequence
         constexpr uint32_t SENT = 0x20000u;  // past every boundary (the largest is 65536)
-        const IvList& LA = L[0];
-        const IvList& LB = L[1];
         const uint32_t nA = LA.n2, nB2 = LB.n2, E = nA + nB2;
         const uint32_t per = (E + 63u) >> 6;
         const uint32_t d0 = lane * per < E ? lane * per : E;

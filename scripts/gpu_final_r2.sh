@@ -10,7 +10,7 @@ timeout 200 python scripts/quick_classes.py > $O/class_throughput.jsonl 2>/dev/n
 timeout 200 python scripts/bench_poolops.py > $O/poolops.jsonl 2>/dev/null
 # kernel-trace stats: the bench command itself (C2 only), then one realdata batch type per run
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -- python bench.py --steps 6 --warmup 2 --no-cpu --no-secondary > $O/prof_bench.log 2>&1
-for spec in w_and:and:weather_sept_85 w_or:or:weather_sept_85 w_xor:xor:weather_sept_85 w_andnot:andnot:weather_sept_85 c1_and:and:census1881 c1_or:or:census1881 wk_and:and:wikileaks-noquotes; do
+for spec in w_and:and:weather_sept_85 w_or:or:weather_sept_85 w_xor:xor:weather_sept_85 w_andnot:andnot:weather_sept_85 c1_and:and:census1881 c1_or:or:census1881 wk_and:and:wikileaks-noquotes c5_and:and:c5 c5_or:or:c5; do
   name=${spec%%:*}; rest=${spec#*:}; op=${rest%%:*}; ds=${rest#*:}
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -o p -- python scripts/prof_weather.py $op $ds > $O/prof_$name.log 2>&1
   grep "min ms" $O/prof_$name.log

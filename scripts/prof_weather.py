@@ -1,4 +1,5 @@
-"""rocprofv3 target: C3 weather_sept_85 all-pairs, one op per run (argv[1]), 10 timed batches."""
+"""rocprofv3 target: all-pairs batches of one realdata set (argv[2], default weather_sept_85; "c5" = the roaring64
+configuration), one op per run (argv[1]), 12 timed batches."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,8 +10,13 @@ from util import load_bundle, all_pairs
 op = sys.argv[1] if len(sys.argv) > 1 else "and"
 name = sys.argv[2] if len(sys.argv) > 2 else "weather_sept_85"
 eng = croaring_amd.Engine(0)
-bufs = load_bundle(name)
-pool = eng.pool_from_serialized(bufs)
+if name == "c5":  # BASELINE config C5: roaring64, wikileaks-noquotes x 10 high-32 buckets
+    from util import c5_inputs
+    bufs = c5_inputs()
+    pool = eng.pool_from_serialized64(bufs)
+else:
+    bufs = load_bundle(name)
+    pool = eng.pool_from_serialized(bufs)
 lhs, rhs = all_pairs(len(bufs))
 res = None
 ts = []
