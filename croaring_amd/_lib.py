@@ -76,6 +76,7 @@ SYMBOLS = [
     ("rhip_many_finalize", _vp, [_vp, _i, _i, _u64, _vp, _vp]),
     ("rhip_last_stats", _i, [_vp, C.POINTER(Stats)]),
     ("rhip_ctx_set_timing", None, [_vp, _i]),
+    ("rhip_debug_host_clock", _i, [_vp, C.POINTER(C.c_double), _i]),
 ]
 
 _lib = None

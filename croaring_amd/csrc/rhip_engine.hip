@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -130,6 +131,14 @@ struct rhip_ctx_s {
     DBuf many[20];
     DBuf sel[5];  // pool_select / pool_convert scratch
     void* h_pinned = nullptr;  // small pinned readback area
+    // completion word of the pairwise path (inside h_pinned): k_tail's last block writes the call's sequence number
+    // after the statistics; the host polls it (the stream's completion signal costs an interrupt / wake-up)
+    static constexpr size_t PINNED_FLAG_OFF = 2048;
+    uint64_t seq = 0;
+    bool spin_wait = true;
+    volatile uint64_t* done_flag() const { return (volatile uint64_t*)((char*)h_pinned + PINNED_FLAG_OFF); }
+    // host-side phase clock (diagnostics, rhip_debug_host_clock): microseconds accumulated per phase of rhip_pairwise
+    double hclk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     rhip_stats_t stats{};
     bool timing = false;
     hipEvent_t ev[4]{};
@@ -223,6 +232,8 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         HIPCHK(hipEventCreateWithFlags(&c->ev_runs, hipEventDisableTiming));
         for (auto& e : c->ev_join) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         if (const char* e = getenv("RHIP_NO_OVERLAP")) c->overlap = !(e[0] == '1');
+        if (const char* e = getenv("RHIP_SPIN_WAIT")) c->spin_wait = !(e[0] == '0');
+        memset(c->h_pinned, 0, 4096);
         return c;
     } catch (int) {
         return nullptr;
@@ -742,16 +753,20 @@ static void fetch_bounds(rhip_pool_t* P) {
 // device scratch of one call (inside ctx->misc, all of it cleared by k_count): u64 words
 struct PlanScratch {
     size_t n_scan_tiles, n_tail_tiles;
-    size_t w_scan_status, w_tail_status, w_tickets, w_retry, w_ranges, w_stats, n_words;
+    size_t w_scan_status, w_tail_status, w_tail_part, w_tickets, w_retry, w_ranges, w_stats, n_words;
     void layout(size_t n_scan_elems, size_t ub_cand) {
         n_scan_tiles = (n_scan_elems + SCAN_TILE - 1) / SCAN_TILE + 1;
         n_tail_tiles = (ub_cand + TAIL_TILE - 1) / TAIL_TILE + 1;
         size_t w = 0;
         w_scan_status = w; w += n_scan_tiles;
         w_tail_status = w; w += n_tail_tiles;
-        w_tickets = w; w += 3;
-        w_retry = w; w += 1;
-        w_ranges = w; w += 2 * N_SEC;
+        w_tail_part = w; w += 2 * n_tail_tiles;
+        // every counter that many blocks hit with atomics sits alone in a 128-byte line: device-scope atomics on one
+        // line serialise at the memory side, and plain loads of that line (the section ranges) queue behind them
+        w = (w + 15) & ~(size_t)15;
+        w_tickets = w; w += 3 * 16;
+        w_retry = w; w += 16;
+        w_ranges = w; w += (2 * N_SEC + 15) & ~15;
         w_stats = w; w += (sizeof(Stats) + 7) / 8;
         n_words = w;
     }
@@ -771,8 +786,9 @@ struct Plan {
     uint32_t* retry_count() const { return (uint32_t*)(words + sc.w_retry); }
     Stats* stats() const { return (Stats*)(words + sc.w_stats); }
     LbState scan_lb() const { return LbState{words + sc.w_scan_status, (uint32_t*)(words + sc.w_tickets)}; }
-    LbState tail_lb() const { return LbState{words + sc.w_tail_status, (uint32_t*)(words + sc.w_tickets + 1)}; }
-    uint32_t* tail_done() const { return (uint32_t*)(words + sc.w_tickets + 2); }
+    LbState tail_lb() const { return LbState{words + sc.w_tail_status, (uint32_t*)(words + sc.w_tickets + 16)}; }
+    uint32_t* tail_done() const { return (uint32_t*)(words + sc.w_tickets + 32); }
+    u64* tail_part() const { return words + sc.w_tail_part; }
 };
 
 void check_pair_args(rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs, const uint32_t* rhs) {
@@ -801,8 +817,18 @@ unsigned persistent_grid(uint64_t n_items, unsigned items_per_block, unsigned ma
 // Host half of the plan: units, upper bounds (nothing here waits for the device), ONE host-to-device copy of the
 // batch description, then k_count -> k_scan -> k_emit.  On return the class queues are filled at deterministic
 // positions and `ranges` (device) holds every section's [begin, end).
+struct HostClock {  // phase p accumulates the host time between the previous lap and lap(p)
+    rhip_ctx_t* c;
+    std::chrono::steady_clock::time_point t;
+    explicit HostClock(rhip_ctx_t* c_) : c(c_), t(std::chrono::steady_clock::now()) {}
+    void lap(int p) {
+        const auto n = std::chrono::steady_clock::now();
+        c->hclk[p] += std::chrono::duration<double, std::micro>(n - t).count();
+        t = n;
+    }
+};
 Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs,
-          const uint32_t* rhs, int cardmode) {
+          const uint32_t* rhs, int cardmode, HostClock* clk = nullptr) {
     hipStream_t s = c->stream;
     Plan P;
     P.npairs = npairs;
@@ -857,6 +883,7 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
         }
         pair0[npairs] = NU;
     }
+    if (clk) clk->lap(0);
     P.NU = NU;
     P.S = NU + 1;
     P.ub_match = ub_match;
@@ -912,6 +939,7 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     P.d_upair = (uint32_t*)(dp + o_upair);
     P.d_utile = (uint32_t*)(dp + o_utile);
     HIPCHK(hipMemcpyAsync(dp, hs, stage_bytes, hipMemcpyHostToDevice, s));
+    if (clk) clk->lap(1);
     PoolView VA = A->view(), VB = B->view();
     UnitView UV{P.d_upair, P.d_utile, P.d_pair0, (uint32_t)NU, (uint32_t)npairs};
     PlanZero Z{P.words, (uint32_t)P.sc.n_words, cardmode ? c->pair_acc.as<u64>() : nullptr};
@@ -928,6 +956,7 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     if (NU)
         hipLaunchKernelGGL(k_emit, dim3((unsigned)((NU * 64 + 255) / 256)), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV,
                            op, cardmode, c->cand_start.as<u64>(), c->match.as<uint32_t>(), P.CO, Q);
+    if (clk) clk->lap(2);
     return P;
 }
 
@@ -1038,16 +1067,35 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
 
 // many-way / flip paths: their statistics live at a fixed offset of ctx->misc (cleared by the caller)
 constexpr size_t MISC_STATS_OFF = 192;
-void finish_stats(rhip_ctx_t* c, const Stats* dstats, Stats* out, bool had_bb);
+void finish_stats(rhip_ctx_t* c, const Stats* dstats, Stats* out, bool had_bb, uint64_t wait_seq = 0);
 void finish_stats_misc(rhip_ctx_t* c) { finish_stats(c, (const Stats*)((char*)c->misc.p + MISC_STATS_OFF), nullptr, false); }
 
 // the ONE host synchronisation of a call: statistics (and whatever the caller queued before) come back
-void finish_stats(rhip_ctx_t* c, const Stats* dstats, Stats* out, bool had_bb) {
+// wait_seq != 0: the tail kernel publishes that sequence number in pinned memory when everything is written; the host
+// polls it (and the stream's state now and then, so that a device fault still surfaces) instead of blocking.
+void finish_stats(rhip_ctx_t* c, const Stats* dstats, Stats* out, bool had_bb, uint64_t wait_seq) {
     hipStream_t s = c->stream;
     // dstats == nullptr: the last kernel of the call already wrote the totals into the pinned area
     if (dstats) HIPCHK(hipMemcpyAsync(c->h_pinned, dstats, sizeof(Stats), hipMemcpyDeviceToHost, s));
     if (c->timing) HIPCHK(hipEventRecord(c->ev[1], s));
-    HIPCHK(hipStreamSynchronize(s));
+    if (wait_seq && c->spin_wait && !c->timing && !dstats) {
+        volatile uint64_t* flag = c->done_flag();
+        for (uint32_t spins = 0;; ++spins) {
+            if (__atomic_load_n((const uint64_t*)flag, __ATOMIC_ACQUIRE) == wait_seq) break;
+            if ((spins & 0x3FFFu) == 0x3FFFu) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q == hipSuccess) {  // stream drained: the word is there now, or the kernel never ran
+                    if (__atomic_load_n((const uint64_t*)flag, __ATOMIC_ACQUIRE) == wait_seq) break;
+                    set_err("tail kernel finished without publishing its completion word");
+                    throw (int)RHIP_ERR_DEVICE;
+                }
+                if (q != hipErrorNotReady) { set_err("device error while waiting: %s", hipGetErrorString(q)); throw (int)RHIP_ERR_DEVICE; }
+            }
+            __builtin_ia32_pause();
+        }
+    } else {
+        HIPCHK(hipStreamSynchronize(s));
+    }
     Stats st{};
     memcpy(&st, c->h_pinned, sizeof(Stats));
     if (out) *out = st;
@@ -1082,7 +1130,8 @@ extern "C" rhip_pool_t* rhip_pairwise(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A
         }
         hipStream_t s = c->stream;
         if (c->timing) HIPCHK(hipEventRecord(c->ev[0], s));
-        Plan P = plan(c, op, A, B, npairs, lhs, rhs, 0);
+        HostClock clk(c);
+        Plan P = plan(c, op, A, B, npairs, lhs, rhs, 0, &clk);
         const CandOut& CO = P.CO;
         R = reuse ? reuse : new rhip_pool_s();
         reuse = nullptr;
@@ -1103,14 +1152,18 @@ extern "C" rhip_pool_t* rhip_pairwise(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A
         // drop empty results, build the result directory, totals
         DirOut D{R->bm_start.as<u64>(), R->key.as<u64>(), R->type.as<uint8_t>(), R->card.as<uint32_t>(),
                  R->nruns.as<uint32_t>(), R->off.as<u64>()};
+        const uint64_t seq = ++c->seq;
         hipLaunchKernelGGL(k_tail, dim3((unsigned)std::max<uint64_t>(1, (P.ub_cand + TAIL_TILE - 1) / TAIL_TILE)), dim3(256), 0,
-                           s, P.ranges(), CO, O.meta, D, (uint32_t)npairs, P.tail_lb(), P.stats(), P.tail_done(),
-                           (Stats*)c->h_pinned);
+                           s, P.ranges(), CO, O.meta, D, (uint32_t)npairs, P.tail_lb(), P.tail_part(), P.stats(), P.tail_done(),
+                           (Stats*)c->h_pinned, (u64*)c->done_flag(), (u64)seq);
+        clk.lap(3);
         Stats st;
-        finish_stats(c, nullptr, &st, P.may_bb);
+        finish_stats(c, nullptr, &st, P.may_bb, seq);
+        clk.lap(4);
         R->n_cont = st.result_containers;
         R->arena_used = st.slot_bytes + 64;
         for (int t = 0; t < 3; ++t) R->census[t] = st.n_type[t] ? 1 : 0;
+        clk.lap(5);
         return R;
     } catch (int e) {
         last_status() = e;
@@ -1156,6 +1209,16 @@ extern "C" int rhip_pairwise_cardinality(rhip_ctx_t* c, rhip_op op_, rhip_pool_t
         }
         return RHIP_OK;
     } catch (int e) { return e; }
+}
+
+// host-side phase clock of rhip_pairwise, microseconds accumulated since the last reset: [0] pair-list passes,
+// [1] scratch sizing + host-to-device copy of the batch description, [2] planning launches, [3] class + tail launches,
+// [4] wait for completion, [5] result bookkeeping
+extern "C" int rhip_debug_host_clock(rhip_ctx_t* c, double out[8], int reset) {
+    if (!c || !out) return RHIP_ERR_ARG;
+    for (int i = 0; i < 8; ++i) out[i] = c->hclk[i];
+    if (reset) for (int i = 0; i < 8; ++i) c->hclk[i] = 0;
+    return RHIP_OK;
 }
 
 #ifdef RHIP_PHASES

@@ -77,6 +77,12 @@ class Engine:
         if self.lib.rhip_ctx_synchronize(self.h) != 0:
             raise RoaringHipError(self._err())
 
+    def host_clock(self, reset: bool = True) -> list:
+        """Host microseconds of rhip_pairwise by phase since the last reset (include/roaring_hip.h)."""
+        out = (C.c_double * 8)()
+        self.lib.rhip_debug_host_clock(self.h, out, 1 if reset else 0)
+        return list(out)
+
     def set_timing(self, on: bool):
         self.lib.rhip_ctx_set_timing(self.h, 1 if on else 0)
 

@@ -237,6 +237,12 @@ typedef struct rhip_stats_s {
 int rhip_last_stats(rhip_ctx_t *ctx, rhip_stats_t *out);
 /* enable/disable HIP-event timing of kernel launches (adds two event records per call) */
 void rhip_ctx_set_timing(rhip_ctx_t *ctx, int enabled);
+/* Diagnostics: host time of rhip_pairwise by phase, microseconds accumulated since the last reset:
+ * [0] passes over the pair list, [1] scratch sizing + host-to-device copy of the batch description,
+ * [2] planning launches, [3] class + tail launches, [4] wait for completion, [5] result bookkeeping.
+ * The wait polls a completion word the last kernel writes into pinned memory; RHIP_SPIN_WAIT=0 in the environment
+ * (read at rhip_ctx_create) makes it block on the stream instead. */
+int rhip_debug_host_clock(rhip_ctx_t *ctx, double out_us[8], int reset);
 
 #ifdef __cplusplus
 }

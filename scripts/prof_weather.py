@@ -20,8 +20,12 @@ else:
 lhs, rhs = all_pairs(len(bufs))
 res = None
 ts = []
-for _ in range(12):
+for it in range(12):
+    if it == 2:
+        eng.host_clock(True)
     t = time.perf_counter()
     res = eng.pairwise(op, pool, lhs, pool, rhs, reuse=res)
     ts.append(time.perf_counter() - t)
-print(op, name, "min ms", min(ts) * 1e3)
+hc = [round(x / 10, 1) for x in eng.host_clock()]
+print(op, name, "min ms", min(ts) * 1e3, "mean(last 10) ms", sum(ts[2:]) / 10 * 1e3,
+      "host us/batch [pairs, scratch+h2d, plan launches, class launches, wait, bookkeeping]:", hc[:6])

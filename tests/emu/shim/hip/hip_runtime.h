@@ -45,7 +45,7 @@ static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 
 // ---------------------------------------------------------------- runtime API subset
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorNotReady = 600 };
 typedef struct hipemu_stream* hipStream_t;
 struct hipemu_event {
     std::chrono::steady_clock::time_point t;
@@ -63,6 +63,7 @@ static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, i
 static inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = 0; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) {
@@ -196,6 +197,7 @@ static inline unsigned mbcnt(unsigned mask, unsigned add, int hi) {
 
 #define HIPEMU_SITE ((int)(__LINE__ * 131 + sizeof(__FILE__)))
 #define __syncthreads() hipemu::block_sync()
+#define __threadfence_system() ((void)0)
 #define __threadfence() ((void)0)  /* blocks of the emulator run one after another: every write is visible */
 #define __shfl(v, src, ...) hipemu::shfl(HIPEMU_SITE, (v), (src))
 #define __shfl_up(v, d, ...) hipemu::shfl_up(HIPEMU_SITE, (v), (d))
