@@ -136,6 +136,7 @@ struct rhip_ctx_s {
     static constexpr size_t PINNED_FLAG_OFF = 2048;
     uint64_t seq = 0;
     bool spin_wait = true;
+    bool explicit_units = false;  // RHIP_EXPLICIT_UNITS=1: always stage the unit arrays (tests of that path)
     volatile uint64_t* done_flag() const { return (volatile uint64_t*)((char*)h_pinned + PINNED_FLAG_OFF); }
     // host-side phase clock (diagnostics, rhip_debug_host_clock): microseconds accumulated per phase of rhip_pairwise
     double hclk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -180,6 +181,7 @@ struct rhip_pool_s {
     std::vector<uint64_t> h_cards;  // per-bitmap cardinalities cache
     std::vector<uint64_t> h_w;      // per-bitmap result-slot bound (k_bitmap_bounds), see fetch_bounds
     std::vector<uint32_t> h_n;      // per-bitmap container count
+    uint32_t max_n = 0;             // largest of them
     bool host_w = false;
     int8_t census[3] = {1, 1, 1};   // does the pool hold bitset / array / run containers (1 until known otherwise)
     PoolView view() const {
@@ -233,6 +235,7 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         for (auto& e : c->ev_join) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         if (const char* e = getenv("RHIP_NO_OVERLAP")) c->overlap = !(e[0] == '1');
         if (const char* e = getenv("RHIP_SPIN_WAIT")) c->spin_wait = !(e[0] == '0');
+        if (const char* e = getenv("RHIP_EXPLICIT_UNITS")) c->explicit_units = e[0] == '1';
         memset(c->h_pinned, 0, 4096);
         return c;
     } catch (int) {
@@ -746,7 +749,11 @@ static void fetch_bounds(rhip_pool_t* P) {
     }
     for (int t = 0; t < 3; ++t) P->census[t] = census[t] ? 1 : 0;
     P->h_n.resize((size_t)P->n_bitmaps);
-    for (uint32_t b = 0; b < P->n_bitmaps; ++b) P->h_n[b] = (uint32_t)(P->h_bm_start[b + 1] - P->h_bm_start[b]);
+    P->max_n = 0;
+    for (uint32_t b = 0; b < P->n_bitmaps; ++b) {
+        P->h_n[b] = (uint32_t)(P->h_bm_start[b + 1] - P->h_bm_start[b]);
+        P->max_n = std::max(P->max_n, P->h_n[b]);
+    }
     P->host_w = true;
 }
 
@@ -837,6 +844,9 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     const bool btiles = !cardmode && (op == OP_OR || op == OP_XOR);
     const int bmode = (cardmode || op == OP_AND) ? 0 : (op == OP_ANDNOT ? 1 : 2);
     // ---- pass 1 over the pair list: range check, units and every upper bound (directory mirrors only)
+    // No bitmap of either pool above 256 containers (one tile): the units are implicit -- unit = pair (and / andnot /
+    // cardinality) or 2 pair + side (or / xor) -- and only the two index lists travel to the device.
+    const bool implicit = A->max_n <= 256 && B->max_n <= 256 && !c->explicit_units;
     size_t NU = 0;
     uint64_t ub_match = 0, ub = 0, bound = 0;
     {
@@ -857,21 +867,24 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
             else { ub += nA + nB; bound += wA + wB; }
         }
     }
+    if (implicit) NU = npairs * (btiles ? 2 : 1);
     if (NU >= 0x7FFFFFF0ull) { set_err("batch too large: %zu planning units", NU); throw (int)RHIP_ERR_ARG; }
     if (ub >= 0xFFFFFFF0ull) { set_err("batch too large: %llu candidate containers", (unsigned long long)ub); throw (int)RHIP_ERR_ARG; }
-    // staging layout (host pinned == device): pair0[npairs+1] u64 | lhs | rhs | upair | utile (u32 each)
-    const size_t o_pair0 = 0, o_lhs = 8 * (npairs + 1), o_rhs = o_lhs + 4 * npairs, o_upair = o_rhs + 4 * npairs,
-                 o_utile = o_upair + 4 * NU, stage_bytes = o_utile + 4 * NU;
+    // staging layout (host pinned == device): lhs | rhs (u32 each) and, with explicit units, pair0[npairs+1] u64 |
+    // upair | utile (u32 each)
+    const size_t o_lhs = 0, o_rhs = o_lhs + 4 * npairs, o_pair0 = (o_rhs + 4 * npairs + 7) & ~(size_t)7,
+                 o_upair = o_pair0 + (implicit ? 0 : 8 * (npairs + 1)), o_utile = o_upair + (implicit ? 0 : 4 * NU),
+                 stage_bytes = o_utile + (implicit ? 0 : 4 * NU);
     c->ensure_stage(stage_bytes + 16);
     char* hs = (char*)c->h_stage;
-    uint64_t* pair0 = (uint64_t*)(hs + o_pair0);
-    uint32_t* upair = (uint32_t*)(hs + o_upair);
-    uint32_t* utile = (uint32_t*)(hs + o_utile);
     if (npairs) {
         memcpy(hs + o_lhs, lhs, 4 * npairs);
         memcpy(hs + o_rhs, rhs, 4 * npairs);
     }
-    {   // ---- pass 2: the units
+    if (!implicit) {   // ---- pass 2: the units
+        uint64_t* pair0 = (uint64_t*)(hs + o_pair0);
+        uint32_t* upair = (uint32_t*)(hs + o_upair);
+        uint32_t* utile = (uint32_t*)(hs + o_utile);
         const uint32_t* nAv = A->h_n.data();
         const uint32_t* nBv = B->h_n.data();
         size_t u = 0;
@@ -941,7 +954,7 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     HIPCHK(hipMemcpyAsync(dp, hs, stage_bytes, hipMemcpyHostToDevice, s));
     if (clk) clk->lap(1);
     PoolView VA = A->view(), VB = B->view();
-    UnitView UV{P.d_upair, P.d_utile, P.d_pair0, (uint32_t)NU, (uint32_t)npairs};
+    UnitView UV{P.d_upair, P.d_utile, P.d_pair0, (uint32_t)NU, (uint32_t)npairs, implicit ? (btiles ? 2u : 1u) : 0u};
     PlanZero Z{P.words, (uint32_t)P.sc.n_words, cardmode ? c->pair_acc.as<u64>() : nullptr};
     const size_t zero_threads = std::max<size_t>(P.sc.n_words, cardmode ? npairs : 0);
     unsigned gp = (unsigned)std::max<size_t>(1, (std::max<size_t>(NU * 64, std::min<size_t>(zero_threads, 1 << 16)) + 255) / 256);

@@ -179,7 +179,25 @@ struct UnitView {
     const u64* pair_unit0;  // [npairs+1] first unit of each pair
     uint32_t n_units;
     uint32_t n_pairs;
+    uint32_t implicit;      // 0: the arrays above; 1 / 2: every pair has exactly that many one-tile units (A, then B)
+                            //    and the arrays are not there (no bitmap of the batch has more than 256 containers)
 };
+struct UnitId { uint32_t pair; bool bside; u64 tile; u64 unit0; };
+__device__ __forceinline__ UnitId unit_id(const UnitView& U, uint32_t u) {
+    UnitId r;
+    if (U.implicit) {
+        r.pair = U.implicit == 2 ? u >> 1 : u;
+        r.bside = U.implicit == 2 && (u & 1u);
+        r.tile = 0;
+        r.unit0 = (u64)r.pair * U.implicit;
+    } else {
+        r.pair = U.pair[u];
+        r.bside = (U.tile[u] & UNIT_B) != 0;
+        r.tile = U.tile[u] & ~UNIT_B;
+        r.unit0 = U.pair_unit0[r.pair];
+    }
+    return r;
+}
 struct PlanZero {   // scratch the first kernel of a call clears for the later ones
     u64* words;     // scan states, tickets, retry counter, statistics: one contiguous region
     uint32_t n_words;
@@ -229,9 +247,10 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
     const uint32_t u = (uint32_t)(gid >> 6);
     if (u >= U.n_units) return;
     const uint32_t lane = lane_id();
-    const uint32_t p = U.pair[u];
-    const bool bside = (U.tile[u] & UNIT_B) != 0;
-    const u64 tile = U.tile[u] & ~UNIT_B;
+    const UnitId uid = unit_id(U, u);
+    const uint32_t p = uid.pair;
+    const bool bside = uid.bside;
+    const u64 tile = uid.tile;
     const u64 a0 = A.bm_start[lhs[p]], a1 = A.bm_start[lhs[p] + 1];
     const u64 b0 = B.bm_start[rhs[p]], b1 = B.bm_start[rhs[p] + 1];
     // s* = the side this tile walks, l* = the side it searches
@@ -336,12 +355,13 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
     if (u >= U.n_units) return;
     const uint32_t lane = lane_id();
     const size_t S = (size_t)U.n_units + 1;
-    const uint32_t p = U.pair[u];
-    const bool bside = (U.tile[u] & UNIT_B) != 0;
-    const u64 tile = U.tile[u] & ~UNIT_B;
+    const UnitId uid = unit_id(U, u);
+    const uint32_t p = uid.pair;
+    const bool bside = uid.bside;
+    const u64 tile = uid.tile;
     const u64 a0 = A.bm_start[lhs[p]], a1 = A.bm_start[lhs[p] + 1];
     const u64 b0 = B.bm_start[rhs[p]], b1 = B.bm_start[rhs[p] + 1];
-    const u64 u0 = U.pair_unit0[p];
+    const u64 u0 = uid.unit0;
     const u64 base = starts[SEC_CAND * S + u0];
     u64 qbb = starts[SEC_BB * S + u] - starts[SEC_BB * S];
     u64 qgen = starts[SEC_GEN * S + u] - starts[SEC_GEN * S];
@@ -446,7 +466,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
             qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv); qruns += __popcll(mrn); qprobe += __popcll(mpr); qbba += __popcll(mba); qusm += __popcll(mus);
         }
     } else {
-        const u64 nAt = (a1 - a0 + 255) / 256;
+        const u64 nAt = U.implicit ? 1 : (a1 - a0 + 255) / 256;  // A-tiles of the pair in front of its B-tiles
         const u64 s0 = b0 + tile * 256;
         uint32_t mbefore = (uint32_t)(starts[SEC_M * S + u] - starts[SEC_M * S + u0 + nAt]);
 #pragma unroll
@@ -510,48 +530,64 @@ __global__ __launch_bounds__(256) void k_tail(const u64* __restrict__ ranges, Ca
     __shared__ u64 s_bytes[4];
     __shared__ uint32_t s_types[4][3];
     __shared__ u64 s_tot[4][3];
+    __shared__ uint32_t s_cnt[4 * TAIL_PER_THREAD];
     const u64 n = ranges[2 * SEC_CAND + 1] - ranges[2 * SEC_CAND];
     if (threadIdx.x == 0) s_tile = atomicAdd(lb.ticket, 1u);
     __syncthreads();
     const uint32_t tile = s_tile;
     const u64 n_tiles = n ? (n + TAIL_TILE - 1) / TAIL_TILE : 1;
     if (tile >= n_tiles) return;
-    const u64 base = (u64)tile * TAIL_TILE + (u64)TAIL_PER_THREAD * threadIdx.x;
-    u64 m[TAIL_PER_THREAD];
-    uint32_t keep = 0;
+    // candidate (k, thread) of the tile = tile base + 256 k + thread: every load and store below is lane-contiguous,
+    // and all the loads are issued before the first wait
+    const u64 tbase = (u64)tile * TAIL_TILE + threadIdx.x;
+    const uint32_t wv = threadIdx.x >> 6, lane = lane_id();
+    u64 m[TAIL_PER_THREAD], ckey[TAIL_PER_THREAD], coff[TAIL_PER_THREAD];
+    uint32_t cp[TAIL_PER_THREAD], cprev[TAIL_PER_THREAD], rank[TAIL_PER_THREAD];
 #pragma unroll
     for (int k = 0; k < (int)TAIL_PER_THREAD; ++k) {
-        m[k] = base + k < n ? meta[base + k] : 0;
-        keep += meta_card(m[k]) ? 1u : 0u;
+        const u64 i = tbase + 256ull * k;
+        const bool in = i < n;
+        m[k] = in ? meta[i] : 0;
+        cp[k] = in ? C.pair[i] : 0u;
+        cprev[k] = in && i ? C.pair[i - 1] + 1u : 0u;
+        ckey[k] = in ? C.key[i] : 0;
+        coff[k] = in ? C.off[i] : 0;
     }
-    u64 total;
-    u64 ex = blk_exscan64(keep, sm, &total);
-    if (threadIdx.x < 64) {
-        const u64 pfx = lb_exclusive_prefix(lb.status, tile, total);
-        if (threadIdx.x == 0) s_prefix = pfx;
+#pragma unroll
+    for (int k = 0; k < (int)TAIL_PER_THREAD; ++k) {
+        const u64 bal = __ballot(meta_card(m[k]) != 0);
+        rank[k] = mbcnt(bal);
+        if (lane == 0) s_cnt[4 * k + wv] = (uint32_t)__popcll(bal);
     }
     __syncthreads();
-    ex += s_prefix;
+    if (threadIdx.x < 64) {
+        const uint32_t v = lane < 4 * TAIL_PER_THREAD ? s_cnt[lane] : 0u;
+        const uint32_t inc = wave_incl_scan(v);
+        if (lane < 4 * TAIL_PER_THREAD) s_cnt[lane] = inc - v;
+        const u64 tot = __shfl(inc, 63);
+        const u64 pfx = lb_exclusive_prefix(lb.status, tile, tot);
+        if (lane == 0) { s_prefix = pfx; sm[0] = tot; }
+    }
+    __syncthreads();
+    const u64 total = sm[0];
     u64 bytes = 0;
     uint32_t nty[3] = {0, 0, 0};
 #pragma unroll
     for (int k = 0; k < (int)TAIL_PER_THREAD; ++k) {
-        const u64 i = base + k;
+        const u64 i = tbase + 256ull * k;
         if (i < n) {
+            const u64 ex = s_prefix + s_cnt[4 * k + wv] + rank[k];
             // result bitmaps starting at candidate i: every pair in (pair of candidate i-1, pair of candidate i]
-            const uint32_t pi = C.pair[i];
-            const uint32_t pprev = i ? C.pair[i - 1] + 1u : 0u;
-            for (uint32_t q = pprev; q <= pi; ++q) R.bm_start[q] = ex;
+            for (uint32_t q = cprev[k]; q <= cp[k]; ++q) R.bm_start[q] = ex;
             if (meta_card(m[k])) {
                 const uint32_t ty = meta_type(m[k]);
-                R.key[ex] = C.key[i];
+                R.key[ex] = ckey[k];
                 R.type[ex] = (uint8_t)ty;
                 R.card[ex] = meta_card(m[k]);
                 R.nruns[ex] = meta_nruns(m[k]);
-                R.off[ex] = C.off[i];
+                R.off[ex] = coff[k];
                 bytes += payload_bytes((uint8_t)ty, meta_card(m[k]), meta_nruns(m[k]));
                 nty[ty - 1]++;
-                ++ex;
             }
         }
     }

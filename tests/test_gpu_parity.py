@@ -543,3 +543,18 @@ def test_tiny_interval_pairs(engine, oracle):
         assert not bad, f"{op}: {len(bad)} mismatching pairs, first {bad[:6]}"
     for h in hs:
         oracle.free(h)
+
+
+@pytest.mark.gpu
+def test_explicit_unit_arrays(oracle, synth, monkeypatch):
+    """Small bitmaps (<= 256 containers each) plan on implicit units; RHIP_EXPLICIT_UNITS=1 forces the staged unit
+    arrays of the general path on the same inputs (the large-directory cases reach that path by themselves)."""
+    import croaring_amd
+    monkeypatch.setenv("RHIP_EXPLICIT_UNITS", "1")
+    eng = croaring_amd.Engine()
+    try:
+        test_edge_cases(eng, oracle)
+        for op in OPS:
+            test_synth_every_type_pair(eng, oracle, synth, op)
+    finally:
+        eng.close()
