@@ -157,28 +157,43 @@ __global__ __launch_bounds__(256) void k_bba(const uint8_t* __restrict__ arenaA,
 }
 
 // ------------------------------------------------------------------ pass-through copy
-// One wave per container while the queue is long; the item says where from, where to, how much -- no directory loads.
+// The item says where from, where to, how much -- no directory loads.  A wave takes FOUR items at a time: when all
+// of them are short (<= 256 bytes, the pass-through containers of sparse data) each quarter-wave copies one, 16 bytes
+// per lane; otherwise the whole wave copies them one after the other.
 __global__ __launch_bounds__(256) void k_copy(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                               OutView O, const CopyItem* __restrict__ q,
                                               const u64* __restrict__ qrange) {
-    const uint32_t lane = lane_id();
+    const uint32_t lane = lane_id(), grp = lane >> 4, gl = lane & 15u;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
     uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     CopyItem tn;
-    if (w < n) tn = q[w];
-    for (; w < n; w += nwaves) {
+    if (4 * w + grp < n) tn = q[4 * w + grp];
+    for (; 4 * w < n; w += nwaves) {
+        const bool have = 4 * w + grp < n;
         const CopyItem t = tn;
-        if (w + nwaves < n) tn = q[w + nwaves];
-        const uint8_t* base = (t.src & COPY_FROM_B) ? arenaB : arenaA;
-        const uint4* __restrict__ ps = (const uint4*)(base + (t.src & ~COPY_FROM_B));
-        uint4* __restrict__ po = (uint4*)(O.arena + t.offo);
-        for (uint32_t i = lane; i < t.n16; i += 64) po[i] = ps[i];
-        if (lane == 0) O.meta[t.out] = t.meta;
+        if (4 * (w + nwaves) + grp < n) tn = q[4 * (w + nwaves) + grp];
+        if (__ballot(have && t.n16 > 16u) == 0) {
+            if (have) {
+                const uint8_t* base = (t.src & COPY_FROM_B) ? arenaB : arenaA;
+                if (gl < t.n16) ((uint4*)(O.arena + t.offo))[gl] = ((const uint4*)(base + (t.src & ~COPY_FROM_B)))[gl];
+                if (gl == 0) O.meta[t.out] = t.meta;
+            }
+        } else {
+#pragma unroll
+            for (uint32_t g = 0; g < 4; ++g) {
+                if (4 * w + g >= n) break;
+                const u64 src = __shfl(t.src, 16 * g), offo = __shfl(t.offo, 16 * g);
+                const uint32_t n16 = __shfl(t.n16, 16 * g);
+                const uint8_t* base = (src & COPY_FROM_B) ? arenaB : arenaA;
+                const uint4* __restrict__ ps = (const uint4*)(base + (src & ~COPY_FROM_B));
+                uint4* __restrict__ po = (uint4*)(O.arena + offo);
+                for (uint32_t i = lane; i < n16; i += 64) po[i] = ps[i];
+            }
+            if (have && gl == 0) O.meta[t.out] = t.meta;
+        }
     }
 }
-
-
 
 
 // ------------------------------------------------------------------ synthetic C2 pool

@@ -137,10 +137,13 @@ enum { SEC_CAND = 0, SEC_M = 1, SEC_BB = 2, SEC_GEN = 3, SEC_COPY = 4, SEC_FILT 
        SEC_PROBE = 10,
        SEC_BBA = 11,
        SEC_USMALL = 12,
-       N_SEC = 13 };
+       SEC_RUNS16 = 13,
+       N_SEC = 14 };
 // work class of a matched container pair
 // ia / ib = number of intervals of the operand when it is read as an interval list (runs: n_runs, arrays: card)
-__device__ __forceinline__ int classify(int op, int cardmode, uint8_t ta, uint8_t tb, uint32_t ia, uint32_t ib) {
+// ca / cb = cardinalities
+__device__ __forceinline__ int classify(int op, int cardmode, uint8_t ta, uint8_t tb, uint32_t ia, uint32_t ib,
+                                        uint32_t ca, uint32_t cb) {
     if (ta == T_BITSET && tb == T_BITSET) {
         // Two bitsets whose and / andnot is EXPECTED (cardinalities, independence) to fall to <= 4096 values take
         // the kernel that can emit an array straight away; everything else streams through k_bb, which re-queues
@@ -151,8 +154,11 @@ __device__ __forceinline__ int classify(int op, int cardmode, uint8_t ta, uint8_
     }
     // interval algebra in O(n log n) when a run container meets a run / a short array
     if ((ta == T_RUN || tb == T_RUN) && ta != T_BITSET && tb != T_BITSET && ia <= RUNS_MAX_INTERVALS &&
-        ib <= RUNS_MAX_INTERVALS)
+        ib <= RUNS_MAX_INTERVALS) {
+        // short lists with few values (the containers of sparse, run-compressed data): four pairs per wave
+        if (ia <= R16_MAX_IV && ib <= R16_MAX_IV && ca + cb <= R16_MAX_CARD) return CLS_RUNS16;
         return CLS_RUNS;
+    }
     // array filtered by membership in an array / bitset: and (either order), array \ x; a short streamed array
     // (the smaller one when both are arrays) probes global memory directly, a long one goes through the LDS image
     if (cardmode || op == OP_AND) {
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         k[t] = act[t] ? SV.key[s0 + 64 * t + lane] : 0;
     }
     lower_bound4(LV.key, l0, l1, k, act, j);
-    uint32_t matched = 0, nbb = 0, nfilt = 0, nwave = 0, nruns_cls = 0, nprobe = 0, nbba = 0, nusm = 0, slot16 = 0, bytes = 0;
+    uint32_t matched = 0, nbb = 0, nfilt = 0, nwave = 0, nruns_cls = 0, nprobe = 0, nbba = 0, nusm = 0, nr16 = 0, slot16 = 0, bytes = 0;
     const bool keep_unmatched = bside || !(cardmode || op == OP_AND);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
                 const uint8_t tl = LV.type[j[t]];
                 const uint32_t cl = LV.card[j[t]], nl = LV.nruns[j[t]];
                 bytes += payload_bytes(tl, cl, nl);
-                cls = classify(op, cardmode, ts, tl, ts == T_RUN ? ns : cs, tl == T_RUN ? nl : cl);
+                cls = classify(op, cardmode, ts, tl, ts == T_RUN ? ns : cs, tl == T_RUN ? nl : cl, cs, cl);
                 if (!cardmode) slot16 += matched_slot(op, cs, cl) >> 4;
             } else if (!cardmode) {
                 const uint32_t sl = align16(ps) >> 4;
@@ -299,6 +305,7 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         nprobe += (uint32_t)__popcll(__ballot(cls == CLS_PROBE));
         nbba += (uint32_t)__popcll(__ballot(cls == CLS_BBA));
         nusm += (uint32_t)__popcll(__ballot(cls == CLS_USMALL));
+        nr16 += (uint32_t)__popcll(__ballot(cls == CLS_RUNS16));
     }
     slot16 = wave_sum(slot16);
     bytes = wave_sum(bytes);
@@ -310,10 +317,11 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         counts[SEC_CAND * S + u] = bside ? ncopy : matched + ncopy;
         counts[SEC_M * S + u] = matched;
         counts[SEC_BB * S + u] = nbb;
-        counts[SEC_GEN * S + u] = bside ? 0u : matched - nbb - nfilt - nwave - nruns_cls - nprobe - nbba - nusm;
+        counts[SEC_GEN * S + u] = bside ? 0u : matched - nbb - nfilt - nwave - nruns_cls - nprobe - nbba - nusm - nr16;
         counts[SEC_PROBE * S + u] = nprobe;
         counts[SEC_BBA * S + u] = nbba;
         counts[SEC_USMALL * S + u] = nusm;
+        counts[SEC_RUNS16 * S + u] = nr16;
         counts[SEC_RUNS * S + u] = nruns_cls;
         counts[SEC_FILT * S + u] = nfilt;
         counts[SEC_WAVE * S + u] = nwave;
@@ -341,6 +349,7 @@ struct EmitQueues {
     FatItem* probe; // section SEC_PROBE
     BBItem* bba;    // section SEC_BBA
     FatItem* usmall; // section SEC_USMALL
+    GenItem* runs16; // section SEC_RUNS16
 };
 struct CandOut {     // candidate (pre-compaction) result directory
     u64* key;        // [cand]
@@ -372,6 +381,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
     u64 qprobe = starts[SEC_PROBE * S + u] - starts[SEC_PROBE * S];
     u64 qbba = starts[SEC_BBA * S + u] - starts[SEC_BBA * S];
     u64 qusm = starts[SEC_USMALL * S + u] - starts[SEC_USMALL * S];
+    u64 qr16 = starts[SEC_RUNS16 * S + u] - starts[SEC_RUNS16 * S];
     u64 slot_run = 16ull * (starts[SEC_SLOT * S + u] - starts[SEC_SLOT * S]);  // arena offset of the unit's first slot
     if (!bside) {
         const u64 s0 = a0 + tile * 256;
@@ -420,7 +430,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 O.pair[base + pos] = p;
             }
             const uint32_t outidx = cardmode ? p : (uint32_t)(base + pos);
-            const int cls = (emit && found) ? classify(op, cardmode, ta, tb, ta == T_RUN ? nra : ca, tb == T_RUN ? nrb : cb) : -1;
+            const int cls = (emit && found) ? classify(op, cardmode, ta, tb, ta == T_RUN ? nra : ca, tb == T_RUN ? nrb : cb, ca, cb) : -1;
             const bool isbb = cls == CLS_BB;
             const bool isbba = cls == CLS_BBA;
             const bool isusm = cls == CLS_USMALL;
@@ -428,24 +438,26 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
             const bool isfilt = cls == CLS_FILT;
             const bool iswave = cls == CLS_WAVE;
             const bool isruns = cls == CLS_RUNS;
+            const bool isr16 = cls == CLS_RUNS16;
             const bool isprobe = cls == CLS_PROBE;
             const bool iscopy = emit && !found;
             const u64 mbb = __ballot(isbb), mgen = __ballot(isgen), mcp = __ballot(iscopy), mfl = __ballot(isfilt);
             const u64 mwv = __ballot(iswave), mrn = __ballot(isruns), mpr = __ballot(isprobe), mba = __ballot(isbba);
-            const u64 mus = __ballot(isusm);
+            const u64 mus = __ballot(isusm), mr16 = __ballot(isr16);
             if (isbb || isbba) {
                 BBItem it;
                 it.offa = A.off[ai]; it.offb = B.off[bj]; it.offo = offo; it.out = outidx; it.slot = sl;
                 if (isbb) Q.bb[qbb + mbcnt(mbb)] = it;
                 else Q.bba[qbba + mbcnt(mba)] = it;
             }
-            if (isgen || isruns) {
+            if (isgen || isruns || isr16) {
                 GenItem it;
                 it.offa = A.off[ai]; it.offb = B.off[bj];
                 it.out = outidx; it.ca = ca; it.cb = cb; it.types = (uint32_t)ta | ((uint32_t)tb << 8);
                 it.nra = nra; it.nrb = nrb; it.offo = offo;
                 if (isgen) Q.gen[qgen + mbcnt(mgen)] = it;
-                else Q.runs[qruns + mbcnt(mrn)] = it;
+                else if (isruns) Q.runs[qruns + mbcnt(mrn)] = it;
+                else Q.runs16[qr16 + mbcnt(mr16)] = it;
             }
             if (isfilt || iswave || isprobe || isusm) {
                 FatItem it;
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 it.out = outidx; it.n16 = (pa + 15u) >> 4;
                 Q.copy[qcopy + mbcnt(mcp)] = it;
             }
-            qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv); qruns += __popcll(mrn); qprobe += __popcll(mpr); qbba += __popcll(mba); qusm += __popcll(mus);
+            qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv); qruns += __popcll(mrn); qprobe += __popcll(mpr); qbba += __popcll(mba); qusm += __popcll(mus); qr16 += __popcll(mr16);
         }
     } else {
         const u64 nAt = U.implicit ? 1 : (a1 - a0 + 255) / 256;  // A-tiles of the pair in front of its B-tiles

@@ -197,6 +197,175 @@ __global__ __launch_bounds__(256) void k_runs(const uint8_t* __restrict__ arenaA
     }
 }
 
+// ------------------------------------------------------------------ short interval lists: four pairs per wave
+// The same interval algebra as k_runs for pairs with <= R16_MAX_IV intervals per operand and <= R16_MAX_CARD values in
+// all: sparse run-compressed data (wikileaks-noquotes: three quarters of the matched pairs) is made of such pairs,
+// and a wave that spends its ~2 000 instructions on one of them leaves 50-60 lanes idle throughout.  Here every
+// 16-lane group of the wave owns one pair: merge path over 16 lanes, group-wide scans and sums (shuffles that never
+// leave the group), group-private LDS.  Control flow around the collectives stays wave-uniform: the four groups walk
+// their items in lockstep and the only loops with collectives inside have constant trip counts.
+__device__ __forceinline__ uint32_t grp16_incl_scan(uint32_t v, uint32_t gl) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const uint32_t t = __shfl_up(v, o);
+        if (gl >= (uint32_t)o) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t grp16_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__global__ __launch_bounds__(256) void k_runs16(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                                OutView O, const GenItem* __restrict__ q,
+                                                const u64* __restrict__ qrange, int op, int cardmode, u64* pair_acc,
+                                                GenItem* retry_q, uint32_t* retry_count) {
+    constexpr uint32_t NB = 64;  // >= result runs of a pair: at most (boundaries of both lists) / 2 = 2 * R16_MAX_IV
+    __shared__ __attribute__((aligned(16))) uint8_t lists_all[16][2][128];  // per group: both payloads, 16-byte padded
+    __shared__ uint16_t lds_all[16][3 * NB];
+    const uint32_t lane = lane_id(), grp = lane >> 4, gl = lane & 15u;
+    const uint32_t gslot = (threadIdx.x >> 4);  // group index inside the block
+    uint8_t* lsA = lists_all[gslot][0];
+    uint8_t* lsB = lists_all[gslot][1];
+    uint16_t* RS = lds_all[gslot];
+    uint16_t* RE = RS + NB;
+    uint16_t* PL = RS + 2 * NB;
+    const uint32_t glast = (lane & 48u) | 15u;  // last lane of this group
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
+    uint32_t wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    GenItem tnext = {};
+    if (4 * wi + grp < n) tnext = q[4 * wi + grp];
+    for (; 4 * wi < n; wi += nwaves) {
+        const bool have = 4 * wi + grp < n;
+        const GenItem t = tnext;
+        if (4 * (wi + nwaves) + grp < n) tnext = q[4 * (wi + nwaves) + grp];
+        const uint32_t ta = t.types & 0xFFu, tb = t.types >> 8;
+        IvList LA, LB;
+        LA.p = lsA; LA.is_run = ta == T_RUN; LA.n2 = have ? 2u * (ta == T_RUN ? t.nra : t.ca) : 0u;
+        LB.p = lsB; LB.is_run = tb == T_RUN; LB.n2 = have ? 2u * (tb == T_RUN ? t.nrb : t.cb) : 0u;
+        {   // stage both payloads (<= 124 bytes each): lanes 0-7 of the group load A, lanes 8-15 load B
+            const uint32_t na16 = ((LA.is_run ? 2u : 1u) * LA.n2 + 15u) >> 4;
+            const uint32_t nb16 = ((LB.is_run ? 2u : 1u) * LB.n2 + 15u) >> 4;
+            if (gl < 8u) {
+                if (gl < na16) ((uint4*)lsA)[gl] = ((const uint4*)(arenaA + t.offa))[gl];
+            } else if (gl - 8u < nb16) {
+                ((uint4*)lsB)[gl - 8u] = ((const uint4*)(arenaB + t.offb))[gl - 8u];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- merge path over the 16 lanes of the group (see k_runs)
+        constexpr uint32_t SENT = 0x20000u;
+        const uint32_t nA = LA.n2, nB2 = LB.n2, E = nA + nB2;
+        const uint32_t per = (E + 15u) >> 4;
+        const uint32_t d0 = gl * per < E ? gl * per : E;
+        const uint32_t d1 = d0 + per < E ? d0 + per : E;
+        uint32_t ia0;
+        {
+            uint32_t lo = d0 > nB2 ? d0 - nB2 : 0u, hi = d0 < nA ? d0 : nA;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (LA.at(mid) <= LB.at(d0 - mid - 1u)) lo = mid + 1u;
+                else hi = mid;
+            }
+            ia0 = lo;
+        }
+        const uint32_t ib0 = d0 - ia0, steps = d1 - d0;
+        auto walk = [&](auto&& fn) {
+            uint32_t ia = ia0, ib = ib0, inA = ia0 & 1u, inB = ib0 & 1u;
+            uint32_t pa = ia < nA ? LA.at(ia) : SENT, pb = ib < nB2 ? LB.at(ib) : SENT;
+            for (uint32_t sidx = 0; sidx < steps; ++sidx) {
+                uint32_t pcur;
+                if (pa <= pb) {
+                    pcur = pa; inA ^= 1u; ++ia;
+                    pa = ia < nA ? LA.at(ia) : SENT;
+                } else {
+                    pcur = pb; inB ^= 1u; ++ib;
+                    pb = ib < nB2 ? LB.at(ib) : SENT;
+                }
+                const uint32_t pnext = pa < pb ? pa : pb;
+                if (pnext != pcur) fn(pcur, bop(op, inA, inB));
+            }
+        };
+        bool has_eff = false, g_last = false;
+        walk([&](uint32_t, bool g) { has_eff = true; g_last = g; });
+        bool gprev = false;
+        {
+            const uint32_t mh = (uint32_t)(__ballot(has_eff) >> (16u * grp)) & 0xFFFFu;
+            const uint32_t mg = (uint32_t)(__ballot(g_last) >> (16u * grp)) & 0xFFFFu;
+            const uint32_t below = mh & ((1u << gl) - 1u);
+            if (below) gprev = (mg >> (31 - __clz((int)below))) & 1u;
+        }
+        uint32_t ns = 0, ne = 0;
+        {
+            bool gp = gprev;
+            walk([&](uint32_t, bool g) { ns += (g && !gp) ? 1u : 0u; ne += (!g && gp) ? 1u : 0u; gp = g; });
+        }
+        const uint32_t incs = grp16_incl_scan(ns, gl), ince = grp16_incl_scan(ne, gl);
+        const uint32_t rn = __shfl(incs, glast);
+        {
+            uint32_t ks = incs - ns, ke = ince - ne;
+            bool gp = gprev;
+            walk([&](uint32_t pcur, bool g) {
+                if (g && !gp) RS[ks++] = (uint16_t)pcur;
+                if (!g && gp) RE[ke++] = (uint16_t)(pcur - 1u);
+                gp = g;
+            });
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- cardinality, typing
+        uint32_t cnt = 0;
+        for (uint32_t k = gl; k < rn; k += 16) cnt += (uint32_t)RE[k] - (uint32_t)RS[k] + 1u;
+        const uint32_t rc = grp16_sum(cnt);
+        if (cardmode) {  // (wave-uniform)
+            if (have && gl == 0 && rc) atomicAdd(&pair_acc[t.out], (u64)rc);
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
+        const bool fulla = ta == T_RUN && t.ca == 65536u, fullb = tb == T_RUN && t.cb == 65536u;
+        int ty = T_ARRAY;
+        if (rc) ty = decide_type(op, (int)ta, (int)tb, t.ca, t.cb, fulla, fullb, rc, rn);
+        const bool redo = have && rc && ty == T_BITSET;  // cannot happen below 4097 values; kept for safety
+        if (redo && gl == 0) retry_q[atomicAdd(retry_count, 1u)] = t;
+        const bool wr = have && rc && !redo;
+        uint8_t* outp = O.arena + t.offo;
+        if (wr && ty == T_RUN) {
+            uint32_t* __restrict__ o32 = (uint32_t*)outp;
+            for (uint32_t k = gl; k < rn; k += 16)
+                o32[k] = (uint32_t)RS[k] | (((uint32_t)RE[k] - (uint32_t)RS[k]) << 16);
+        }
+        const bool arr = wr && ty != T_RUN;
+        {   // runs -> sorted array: exclusive prefix of run lengths (constant trip count: rn < NB), then one binary
+            // search per output value
+            uint32_t runbase = 0;
+#pragma unroll
+            for (uint32_t k0 = 0; k0 < NB; k0 += 16) {
+                const uint32_t k = k0 + gl;
+                const uint32_t len = (arr && k < rn) ? (uint32_t)RE[k] - (uint32_t)RS[k] + 1u : 0u;
+                const uint32_t inc = grp16_incl_scan(len, gl);
+                if (arr && k < rn) PL[k] = (uint16_t)(runbase + inc - len);
+                runbase += __shfl(inc, glast);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (arr) {
+                uint16_t* __restrict__ o16 = (uint16_t*)outp;
+                for (uint32_t i = gl; i < rc; i += 16) {
+                    uint32_t lo = 0, hi = rn;  // last k with PL[k] <= i
+                    while (lo + 1 < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (PL[mid] <= i) lo = mid;
+                        else hi = mid;
+                    }
+                    o16[i] = (uint16_t)(RS[lo] + (i - PL[lo]));
+                }
+            }
+        }
+        if (have && !redo && gl == 0) O.meta[t.out] = pack_meta(ty, rc, (ty == T_RUN) ? rn : 0u);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ------------------------------------------------------------------ wave-level general pair kernel (K5, K7, K13-K16)
 // Every type pair the specialised kernels do not take (all pairs with a run container, plus
 // bitset x bitset results that must become arrays): ONE WAVE per container pair, two wave-private

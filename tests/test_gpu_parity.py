@@ -502,10 +502,10 @@ def test_array_filter_probe_boundaries(engine, oracle):
 
 
 def test_tiny_interval_pairs(engine, oracle):
-    """Short interval lists (the k_tiny thread-per-pair sweep and its hand-over to k_runs): run containers of 1 .. 70
-    runs and arrays of 1 .. 70 values around every classification boundary (64 / 65 intervals; array cardinality
-    31 / 32 / 33 under xor; run cardinality 32 / 33 under andnot), touching and nested intervals, both ends of the
-    u16 range, full containers; four ops + cardinalities, both operand orders."""
+    """Short interval lists (k_runs16: four pairs per wave, and its hand-over to k_runs): run containers of 1 .. 70
+    runs and arrays of 1 .. 70 values around the classification boundaries (31 / 32 intervals per operand; 512 / 513
+    values in both operands together), touching and nested intervals, both ends of the u16 range, full containers;
+    four ops + cardinalities, both operand orders."""
     rng = np.random.default_rng(314)
 
     def runs(k, maxlen):
@@ -522,7 +522,12 @@ def test_tiny_interval_pairs(engine, oracle):
     shapes += [("run", np.arange(65536)), ("run", np.arange(0, 33)), ("run", np.arange(0, 32)),
                ("run", np.concatenate([np.arange(0, 10), np.arange(65500, 65536)])),
                ("arr", np.array([0, 65535])), ("arr", np.array([9, 10, 65499, 65500])),
-               ("run", np.concatenate([np.arange(100, 200), np.arange(201, 300), np.arange(301, 5000)]))]
+               ("run", np.concatenate([np.arange(100, 200), np.arange(201, 300), np.arange(301, 5000)])),
+               # 256 + 256 = 512 values (four per wave), 256 + 257 = 513 (one per wave); 481 / 482 + a 31-value array
+               ("run", np.arange(1000, 1256)), ("run", np.arange(1100, 1356)), ("run", np.arange(5000, 5257)),
+               ("run", np.concatenate([np.arange(40, 300), np.arange(1200, 1421)])),
+               ("run", np.concatenate([np.arange(40, 300), np.arange(1200, 1422)])),
+               ("arr", np.arange(31) * 41 + 50)]
     hs = [oracle.from_sorted(np.asarray(v, np.uint32) + (9 << 16), run_optimize=(kind == "run")) for kind, v in shapes]
     bufs = [oracle.serialize(h) for h in hs]
     pool = engine.pool_from_serialized(bufs)
