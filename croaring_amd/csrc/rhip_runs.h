@@ -55,16 +55,15 @@ __global__ __launch_bounds__(256) void k_runs(const uint8_t* __restrict__ arenaA
                                               const u64* __restrict__ qrange, int op, int cardmode, u64* pair_acc,
                                               GenItem* retry_q, uint32_t* retry_count) {
     constexpr uint32_t NB = 2 * RUNS_MAX_INTERVALS;  // max boundaries per list = max result runs
-    // per wave (~5 KiB): both operand lists staged in LDS, result run starts / ends, a prefix table for the expansion
+    // per wave (~4 KiB): both operand lists staged in LDS, result run starts / ends
     __shared__ __attribute__((aligned(16))) uint8_t lists_all[4][2][1024];  // 4 * RUNS_MAX_INTERVALS, padded to 16 bytes
-    __shared__ uint16_t lds_all[4][3 * NB + 2];
+    __shared__ uint16_t lds_all[4][2 * NB + 2];
     const uint32_t lane = lane_id();
     uint16_t* base = lds_all[threadIdx.x >> 6];
     uint8_t* lsA = lists_all[threadIdx.x >> 6][0];
     uint8_t* lsB = lists_all[threadIdx.x >> 6][1];
     uint16_t* RS = base;            // result run starts
     uint16_t* RE = base + NB;       // result run ends (inclusive)
-    uint16_t* PL = base + 2 * NB;   // exclusive prefix of run lengths (array expansion)
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
     uint32_t wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -170,26 +169,28 @@ __global__ __launch_bounds__(256) void k_runs(const uint8_t* __restrict__ arenaA
             for (uint32_t k = lane; k < rn; k += 64)
                 o32[k] = (uint32_t)RS[k] | (((uint32_t)RE[k] - (uint32_t)RS[k]) << 16);
         } else if (rc) {
-            // expand runs into a sorted array: exclusive prefix of run lengths (PL), then one
-            // binary search per output value
+            // expand runs into a sorted array.  An array-typed result has short runs (2 rc <= 4 rn + 2), so: one lane
+            // per run writes its first 8 values at the scanned position; the few longer runs are finished by the whole
+            // wave, one after the other.  (A binary search per output value -- 8 dependent LDS reads for each of up to
+            // 4096 values -- cost 20 us per pair on run-compressed data.)
+            uint16_t* __restrict__ o16 = (uint16_t*)outp;
             uint32_t runbase = 0;
             for (uint32_t k0 = 0; k0 < rn; k0 += 64) {
                 const uint32_t k = k0 + lane;
-                const uint32_t len = k < rn ? (uint32_t)RE[k] - (uint32_t)RS[k] + 1u : 0u;
+                const uint32_t st = k < rn ? (uint32_t)RS[k] : 0u;
+                const uint32_t len = k < rn ? (uint32_t)RE[k] - st + 1u : 0u;
                 const uint32_t inc = wave_incl_scan(len);
-                if (k < rn) PL[k] = (uint16_t)(runbase + inc - len);
+                const uint32_t pos = runbase + inc - len;
                 runbase += __shfl(inc, 63);
-            }
-            __builtin_amdgcn_wave_barrier();
-            uint16_t* __restrict__ o16 = (uint16_t*)outp;
-            for (uint32_t i = lane; i < rc; i += 64) {
-                uint32_t lo = 0, hi = rn;  // last k with PL[k] <= i
-                while (lo + 1 < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (PL[mid] <= i) lo = mid;
-                    else hi = mid;
+                const uint32_t lim = len < 8u ? len : 8u;
+                for (uint32_t j = 0; j < lim; ++j) o16[pos + j] = (uint16_t)(st + j);
+                u64 longm = __ballot(len > 8u);
+                while (longm) {
+                    const int src = __ffsll((long long)longm) - 1;
+                    longm &= longm - 1;
+                    const uint32_t ls = __shfl(st, src), ll = __shfl(len, src), lp = __shfl(pos, src);
+                    for (uint32_t j = 8u + lane; j < ll; j += 64) o16[lp + j] = (uint16_t)(ls + j);
                 }
-                o16[i] = (uint16_t)(RS[lo] + (i - PL[lo]));
             }
         }
         if (lane == 0) O.meta[t.out] = pack_meta(ty, rc, (ty == T_RUN) ? rn : 0u);
@@ -223,14 +224,13 @@ __global__ __launch_bounds__(256) void k_runs16(const uint8_t* __restrict__ aren
                                                 GenItem* retry_q, uint32_t* retry_count) {
     constexpr uint32_t NB = 64;  // >= result runs of a pair: at most (boundaries of both lists) / 2 = 2 * R16_MAX_IV
     __shared__ __attribute__((aligned(16))) uint8_t lists_all[16][2][128];  // per group: both payloads, 16-byte padded
-    __shared__ uint16_t lds_all[16][3 * NB];
+    __shared__ uint16_t lds_all[16][2 * NB];
     const uint32_t lane = lane_id(), grp = lane >> 4, gl = lane & 15u;
     const uint32_t gslot = (threadIdx.x >> 4);  // group index inside the block
     uint8_t* lsA = lists_all[gslot][0];
     uint8_t* lsB = lists_all[gslot][1];
     uint16_t* RS = lds_all[gslot];
     uint16_t* RE = RS + NB;
-    uint16_t* PL = RS + 2 * NB;
     const uint32_t glast = (lane & 48u) | 15u;  // last lane of this group
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
@@ -336,28 +336,29 @@ __global__ __launch_bounds__(256) void k_runs16(const uint8_t* __restrict__ aren
                 o32[k] = (uint32_t)RS[k] | (((uint32_t)RE[k] - (uint32_t)RS[k]) << 16);
         }
         const bool arr = wr && ty != T_RUN;
-        {   // runs -> sorted array: exclusive prefix of run lengths (constant trip count: rn < NB), then one binary
-            // search per output value
+        {   // runs -> sorted array as in k_runs: a lane per run for its first 8 values, the group for the rest of a
+            // longer one.  Constant trip count (rn < NB) and a wave-uniform long-run loop keep the collectives legal.
+            uint16_t* __restrict__ o16 = (uint16_t*)outp;
             uint32_t runbase = 0;
 #pragma unroll
             for (uint32_t k0 = 0; k0 < NB; k0 += 16) {
                 const uint32_t k = k0 + gl;
-                const uint32_t len = (arr && k < rn) ? (uint32_t)RE[k] - (uint32_t)RS[k] + 1u : 0u;
+                const bool v = arr && k < rn;
+                const uint32_t st = v ? (uint32_t)RS[k] : 0u;
+                const uint32_t len = v ? (uint32_t)RE[k] - st + 1u : 0u;
                 const uint32_t inc = grp16_incl_scan(len, gl);
-                if (arr && k < rn) PL[k] = (uint16_t)(runbase + inc - len);
+                const uint32_t pos = runbase + inc - len;
                 runbase += __shfl(inc, glast);
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (arr) {
-                uint16_t* __restrict__ o16 = (uint16_t*)outp;
-                for (uint32_t i = gl; i < rc; i += 16) {
-                    uint32_t lo = 0, hi = rn;  // last k with PL[k] <= i
-                    while (lo + 1 < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (PL[mid] <= i) lo = mid;
-                        else hi = mid;
-                    }
-                    o16[i] = (uint16_t)(RS[lo] + (i - PL[lo]));
+                const uint32_t lim = len < 8u ? len : 8u;
+                for (uint32_t j = 0; j < lim; ++j) o16[pos + j] = (uint16_t)(st + j);
+                uint32_t lm = (uint32_t)(__ballot(len > 8u) >> (16u * grp)) & 0xFFFFu;
+                while (__ballot(lm != 0u)) {
+                    const bool act = lm != 0u;
+                    const uint32_t src = (lane & 48u) | (act ? (uint32_t)__ffs((int)lm) - 1u : 0u);
+                    lm &= lm - 1u;
+                    const uint32_t ls = __shfl(st, src), ll = __shfl(len, src), lp = __shfl(pos, src);
+                    if (act)
+                        for (uint32_t j = 8u + gl; j < ll; j += 16) o16[lp + j] = (uint16_t)(ls + j);
                 }
             }
         }
