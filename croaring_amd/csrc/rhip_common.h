@@ -8,9 +8,13 @@ typedef unsigned long long u64;
 
 enum { T_BITSET = 1, T_ARRAY = 2, T_RUN = 3 };
 enum { OP_AND = 0, OP_OR = 1, OP_XOR = 2, OP_ANDNOT = 3 };
-enum { CLS_BB = 0, CLS_GEN = 1, CLS_COPY = 2, CLS_RETRY = 3, CLS_FILT = 4, CLS_WAVE = 5, CLS_RUNS = 6, CLS_PROBE = 7, CLS_BBA = 8, CLS_USMALL = 9, CLS_RUNS16 = 10, N_CLS = 11 };
-#define R16_MAX_IV 31u     // k_runs16 item: at most that many intervals per operand ...
-#define R16_MAX_CARD 512u  // ... and that many values in both together (the result array is written 16 lanes wide)
+enum { CLS_BB = 0, CLS_GEN = 1, CLS_COPY = 2, CLS_RETRY = 3, CLS_FILT = 4, CLS_WAVE = 5, CLS_RUNS = 6, CLS_PROBE = 7, CLS_BBA = 8, CLS_USMALL = 9, CLS_RUNS16 = 10, CLS_RUNS16W = 11, N_CLS = 12 };
+// interval pairs that run four to a wave (k_ivl<16, .>): at most that many intervals per operand and values in both
+// operands together; two size classes, because the four pairs of a wave advance in lockstep
+#define R16_MAX_IV 31u
+#define R16_MAX_CARD 1024u
+#define R16W_MAX_IV 127u
+#define R16W_MAX_CARD 4096u
 #define USMALL_MAX 128u  // smaller array of a k_usmall item (or / xor of two arrays): at most two values per lane
 #define PROBE_MAX 128u  // streamed array of a k_probe item: at most two values per lane
 #define RUNS_MAX_INTERVALS 255u  // per operand, for the interval kernel (k_runs); 255 keeps its LDS at 4 x 8 KiB - 64 B

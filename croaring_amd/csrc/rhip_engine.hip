@@ -939,6 +939,7 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     c->q[CLS_BBA].ensure(sizeof(BBItem) * (ub_match + 1));
     c->q[CLS_USMALL].ensure(sizeof(FatItem) * (ub_match + 1));
     c->q[CLS_RUNS16].ensure(sizeof(GenItem) * (ub_match + 1));
+    c->q[CLS_RUNS16W].ensure(sizeof(GenItem) * (ub_match + 1));
     c->q[CLS_COPY].ensure(sizeof(CopyItem) * (P.ub_cand + 1));
     if (cardmode) c->pair_acc.ensure(8 * (npairs + 1));
     if (!cardmode) {
@@ -967,7 +968,7 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     EmitQueues Q{c->q[CLS_BB].as<BBItem>(), c->q[CLS_GEN].as<GenItem>(), c->q[CLS_COPY].as<CopyItem>(),
                  c->q[CLS_FILT].as<FatItem>(), c->q[CLS_WAVE].as<FatItem>(), c->q[CLS_RUNS].as<GenItem>(),
                  c->q[CLS_PROBE].as<FatItem>(), c->q[CLS_BBA].as<BBItem>(), c->q[CLS_USMALL].as<FatItem>(),
-                 c->q[CLS_RUNS16].as<GenItem>()};
+                 c->q[CLS_RUNS16].as<GenItem>(), c->q[CLS_RUNS16W].as<GenItem>()};
     if (NU)
         hipLaunchKernelGGL(k_emit, dim3((unsigned)((NU * 64 + 255) / 256)), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV,
                            op, cardmode, c->cand_start.as<u64>(), c->match.as<uint32_t>(), P.CO, Q);
@@ -981,7 +982,7 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
 // planning and joined before the tail -- four streams in all, one per hardware queue of the device (a fifth
 // stream shares a queue with another and serialises behind it):
 //     main : k_bb -> [ev_bb] -> k_usmall | k_probe -> k_bba -> k_copy -> [join] -> k_tail      streaming / light classes
-//     aux0 : k_runs16 -> k_runs -> k_genw(general) -> [wait ev_bb] -> k_genw(retry)              few items, heavy waves
+//     aux0 : k_ivl<16,31> -> k_ivl<16,127> -> k_ivl<64,255> -> k_genw(general) -> [wait ev_bb] -> k_genw(retry)              few items, heavy waves
 //     aux1 : k_filter                                                                and / andnot / cardinality
 //     aux2 : k_wave                                                                  or / xor / bitset \ array
 // Schedules that were measured and dropped (profiles/r02_schedule_notes.md): persistent grids for every class (the
@@ -1020,15 +1021,18 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
     };
     if (fork) HIPCHK(hipEventRecord(c->ev_fork, s));
     if (has_runs) {
-        // short interval lists, four pairs per wave (most of a sparse run-compressed batch)
-        hipLaunchKernelGGL(k_runs16, dim3(bounded_grid(nm, 4096)), dim3(256), 0, on(0), VA.arena, VB.arena, O,
-                           c->q[CLS_RUNS16].as<GenItem>(), ranges + 2 * SEC_RUNS16, op, cardmode, c->pair_acc.as<u64>(),
-                           c->q[CLS_RETRY].as<GenItem>(), retry_count);
-        // the two small classes: few items as a rule, so few blocks (an empty block of a 32 KiB-LDS kernel still
-        // queues for a slot); many items (run-dominant data) simply loop
-        hipLaunchKernelGGL(k_runs, dim3(bounded_grid(nm, 2048)), dim3(256), 0, on(0), VA.arena, VB.arena, O,
-                           c->q[CLS_RUNS].as<GenItem>(), ranges + 2 * SEC_RUNS, op, cardmode, c->pair_acc.as<u64>(),
-                           c->q[CLS_RETRY].as<GenItem>(), retry_count);
+        // interval algebra: short lists four pairs per wave in two size classes (most of a sparse run-compressed
+        // batch), long lists one pair per wave; then the general image class.  Few items as a rule, so few blocks (an
+        // empty block of an LDS-heavy kernel still queues for a slot); many items simply loop.
+        hipLaunchKernelGGL((k_ivl<16, R16_MAX_IV>), dim3(bounded_grid(nm, 4096)), dim3(256), 0, on(0), VA.arena, VB.arena,
+                           O, c->q[CLS_RUNS16].as<GenItem>(), ranges + 2 * SEC_RUNS16, op, cardmode,
+                           c->pair_acc.as<u64>(), c->q[CLS_RETRY].as<GenItem>(), retry_count);
+        hipLaunchKernelGGL((k_ivl<16, R16W_MAX_IV>), dim3(bounded_grid(nm, 2048)), dim3(256), 0, on(0), VA.arena, VB.arena,
+                           O, c->q[CLS_RUNS16W].as<GenItem>(), ranges + 2 * SEC_RUNS16W, op, cardmode,
+                           c->pair_acc.as<u64>(), c->q[CLS_RETRY].as<GenItem>(), retry_count);
+        hipLaunchKernelGGL((k_ivl<64, RUNS_MAX_INTERVALS>), dim3(bounded_grid(nm, 2048)), dim3(256), 0, on(0), VA.arena,
+                           VB.arena, O, c->q[CLS_RUNS].as<GenItem>(), ranges + 2 * SEC_RUNS, op, cardmode,
+                           c->pair_acc.as<u64>(), c->q[CLS_RETRY].as<GenItem>(), retry_count);
         hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 512)), dim3(256), 0, on(0), VA.arena, VB.arena, O,
                            c->q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, cardmode,
                            c->pair_acc.as<u64>());

@@ -7,7 +7,7 @@
 //             statistics scratch of the call
 //   k_scan    ONE decoupled look-back exclusive scan over the 10 concatenated count sections
 //   k_emit    candidates in merged key order, slot offsets, work items at deterministic queue positions
-//   (class kernels: k_bb / k_filter / k_wave / k_runs / k_genw / k_copy, concurrently on auxiliary streams)
+//   (class kernels: k_bb / k_filter / k_wave / k_ivl / k_genw / k_copy ..., concurrently on auxiliary streams)
 //   k_tail    drop empty results + build the result directory + per-bitmap starts + statistics, one look-back pass
 // Nothing is read back in between: every buffer is sized from host-side upper bounds (container counts and
 // per-bitmap payload bounds mirrored on the host), every kernel takes its item count from device memory.
@@ -138,7 +138,8 @@ enum { SEC_CAND = 0, SEC_M = 1, SEC_BB = 2, SEC_GEN = 3, SEC_COPY = 4, SEC_FILT 
        SEC_BBA = 11,
        SEC_USMALL = 12,
        SEC_RUNS16 = 13,
-       N_SEC = 14 };
+       SEC_RUNS16W = 14,
+       N_SEC = 15 };
 // work class of a matched container pair
 // ia / ib = number of intervals of the operand when it is read as an interval list (runs: n_runs, arrays: card)
 // ca / cb = cardinalities
@@ -157,6 +158,7 @@ __device__ __forceinline__ int classify(int op, int cardmode, uint8_t ta, uint8_
         ib <= RUNS_MAX_INTERVALS) {
         // short lists with few values (the containers of sparse, run-compressed data): four pairs per wave
         if (ia <= R16_MAX_IV && ib <= R16_MAX_IV && ca + cb <= R16_MAX_CARD) return CLS_RUNS16;
+        if (ia <= R16W_MAX_IV && ib <= R16W_MAX_IV && ca + cb <= R16W_MAX_CARD) return CLS_RUNS16W;
         return CLS_RUNS;
     }
     // array filtered by membership in an array / bitset: and (either order), array \ x; a short streamed array
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         k[t] = act[t] ? SV.key[s0 + 64 * t + lane] : 0;
     }
     lower_bound4(LV.key, l0, l1, k, act, j);
-    uint32_t matched = 0, nbb = 0, nfilt = 0, nwave = 0, nruns_cls = 0, nprobe = 0, nbba = 0, nusm = 0, nr16 = 0, slot16 = 0, bytes = 0;
+    uint32_t matched = 0, nbb = 0, nfilt = 0, nwave = 0, nruns_cls = 0, nprobe = 0, nbba = 0, nusm = 0, nr16 = 0, nr16w = 0, slot16 = 0, bytes = 0;
     const bool keep_unmatched = bside || !(cardmode || op == OP_AND);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -306,6 +308,7 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         nbba += (uint32_t)__popcll(__ballot(cls == CLS_BBA));
         nusm += (uint32_t)__popcll(__ballot(cls == CLS_USMALL));
         nr16 += (uint32_t)__popcll(__ballot(cls == CLS_RUNS16));
+        nr16w += (uint32_t)__popcll(__ballot(cls == CLS_RUNS16W));
     }
     slot16 = wave_sum(slot16);
     bytes = wave_sum(bytes);
@@ -317,11 +320,12 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         counts[SEC_CAND * S + u] = bside ? ncopy : matched + ncopy;
         counts[SEC_M * S + u] = matched;
         counts[SEC_BB * S + u] = nbb;
-        counts[SEC_GEN * S + u] = bside ? 0u : matched - nbb - nfilt - nwave - nruns_cls - nprobe - nbba - nusm - nr16;
+        counts[SEC_GEN * S + u] = bside ? 0u : matched - nbb - nfilt - nwave - nruns_cls - nprobe - nbba - nusm - nr16 - nr16w;
         counts[SEC_PROBE * S + u] = nprobe;
         counts[SEC_BBA * S + u] = nbba;
         counts[SEC_USMALL * S + u] = nusm;
         counts[SEC_RUNS16 * S + u] = nr16;
+        counts[SEC_RUNS16W * S + u] = nr16w;
         counts[SEC_RUNS * S + u] = nruns_cls;
         counts[SEC_FILT * S + u] = nfilt;
         counts[SEC_WAVE * S + u] = nwave;
@@ -350,6 +354,7 @@ struct EmitQueues {
     BBItem* bba;    // section SEC_BBA
     FatItem* usmall; // section SEC_USMALL
     GenItem* runs16; // section SEC_RUNS16
+    GenItem* runs16w; // section SEC_RUNS16W
 };
 struct CandOut {     // candidate (pre-compaction) result directory
     u64* key;        // [cand]
@@ -382,6 +387,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
     u64 qbba = starts[SEC_BBA * S + u] - starts[SEC_BBA * S];
     u64 qusm = starts[SEC_USMALL * S + u] - starts[SEC_USMALL * S];
     u64 qr16 = starts[SEC_RUNS16 * S + u] - starts[SEC_RUNS16 * S];
+    u64 qr16w = starts[SEC_RUNS16W * S + u] - starts[SEC_RUNS16W * S];
     u64 slot_run = 16ull * (starts[SEC_SLOT * S + u] - starts[SEC_SLOT * S]);  // arena offset of the unit's first slot
     if (!bside) {
         const u64 s0 = a0 + tile * 256;
@@ -439,25 +445,27 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
             const bool iswave = cls == CLS_WAVE;
             const bool isruns = cls == CLS_RUNS;
             const bool isr16 = cls == CLS_RUNS16;
+            const bool isr16w = cls == CLS_RUNS16W;
             const bool isprobe = cls == CLS_PROBE;
             const bool iscopy = emit && !found;
             const u64 mbb = __ballot(isbb), mgen = __ballot(isgen), mcp = __ballot(iscopy), mfl = __ballot(isfilt);
             const u64 mwv = __ballot(iswave), mrn = __ballot(isruns), mpr = __ballot(isprobe), mba = __ballot(isbba);
-            const u64 mus = __ballot(isusm), mr16 = __ballot(isr16);
+            const u64 mus = __ballot(isusm), mr16 = __ballot(isr16), mr16w = __ballot(isr16w);
             if (isbb || isbba) {
                 BBItem it;
                 it.offa = A.off[ai]; it.offb = B.off[bj]; it.offo = offo; it.out = outidx; it.slot = sl;
                 if (isbb) Q.bb[qbb + mbcnt(mbb)] = it;
                 else Q.bba[qbba + mbcnt(mba)] = it;
             }
-            if (isgen || isruns || isr16) {
+            if (isgen || isruns || isr16 || isr16w) {
                 GenItem it;
                 it.offa = A.off[ai]; it.offb = B.off[bj];
                 it.out = outidx; it.ca = ca; it.cb = cb; it.types = (uint32_t)ta | ((uint32_t)tb << 8);
                 it.nra = nra; it.nrb = nrb; it.offo = offo;
                 if (isgen) Q.gen[qgen + mbcnt(mgen)] = it;
                 else if (isruns) Q.runs[qruns + mbcnt(mrn)] = it;
-                else Q.runs16[qr16 + mbcnt(mr16)] = it;
+                else if (isr16) Q.runs16[qr16 + mbcnt(mr16)] = it;
+                else Q.runs16w[qr16w + mbcnt(mr16w)] = it;
             }
             if (isfilt || iswave || isprobe || isusm) {
                 FatItem it;
@@ -475,7 +483,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 it.out = outidx; it.n16 = (pa + 15u) >> 4;
                 Q.copy[qcopy + mbcnt(mcp)] = it;
             }
-            qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv); qruns += __popcll(mrn); qprobe += __popcll(mpr); qbba += __popcll(mba); qusm += __popcll(mus); qr16 += __popcll(mr16);
+            qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv); qruns += __popcll(mrn); qprobe += __popcll(mpr); qbba += __popcll(mba); qusm += __popcll(mus); qr16 += __popcll(mr16); qr16w += __popcll(mr16w);
         }
     } else {
         const u64 nAt = U.implicit ? 1 : (a1 - a0 + 255) / 256;  // A-tiles of the pair in front of its B-tiles

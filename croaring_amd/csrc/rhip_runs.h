@@ -17,8 +17,8 @@
 // a position is "effective" (an array's v+1 / next-v pair, or a boundary shared by both lists, toggles twice at
 // one position); a result run starts at an effective event where op(inA, inB) turns 1 and ends before one where it
 // turns 0, "turns" being relative to the previous effective event -- across lanes that is one ballot pair and a
-// count-leading-zeros.  Three walks: (1) last effective state per lane, (2) count starts / ends, (3) write them at
-// wave-scanned positions.  The run list is then typed by the reference's rules (convert_run_to_efficient_container
+// count-leading-zeros.  Two walks: (1) first / last effective state per lane and its starts / ends, (2) write them
+// at scanned positions.  The run list is then typed by the reference's rules (convert_run_to_efficient_container
 // etc.) and written as runs or expanded into an array; the rare bitset result is re-queued for k_genw.
 // (Round 1 evaluated every boundary with a binary search into the other list, twice: 7 ns per pair of 100-run
 // containers; the merge walk does the same in a fraction of the LDS round trips.)
@@ -50,44 +50,89 @@ __device__ __forceinline__ bool bop(int op, uint32_t a, uint32_t b) {
     return op == OP_AND ? (a & b) : op == OP_OR ? (a | b) : op == OP_XOR ? (a ^ b) : (a & ~b & 1u);
 }
 
-__global__ __launch_bounds__(256) void k_runs(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
-                                              OutView O, const GenItem* __restrict__ q,
-                                              const u64* __restrict__ qrange, int op, int cardmode, u64* pair_acc,
-                                              GenItem* retry_q, uint32_t* retry_count) {
-    constexpr uint32_t NB = 2 * RUNS_MAX_INTERVALS;  // max boundaries per list = max result runs
-    // per wave (~4 KiB): both operand lists staged in LDS, result run starts / ends
-    __shared__ __attribute__((aligned(16))) uint8_t lists_all[4][2][1024];  // 4 * RUNS_MAX_INTERVALS, padded to 16 bytes
-    __shared__ uint16_t lds_all[4][2 * NB + 2];
-    const uint32_t lane = lane_id();
-    uint16_t* base = lds_all[threadIdx.x >> 6];
-    uint8_t* lsA = lists_all[threadIdx.x >> 6][0];
-    uint8_t* lsB = lists_all[threadIdx.x >> 6][1];
-    uint16_t* RS = base;            // result run starts
-    uint16_t* RE = base + NB;       // result run ends (inclusive)
+// G lanes per pair (64 / G pairs per wave), at most MAXIV intervals per operand.  The walk of a lane's chunk is a chain
+// of dependent LDS reads, so a wave is latency-bound whatever its width: sparse run-compressed data (wikileaks-noquotes:
+// nine tenths of the matched pairs have <= 127 intervals a side) runs FOUR pairs per wave on 16-lane groups -- group-wide
+// scans and sums by shuffles that never leave the group, group-private LDS -- and only long lists take the whole wave.
+// Control flow around the collectives stays wave-uniform: the groups of a wave walk their items in lockstep.
+template <uint32_t G>
+struct Grp {
+    uint32_t lane, grp, gl, glast;
+    __device__ __forceinline__ Grp() {
+        lane = lane_id(); grp = lane / G; gl = lane % G; glast = (lane & ~(G - 1u)) | (G - 1u);
+    }
+    __device__ __forceinline__ u64 ballot(bool p) const {  // the group's slice of the wave ballot
+        const u64 b = __ballot(p);
+        if (G == 64) return b;
+        return (b >> (G * grp)) & ((1ull << (G & 63u)) - 1ull);
+    }
+    __device__ __forceinline__ uint32_t incl_scan(uint32_t v) const {
+        if (G == 64) return wave_incl_scan(v);
+#pragma unroll
+        for (uint32_t o = 1; o < G; o <<= 1) {
+            const uint32_t t = __shfl_up(v, o);
+            if (gl >= o) v += t;
+        }
+        return v;
+    }
+    __device__ __forceinline__ uint32_t sum(uint32_t v) const {
+        if (G == 64) return wave_sum(v);
+#pragma unroll
+        for (uint32_t o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    }
+    __device__ __forceinline__ uint32_t wave_max(uint32_t v) const {  // v is group-uniform: max over the groups
+#pragma unroll
+        for (uint32_t o = G; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_xor(v, o);
+            v = t > v ? t : v;
+        }
+        return v;
+    }
+};
+
+template <uint32_t G, uint32_t MAXIV>
+__global__ __launch_bounds__(256) void k_ivl(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                             OutView O, const GenItem* __restrict__ q,
+                                             const u64* __restrict__ qrange, int op, int cardmode, u64* pair_acc,
+                                             GenItem* retry_q, uint32_t* retry_count) {
+    constexpr uint32_t NG = 64 / G;                        // pairs per wave
+    constexpr uint32_t NB = 2 * MAXIV + 2;                 // >= result runs: (boundaries of both lists) / 2
+    constexpr uint32_t LBYTES = (4 * MAXIV + 15) & ~15u;   // staged payload of one operand, 16-byte padded
+    __shared__ __attribute__((aligned(16))) uint8_t lists_all[4 * NG][2][LBYTES];
+    __shared__ __attribute__((aligned(4))) uint16_t rse_all[4 * NG][2 * NB];  // result runs: start, end (inclusive)
+    const Grp<G> gr;
+    const uint32_t lane = gr.lane, gl = gr.gl;
+    const uint32_t gslot = threadIdx.x / G;
+    uint8_t* lsA = lists_all[gslot][0];
+    uint8_t* lsB = lists_all[gslot][1];
+    uint16_t* RSE = rse_all[gslot];
+    const uint32_t* RUN = (const uint32_t*)RSE;  // run k = RUN[k]: start | end << 16
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
     uint32_t wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    GenItem tnext;
-    if (wi < n) tnext = q[wi];
-    for (; wi < n; wi += nwaves) {
+    GenItem tnext = {};
+    if (NG * wi + gr.grp < n) tnext = q[NG * wi + gr.grp];
+    for (; NG * wi < n; wi += nwaves) {
+        const bool have = NG * wi + gr.grp < n;
         const GenItem t = tnext;
-        if (wi + nwaves < n) tnext = q[wi + nwaves];  // next work item in flight while this one is processed
+        if (NG * (wi + nwaves) + gr.grp < n) tnext = q[NG * (wi + nwaves) + gr.grp];  // next item in flight meanwhile
         const uint32_t ta = t.types & 0xFFu, tb = t.types >> 8;
         IvList LA, LB;
-        LA.p = lsA; LA.is_run = ta == T_RUN; LA.n2 = 2u * (ta == T_RUN ? t.nra : t.ca);
-        LB.p = lsB; LB.is_run = tb == T_RUN; LB.n2 = 2u * (tb == T_RUN ? t.nrb : t.cb);
-        {   // stage both payloads (<= 1 KiB each, 16-byte padded slots): one 16-byte load per lane
+        LA.p = lsA; LA.is_run = ta == T_RUN; LA.n2 = have ? 2u * (ta == T_RUN ? t.nra : t.ca) : 0u;
+        LB.p = lsB; LB.is_run = tb == T_RUN; LB.n2 = have ? 2u * (tb == T_RUN ? t.nrb : t.cb) : 0u;
+        {   // stage both payloads: 16 bytes per lane and round
             const uint32_t na16 = ((LA.is_run ? 2u : 1u) * LA.n2 + 15u) >> 4;
             const uint32_t nb16 = ((LB.is_run ? 2u : 1u) * LB.n2 + 15u) >> 4;
-            if (lane < na16) ((uint4*)lsA)[lane] = ((const uint4*)(arenaA + t.offa))[lane];
-            if (lane < nb16) ((uint4*)lsB)[lane] = ((const uint4*)(arenaB + t.offb))[lane];
+            for (uint32_t i = gl; i < na16; i += G) ((uint4*)lsA)[i] = ((const uint4*)(arenaA + t.offa))[i];
+            for (uint32_t i = gl; i < nb16; i += G) ((uint4*)lsB)[i] = ((const uint4*)(arenaB + t.offb))[i];
             __builtin_amdgcn_wave_barrier();
         }
         // ---- merge path: this lane's chunk of the merged boundary sequence
         constexpr uint32_t SENT = 0x20000u;  // past every boundary (the largest is 65536)
         const uint32_t nA = LA.n2, nB2 = LB.n2, E = nA + nB2;
-        const uint32_t per = (E + 63u) >> 6;
-        const uint32_t d0 = lane * per < E ? lane * per : E;
+        const uint32_t per = (E + G - 1u) / G;
+        const uint32_t d0 = gl * per < E ? gl * per : E;
         const uint32_t d1 = d0 + per < E ? d0 + per : E;
         uint32_t ia0;
         {
@@ -117,207 +162,48 @@ __global__ __launch_bounds__(256) void k_runs(const uint8_t* __restrict__ arenaA
                 if (pnext != pcur) fn(pcur, bop(op, inA, inB));
             }
         };
-        // walk 1: does the chunk hold an effective event, and the state after its last one
-        bool has_eff = false, g_last = false;
-        walk([&](uint32_t, bool g) { has_eff = true; g_last = g; });
+        // walk 1: first / last effective state of the chunk and its run starts / ends, counted as if the state before
+        // the chunk were 0; the true state (a ballot pair and a count-leading-zeros) only changes the first event
+        bool has_eff = false, g_first = false, g_last = false;
+        uint32_t ns = 0, ne = 0;
+        {
+            bool gp = false;
+            walk([&](uint32_t, bool g) {
+                if (!has_eff) g_first = g;
+                has_eff = true; g_last = g;
+                ns += (g && !gp) ? 1u : 0u; ne += (!g && gp) ? 1u : 0u;
+                gp = g;
+            });
+        }
         bool gprev = false;  // state after the last effective event BEFORE this chunk
         {
-            const u64 mh = __ballot(has_eff), mg = __ballot(g_last);
-            const u64 below = mh & ((1ull << lane) - 1ull);
+            const u64 mh = gr.ballot(has_eff), mg = gr.ballot(g_last);
+            const u64 below = mh & ((1ull << gl) - 1ull);
             if (below) gprev = (mg >> (63 - __clzll((long long)below))) & 1ull;
         }
-        // walk 2: result run starts / ends in this chunk
-        uint32_t ns = 0, ne = 0;
-        {
-            bool gp = gprev;
-            walk([&](uint32_t, bool g) { ns += (g && !gp) ? 1u : 0u; ne += (!g && gp) ? 1u : 0u; gp = g; });
+        if (gprev && has_eff) {
+            if (g_first) ns -= 1u;  // no start: the state was 1 already
+            else ne += 1u;          // the first event ends a run begun in an earlier chunk
         }
-        const uint32_t incs = wave_incl_scan(ns), ince = wave_incl_scan(ne);
-        const uint32_t rn = __shfl(incs, 63);  // == total ends: every run that starts also ends (both states end at 0)
-        // walk 3: write them
+        const uint32_t incs = gr.incl_scan(ns), ince = gr.incl_scan(ne);
+        const uint32_t rn = __shfl(incs, gr.glast);  // == total ends: every run that starts also ends (both states end at 0)
+        // walk 2: write the transitions; they alternate start, end, start, ... over the whole sequence
         {
-            uint32_t ks = incs - ns, ke = ince - ne;
+            uint32_t kt = (incs - ns) + (ince - ne);
             bool gp = gprev;
             walk([&](uint32_t pcur, bool g) {
-                if (g && !gp) RS[ks++] = (uint16_t)pcur;
-                if (!g && gp) RE[ke++] = (uint16_t)(pcur - 1u);
+                if (g != gp) RSE[kt++] = (uint16_t)(g ? pcur : pcur - 1u);
                 gp = g;
             });
         }
         __builtin_amdgcn_wave_barrier();
         // ---- cardinality, typing
         uint32_t cnt = 0;
-        for (uint32_t k = lane; k < rn; k += 64) cnt += (uint32_t)RE[k] - (uint32_t)RS[k] + 1u;
-        const uint32_t rc = wave_sum(cnt);
-        if (cardmode) {
-            if (lane == 0 && rc) atomicAdd(&pair_acc[t.out], (u64)rc);
-            __builtin_amdgcn_wave_barrier();
-            continue;
+        for (uint32_t k = gl; k < rn; k += G) {
+            const uint32_t w = RUN[k];
+            cnt += (w >> 16) - (w & 0xFFFFu) + 1u;
         }
-        const bool fulla = ta == T_RUN && t.ca == 65536u, fullb = tb == T_RUN && t.cb == 65536u;
-        int ty = T_ARRAY;
-        if (rc) ty = decide_type(op, (int)ta, (int)tb, t.ca, t.cb, fulla, fullb, rc, rn);
-        if (rc && ty == T_BITSET) {
-            // rare for this class: let the image kernel redo the pair
-            if (lane == 0) retry_q[atomicAdd(retry_count, 1u)] = t;
-            __builtin_amdgcn_wave_barrier();
-            continue;
-        }
-        uint8_t* outp = O.arena + t.offo;
-        if (rc && ty == T_RUN) {
-            uint32_t* __restrict__ o32 = (uint32_t*)outp;
-            for (uint32_t k = lane; k < rn; k += 64)
-                o32[k] = (uint32_t)RS[k] | (((uint32_t)RE[k] - (uint32_t)RS[k]) << 16);
-        } else if (rc) {
-            // expand runs into a sorted array.  An array-typed result has short runs (2 rc <= 4 rn + 2), so: one lane
-            // per run writes its first 8 values at the scanned position; the few longer runs are finished by the whole
-            // wave, one after the other.  (A binary search per output value -- 8 dependent LDS reads for each of up to
-            // 4096 values -- cost 20 us per pair on run-compressed data.)
-            uint16_t* __restrict__ o16 = (uint16_t*)outp;
-            uint32_t runbase = 0;
-            for (uint32_t k0 = 0; k0 < rn; k0 += 64) {
-                const uint32_t k = k0 + lane;
-                const uint32_t st = k < rn ? (uint32_t)RS[k] : 0u;
-                const uint32_t len = k < rn ? (uint32_t)RE[k] - st + 1u : 0u;
-                const uint32_t inc = wave_incl_scan(len);
-                const uint32_t pos = runbase + inc - len;
-                runbase += __shfl(inc, 63);
-                const uint32_t lim = len < 8u ? len : 8u;
-                for (uint32_t j = 0; j < lim; ++j) o16[pos + j] = (uint16_t)(st + j);
-                u64 longm = __ballot(len > 8u);
-                while (longm) {
-                    const int src = __ffsll((long long)longm) - 1;
-                    longm &= longm - 1;
-                    const uint32_t ls = __shfl(st, src), ll = __shfl(len, src), lp = __shfl(pos, src);
-                    for (uint32_t j = 8u + lane; j < ll; j += 64) o16[lp + j] = (uint16_t)(ls + j);
-                }
-            }
-        }
-        if (lane == 0) O.meta[t.out] = pack_meta(ty, rc, (ty == T_RUN) ? rn : 0u);
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// ------------------------------------------------------------------ short interval lists: four pairs per wave
-// The same interval algebra as k_runs for pairs with <= R16_MAX_IV intervals per operand and <= R16_MAX_CARD values in
-// all: sparse run-compressed data (wikileaks-noquotes: three quarters of the matched pairs) is made of such pairs,
-// and a wave that spends its ~2 000 instructions on one of them leaves 50-60 lanes idle throughout.  Here every
-// 16-lane group of the wave owns one pair: merge path over 16 lanes, group-wide scans and sums (shuffles that never
-// leave the group), group-private LDS.  Control flow around the collectives stays wave-uniform: the four groups walk
-// their items in lockstep and the only loops with collectives inside have constant trip counts.
-__device__ __forceinline__ uint32_t grp16_incl_scan(uint32_t v, uint32_t gl) {
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-        const uint32_t t = __shfl_up(v, o);
-        if (gl >= (uint32_t)o) v += t;
-    }
-    return v;
-}
-__device__ __forceinline__ uint32_t grp16_sum(uint32_t v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__global__ __launch_bounds__(256) void k_runs16(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
-                                                OutView O, const GenItem* __restrict__ q,
-                                                const u64* __restrict__ qrange, int op, int cardmode, u64* pair_acc,
-                                                GenItem* retry_q, uint32_t* retry_count) {
-    constexpr uint32_t NB = 64;  // >= result runs of a pair: at most (boundaries of both lists) / 2 = 2 * R16_MAX_IV
-    __shared__ __attribute__((aligned(16))) uint8_t lists_all[16][2][128];  // per group: both payloads, 16-byte padded
-    __shared__ uint16_t lds_all[16][2 * NB];
-    const uint32_t lane = lane_id(), grp = lane >> 4, gl = lane & 15u;
-    const uint32_t gslot = (threadIdx.x >> 4);  // group index inside the block
-    uint8_t* lsA = lists_all[gslot][0];
-    uint8_t* lsB = lists_all[gslot][1];
-    uint16_t* RS = lds_all[gslot];
-    uint16_t* RE = RS + NB;
-    const uint32_t glast = (lane & 48u) | 15u;  // last lane of this group
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    uint32_t wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    GenItem tnext = {};
-    if (4 * wi + grp < n) tnext = q[4 * wi + grp];
-    for (; 4 * wi < n; wi += nwaves) {
-        const bool have = 4 * wi + grp < n;
-        const GenItem t = tnext;
-        if (4 * (wi + nwaves) + grp < n) tnext = q[4 * (wi + nwaves) + grp];
-        const uint32_t ta = t.types & 0xFFu, tb = t.types >> 8;
-        IvList LA, LB;
-        LA.p = lsA; LA.is_run = ta == T_RUN; LA.n2 = have ? 2u * (ta == T_RUN ? t.nra : t.ca) : 0u;
-        LB.p = lsB; LB.is_run = tb == T_RUN; LB.n2 = have ? 2u * (tb == T_RUN ? t.nrb : t.cb) : 0u;
-        {   // stage both payloads (<= 124 bytes each): lanes 0-7 of the group load A, lanes 8-15 load B
-            const uint32_t na16 = ((LA.is_run ? 2u : 1u) * LA.n2 + 15u) >> 4;
-            const uint32_t nb16 = ((LB.is_run ? 2u : 1u) * LB.n2 + 15u) >> 4;
-            if (gl < 8u) {
-                if (gl < na16) ((uint4*)lsA)[gl] = ((const uint4*)(arenaA + t.offa))[gl];
-            } else if (gl - 8u < nb16) {
-                ((uint4*)lsB)[gl - 8u] = ((const uint4*)(arenaB + t.offb))[gl - 8u];
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        // ---- merge path over the 16 lanes of the group (see k_runs)
-        constexpr uint32_t SENT = 0x20000u;
-        const uint32_t nA = LA.n2, nB2 = LB.n2, E = nA + nB2;
-        const uint32_t per = (E + 15u) >> 4;
-        const uint32_t d0 = gl * per < E ? gl * per : E;
-        const uint32_t d1 = d0 + per < E ? d0 + per : E;
-        uint32_t ia0;
-        {
-            uint32_t lo = d0 > nB2 ? d0 - nB2 : 0u, hi = d0 < nA ? d0 : nA;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (LA.at(mid) <= LB.at(d0 - mid - 1u)) lo = mid + 1u;
-                else hi = mid;
-            }
-            ia0 = lo;
-        }
-        const uint32_t ib0 = d0 - ia0, steps = d1 - d0;
-        auto walk = [&](auto&& fn) {
-            uint32_t ia = ia0, ib = ib0, inA = ia0 & 1u, inB = ib0 & 1u;
-            uint32_t pa = ia < nA ? LA.at(ia) : SENT, pb = ib < nB2 ? LB.at(ib) : SENT;
-            for (uint32_t sidx = 0; sidx < steps; ++sidx) {
-                uint32_t pcur;
-                if (pa <= pb) {
-                    pcur = pa; inA ^= 1u; ++ia;
-                    pa = ia < nA ? LA.at(ia) : SENT;
-                } else {
-                    pcur = pb; inB ^= 1u; ++ib;
-                    pb = ib < nB2 ? LB.at(ib) : SENT;
-                }
-                const uint32_t pnext = pa < pb ? pa : pb;
-                if (pnext != pcur) fn(pcur, bop(op, inA, inB));
-            }
-        };
-        bool has_eff = false, g_last = false;
-        walk([&](uint32_t, bool g) { has_eff = true; g_last = g; });
-        bool gprev = false;
-        {
-            const uint32_t mh = (uint32_t)(__ballot(has_eff) >> (16u * grp)) & 0xFFFFu;
-            const uint32_t mg = (uint32_t)(__ballot(g_last) >> (16u * grp)) & 0xFFFFu;
-            const uint32_t below = mh & ((1u << gl) - 1u);
-            if (below) gprev = (mg >> (31 - __clz((int)below))) & 1u;
-        }
-        uint32_t ns = 0, ne = 0;
-        {
-            bool gp = gprev;
-            walk([&](uint32_t, bool g) { ns += (g && !gp) ? 1u : 0u; ne += (!g && gp) ? 1u : 0u; gp = g; });
-        }
-        const uint32_t incs = grp16_incl_scan(ns, gl), ince = grp16_incl_scan(ne, gl);
-        const uint32_t rn = __shfl(incs, glast);
-        {
-            uint32_t ks = incs - ns, ke = ince - ne;
-            bool gp = gprev;
-            walk([&](uint32_t pcur, bool g) {
-                if (g && !gp) RS[ks++] = (uint16_t)pcur;
-                if (!g && gp) RE[ke++] = (uint16_t)(pcur - 1u);
-                gp = g;
-            });
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- cardinality, typing
-        uint32_t cnt = 0;
-        for (uint32_t k = gl; k < rn; k += 16) cnt += (uint32_t)RE[k] - (uint32_t)RS[k] + 1u;
-        const uint32_t rc = grp16_sum(cnt);
+        const uint32_t rc = gr.sum(cnt);
         if (cardmode) {  // (wave-uniform)
             if (have && gl == 0 && rc) atomicAdd(&pair_acc[t.out], (u64)rc);
             __builtin_amdgcn_wave_barrier();
@@ -326,39 +212,45 @@ __global__ __launch_bounds__(256) void k_runs16(const uint8_t* __restrict__ aren
         const bool fulla = ta == T_RUN && t.ca == 65536u, fullb = tb == T_RUN && t.cb == 65536u;
         int ty = T_ARRAY;
         if (rc) ty = decide_type(op, (int)ta, (int)tb, t.ca, t.cb, fulla, fullb, rc, rn);
-        const bool redo = have && rc && ty == T_BITSET;  // cannot happen below 4097 values; kept for safety
+        // a bitset result (rare for this class): let the image kernel redo the pair
+        const bool redo = have && rc && ty == T_BITSET;
         if (redo && gl == 0) retry_q[atomicAdd(retry_count, 1u)] = t;
         const bool wr = have && rc && !redo;
         uint8_t* outp = O.arena + t.offo;
         if (wr && ty == T_RUN) {
             uint32_t* __restrict__ o32 = (uint32_t*)outp;
-            for (uint32_t k = gl; k < rn; k += 16)
-                o32[k] = (uint32_t)RS[k] | (((uint32_t)RE[k] - (uint32_t)RS[k]) << 16);
+            for (uint32_t k = gl; k < rn; k += G) {
+                const uint32_t w = RUN[k];
+                o32[k] = (w & 0xFFFFu) | (((w >> 16) - (w & 0xFFFFu)) << 16);
+            }
         }
-        const bool arr = wr && ty != T_RUN;
-        {   // runs -> sorted array as in k_runs: a lane per run for its first 8 values, the group for the rest of a
-            // longer one.  Constant trip count (rn < NB) and a wave-uniform long-run loop keep the collectives legal.
+        {   // runs -> sorted array.  An array-typed result has short runs (2 rc <= 4 rn + 2), so: one lane per run
+            // writes its first 8 values at the scanned position; the few longer runs are finished by the whole group,
+            // one after the other.  (A binary search per output value -- 8 dependent LDS reads for each of up to 4096
+            // values -- was the slowest part of the kernel on run-compressed data.)
+            const bool arr = wr && ty != T_RUN;
             uint16_t* __restrict__ o16 = (uint16_t*)outp;
+            const uint32_t rnm = gr.wave_max(arr ? rn : 0u);
             uint32_t runbase = 0;
-#pragma unroll
-            for (uint32_t k0 = 0; k0 < NB; k0 += 16) {
+            for (uint32_t k0 = 0; k0 < rnm; k0 += G) {
                 const uint32_t k = k0 + gl;
                 const bool v = arr && k < rn;
-                const uint32_t st = v ? (uint32_t)RS[k] : 0u;
-                const uint32_t len = v ? (uint32_t)RE[k] - st + 1u : 0u;
-                const uint32_t inc = grp16_incl_scan(len, gl);
+                const uint32_t w = v ? RUN[k] : 0u;
+                const uint32_t st = w & 0xFFFFu;
+                const uint32_t len = v ? (w >> 16) - st + 1u : 0u;
+                const uint32_t inc = gr.incl_scan(len);
                 const uint32_t pos = runbase + inc - len;
-                runbase += __shfl(inc, glast);
+                runbase += __shfl(inc, gr.glast);
                 const uint32_t lim = len < 8u ? len : 8u;
                 for (uint32_t j = 0; j < lim; ++j) o16[pos + j] = (uint16_t)(st + j);
-                uint32_t lm = (uint32_t)(__ballot(len > 8u) >> (16u * grp)) & 0xFFFFu;
-                while (__ballot(lm != 0u)) {
-                    const bool act = lm != 0u;
-                    const uint32_t src = (lane & 48u) | (act ? (uint32_t)__ffs((int)lm) - 1u : 0u);
-                    lm &= lm - 1u;
+                u64 lm = gr.ballot(len > 8u);
+                while (__ballot(lm != 0ull)) {
+                    const bool act = lm != 0ull;
+                    const uint32_t src = (lane & ~(G - 1u)) | (act ? (uint32_t)__ffsll((long long)lm) - 1u : 0u);
+                    lm &= lm - 1ull;
                     const uint32_t ls = __shfl(st, src), ll = __shfl(len, src), lp = __shfl(pos, src);
                     if (act)
-                        for (uint32_t j = 8u + gl; j < ll; j += 16) o16[lp + j] = (uint16_t)(ls + j);
+                        for (uint32_t j = 8u + gl; j < ll; j += G) o16[lp + j] = (uint16_t)(ls + j);
                 }
             }
         }

@@ -502,10 +502,10 @@ def test_array_filter_probe_boundaries(engine, oracle):
 
 
 def test_tiny_interval_pairs(engine, oracle):
-    """Short interval lists (k_runs16: four pairs per wave, and its hand-over to k_runs): run containers of 1 .. 70
-    runs and arrays of 1 .. 70 values around the classification boundaries (31 / 32 intervals per operand; 512 / 513
-    values in both operands together), touching and nested intervals, both ends of the u16 range, full containers;
-    four ops + cardinalities, both operand orders."""
+    """Interval pairs in all three size classes of k_ivl (four pairs per wave up to 31 and up to 127 intervals a side,
+    one pair per wave beyond): run containers of 1 .. 128 runs and arrays of 1 .. 128 values around the classification
+    boundaries (31 / 32 and 127 / 128 intervals per operand; value totals around 512, 1024 and 4096), touching and
+    nested intervals, both ends of the u16 range, full containers; four ops + cardinalities, both operand orders."""
     rng = np.random.default_rng(314)
 
     def runs(k, maxlen):
@@ -514,7 +514,7 @@ def test_tiny_interval_pairs(engine, oracle):
         return np.unique(np.concatenate(parts))
 
     shapes = []
-    for k in (1, 2, 3, 8, 16, 31, 32, 33, 63, 64, 65, 70):
+    for k in (1, 2, 3, 8, 16, 31, 32, 33, 63, 64, 65, 70, 127, 128):
         shapes.append(("run", runs(k, 400)))
         shapes.append(("run", runs(k, 2)))
         shapes.append(("arr", np.sort(rng.choice(65536, k, replace=False))))
@@ -527,7 +527,10 @@ def test_tiny_interval_pairs(engine, oracle):
                ("run", np.arange(1000, 1256)), ("run", np.arange(1100, 1356)), ("run", np.arange(5000, 5257)),
                ("run", np.concatenate([np.arange(40, 300), np.arange(1200, 1421)])),
                ("run", np.concatenate([np.arange(40, 300), np.arange(1200, 1422)])),
-               ("arr", np.arange(31) * 41 + 50)]
+               ("arr", np.arange(31) * 41 + 50),
+               # 512 + 512 = 1024 and 512 + 513 values; 2048 + 2048 = 4096 and 2048 + 2049
+               ("run", np.arange(2000, 2512)), ("run", np.arange(2300, 2812)), ("run", np.arange(9000, 9513)),
+               ("run", np.arange(20000, 22048)), ("run", np.arange(21000, 23048)), ("run", np.arange(40000, 42049))]
     hs = [oracle.from_sorted(np.asarray(v, np.uint32) + (9 << 16), run_optimize=(kind == "run")) for kind, v in shapes]
     bufs = [oracle.serialize(h) for h in hs]
     pool = engine.pool_from_serialized(bufs)
