@@ -13,7 +13,7 @@
 // (arrays: e = s).  Membership is a parity: x is in the operand iff an odd number of its boundaries are <= x.  The
 // two lists (staged in LDS) are merged by MERGE PATH: lane l owns merged positions [l * per, (l+1) * per) and finds
 // its split (ia, ib) with one binary search along its diagonal; the state before its chunk is just (ia & 1, ib & 1).
-// It then walks its <= 16 events sequentially (two LDS reads per event), toggling inA / inB.  Only the LAST event at
+// It then walks its <= 16 events sequentially (one LDS read per event, no branch), toggling inA / inB.  Only the LAST event at
 // a position is "effective" (an array's v+1 / next-v pair, or a boundary shared by both lists, toggles twice at
 // one position); a result run starts at an effective event where op(inA, inB) turns 1 and ends before one where it
 // turns 0, "turns" being relative to the previous effective event -- across lanes that is one ballot pair and a
@@ -22,34 +22,6 @@
 // etc.) and written as runs or expanded into an array; the rare bitset result is re-queued for k_genw.
 // (Round 1 evaluated every boundary with a binary search into the other list, twice: 7 ns per pair of 100-run
 // containers; the merge walk does the same in a fraction of the LDS round trips.)
-struct IvList {
-    const uint8_t* p;
-    uint32_t n2;     // number of boundaries (2 x intervals)
-    bool is_run;
-    __device__ __forceinline__ uint32_t at(uint32_t j) const {
-        if (is_run) {
-            const uint32_t w = ((const uint32_t*)p)[j >> 1];
-            const uint32_t s = w & 0xFFFFu;
-            return (j & 1u) ? s + (w >> 16) + 1u : s;
-        }
-        const uint32_t v = ((const uint16_t*)p)[j >> 1];
-        return v + (j & 1u);
-    }
-    __device__ __forceinline__ uint32_t lower(uint32_t x) const {  // first j with at(j) >= x
-        uint32_t lo = 0, hi = n2;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (at(mid) < x) lo = mid + 1;
-            else hi = mid;
-        }
-        return lo;
-    }
-};
-__device__ __forceinline__ bool bop(int op, uint32_t a, uint32_t b) {
-    a &= 1u; b &= 1u;
-    return op == OP_AND ? (a & b) : op == OP_OR ? (a | b) : op == OP_XOR ? (a ^ b) : (a & ~b & 1u);
-}
-
 // G lanes per pair (64 / G pairs per wave), at most MAXIV intervals per operand.  The walk of a lane's chunk is a chain
 // of dependent LDS reads, so a wave is latency-bound whatever its width: sparse run-compressed data (wikileaks-noquotes:
 // nine tenths of the matched pairs have <= 127 intervals a side) runs FOUR pairs per wave on 16-lane groups -- group-wide
@@ -118,19 +90,41 @@ __global__ __launch_bounds__(256) void k_ivl(const uint8_t* __restrict__ arenaA,
         const GenItem t = tnext;
         if (NG * (wi + nwaves) + gr.grp < n) tnext = q[NG * (wi + nwaves) + gr.grp];  // next item in flight meanwhile
         const uint32_t ta = t.types & 0xFFu, tb = t.types >> 8;
-        IvList LA, LB;
-        LA.p = lsA; LA.is_run = ta == T_RUN; LA.n2 = have ? 2u * (ta == T_RUN ? t.nra : t.ca) : 0u;
-        LB.p = lsB; LB.is_run = tb == T_RUN; LB.n2 = have ? 2u * (tb == T_RUN ? t.nrb : t.cb) : 0u;
-        {   // stage both payloads: 16 bytes per lane and round
-            const uint32_t na16 = ((LA.is_run ? 2u : 1u) * LA.n2 + 15u) >> 4;
-            const uint32_t nb16 = ((LB.is_run ? 2u : 1u) * LB.n2 + 15u) >> 4;
-            for (uint32_t i = gl; i < na16; i += G) ((uint4*)lsA)[i] = ((const uint4*)(arenaA + t.offa))[i];
-            for (uint32_t i = gl; i < nb16; i += G) ((uint4*)lsB)[i] = ((const uint4*)(arenaB + t.offb))[i];
+        // boundary counts (2 x intervals); an absent item is a pair of empty lists
+        const uint32_t nA = have ? 2u * (ta == T_RUN ? t.nra : t.ca) : 0u;
+        const uint32_t nB2 = have ? 2u * (tb == T_RUN ? t.nrb : t.cb) : 0u;
+        {   // stage both payloads in BOUNDARY form, u16 x[j] with boundary j = x[j] + (j & 1): a run (s, len) becomes
+            // (s, s + len), an array value v becomes (v, v) -- reading a boundary is then one LDS load and one add
+            // whatever the container type, and the walk below has no branch on it.  16 payload bytes per lane and round.
+            auto stage = [&](uint8_t* ls, const uint8_t* __restrict__ src, bool is_run, uint32_t n2) {
+                if (is_run) {
+                    const uint32_t n16 = (2u * n2 + 15u) >> 4;
+                    for (uint32_t i = gl; i < n16; i += G) {
+                        uint4 x = ((const uint4*)src)[i];
+                        x.x += x.x << 16; x.y += x.y << 16; x.z += x.z << 16; x.w += x.w << 16;
+                        ((uint4*)ls)[i] = x;
+                    }
+                } else {
+                    const uint32_t n16 = (n2 + 15u) >> 4;
+                    for (uint32_t i = gl; i < n16; i += G) {
+                        const uint4 x = ((const uint4*)src)[i];
+                        ((uint4*)ls)[2 * i] = make_uint4((x.x & 0xFFFFu) * 0x10001u, (x.x >> 16) * 0x10001u,
+                                                         (x.y & 0xFFFFu) * 0x10001u, (x.y >> 16) * 0x10001u);
+                        ((uint4*)ls)[2 * i + 1] = make_uint4((x.z & 0xFFFFu) * 0x10001u, (x.z >> 16) * 0x10001u,
+                                                             (x.w & 0xFFFFu) * 0x10001u, (x.w >> 16) * 0x10001u);
+                    }
+                }
+            };
+            stage(lsA, arenaA + t.offa, ta == T_RUN, nA);
+            stage(lsB, arenaB + t.offb, tb == T_RUN, nB2);
             __builtin_amdgcn_wave_barrier();
         }
+        const uint16_t* __restrict__ LL = (const uint16_t*)lsA;  // A's boundaries at [0, HALF), B's at [HALF, 2 HALF)
+        constexpr uint32_t HALF = LBYTES / 2;
+        auto bnd = [&](uint32_t base, uint32_t j) -> uint32_t { return (uint32_t)LL[base + j] + (j & 1u); };
         // ---- merge path: this lane's chunk of the merged boundary sequence
         constexpr uint32_t SENT = 0x20000u;  // past every boundary (the largest is 65536)
-        const uint32_t nA = LA.n2, nB2 = LB.n2, E = nA + nB2;
+        const uint32_t E = nA + nB2;
         const uint32_t per = (E + G - 1u) / G;
         const uint32_t d0 = gl * per < E ? gl * per : E;
         const uint32_t d1 = d0 + per < E ? d0 + per : E;
@@ -139,27 +133,31 @@ __global__ __launch_bounds__(256) void k_ivl(const uint8_t* __restrict__ arenaA,
             uint32_t lo = d0 > nB2 ? d0 - nB2 : 0u, hi = d0 < nA ? d0 : nA;
             while (lo < hi) {  // A goes first on ties: A[mid] <= B[d0 - mid - 1] means more of A lies before the diagonal
                 const uint32_t mid = (lo + hi) >> 1;
-                if (LA.at(mid) <= LB.at(d0 - mid - 1u)) lo = mid + 1u;
-                else hi = mid;
+                const bool more = bnd(0, mid) <= bnd(HALF, d0 - mid - 1u);
+                lo = more ? mid + 1u : lo;
+                hi = more ? hi : mid;
             }
             ia0 = lo;
         }
         const uint32_t ib0 = d0 - ia0, steps = d1 - d0;
-        // walk the chunk; fn(p, g) is called for every EFFECTIVE event (last event at position p), g = op state after it
+        // op as a truth table over (inA, inB): bit (inA + 2 inB)
+        const uint32_t tt = op == OP_AND ? 0x8u : op == OP_OR ? 0xEu : op == OP_XOR ? 0x6u : 0x2u;
+        // Walk the chunk, branch-free: fn(p, eff, g) for every event at position p; eff = it is the LAST event at that
+        // position (the only kind that counts), g = op state after it.
         auto walk = [&](auto&& fn) {
             uint32_t ia = ia0, ib = ib0, inA = ia0 & 1u, inB = ib0 & 1u;
-            uint32_t pa = ia < nA ? LA.at(ia) : SENT, pb = ib < nB2 ? LB.at(ib) : SENT;
+            uint32_t pa = ia < nA ? bnd(0, ia) : SENT, pb = ib < nB2 ? bnd(HALF, ib) : SENT;
             for (uint32_t sidx = 0; sidx < steps; ++sidx) {
-                uint32_t pcur;
-                if (pa <= pb) {
-                    pcur = pa; inA ^= 1u; ++ia;
-                    pa = ia < nA ? LA.at(ia) : SENT;
-                } else {
-                    pcur = pb; inB ^= 1u; ++ib;
-                    pb = ib < nB2 ? LB.at(ib) : SENT;
-                }
+                const bool tA = pa <= pb;
+                const uint32_t pcur = tA ? pa : pb;
+                inA ^= tA ? 1u : 0u; inB ^= tA ? 0u : 1u;
+                ia += tA ? 1u : 0u; ib += tA ? 0u : 1u;
+                const uint32_t idx = tA ? ia : ib, lim = tA ? nA : nB2;
+                const uint32_t raw = bnd(tA ? 0u : HALF, idx);  // (a slot past the list is inside the staging area)
+                const uint32_t val = idx < lim ? raw : SENT;
+                pa = tA ? val : pa; pb = tA ? pb : val;
                 const uint32_t pnext = pa < pb ? pa : pb;
-                if (pnext != pcur) fn(pcur, bop(op, inA, inB));
+                fn(pcur, pnext != pcur, ((tt >> (inA + 2u * inB)) & 1u) != 0u);
             }
         };
         // walk 1: first / last effective state of the chunk and its run starts / ends, counted as if the state before
@@ -168,11 +166,12 @@ __global__ __launch_bounds__(256) void k_ivl(const uint8_t* __restrict__ arenaA,
         uint32_t ns = 0, ne = 0;
         {
             bool gp = false;
-            walk([&](uint32_t, bool g) {
-                if (!has_eff) g_first = g;
-                has_eff = true; g_last = g;
-                ns += (g && !gp) ? 1u : 0u; ne += (!g && gp) ? 1u : 0u;
-                gp = g;
+            walk([&](uint32_t, bool eff, bool g) {
+                g_first = (eff && !has_eff) ? g : g_first;
+                has_eff = has_eff || eff;
+                g_last = eff ? g : g_last;
+                ns += (eff && g && !gp) ? 1u : 0u; ne += (eff && !g && gp) ? 1u : 0u;
+                gp = eff ? g : gp;
             });
         }
         bool gprev = false;  // state after the last effective event BEFORE this chunk
@@ -191,9 +190,9 @@ __global__ __launch_bounds__(256) void k_ivl(const uint8_t* __restrict__ arenaA,
         {
             uint32_t kt = (incs - ns) + (ince - ne);
             bool gp = gprev;
-            walk([&](uint32_t pcur, bool g) {
-                if (g != gp) RSE[kt++] = (uint16_t)(g ? pcur : pcur - 1u);
-                gp = g;
+            walk([&](uint32_t pcur, bool eff, bool g) {
+                if (eff && g != gp) RSE[kt++] = (uint16_t)(g ? pcur : pcur - 1u);
+                gp = eff ? g : gp;
             });
         }
         __builtin_amdgcn_wave_barrier();
