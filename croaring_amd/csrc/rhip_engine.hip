@@ -760,7 +760,7 @@ static void fetch_bounds(rhip_pool_t* P) {
 // device scratch of one call (inside ctx->misc, all of it cleared by k_count): u64 words
 struct PlanScratch {
     size_t n_scan_tiles, n_tail_tiles;
-    size_t w_scan_status, w_tail_status, w_tail_part, w_tickets, w_retry, w_ranges, w_stats, n_words;
+    size_t w_scan_status, w_tail_status, w_tail_part, w_tickets, w_retry, w_ranges, n_words;
     void layout(size_t n_scan_elems, size_t ub_cand) {
         n_scan_tiles = (n_scan_elems + SCAN_TILE - 1) / SCAN_TILE + 1;
         n_tail_tiles = (ub_cand + TAIL_TILE - 1) / TAIL_TILE + 1;
@@ -771,10 +771,9 @@ struct PlanScratch {
         // every counter that many blocks hit with atomics sits alone in a 128-byte line: device-scope atomics on one
         // line serialise at the memory side, and plain loads of that line (the section ranges) queue behind them
         w = (w + 15) & ~(size_t)15;
-        w_tickets = w; w += 3 * 16;
+        w_tickets = w; w += 2 * 16;
         w_retry = w; w += 16;
         w_ranges = w; w += (2 * N_SEC + 15) & ~15;
-        w_stats = w; w += (sizeof(Stats) + 7) / 8;
         n_words = w;
     }
 };
@@ -791,10 +790,8 @@ struct Plan {
     CandOut CO{nullptr, nullptr, nullptr};
     u64* ranges() const { return words + sc.w_ranges; }
     uint32_t* retry_count() const { return (uint32_t*)(words + sc.w_retry); }
-    Stats* stats() const { return (Stats*)(words + sc.w_stats); }
     LbState scan_lb() const { return LbState{words + sc.w_scan_status, (uint32_t*)(words + sc.w_tickets)}; }
     LbState tail_lb() const { return LbState{words + sc.w_tail_status, (uint32_t*)(words + sc.w_tickets + 16)}; }
-    uint32_t* tail_done() const { return (uint32_t*)(words + sc.w_tickets + 32); }
     u64* tail_part() const { return words + sc.w_tail_part; }
 };
 
@@ -982,9 +979,10 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
 // planning and joined before the tail -- four streams in all, one per hardware queue of the device (a fifth
 // stream shares a queue with another and serialises behind it):
 //     main : k_bb -> [ev_bb] -> k_usmall | k_probe -> k_bba -> k_copy -> [join] -> k_tail      streaming / light classes
-//     aux0 : k_ivl<16,31> -> k_ivl<16,127> -> k_ivl<64,255> -> k_genw(general) -> [wait ev_bb] -> k_genw(retry)              few items, heavy waves
+//     aux0 : k_ivl<16,31> -> k_ivl<16,127> -> k_ivl<64,255> -> [wait ev_bb] -> k_genw(retry)     interval algebra
 //     aux1 : k_filter                                                                and / andnot / cardinality
 //     aux2 : k_wave                                                                  or / xor / bitset \ array
+//     k_genw(general): on aux1 for or / xor, aux2 for and / cardinality (the stream the op leaves idle), else after k_filter
 // Schedules that were measured and dropped (profiles/r02_schedule_notes.md): persistent grids for every class (the
 // first kernel's long-lived blocks hold every LDS slot and the others start when it ends); the few-item classes
 // alone before the fork (their 15-75 us then add to every batch); stream priority for aux0 (no effect: a 248-VGPR
@@ -1033,9 +1031,6 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
         hipLaunchKernelGGL((k_ivl<64, RUNS_MAX_INTERVALS>), dim3(bounded_grid(nm, 2048)), dim3(256), 0, on(0), VA.arena,
                            VB.arena, O, c->q[CLS_RUNS].as<GenItem>(), ranges + 2 * SEC_RUNS, op, cardmode,
                            c->pair_acc.as<u64>(), c->q[CLS_RETRY].as<GenItem>(), retry_count);
-        hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 512)), dim3(256), 0, on(0), VA.arena, VB.arena, O,
-                           c->q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, cardmode,
-                           c->pair_acc.as<u64>());
     }
     if (has_filt)
         hipLaunchKernelGGL(k_filter, dim3(bounded_grid(nm)), dim3(256), 0, on(1), VA.arena, VB.arena, O,
@@ -1043,6 +1038,10 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
     if (has_wave)
         hipLaunchKernelGGL(k_wave, dim3(bounded_grid(nm)), dim3(256), 0, on(2), VA.arena, VB.arena, O,
                            c->q[CLS_WAVE].as<FatItem>(), ranges + 2 * SEC_WAVE, op);
+    if (has_runs)  // the general image class, beside the interval chain: on the auxiliary stream this op leaves idle
+        hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 512)), dim3(256), 0, on(!has_filt ? 1 : !has_wave ? 2 : 1),
+                           VA.arena, VB.arena, O, c->q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN,
+                           (const uint32_t*)nullptr, op, cardmode, c->pair_acc.as<u64>());
     if (has_bb) {
         unsigned grid = persistent_grid(nm, 4, 256 * 32);
         if (c->timing) HIPCHK(hipEventRecord(c->ev[2], s));
@@ -1177,7 +1176,7 @@ extern "C" rhip_pool_t* rhip_pairwise(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A
                  R->nruns.as<uint32_t>(), R->off.as<u64>()};
         const uint64_t seq = ++c->seq;
         hipLaunchKernelGGL(k_tail, dim3((unsigned)std::max<uint64_t>(1, (P.ub_cand + TAIL_TILE - 1) / TAIL_TILE)), dim3(256), 0,
-                           s, P.ranges(), CO, O.meta, D, (uint32_t)npairs, P.tail_lb(), P.tail_part(), P.stats(), P.tail_done(),
+                           s, P.ranges(), CO, O.meta, D, (uint32_t)npairs, P.tail_lb(), P.tail_part(),
                            (Stats*)c->h_pinned, (u64*)c->done_flag(), (u64)seq);
         clk.lap(3);
         Stats st;

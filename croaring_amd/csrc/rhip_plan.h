@@ -538,14 +538,14 @@ struct DirOut {
 // the result directory.  A thread that sees the first candidate of a result bitmap (or a gap of bitmaps with no
 // candidates) writes the bitmap starts; the block holding the last candidate finishes them and the totals.
 // n_cand is read from `ranges` (device), the launch is sized by the host's upper bound.
+#define TAIL_READY (1ull << 63)
 constexpr uint32_t TAIL_PER_THREAD = 8;
 constexpr uint32_t TAIL_TILE = 256 * TAIL_PER_THREAD;  // candidates per block
 __global__ __launch_bounds__(256) void k_tail(const u64* __restrict__ ranges, CandOut C, const u64* __restrict__ meta,
                                               DirOut R, uint32_t n_pairs, LbState lb, u64* __restrict__ part,
-                                              Stats* __restrict__ stats, uint32_t* __restrict__ done,
                                               Stats* __restrict__ host_stats, u64* host_flag, u64 seq) {
     __shared__ u64 sm[4];
-    __shared__ uint32_t s_tile, s_last;
+    __shared__ uint32_t s_tile;
     __shared__ u64 s_prefix;
     __shared__ u64 s_bytes[4];
     __shared__ uint32_t s_types[4][3];
@@ -627,57 +627,56 @@ __global__ __launch_bounds__(256) void k_tail(const u64* __restrict__ ranges, Ca
             b += s_bytes[w];
             for (int t = 0; t < 3; ++t) ty[t] += s_types[w][t];
         }
-        // per-tile partial sums (no same-address atomics: 4 per tile on one line cost 0.2 us per tile); the block
-        // that finishes last adds them up.  Each count is <= TAIL_TILE, so three fit one word.
-        lb_store(&part[2 * (size_t)tile], b);
-        lb_store(&part[2 * (size_t)tile + 1], (u64)ty[0] | ((u64)ty[1] << 16) | ((u64)ty[2] << 32));
-        if (tile == n_tiles - 1) {
-            // the last tile closes the directory: bitmaps after the last candidate are empty
-            const u64 kept = s_prefix + total;
-            const uint32_t plast = n ? C.pair[n - 1] + 1u : 0u;
-            for (uint32_t q = plast; q <= n_pairs; ++q) R.bm_start[q] = kept;
-            stats->result_containers = kept;
-            stats->n_cand = n;
-            stats->matched_pairs = ranges[2 * SEC_M + 1] - ranges[2 * SEC_M];
-            stats->passthrough = ranges[2 * SEC_COPY + 1] - ranges[2 * SEC_COPY];
-            stats->n_bb = ranges[2 * SEC_BB + 1] - ranges[2 * SEC_BB] + ranges[2 * SEC_BBA + 1] - ranges[2 * SEC_BBA];
-            stats->bytes_in = ranges[2 * SEC_BYTES + 1] - ranges[2 * SEC_BYTES];
-            stats->slot_bytes = 16ull * (ranges[2 * SEC_SLOT + 1] - ranges[2 * SEC_SLOT]);
-        }
-        __threadfence();
-        s_last = atomicAdd(done, 1u) == (uint32_t)(n_tiles - 1) ? 1u : 0u;
+        // Per-tile partial sums, published like the look-back states: the value and a "ready" bit in ONE word written
+        // with a device-coherent store.  No fence and no counter: an agent-scope release here writes back the XCD's
+        // whole L2 -- once per tile, in a kernel whose L2 is full of freshly stored directory lines (it doubled the
+        // kernel), and same-address atomics for the sums cost 0.2 us per tile.  Each count is <= TAIL_TILE, so three
+        // fit one word.
+        lb_store(&part[2 * (size_t)tile], TAIL_READY | b);
+        lb_store(&part[2 * (size_t)tile + 1], TAIL_READY | (u64)ty[0] | ((u64)ty[1] << 16) | ((u64)ty[2] << 32));
     }
-    __syncthreads();
-    if (!s_last) return;
-    // the block that finishes last hands the totals to the host (pinned memory): no copy kernel after the tail
-    __threadfence();
+    if (tile != n_tiles - 1) return;
+    // ---- the block of the last tile closes the call.  Every other tile has started (tickets are handed out in start
+    // order), so its partial sums arrive; this block adds them up and hands the totals to the host in pinned memory:
+    // no copy kernel after the tail.  (The directory stores of other blocks may still be in flight then -- whatever
+    // reads them is stream-ordered behind this kernel; the host itself only reads the totals.)
+    const u64 kept = s_prefix + total;
+    {   // bitmaps after the last candidate are empty
+        const uint32_t plast = n ? C.pair[n - 1] + 1u : 0u;
+        for (u64 q = (u64)plast + threadIdx.x; q <= n_pairs; q += 256) R.bm_start[q] = kept;
+    }
     u64 tb = 0, t0 = 0, t1 = 0, t2 = 0;
     for (u64 t = threadIdx.x; t < n_tiles; t += 256) {
-        tb += lb_load(&part[2 * t]);
-        const u64 pk = lb_load(&part[2 * t + 1]);
+        u64 pb, pk;
+        while (!((pb = lb_load(&part[2 * t])) & TAIL_READY)) {}
+        while (!((pk = lb_load(&part[2 * t + 1])) & TAIL_READY)) {}
+        tb += pb & ~TAIL_READY;
         t0 += pk & 0xFFFFu; t1 += (pk >> 16) & 0xFFFFu; t2 += (pk >> 32) & 0xFFFFu;
     }
     tb = wave_sum64(tb); t0 = wave_sum64(t0); t1 = wave_sum64(t1); t2 = wave_sum64(t2);
-    __syncthreads();  // s_bytes / s_types of this block's own tile were consumed above
+    __syncthreads();  // s_bytes of this block's own tile was consumed above
     if (lane_id() == 0) {
         s_bytes[threadIdx.x >> 6] = tb;
         s_tot[threadIdx.x >> 6][0] = t0; s_tot[threadIdx.x >> 6][1] = t1; s_tot[threadIdx.x >> 6][2] = t2;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const volatile u64* sv = (const volatile u64*)stats;
-        Stats st;
-        u64* lv = (u64*)&st;
-        for (uint32_t k = 0; k < sizeof(Stats) / 8; ++k) lv[k] = sv[k];
-        st.bytes_out = 0;
-        st.n_type[0] = st.n_type[1] = st.n_type[2] = 0;
+        Stats st = {};
+        st.result_containers = kept;
+        st.n_cand = n;
+        st.matched_pairs = ranges[2 * SEC_M + 1] - ranges[2 * SEC_M];
+        st.passthrough = ranges[2 * SEC_COPY + 1] - ranges[2 * SEC_COPY];
+        st.n_bb = ranges[2 * SEC_BB + 1] - ranges[2 * SEC_BB] + ranges[2 * SEC_BBA + 1] - ranges[2 * SEC_BBA];
+        st.bytes_in = ranges[2 * SEC_BYTES + 1] - ranges[2 * SEC_BYTES];
+        st.slot_bytes = 16ull * (ranges[2 * SEC_SLOT + 1] - ranges[2 * SEC_SLOT]);
         for (int w = 0; w < 4; ++w) {
             st.bytes_out += s_bytes[w];
             for (int t = 0; t < 3; ++t) st.n_type[t] += s_tot[w][t];
         }
+        const u64* lv = (const u64*)&st;
         u64* hv = (u64*)host_stats;
         for (uint32_t k = 0; k < sizeof(Stats) / 8; ++k) hv[k] = lv[k];
-        // "this call is complete": the host polls this word instead of waiting for the stream's completion signal
+        // "the totals are there": the host polls this word instead of waiting for the stream's completion signal
         __threadfence_system();
         __atomic_store_n(host_flag, seq, __ATOMIC_RELEASE);
     }
