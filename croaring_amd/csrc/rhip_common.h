@@ -208,3 +208,46 @@ __device__ int decide_type(int op, int ta, int tb, uint32_t ca, uint32_t cb, boo
             return ca <= 4096u ? T_ARRAY : type_ba(rc);
     }
 }
+
+// ------------------------------------------------------------------ sub-wave groups
+// G consecutive lanes (G = 16, 32 or 64) that work on one item: the group's view of the wave collectives.  The wave
+// must reach each of them in uniform control flow; only what a lane reads is restricted to its own group.
+template <uint32_t G>
+struct Grp {
+    uint32_t lane, grp, gl, glast;
+    __device__ __forceinline__ Grp() {
+        lane = lane_id(); grp = lane / G; gl = lane % G; glast = (lane & ~(G - 1u)) | (G - 1u);
+    }
+    __device__ __forceinline__ u64 ballot(bool p) const {  // the group's slice of the wave ballot
+        const u64 b = __ballot(p);
+        if (G == 64) return b;
+        return (b >> (G * grp)) & ((1ull << (G & 63u)) - 1ull);
+    }
+    __device__ __forceinline__ uint32_t rank(u64 m) const {  // group ballot bits below this lane
+        return (uint32_t)__popcll(m & ((1ull << gl) - 1ull));
+    }
+    __device__ __forceinline__ uint32_t incl_scan(uint32_t v) const {
+        if (G == 64) return wave_incl_scan(v);
+#pragma unroll
+        for (uint32_t o = 1; o < G; o <<= 1) {
+            const uint32_t t = __shfl_up(v, o);
+            if (gl >= o) v += t;
+        }
+        return v;
+    }
+    __device__ __forceinline__ uint32_t sum(uint32_t v) const {
+        if (G == 64) return wave_sum(v);
+#pragma unroll
+        for (uint32_t o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    }
+    __device__ __forceinline__ uint32_t wave_max(uint32_t v) const {  // v is group-uniform: max over the groups
+#pragma unroll
+        for (uint32_t o = G; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_xor(v, o);
+            v = t > v ? t : v;
+        }
+        return v;
+    }
+};
+

@@ -126,6 +126,8 @@ struct rhip_ctx_s {
     // scratch (grow-only): candidate directory + queues + scan temporaries
     DBuf plan_in, match, cand, cand_start, o_key, o_meta, o_slot, o_off, o_pair, flag, newidx, q[N_CLS], misc, misc2, prim_tmp, pair_acc;
     void* h_stage = nullptr;  // pinned staging of one batch description (grow-only)
+    void* h_stage_dev = nullptr;  // the same memory as the device addresses it
+    bool zero_copy_plan = true;   // small batch descriptions are read by the planning kernels in place (RHIP_ZERO_COPY_PLAN=0: always copy)
     size_t h_stage_cap = 0;
     void ensure_stage(size_t n);
     DBuf many[20];
@@ -136,7 +138,7 @@ struct rhip_ctx_s {
     static constexpr size_t PINNED_FLAG_OFF = 2048;
     uint64_t seq = 0;
     bool spin_wait = true;
-    bool explicit_units = false;  // RHIP_EXPLICIT_UNITS=1: always stage the unit arrays (tests of that path)
+    int explicit_units = 0;  // RHIP_EXPLICIT_UNITS=1: always stage the unit arrays; =2: implicit units, but never four per wave (tests of those paths)
     volatile uint64_t* done_flag() const { return (volatile uint64_t*)((char*)h_pinned + PINNED_FLAG_OFF); }
     // host-side phase clock (diagnostics, rhip_debug_host_clock): microseconds accumulated per phase of rhip_pairwise
     double hclk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -162,6 +164,7 @@ void rhip_ctx_s::ensure_stage(size_t n) {
         throw (int)RHIP_ERR_ALLOC;
     }
     h_stage_cap = want;
+    if (hipHostGetDevicePointer(&h_stage_dev, h_stage, 0) != hipSuccess) h_stage_dev = nullptr;
 }
 
 struct rhip_pool_s {
@@ -235,7 +238,8 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         for (auto& e : c->ev_join) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         if (const char* e = getenv("RHIP_NO_OVERLAP")) c->overlap = !(e[0] == '1');
         if (const char* e = getenv("RHIP_SPIN_WAIT")) c->spin_wait = !(e[0] == '0');
-        if (const char* e = getenv("RHIP_EXPLICIT_UNITS")) c->explicit_units = e[0] == '1';
+        if (const char* e = getenv("RHIP_EXPLICIT_UNITS")) c->explicit_units = atoi(e);
+        if (const char* e = getenv("RHIP_ZERO_COPY_PLAN")) c->zero_copy_plan = !(e[0] == '0');
         memset(c->h_pinned, 0, 4096);
         return c;
     } catch (int) {
@@ -843,7 +847,7 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     // ---- pass 1 over the pair list: range check, units and every upper bound (directory mirrors only)
     // No bitmap of either pool above 256 containers (one tile): the units are implicit -- unit = pair (and / andnot /
     // cardinality) or 2 pair + side (or / xor) -- and only the two index lists travel to the device.
-    const bool implicit = A->max_n <= 256 && B->max_n <= 256 && !c->explicit_units;
+    const bool implicit = A->max_n <= 256 && B->max_n <= 256 && c->explicit_units != 1;
     size_t NU = 0;
     uint64_t ub_match = 0, ub = 0, bound = 0;
     {
@@ -944,31 +948,45 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
         c->o_pair.ensure(4 * (ub + 2));
         P.CO = CandOut{c->o_key.as<u64>(), c->o_off.as<u64>(), c->o_pair.as<uint32_t>()};
     }
-    char* dp = (char*)c->plan_in.p;
+    // Two short index lists (implicit units) are read by k_count / k_emit straight from the pinned staging area: a few
+    // microseconds of PCIe reads inside the kernels instead of a copy command in front of them.
+    const bool in_place = implicit && c->zero_copy_plan && c->h_stage_dev && stage_bytes <= (1u << 20);
+    char* dp = in_place ? (char*)c->h_stage_dev : (char*)c->plan_in.p;
     P.d_pair0 = (u64*)(dp + o_pair0);
     P.d_lhs = (uint32_t*)(dp + o_lhs);
     P.d_rhs = (uint32_t*)(dp + o_rhs);
     P.d_upair = (uint32_t*)(dp + o_upair);
     P.d_utile = (uint32_t*)(dp + o_utile);
-    HIPCHK(hipMemcpyAsync(dp, hs, stage_bytes, hipMemcpyHostToDevice, s));
+    if (!in_place) HIPCHK(hipMemcpyAsync(dp, hs, stage_bytes, hipMemcpyHostToDevice, s));
     if (clk) clk->lap(1);
     PoolView VA = A->view(), VB = B->view();
     UnitView UV{P.d_upair, P.d_utile, P.d_pair0, (uint32_t)NU, (uint32_t)npairs, implicit ? (btiles ? 2u : 1u) : 0u};
     PlanZero Z{P.words, (uint32_t)P.sc.n_words, cardmode ? c->pair_acc.as<u64>() : nullptr};
     const size_t zero_threads = std::max<size_t>(P.sc.n_words, cardmode ? npairs : 0);
-    unsigned gp = (unsigned)std::max<size_t>(1, (std::max<size_t>(NU * 64, std::min<size_t>(zero_threads, 1 << 16)) + 255) / 256);
-    hipLaunchKernelGGL(k_count, dim3(gp), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, op, cardmode,
-                       c->cand.as<uint32_t>(), c->match.as<uint32_t>(), Z);
+    // planning waves: one unit per wave, or four when every unit is small (no bitmap above 64 containers)
+    const bool quad = implicit && A->max_n <= 64 && B->max_n <= 64 && c->explicit_units != 2;
+    const size_t plan_waves = quad ? (NU + 3) / 4 + 1 : NU;
+    unsigned gp = (unsigned)std::max<size_t>(1, (std::max<size_t>(plan_waves * 64, std::min<size_t>(zero_threads, 1 << 16)) + 255) / 256);
     const u64 n_scan = (u64)N_SEC * S;
-    hipLaunchKernelGGL(k_scan, dim3((unsigned)((n_scan + SCAN_TILE - 1) / SCAN_TILE)), dim3(256), 0, s,
-                       c->cand.as<uint32_t>(), c->cand_start.as<u64>(), n_scan, P.scan_lb(), P.ranges(), (u64)S);
     EmitQueues Q{c->q[CLS_BB].as<BBItem>(), c->q[CLS_GEN].as<GenItem>(), c->q[CLS_COPY].as<CopyItem>(),
                  c->q[CLS_FILT].as<FatItem>(), c->q[CLS_WAVE].as<FatItem>(), c->q[CLS_RUNS].as<GenItem>(),
                  c->q[CLS_PROBE].as<FatItem>(), c->q[CLS_BBA].as<BBItem>(), c->q[CLS_USMALL].as<FatItem>(),
                  c->q[CLS_RUNS16].as<GenItem>(), c->q[CLS_RUNS16W].as<GenItem>()};
-    if (NU)
-        hipLaunchKernelGGL(k_emit, dim3((unsigned)((NU * 64 + 255) / 256)), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV,
-                           op, cardmode, c->cand_start.as<u64>(), c->match.as<uint32_t>(), P.CO, Q);
+    const unsigned ge = (unsigned)((plan_waves * 64 + 255) / 256);
+    if (quad)
+        hipLaunchKernelGGL(k_count<16>, dim3(gp), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, op, cardmode,
+                           c->cand.as<uint32_t>(), c->match.as<uint32_t>(), Z);
+    else
+        hipLaunchKernelGGL(k_count<64>, dim3(gp), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, op, cardmode,
+                           c->cand.as<uint32_t>(), c->match.as<uint32_t>(), Z);
+    hipLaunchKernelGGL(k_scan, dim3((unsigned)((n_scan + SCAN_TILE - 1) / SCAN_TILE)), dim3(256), 0, s,
+                       c->cand.as<uint32_t>(), c->cand_start.as<u64>(), n_scan, P.scan_lb(), P.ranges(), (u64)S);
+    if (NU && quad)
+        hipLaunchKernelGGL(k_emit<16>, dim3(ge), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, op, cardmode,
+                           c->cand_start.as<u64>(), c->match.as<uint32_t>(), P.CO, Q);
+    else if (NU)
+        hipLaunchKernelGGL(k_emit<64>, dim3(ge), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, op, cardmode,
+                           c->cand_start.as<u64>(), c->match.as<uint32_t>(), P.CO, Q);
     if (clk) clk->lap(2);
     return P;
 }

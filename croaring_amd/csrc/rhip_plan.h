@@ -237,11 +237,26 @@ __device__ __forceinline__ void lower_bound4(const u64* __restrict__ key, u64 lo
     for (int t = 0; t < 4; ++t) out[t] = lo[t];
 }
 
+// Unit of group `grp` of planning wave `w`.  With two units per pair (A side, B side) the groups of a wave take the SAME
+// side of consecutive pairs, so that the side-dependent code of k_emit stays wave-uniform around its collectives.
+// The launch needs ceil(n_units / (64 / G)) + 1 waves.
+template <uint32_t G>
+__device__ __forceinline__ uint32_t unit_of_group(const UnitView& U, uint32_t w, uint32_t grp) {
+    constexpr uint32_t NG = 64 / G;
+    if (G == 64) return w;
+    if (U.implicit == 2) return 2u * ((w >> 1) * NG + grp) + (w & 1u);
+    return w * NG + grp;
+}
+
 // match[] entry of a directory element: position of its key in the other side's range (lower bound, relative to the
 // range start) and whether the key is present there
 #define MATCH_FOUND 0x80000000u
 
-// One wave per unit: contributions of the tile to every section; the match positions are kept for k_emit.
+// One group of G lanes per unit (G = 64: tiles of up to 256 directory entries, four rounds of 64; G = 16: four units
+// per wave when no bitmap of the batch has more than 64 containers -- the realdata sets with 10-50 containers per
+// bitmap otherwise leave three quarters of every planning wave idle): contributions of the unit to every section; the
+// match positions are kept for k_emit.
+template <uint32_t G>
 __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uint32_t* __restrict__ lhs,
                                                const uint32_t* __restrict__ rhs, UnitView U, int op, int cardmode,
                                                uint32_t* __restrict__ counts, uint32_t* __restrict__ match, PlanZero Z) {
@@ -252,9 +267,10 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
     if (Z.pair_acc)
         for (u64 i = gid; i < U.n_pairs; i += nthreads) Z.pair_acc[i] = 0;
     if (gid < N_SEC) counts[gid * S + U.n_units] = 0;  // section sentinels
-    const uint32_t u = (uint32_t)(gid >> 6);
+    const Grp<G> gr;
+    const uint32_t u = unit_of_group<G>(U, (uint32_t)(gid >> 6), gr.grp);
     if (u >= U.n_units) return;
-    const uint32_t lane = lane_id();
+    const uint32_t lane = gr.gl;
     const UnitId uid = unit_id(U, u);
     const uint32_t p = uid.pair;
     const bool bside = uid.bside;
@@ -264,15 +280,15 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
     // s* = the side this tile walks, l* = the side it searches
     const PoolView& SV = bside ? B : A;
     const PoolView& LV = bside ? A : B;
-    const u64 s0 = (bside ? b0 : a0) + tile * 256, sEnd = bside ? b1 : a1;
-    const u64 s1 = s0 + 256 < sEnd ? s0 + 256 : sEnd;
+    const u64 s0 = (bside ? b0 : a0) + tile * (4 * G), sEnd = bside ? b1 : a1;
+    const u64 s1 = s0 + 4 * G < sEnd ? s0 + 4 * G : sEnd;
     const u64 l0 = bside ? a0 : b0, l1 = bside ? a1 : b1;
     u64 k[4], j[4];
     bool act[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        act[t] = s0 + 64 * t + lane < s1;
-        k[t] = act[t] ? SV.key[s0 + 64 * t + lane] : 0;
+        act[t] = s0 + G * t + lane < s1;
+        k[t] = act[t] ? SV.key[s0 + G * t + lane] : 0;
     }
     lower_bound4(LV.key, l0, l1, k, act, j);
     uint32_t matched = 0, nbb = 0, nfilt = 0, nwave = 0, nruns_cls = 0, nprobe = 0, nbba = 0, nusm = 0, nr16 = 0, nr16w = 0, slot16 = 0, bytes = 0;
@@ -280,10 +296,10 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const bool found = act[t] && j[t] < l1 && LV.key[j[t]] == k[t];
-        if (act[t]) match[(size_t)u * 256 + 64 * t + lane] = (uint32_t)(j[t] - l0) | (found ? MATCH_FOUND : 0u);
+        if (act[t]) match[(size_t)u * 256 + G * t + lane] = (uint32_t)(j[t] - l0) | (found ? MATCH_FOUND : 0u);
         int cls = -1;
         if (act[t] && (bside ? !found : (found || keep_unmatched))) {
-            const u64 si = s0 + 64 * t + lane;
+            const u64 si = s0 + G * t + lane;
             const uint8_t ts = SV.type[si];
             const uint32_t cs = SV.card[si], ns = SV.nruns[si];
             const uint32_t ps = payload_bytes(ts, cs, ns);
@@ -299,19 +315,19 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
                 slot16 += sl ? sl : 1u;
             }
         }
-        matched += (uint32_t)__popcll(__ballot(found));
-        nbb += (uint32_t)__popcll(__ballot(cls == CLS_BB));
-        nfilt += (uint32_t)__popcll(__ballot(cls == CLS_FILT));
-        nwave += (uint32_t)__popcll(__ballot(cls == CLS_WAVE));
-        nruns_cls += (uint32_t)__popcll(__ballot(cls == CLS_RUNS));
-        nprobe += (uint32_t)__popcll(__ballot(cls == CLS_PROBE));
-        nbba += (uint32_t)__popcll(__ballot(cls == CLS_BBA));
-        nusm += (uint32_t)__popcll(__ballot(cls == CLS_USMALL));
-        nr16 += (uint32_t)__popcll(__ballot(cls == CLS_RUNS16));
-        nr16w += (uint32_t)__popcll(__ballot(cls == CLS_RUNS16W));
+        matched += (uint32_t)__popcll(gr.ballot(found));
+        nbb += (uint32_t)__popcll(gr.ballot(cls == CLS_BB));
+        nfilt += (uint32_t)__popcll(gr.ballot(cls == CLS_FILT));
+        nwave += (uint32_t)__popcll(gr.ballot(cls == CLS_WAVE));
+        nruns_cls += (uint32_t)__popcll(gr.ballot(cls == CLS_RUNS));
+        nprobe += (uint32_t)__popcll(gr.ballot(cls == CLS_PROBE));
+        nbba += (uint32_t)__popcll(gr.ballot(cls == CLS_BBA));
+        nusm += (uint32_t)__popcll(gr.ballot(cls == CLS_USMALL));
+        nr16 += (uint32_t)__popcll(gr.ballot(cls == CLS_RUNS16));
+        nr16w += (uint32_t)__popcll(gr.ballot(cls == CLS_RUNS16W));
     }
-    slot16 = wave_sum(slot16);
-    bytes = wave_sum(bytes);
+    slot16 = gr.sum(slot16);
+    bytes = gr.sum(bytes);
     if (lane == 0) {
         const uint32_t n = (uint32_t)(s1 - s0);
         uint32_t ncopy;
@@ -361,13 +377,15 @@ struct CandOut {     // candidate (pre-compaction) result directory
     u64* off;        // [cand] byte offset of the slot in the result arena
     uint32_t* pair;  // [cand] result bitmap (pair index) of the candidate
 };
+template <uint32_t G>
 __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint32_t* __restrict__ lhs,
                                               const uint32_t* __restrict__ rhs, UnitView U, int op, int cardmode,
                                               const u64* __restrict__ starts, const uint32_t* __restrict__ match,
                                               CandOut O, EmitQueues Q) {
-    const uint32_t u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const Grp<G> gr;
+    const uint32_t u = unit_of_group<G>(U, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, gr.grp);
     if (u >= U.n_units) return;
-    const uint32_t lane = lane_id();
+    const uint32_t lane = gr.gl;
     const size_t S = (size_t)U.n_units + 1;
     const UnitId uid = unit_id(U, u);
     const uint32_t p = uid.pair;
@@ -390,18 +408,18 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
     u64 qr16w = starts[SEC_RUNS16W * S + u] - starts[SEC_RUNS16W * S];
     u64 slot_run = 16ull * (starts[SEC_SLOT * S + u] - starts[SEC_SLOT * S]);  // arena offset of the unit's first slot
     if (!bside) {
-        const u64 s0 = a0 + tile * 256;
+        const u64 s0 = a0 + tile * (4 * G);
         uint32_t mbefore = (uint32_t)(starts[SEC_M * S + u] - starts[SEC_M * S + u0]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const u64 ai = s0 + 64 * t + lane;
+            const u64 ai = s0 + G * t + lane;
             const bool act = ai < a1;
-            const uint32_t mt = act ? match[(size_t)u * 256 + 64 * t + lane] : 0u;
+            const uint32_t mt = act ? match[(size_t)u * 256 + G * t + lane] : 0u;
             const bool found = (mt & MATCH_FOUND) != 0;
             const uint32_t lbcount = mt & ~MATCH_FOUND;
             const u64 bj = b0 + lbcount;
-            const u64 fm = __ballot(found);
-            const uint32_t mb = mbefore + mbcnt(fm);
+            const u64 fm = gr.ballot(found);
+            const uint32_t mb = mbefore + gr.rank(fm);
             mbefore += (uint32_t)__popcll(fm);
             const bool emit = act && (found || (!cardmode && op != OP_AND));
             uint8_t ta = 0, tb = 0;
@@ -427,9 +445,9 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                     sl = sl < 16u ? 16u : sl;
                 }
             }
-            const uint32_t inc = wave_incl_scan(sl);
+            const uint32_t inc = gr.incl_scan(sl);
             const u64 offo = slot_run + inc - sl;
-            slot_run += __shfl(inc, 63);
+            slot_run += __shfl(inc, gr.glast);
             if (emit && !cardmode) {
                 O.key[base + pos] = key;
                 O.off[base + pos] = offo;
@@ -448,58 +466,58 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
             const bool isr16w = cls == CLS_RUNS16W;
             const bool isprobe = cls == CLS_PROBE;
             const bool iscopy = emit && !found;
-            const u64 mbb = __ballot(isbb), mgen = __ballot(isgen), mcp = __ballot(iscopy), mfl = __ballot(isfilt);
-            const u64 mwv = __ballot(iswave), mrn = __ballot(isruns), mpr = __ballot(isprobe), mba = __ballot(isbba);
-            const u64 mus = __ballot(isusm), mr16 = __ballot(isr16), mr16w = __ballot(isr16w);
+            const u64 mbb = gr.ballot(isbb), mgen = gr.ballot(isgen), mcp = gr.ballot(iscopy), mfl = gr.ballot(isfilt);
+            const u64 mwv = gr.ballot(iswave), mrn = gr.ballot(isruns), mpr = gr.ballot(isprobe), mba = gr.ballot(isbba);
+            const u64 mus = gr.ballot(isusm), mr16 = gr.ballot(isr16), mr16w = gr.ballot(isr16w);
             if (isbb || isbba) {
                 BBItem it;
                 it.offa = A.off[ai]; it.offb = B.off[bj]; it.offo = offo; it.out = outidx; it.slot = sl;
-                if (isbb) Q.bb[qbb + mbcnt(mbb)] = it;
-                else Q.bba[qbba + mbcnt(mba)] = it;
+                if (isbb) Q.bb[qbb + gr.rank(mbb)] = it;
+                else Q.bba[qbba + gr.rank(mba)] = it;
             }
             if (isgen || isruns || isr16 || isr16w) {
                 GenItem it;
                 it.offa = A.off[ai]; it.offb = B.off[bj];
                 it.out = outidx; it.ca = ca; it.cb = cb; it.types = (uint32_t)ta | ((uint32_t)tb << 8);
                 it.nra = nra; it.nrb = nrb; it.offo = offo;
-                if (isgen) Q.gen[qgen + mbcnt(mgen)] = it;
-                else if (isruns) Q.runs[qruns + mbcnt(mrn)] = it;
-                else if (isr16) Q.runs16[qr16 + mbcnt(mr16)] = it;
-                else Q.runs16w[qr16w + mbcnt(mr16w)] = it;
+                if (isgen) Q.gen[qgen + gr.rank(mgen)] = it;
+                else if (isruns) Q.runs[qruns + gr.rank(mrn)] = it;
+                else if (isr16) Q.runs16[qr16 + gr.rank(mr16)] = it;
+                else Q.runs16w[qr16w + gr.rank(mr16w)] = it;
             }
             if (isfilt || iswave || isprobe || isusm) {
                 FatItem it;
                 it.offa = A.off[ai]; it.offb = B.off[bj]; it.offo = offo;
                 it.out = outidx; it.ca = ca; it.cb = cb; it.types = (uint32_t)ta | ((uint32_t)tb << 8);
                 it.pad0 = 0; it.pad1 = 0;
-                if (isfilt) Q.filt[qfilt + mbcnt(mfl)] = it;
-                else if (iswave) Q.wave[qwave + mbcnt(mwv)] = it;
-                else if (isprobe) Q.probe[qprobe + mbcnt(mpr)] = it;
-                else Q.usmall[qusm + mbcnt(mus)] = it;
+                if (isfilt) Q.filt[qfilt + gr.rank(mfl)] = it;
+                else if (iswave) Q.wave[qwave + gr.rank(mwv)] = it;
+                else if (isprobe) Q.probe[qprobe + gr.rank(mpr)] = it;
+                else Q.usmall[qusm + gr.rank(mus)] = it;
             }
             if (iscopy) {
                 CopyItem it;
                 it.src = A.off[ai]; it.offo = offo; it.meta = pack_meta(ta, ca, nra);
                 it.out = outidx; it.n16 = (pa + 15u) >> 4;
-                Q.copy[qcopy + mbcnt(mcp)] = it;
+                Q.copy[qcopy + gr.rank(mcp)] = it;
             }
             qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv); qruns += __popcll(mrn); qprobe += __popcll(mpr); qbba += __popcll(mba); qusm += __popcll(mus); qr16 += __popcll(mr16); qr16w += __popcll(mr16w);
         }
     } else {
         const u64 nAt = U.implicit ? 1 : (a1 - a0 + 255) / 256;  // A-tiles of the pair in front of its B-tiles
-        const u64 s0 = b0 + tile * 256;
+        const u64 s0 = b0 + tile * (4 * G);
         uint32_t mbefore = (uint32_t)(starts[SEC_M * S + u] - starts[SEC_M * S + u0 + nAt]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const u64 bi = s0 + 64 * t + lane;
+            const u64 bi = s0 + G * t + lane;
             const bool act = bi < b1;
-            const uint32_t mt = act ? match[(size_t)u * 256 + 64 * t + lane] : 0u;
+            const uint32_t mt = act ? match[(size_t)u * 256 + G * t + lane] : 0u;
             const bool found = (mt & MATCH_FOUND) != 0;
-            const u64 fm = __ballot(found);
-            const uint32_t mb = mbefore + mbcnt(fm);
+            const u64 fm = gr.ballot(found);
+            const uint32_t mb = mbefore + gr.rank(fm);
             mbefore += (uint32_t)__popcll(fm);
             const bool emit = act && !found;
-            const u64 mcp = __ballot(emit);
+            const u64 mcp = gr.ballot(emit);
             uint32_t sl = 0, pb = 0, cb = 0, nrb = 0;
             uint8_t tb = 0;
             if (emit) {
@@ -507,9 +525,9 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 pb = payload_bytes(tb, cb, nrb);
                 sl = align16(pb) < 16u ? 16u : align16(pb);
             }
-            const uint32_t inc = wave_incl_scan(sl);
+            const uint32_t inc = gr.incl_scan(sl);
             const u64 offo = slot_run + inc - sl;
-            slot_run += __shfl(inc, 63);
+            slot_run += __shfl(inc, gr.glast);
             if (emit) {
                 const uint32_t pos = (uint32_t)(bi - b0) + (mt & ~MATCH_FOUND) - mb;
                 O.key[base + pos] = B.key[bi];
@@ -518,7 +536,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 CopyItem it;
                 it.src = B.off[bi] | COPY_FROM_B; it.offo = offo; it.meta = pack_meta(tb, cb, nrb);
                 it.out = (uint32_t)(base + pos); it.n16 = (pb + 15u) >> 4;
-                Q.copy[qcopy + mbcnt(mcp)] = it;
+                Q.copy[qcopy + gr.rank(mcp)] = it;
             }
             qcopy += __popcll(mcp);
         }

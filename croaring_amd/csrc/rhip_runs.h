@@ -27,42 +27,6 @@
 // nine tenths of the matched pairs have <= 127 intervals a side) runs FOUR pairs per wave on 16-lane groups -- group-wide
 // scans and sums by shuffles that never leave the group, group-private LDS -- and only long lists take the whole wave.
 // Control flow around the collectives stays wave-uniform: the groups of a wave walk their items in lockstep.
-template <uint32_t G>
-struct Grp {
-    uint32_t lane, grp, gl, glast;
-    __device__ __forceinline__ Grp() {
-        lane = lane_id(); grp = lane / G; gl = lane % G; glast = (lane & ~(G - 1u)) | (G - 1u);
-    }
-    __device__ __forceinline__ u64 ballot(bool p) const {  // the group's slice of the wave ballot
-        const u64 b = __ballot(p);
-        if (G == 64) return b;
-        return (b >> (G * grp)) & ((1ull << (G & 63u)) - 1ull);
-    }
-    __device__ __forceinline__ uint32_t incl_scan(uint32_t v) const {
-        if (G == 64) return wave_incl_scan(v);
-#pragma unroll
-        for (uint32_t o = 1; o < G; o <<= 1) {
-            const uint32_t t = __shfl_up(v, o);
-            if (gl >= o) v += t;
-        }
-        return v;
-    }
-    __device__ __forceinline__ uint32_t sum(uint32_t v) const {
-        if (G == 64) return wave_sum(v);
-#pragma unroll
-        for (uint32_t o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        return v;
-    }
-    __device__ __forceinline__ uint32_t wave_max(uint32_t v) const {  // v is group-uniform: max over the groups
-#pragma unroll
-        for (uint32_t o = G; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_xor(v, o);
-            v = t > v ? t : v;
-        }
-        return v;
-    }
-};
-
 template <uint32_t G, uint32_t MAXIV>
 __global__ __launch_bounds__(256) void k_ivl(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                              OutView O, const GenItem* __restrict__ q,

@@ -204,13 +204,15 @@ def test_emu_tiny_interval_pairs(emu, oracle):
     G.test_tiny_interval_pairs(emu, oracle)
 
 
-def test_emu_explicit_unit_arrays(oracle, synth, monkeypatch):
-    """Batches whose bitmaps all have <= 256 containers plan on implicit units (unit = pair / 2 pair + side);
-    RHIP_EXPLICIT_UNITS=1 forces the staged unit arrays that larger bitmaps need, on the same small inputs."""
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_emu_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
+    """Batches whose bitmaps all have <= 256 containers plan on implicit units (unit = pair / 2 pair + side), four
+    units per wave up to 64 containers; RHIP_EXPLICIT_UNITS=1 forces the staged unit arrays that larger bitmaps need,
+    =2 implicit units one per wave, on the same small inputs."""
     from emu import build_emu, emu_engine
     if not __import__("os").path.exists(build_emu.CXX):
         pytest.skip("hipemu needs the ROCm clang++ to compile the kernels for the host")
-    monkeypatch.setenv("RHIP_EXPLICIT_UNITS", "1")
+    monkeypatch.setenv("RHIP_EXPLICIT_UNITS", mode)
     eng = emu_engine()
     try:
         G.test_edge_cases(eng, oracle)

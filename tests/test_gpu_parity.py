@@ -554,11 +554,13 @@ def test_tiny_interval_pairs(engine, oracle):
 
 
 @pytest.mark.gpu
-def test_explicit_unit_arrays(oracle, synth, monkeypatch):
-    """Small bitmaps (<= 256 containers each) plan on implicit units; RHIP_EXPLICIT_UNITS=1 forces the staged unit
-    arrays of the general path on the same inputs (the large-directory cases reach that path by themselves)."""
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
+    """Small bitmaps plan on implicit units, four per wave up to 64 containers a bitmap.  RHIP_EXPLICIT_UNITS=1 forces
+    the staged unit arrays of the general path, =2 implicit units with one unit per wave, on the same inputs (larger
+    directories reach those paths by themselves)."""
     import croaring_amd
-    monkeypatch.setenv("RHIP_EXPLICIT_UNITS", "1")
+    monkeypatch.setenv("RHIP_EXPLICIT_UNITS", mode)
     eng = croaring_amd.Engine()
     try:
         test_edge_cases(eng, oracle)
