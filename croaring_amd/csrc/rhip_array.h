@@ -3,7 +3,7 @@
 #include "rhip_common.h"
 
 // ------------------------------------------------------------------ short array probes (K9, K12 for short arrays)
-// and / andnot / and_cardinality where the streamed array Y has at most PROBE_MAX values (two per lane): membership
+// and / andnot / and_cardinality where the streamed array Y has at most PROBE_MAX values (four per lane): membership
 // of every value is decided straight from global / L2 -- one gathered dword when X is a bitset, a two-level search
 // when X is a sorted array: lane k first holds the pivot X[k * step] (step = ceil(nx / 64)), each lane locates its
 // pivot interval with six register shuffles, then at most log2(step) <= 6 dependent probes inside the interval.
@@ -61,32 +61,44 @@ __global__ __launch_bounds__(256) void k_probe(const uint8_t* __restrict__ arena
         const bool x_bitset = (y_is_a ? tb : ta) == T_BITSET;
         const bool keep_present = op == OP_AND;
         const uint16_t* __restrict__ y16 = (const uint16_t*)yp;
-        const uint32_t v0 = lane < ny ? y16[lane] : 0u;
-        const uint32_t v1 = 64u + lane < ny ? y16[64u + lane] : 0u;
-        bool p0, p1;
+        constexpr uint32_t R = PROBE_MAX / 64u;  // values of Y per lane
+        uint32_t v[R];
+        bool pr[R];
+#pragma unroll
+        for (uint32_t r = 0; r < R; ++r) v[r] = 64u * r + lane < ny ? y16[64u * r + lane] : 0u;
         if (x_bitset) {
             const uint32_t* __restrict__ xw = (const uint32_t*)xp;
-            const uint32_t w0 = xw[v0 >> 5], w1 = xw[v1 >> 5];
-            p0 = (w0 >> (v0 & 31)) & 1u;
-            p1 = (w1 >> (v1 & 31)) & 1u;
+            uint32_t wd[R];
+#pragma unroll
+            for (uint32_t r = 0; r < R; ++r) wd[r] = xw[v[r] >> 5];
+#pragma unroll
+            for (uint32_t r = 0; r < R; ++r) pr[r] = (wd[r] >> (v[r] & 31)) & 1u;
         } else {
             const uint16_t* __restrict__ x16 = (const uint16_t*)xp;
             const uint32_t step = (nx + 63u) >> 6;
             const uint32_t pi = lane * step;
             const uint32_t piv = pi < nx ? (uint32_t)x16[pi] : 0xFFFFFFFFu;
-            p0 = probe_sorted(x16, nx, step, piv, v0);
-            p1 = ny > 64u ? probe_sorted(x16, nx, step, piv, v1) : false;
+#pragma unroll
+            for (uint32_t r = 0; r < R; ++r)  // (ny is wave-uniform: whole rounds are skipped)
+                pr[r] = ny > 64u * r ? probe_sorted(x16, nx, step, piv, v[r]) : false;
         }
-        const bool k0 = lane < ny && p0 == keep_present;
-        const bool k1 = 64u + lane < ny && p1 == keep_present;
-        const u64 m0 = __ballot(k0), m1 = __ballot(k1);
-        const uint32_t n0 = (uint32_t)__popcll(m0), run = n0 + (uint32_t)__popcll(m1);
+        bool kp[R];
+        u64 m[R];
+        uint32_t run = 0, before[R];
+#pragma unroll
+        for (uint32_t r = 0; r < R; ++r) {
+            kp[r] = 64u * r + lane < ny && pr[r] == keep_present;
+            m[r] = __ballot(kp[r]);
+            before[r] = run;
+            run += (uint32_t)__popcll(m[r]);
+        }
         if (cardmode) {
             if (lane == 0 && run) atomicAdd(&pair_acc[t.out], (u64)run);
         } else {
             uint16_t* __restrict__ out = (uint16_t*)(O.arena + t.offo);
-            if (k0) out[mbcnt(m0)] = (uint16_t)v0;
-            if (k1) out[n0 + mbcnt(m1)] = (uint16_t)v1;
+#pragma unroll
+            for (uint32_t r = 0; r < R; ++r)
+                if (kp[r]) out[before[r] + mbcnt(m[r])] = (uint16_t)v[r];
             if (lane == 0) O.meta[t.out] = pack_meta(T_ARRAY, run, 0);
         }
     }
@@ -117,7 +129,8 @@ __device__ __forceinline__ void wave_scatter_or(uint32_t* img, const uint4* __re
 }
 
 // ------------------------------------------------------------------ short array merged into a long one (K10, K11)
-// or / xor of two arrays when the smaller one (Y, <= USMALL_MAX values: two per lane) is short and |X| + |Y| <= 4096,
+// or / xor of two arrays when the smaller one (Y, <= USMALL_MAX values: four per lane; the per-rank byte counters below
+// hold up to 255) is short and |X| + |Y| <= 4096,
 // so that the result is an array by the reference's rule before anything is computed (mixed_union.c:162-191,
 // mixed_xor.c:196-219; half of the array pairs of weather_sept_85).  The result is X with a few values inserted
 // (and, under xor, a few removed), so it is built BY RANK instead of through a 65536-bit image:
@@ -191,9 +204,15 @@ __global__ __launch_bounds__(256) void k_usmall(const uint8_t* __restrict__ aren
         const uint16_t* __restrict__ x16 = (const uint16_t*)xp;
         const uint16_t* __restrict__ y16 = (const uint16_t*)yp;
         const uint4* __restrict__ x4 = (const uint4*)xp;
-        // loads first: the two y values of this lane, its pivot of X
-        const bool ok0 = lane < ny, ok1 = 64u + lane < ny;
-        const uint32_t v0 = ok0 ? y16[lane] : 0u, v1 = ok1 ? y16[64u + lane] : 0u;
+        // loads first: the y values of this lane, its pivot of X
+        constexpr uint32_t R = (USMALL_MAX + 63u) / 64u;
+        bool ok[R];
+        uint32_t v[R];
+#pragma unroll
+        for (uint32_t r = 0; r < R; ++r) {
+            ok[r] = 64u * r + lane < ny;
+            v[r] = ok[r] ? y16[64u * r + lane] : 0u;
+        }
         const uint32_t step = (nx + 63u) >> 6;
         const uint32_t pi = lane * step;
         const uint32_t piv = pi < nx ? (uint32_t)x16[pi] : 0xFFFFFFFFu;
@@ -202,18 +221,23 @@ __global__ __launch_bounds__(256) void k_usmall(const uint8_t* __restrict__ aren
         if (op == OP_XOR)
             for (uint32_t i = lane; i < ndl; i += 64) DEL[i] = 0u;
         __builtin_amdgcn_wave_barrier();
-        bool pr0 = false, pr1 = false;
-        const uint32_t r0 = probe_rank(x16, nx, step, piv, v0, &pr0);
-        const uint32_t r1 = ny > 64u ? probe_rank(x16, nx, step, piv, v1, &pr1) : 0u;
-        const bool new0 = ok0 && !pr0, new1 = ok1 && !pr1;
-        const bool del0 = op == OP_XOR && ok0 && pr0, del1 = op == OP_XOR && ok1 && pr1;
-        if (new0) atomicAdd(&D32[r0 >> 2], 1u << (8u * (r0 & 3u)));
-        if (new1) atomicAdd(&D32[r1 >> 2], 1u << (8u * (r1 & 3u)));
-        if (del0) atomicOr(&DEL[r0 >> 5], 1u << (r0 & 31u));
-        if (del1) atomicOr(&DEL[r1 >> 5], 1u << (r1 & 31u));
-        const u64 m0 = __ballot(new0), m1 = __ballot(new1);
-        const uint32_t nnew0 = (uint32_t)__popcll(m0), nnew = nnew0 + (uint32_t)__popcll(m1);
-        const uint32_t ndel = (uint32_t)__popcll(__ballot(del0)) + (uint32_t)__popcll(__ballot(del1));
+        bool isnew[R];
+        uint32_t rk[R], before[R];
+        u64 m[R];
+        uint32_t nnew = 0, ndel = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < R; ++r) {  // (ny is wave-uniform: whole rounds are skipped)
+            bool pr = false;
+            rk[r] = ny > 64u * r ? probe_rank(x16, nx, step, piv, v[r], &pr) : 0u;
+            isnew[r] = ok[r] && !pr;
+            const bool del = op == OP_XOR && ok[r] && pr;
+            if (isnew[r]) atomicAdd(&D32[rk[r] >> 2], 1u << (8u * (rk[r] & 3u)));
+            if (del) atomicOr(&DEL[rk[r] >> 5], 1u << (rk[r] & 31u));
+            m[r] = __ballot(isnew[r]);
+            before[r] = nnew;
+            nnew += (uint32_t)__popcll(m[r]);
+            ndel += (uint32_t)__popcll(__ballot(del));
+        }
         __builtin_amdgcn_wave_barrier();
         uint16_t* __restrict__ o16 = (uint16_t*)(O.arena + t.offo);
         // ---- X, 16 bytes (8 values) per lane and step
@@ -259,8 +283,9 @@ __global__ __launch_bounds__(256) void k_usmall(const uint8_t* __restrict__ aren
             const uint32_t byte = (DEL[g >> 2] >> (8u * (g & 3u))) & 0xFFu;
             return (uint32_t)GP[g] + (uint32_t)__popc(byte & ((1u << (r & 7u)) - 1u));
         };
-        if (new0) o16[r0 - del_below(r0) + mbcnt(m0)] = (uint16_t)v0;
-        if (new1) o16[r1 - del_below(r1) + nnew0 + mbcnt(m1)] = (uint16_t)v1;
+#pragma unroll
+        for (uint32_t r = 0; r < R; ++r)
+            if (isnew[r]) o16[rk[r] - del_below(rk[r]) + before[r] + mbcnt(m[r])] = (uint16_t)v[r];
         if (lane == 0) O.meta[t.out] = pack_meta(T_ARRAY, nx + nnew - ndel, 0);
         __builtin_amdgcn_wave_barrier();  // LDS is reused by the next item
     }

@@ -15,8 +15,8 @@ enum { CLS_BB = 0, CLS_GEN = 1, CLS_COPY = 2, CLS_RETRY = 3, CLS_FILT = 4, CLS_W
 #define R16_MAX_CARD 1024u
 #define R16W_MAX_IV 127u
 #define R16W_MAX_CARD 4096u
-#define USMALL_MAX 128u  // smaller array of a k_usmall item (or / xor of two arrays): at most two values per lane
-#define PROBE_MAX 128u  // streamed array of a k_probe item: at most two values per lane
+#define USMALL_MAX 255u  // smaller array of a k_usmall item (or / xor of two arrays): at most four values per lane
+#define PROBE_MAX 256u  // streamed array of a k_probe item: at most four values per lane
 #define RUNS_MAX_INTERVALS 255u  // per operand, for the interval kernel (k_runs); 255 keeps its LDS at 4 x 8 KiB - 64 B
 #define NONE32 0xFFFFFFFFu
 

@@ -126,8 +126,6 @@ struct rhip_ctx_s {
     // scratch (grow-only): candidate directory + queues + scan temporaries
     DBuf plan_in, match, cand, cand_start, o_key, o_meta, o_slot, o_off, o_pair, flag, newidx, q[N_CLS], misc, misc2, prim_tmp, pair_acc;
     void* h_stage = nullptr;  // pinned staging of one batch description (grow-only)
-    void* h_stage_dev = nullptr;  // the same memory as the device addresses it
-    bool zero_copy_plan = true;   // small batch descriptions are read by the planning kernels in place (RHIP_ZERO_COPY_PLAN=0: always copy)
     size_t h_stage_cap = 0;
     void ensure_stage(size_t n);
     DBuf many[20];
@@ -164,7 +162,6 @@ void rhip_ctx_s::ensure_stage(size_t n) {
         throw (int)RHIP_ERR_ALLOC;
     }
     h_stage_cap = want;
-    if (hipHostGetDevicePointer(&h_stage_dev, h_stage, 0) != hipSuccess) h_stage_dev = nullptr;
 }
 
 struct rhip_pool_s {
@@ -239,7 +236,6 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_NO_OVERLAP")) c->overlap = !(e[0] == '1');
         if (const char* e = getenv("RHIP_SPIN_WAIT")) c->spin_wait = !(e[0] == '0');
         if (const char* e = getenv("RHIP_EXPLICIT_UNITS")) c->explicit_units = atoi(e);
-        if (const char* e = getenv("RHIP_ZERO_COPY_PLAN")) c->zero_copy_plan = !(e[0] == '0');
         memset(c->h_pinned, 0, 4096);
         return c;
     } catch (int) {
@@ -948,16 +944,15 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
         c->o_pair.ensure(4 * (ub + 2));
         P.CO = CandOut{c->o_key.as<u64>(), c->o_off.as<u64>(), c->o_pair.as<uint32_t>()};
     }
-    // Two short index lists (implicit units) are read by k_count / k_emit straight from the pinned staging area: a few
-    // microseconds of PCIe reads inside the kernels instead of a copy command in front of them.
-    const bool in_place = implicit && c->zero_copy_plan && c->h_stage_dev && stage_bytes <= (1u << 20);
-    char* dp = in_place ? (char*)c->h_stage_dev : (char*)c->plan_in.p;
+    // (Letting the planning kernels read two short index lists in place from the pinned staging area was measured:
+    // the PCIe round trips inside k_count / k_emit cost 25 us more per batch than the copy command they replace.)
+    char* dp = (char*)c->plan_in.p;
     P.d_pair0 = (u64*)(dp + o_pair0);
     P.d_lhs = (uint32_t*)(dp + o_lhs);
     P.d_rhs = (uint32_t*)(dp + o_rhs);
     P.d_upair = (uint32_t*)(dp + o_upair);
     P.d_utile = (uint32_t*)(dp + o_utile);
-    if (!in_place) HIPCHK(hipMemcpyAsync(dp, hs, stage_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dp, hs, stage_bytes, hipMemcpyHostToDevice, s));
     if (clk) clk->lap(1);
     PoolView VA = A->view(), VB = B->view();
     UnitView UV{P.d_upair, P.d_utile, P.d_pair0, (uint32_t)NU, (uint32_t)npairs, implicit ? (btiles ? 2u : 1u) : 0u};

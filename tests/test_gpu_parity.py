@@ -417,10 +417,13 @@ def test_array_array_union_boundaries(engine, oracle):
             a = np.sort(rng.choice(univ, min(ca, univ.size), replace=False))
             b = np.sort(rng.choice(univ, min(cb, univ.size), replace=False))
             cases.append((a, b))
-    # the rank-merge kernel (short array into a long one): short side 1 / 64 / 65 / 128 / 129 values, sums at 4096 /
-    # 4097, shared values (xor deletes them), short values below / above / between all long values, both ends of u16
+    # the rank-merge kernel (short array into a long one): short side 1 / 64 / 65 / 128 / 129 / 192 / 193 / 255 / 256
+    # values (four rounds of 64; 255 is its limit: mode 3 packs ~128 new values behind one rank byte counter), sums at
+    # 4096 / 4097, shared values (xor deletes them), short values below / above / between all long values, both ends
     for ny, nx in ((1, 1), (1, 4095), (1, 4096), (64, 900), (65, 900), (127, 1000), (128, 1000), (129, 1000), (128, 3968),
-                   (128, 3969), (100, 3996), (100, 3997), (2, 7), (128, 128), (128, 129), (40, 4000)):
+                   (128, 3969), (100, 3996), (100, 3997), (2, 7), (128, 128), (128, 129), (40, 4000), (192, 700),
+                   (193, 700), (254, 1000), (255, 1000), (256, 1000), (257, 1000), (255, 255), (255, 3841), (255, 3842),
+                   (200, 200)):
         big = np.sort(rng.choice(np.arange(300, 65000), nx, replace=False))
         for mode in range(4):
             if mode == 0:
@@ -433,6 +436,8 @@ def test_array_array_union_boundaries(engine, oracle):
             else:
                 small = np.unique(np.concatenate([np.arange(0, ny // 2 + 1), 65535 - np.arange(0, ny // 2 + 1)]))[:ny]
             cases.append((np.sort(small), big))
+    cases.append((np.arange(255), np.arange(300, 1300)))        # 255 new values at rank 0: the byte counter's limit
+    cases.append((np.arange(65281, 65536), np.arange(300, 1300)))  # ... and at rank nx
     hs = []
     for a, b in cases:
         hs.append(oracle.from_sorted(np.asarray(a, np.uint32) + (7 << 16), run_optimize=False))
@@ -457,11 +462,11 @@ def test_array_array_union_boundaries(engine, oracle):
 
 def test_array_filter_probe_boundaries(engine, oracle):
     """and / andnot / and_cardinality with an array operand around every boundary of the two filter kernels: streamed
-    side of 1 .. 129 values (k_probe holds at most 128: one or two per lane), probed arrays whose pivot step changes
+    side of 1 .. 257 values (k_probe holds at most 256: one to four per lane), probed arrays whose pivot step changes
     (64 / 65 / 128 / 129 / 4096 values), a bitset partner, values at both ends of the u16 range, hits at pivots and
     between them, identical and disjoint operands; both operand orders."""
     rng = np.random.default_rng(99)
-    small = [1, 2, 31, 63, 64, 65, 100, 127, 128, 129, 200]
+    small = [1, 2, 31, 63, 64, 65, 100, 127, 128, 129, 192, 193, 200, 255, 256, 257]
     large = [1, 5, 63, 64, 65, 127, 128, 129, 640, 1000, 4095, 4096]
     cases = []
     for ny in small:
