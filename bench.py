@@ -299,6 +299,25 @@ def run_realdata(eng, D: Dist, name: str, tag: str, chk, is64=False, ops=("and",
                "ms_batch_median": tmed * 1e3, "ms_batch_min": tmin * 1e3, "alg_GBps": alg / tmed / 1e9,
                "frac": alg / tmed / 1e9 / HBM_PEAK_GBS, "checksum": int(csum), "checksum_ok": want is None or int(csum) == want,
                "matched_pairs_rank0": int(st["matched_pairs"]), "passthrough_rank0": int(st["passthrough"])}
+        # the same batch with TWO calls in flight (rhip_pairwise_begin / _end): the host half of call i+1 overlaps
+        # the kernels of call i; per-call period over 40 calls, result of the last one checked
+        n_pipe = 40
+        slots, prev = [res[0], None], None
+        res[0] = None
+        D.barrier()
+        t0 = time.perf_counter()
+        for it in range(n_pipe):
+            cur = eng.pairwise_begin(op, pool, lhs, pool, rhs, reuse=slots[it & 1])
+            slots[it & 1] = None
+            if prev is not None:
+                slots[(it - 1) & 1] = prev.end()
+            prev = cur
+        slots[(n_pipe - 1) & 1] = prev.end()
+        D.barrier()
+        tp = (time.perf_counter() - t0) / n_pipe
+        row["ms_batch_pipelined2"] = tp * 1e3
+        row["ops_per_s_pipelined2"] = L.size / tp
+        row["pipelined2_checksum_ok"] = bool(D.sum(float(slots[(n_pipe - 1) & 1].cardinalities().sum())) == csum)
         if hs is not None:
             row["cpu1_ops_per_s"] = cpu_pairs_rate(chk, hs, L, R, op, is64=is64)
             row["cpu_kind"] = chk.name

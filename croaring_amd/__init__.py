@@ -6,6 +6,6 @@ reference's operator interface.  Importing the package does not need a GPU; crea
 `Engine` does, and fails loudly without one.
 """
 from ._lib import LIB_PATH, RoaringHipError, load  # noqa: F401
-from .engine import Engine, Pool, OPS, synth_sparse_portable  # noqa: F401
+from .engine import Batch, Engine, Pool, OPS, synth_sparse_portable  # noqa: F401
 
-__all__ = ["Engine", "Pool", "OPS", "synth_sparse_portable", "RoaringHipError", "load", "LIB_PATH"]
+__all__ = ["Batch", "Engine", "Pool", "OPS", "synth_sparse_portable", "RoaringHipError", "load", "LIB_PATH"]

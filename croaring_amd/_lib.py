@@ -62,6 +62,8 @@ SYMBOLS = [
     ("rhip_pool_portable_sizes", _i, [_vp, _sz, _vp, _vp]),
     ("rhip_pool_portable_serialize_many", _sz, [_vp, _sz, _vp, _vp, _sz, _vp]),
     ("rhip_pairwise", _vp, [_vp, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
+    ("rhip_pairwise_begin", _vp, [_vp, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
+    ("rhip_pairwise_end", _vp, [_vp]),
     ("rhip_pairwise_cardinality", _i, [_vp, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     ("rhip_pairwise_predicate", _i, [_vp, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     ("rhip_pairwise_inplace", _i, [_vp, _i, _vp, _vp, _sz, _vp, _vp]),

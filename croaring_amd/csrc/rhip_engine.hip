@@ -125,19 +125,25 @@ struct rhip_ctx_s {
     hipStream_t stream = nullptr;
     // scratch (grow-only): candidate directory + queues + scan temporaries
     DBuf plan_in, match, cand, cand_start, o_key, o_meta, o_slot, o_off, o_pair, flag, newidx, q[N_CLS], misc, misc2, prim_tmp, pair_acc;
-    void* h_stage = nullptr;  // pinned staging of one batch description (grow-only)
-    size_t h_stage_cap = 0;
-    void ensure_stage(size_t n);
+    // Batches in flight (rhip_pairwise_begin .. _end): each has a slot = its own pinned staging of the batch description,
+    // statistics area and completion word.  Device scratch is shared: the batches' kernels are ordered by the stream.
+    static constexpr int N_SLOTS = RHIP_MAX_BATCHES_IN_FLIGHT;
+    void* h_stage[N_SLOTS] = {};  // grow-only
+    size_t h_stage_cap[N_SLOTS] = {};
+    bool slot_busy[N_SLOTS] = {};
+    void ensure_stage(int slot, size_t n);
+    int acquire_slot();
     DBuf many[20];
     DBuf sel[5];  // pool_select / pool_convert scratch
     void* h_pinned = nullptr;  // small pinned readback area
     // completion word of the pairwise path (inside h_pinned): k_tail's last block writes the call's sequence number
     // after the statistics; the host polls it (the stream's completion signal costs an interrupt / wake-up)
-    static constexpr size_t PINNED_FLAG_OFF = 2048;
+    static constexpr size_t PINNED_STATS_OFF = 1024, PINNED_STATS_STRIDE = 192, PINNED_FLAG_OFF = 2048;
     uint64_t seq = 0;
     bool spin_wait = true;
     int explicit_units = 0;  // RHIP_EXPLICIT_UNITS=1: always stage the unit arrays; =2: implicit units, but never four per wave (tests of those paths)
-    volatile uint64_t* done_flag() const { return (volatile uint64_t*)((char*)h_pinned + PINNED_FLAG_OFF); }
+    volatile uint64_t* done_flag(int slot) const { return (volatile uint64_t*)((char*)h_pinned + PINNED_FLAG_OFF + 64 * slot); }
+    void* slot_stats(int slot) const { return (char*)h_pinned + PINNED_STATS_OFF + PINNED_STATS_STRIDE * slot; }
     // host-side phase clock (diagnostics, rhip_debug_host_clock): microseconds accumulated per phase of rhip_pairwise
     double hclk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     rhip_stats_t stats{};
@@ -150,18 +156,26 @@ struct rhip_ctx_s {
     bool overlap = true;
 };
 
-void rhip_ctx_s::ensure_stage(size_t n) {
-    if (n <= h_stage_cap) return;
-    if (h_stage) (void)hipHostFree(h_stage);
-    h_stage = nullptr;
-    h_stage_cap = 0;
+void rhip_ctx_s::ensure_stage(int slot, size_t n) {
+    if (n <= h_stage_cap[slot]) return;
+    if (h_stage[slot]) (void)hipHostFree(h_stage[slot]);
+    h_stage[slot] = nullptr;
+    h_stage_cap[slot] = 0;
     const size_t want = n + n / 4 + 4096;
-    if (hipHostMalloc(&h_stage, want, hipHostMallocDefault) != hipSuccess) {
-        h_stage = nullptr;
+    if (hipHostMalloc(&h_stage[slot], want, hipHostMallocDefault) != hipSuccess) {
+        h_stage[slot] = nullptr;
         set_err("hipHostMalloc(%zu) failed", want);
         throw (int)RHIP_ERR_ALLOC;
     }
-    h_stage_cap = want;
+    h_stage_cap[slot] = want;
+}
+int rhip_ctx_s::acquire_slot() {
+    for (int k = 0; k < N_SLOTS; ++k) {
+        const int slot = (int)((seq + 1 + k) % N_SLOTS);
+        if (!slot_busy[slot]) return slot;
+    }
+    set_err("%d batches in flight: call rhip_pairwise_end first", N_SLOTS);
+    throw (int)RHIP_ERR_ARG;
 }
 
 struct rhip_pool_s {
@@ -171,6 +185,7 @@ struct rhip_pool_s {
     bool is64 = false;
     DBuf bm_start, key, type, card, nruns, off, arena;
     uint64_t arena_used = 0;
+    bool pending = false;       // result of a batch that has begun and not ended: not usable yet
     uint64_t compact_mark = 0;  // arena_used right after the last compaction (0: never updated in place), see rhip_pairwise_inplace
     // host mirror of the directory (filled lazily for serialization); planning only needs bm_start
     bool host_dir = false;
@@ -249,7 +264,7 @@ extern "C" void rhip_ctx_destroy(rhip_ctx_t* c) {
     (void)hipStreamSynchronize(c->stream);
     DBuf* all[] = {&c->plan_in, &c->match, &c->cand, &c->cand_start, &c->o_key, &c->o_meta, &c->o_slot, &c->o_off, &c->o_pair,
                    &c->flag, &c->newidx, &c->misc, &c->misc2, &c->prim_tmp, &c->pair_acc};
-    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (auto& hs : c->h_stage) if (hs) (void)hipHostFree(hs);
     for (auto* b : all) b->release();
     for (auto& b : c->q) b.release();
     for (auto& b : c->many) b.release();
@@ -797,6 +812,7 @@ struct Plan {
 
 void check_pair_args(rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs, const uint32_t* rhs) {
     if (!A || !B) { set_err("null pool"); throw (int)RHIP_ERR_ARG; }
+    if (A->pending || B->pending) { set_err("operand pool is the result of a batch still in flight"); throw (int)RHIP_ERR_ARG; }
     if (npairs && (!lhs || !rhs)) { set_err("null pair index array"); throw (int)RHIP_ERR_ARG; }
     if (A->is64 != B->is64) { set_err("mixing 32-bit and 64-bit pools"); throw (int)RHIP_ERR_ARG; }
     if (A->ctx->device != B->ctx->device) { set_err("operand pools live on different devices"); throw (int)RHIP_ERR_ARG; }
@@ -832,7 +848,7 @@ struct HostClock {  // phase p accumulates the host time between the previous la
     }
 };
 Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs,
-          const uint32_t* rhs, int cardmode, HostClock* clk = nullptr) {
+          const uint32_t* rhs, int cardmode, int slot, HostClock* clk = nullptr) {
     hipStream_t s = c->stream;
     Plan P;
     P.npairs = npairs;
@@ -872,8 +888,8 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     const size_t o_lhs = 0, o_rhs = o_lhs + 4 * npairs, o_pair0 = (o_rhs + 4 * npairs + 7) & ~(size_t)7,
                  o_upair = o_pair0 + (implicit ? 0 : 8 * (npairs + 1)), o_utile = o_upair + (implicit ? 0 : 4 * NU),
                  stage_bytes = o_utile + (implicit ? 0 : 4 * NU);
-    c->ensure_stage(stage_bytes + 16);
-    char* hs = (char*)c->h_stage;
+    c->ensure_stage(slot, stage_bytes + 16);
+    char* hs = (char*)c->h_stage[slot];
     if (npairs) {
         memcpy(hs + o_lhs, lhs, 4 * npairs);
         memcpy(hs + o_rhs, rhs, 4 * npairs);
@@ -1102,19 +1118,19 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
 
 // many-way / flip paths: their statistics live at a fixed offset of ctx->misc (cleared by the caller)
 constexpr size_t MISC_STATS_OFF = 192;
-void finish_stats(rhip_ctx_t* c, const Stats* dstats, Stats* out, bool had_bb, uint64_t wait_seq = 0);
+void finish_stats(rhip_ctx_t* c, const Stats* dstats, Stats* out, bool had_bb, uint64_t wait_seq = 0, int slot = 0);
 void finish_stats_misc(rhip_ctx_t* c) { finish_stats(c, (const Stats*)((char*)c->misc.p + MISC_STATS_OFF), nullptr, false); }
 
 // the ONE host synchronisation of a call: statistics (and whatever the caller queued before) come back
 // wait_seq != 0: the tail kernel publishes that sequence number in pinned memory when everything is written; the host
 // polls it (and the stream's state now and then, so that a device fault still surfaces) instead of blocking.
-void finish_stats(rhip_ctx_t* c, const Stats* dstats, Stats* out, bool had_bb, uint64_t wait_seq) {
+void finish_stats(rhip_ctx_t* c, const Stats* dstats, Stats* out, bool had_bb, uint64_t wait_seq, int slot) {
     hipStream_t s = c->stream;
     // dstats == nullptr: the last kernel of the call already wrote the totals into the pinned area
     if (dstats) HIPCHK(hipMemcpyAsync(c->h_pinned, dstats, sizeof(Stats), hipMemcpyDeviceToHost, s));
     if (c->timing) HIPCHK(hipEventRecord(c->ev[1], s));
     if (wait_seq && c->spin_wait && !c->timing && !dstats) {
-        volatile uint64_t* flag = c->done_flag();
+        volatile uint64_t* flag = c->done_flag(slot);
         for (uint32_t spins = 0;; ++spins) {
             if (__atomic_load_n((const uint64_t*)flag, __ATOMIC_ACQUIRE) == wait_seq) break;
             if ((spins & 0x3FFFu) == 0x3FFFu) {
@@ -1132,7 +1148,7 @@ void finish_stats(rhip_ctx_t* c, const Stats* dstats, Stats* out, bool had_bb, u
         HIPCHK(hipStreamSynchronize(s));
     }
     Stats st{};
-    memcpy(&st, c->h_pinned, sizeof(Stats));
+    memcpy(&st, wait_seq ? c->slot_stats(slot) : c->h_pinned, sizeof(Stats));  // a batch's totals are in its slot
     if (out) *out = st;
     c->stats.matched_pairs = st.matched_pairs;
     c->stats.passthrough = st.passthrough;
@@ -1149,24 +1165,39 @@ void finish_stats(rhip_ctx_t* c, const Stats* dstats, Stats* out, bool had_bb, u
 }
 }  // namespace
 
-extern "C" rhip_pool_t* rhip_pairwise(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A, rhip_pool_t* B, size_t npairs,
-                                      const uint32_t* lhs, const uint32_t* rhs, rhip_pool_t* reuse) {
+struct rhip_batch_s {
+    rhip_ctx_t* c;
+    rhip_pool_t* R;
+    uint64_t seq;
+    int slot;
+    bool may_bb;
+};
+
+// Everything of a pairwise call up to and including the launch of k_tail: nothing here waits for the device.
+extern "C" rhip_batch_t* rhip_pairwise_begin(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A, rhip_pool_t* B, size_t npairs,
+                                            const uint32_t* lhs, const uint32_t* rhs, rhip_pool_t* reuse) {
     rhip_pool_t* R = nullptr;
     try {
         if (!c) { set_err("null context"); throw (int)RHIP_ERR_ARG; }
         int op = (int)op_;
         if (op < 0 || op > 3) { set_err("bad op"); throw (int)RHIP_ERR_ARG; }
         DeviceGuard dguard_(c->device);
+        if (reuse && reuse->pending) {
+            reuse = nullptr;  // still owned by its batch
+            set_err("`reuse` is the result of a batch still in flight");
+            throw (int)RHIP_ERR_ARG;
+        }
         check_pair_args(A, B, npairs, lhs, rhs);
         if (reuse && (reuse == A || reuse == B)) {
             reuse = nullptr;  // not ours to recycle
             set_err("`reuse` must not be one of the operand pools");
             throw (int)RHIP_ERR_ARG;
         }
+        const int slot = c->acquire_slot();
         hipStream_t s = c->stream;
         if (c->timing) HIPCHK(hipEventRecord(c->ev[0], s));
         HostClock clk(c);
-        Plan P = plan(c, op, A, B, npairs, lhs, rhs, 0, &clk);
+        Plan P = plan(c, op, A, B, npairs, lhs, rhs, 0, slot, &clk);
         const CandOut& CO = P.CO;
         R = reuse ? reuse : new rhip_pool_s();
         reuse = nullptr;
@@ -1190,22 +1221,54 @@ extern "C" rhip_pool_t* rhip_pairwise(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A
         const uint64_t seq = ++c->seq;
         hipLaunchKernelGGL(k_tail, dim3((unsigned)std::max<uint64_t>(1, (P.ub_cand + TAIL_TILE - 1) / TAIL_TILE)), dim3(256), 0,
                            s, P.ranges(), CO, O.meta, D, (uint32_t)npairs, P.tail_lb(), P.tail_part(),
-                           (Stats*)c->h_pinned, (u64*)c->done_flag(), (u64)seq);
+                           (Stats*)c->slot_stats(slot), (u64*)c->done_flag(slot), (u64)seq);
         clk.lap(3);
-        Stats st;
-        finish_stats(c, nullptr, &st, P.may_bb, seq);
-        clk.lap(4);
-        R->n_cont = st.result_containers;
-        R->arena_used = st.slot_bytes + 64;
-        for (int t = 0; t < 3; ++t) R->census[t] = st.n_type[t] ? 1 : 0;
-        clk.lap(5);
-        return R;
+        rhip_batch_t* b = new rhip_batch_s{c, R, seq, slot, P.may_bb};
+        c->slot_busy[slot] = true;
+        R->pending = true;
+        return b;
     } catch (int e) {
         last_status() = e;
         if (R) { R->release(); delete R; }
         if (reuse) { reuse->release(); delete reuse; }
         return nullptr;
     }
+}
+
+// The ONE host wait of the call; the result pool becomes usable.  Batches may be ended in any order.
+extern "C" rhip_pool_t* rhip_pairwise_end(rhip_batch_t* b) {
+    if (!b) { set_err("null batch"); last_status() = RHIP_ERR_ARG; return nullptr; }
+    rhip_ctx_t* c = b->c;
+    rhip_pool_t* R = b->R;
+    const int slot = b->slot;
+    try {
+        DeviceGuard dguard_(c->device);
+        HostClock clk(c);
+        Stats st;
+        finish_stats(c, nullptr, &st, b->may_bb, b->seq, slot);
+        clk.lap(4);
+        R->n_cont = st.result_containers;
+        R->arena_used = st.slot_bytes + 64;
+        for (int t = 0; t < 3; ++t) R->census[t] = st.n_type[t] ? 1 : 0;
+        R->pending = false;
+        c->slot_busy[slot] = false;
+        delete b;
+        clk.lap(5);
+        return R;
+    } catch (int e) {
+        last_status() = e;
+        c->slot_busy[slot] = false;
+        R->release();
+        delete R;
+        delete b;
+        return nullptr;
+    }
+}
+
+extern "C" rhip_pool_t* rhip_pairwise(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A, rhip_pool_t* B, size_t npairs,
+                                      const uint32_t* lhs, const uint32_t* rhs, rhip_pool_t* reuse) {
+    rhip_batch_t* b = rhip_pairwise_begin(c, op_, A, B, npairs, lhs, rhs, reuse);
+    return b ? rhip_pairwise_end(b) : nullptr;
 }
 
 extern "C" int rhip_pairwise_cardinality(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A, rhip_pool_t* B, size_t npairs,
@@ -1226,7 +1289,7 @@ extern "C" int rhip_pairwise_cardinality(rhip_ctx_t* c, rhip_op op_, rhip_pool_t
             if ((e = rhip_pool_cardinalities(B, cB.data())) != 0) throw e;
         }
         if (c->timing) HIPCHK(hipEventRecord(c->ev[0], s));
-        Plan P = plan(c, OP_AND, A, B, npairs, lhs, rhs, 1);
+        Plan P = plan(c, OP_AND, A, B, npairs, lhs, rhs, 1, c->acquire_slot());
         OutView O{};
         PoolView VA = A->view(), VB = B->view();
         run_kernels(c, OP_AND, VA, VB, O, P, 1);

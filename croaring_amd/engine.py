@@ -179,6 +179,21 @@ class Engine:
             raise RoaringHipError(f"pairwise {op} failed: " + self._err())
         return Pool(self, h)
 
+    def pairwise_begin(self, op: str, A: "Pool", lhs, B: Optional["Pool"] = None, rhs=None,
+                       reuse: Optional["Pool"] = None) -> "Batch":
+        """First half of `pairwise`: enqueue the batch and return without waiting for the device (rhip_pairwise_begin).
+        `Batch.end()` returns the result pool.  Up to 4 batches may be in flight; keep the operand pools alive and
+        unmodified until their batch has ended."""
+        B = A if B is None else B
+        lhs, rhs = _pair_ids(lhs, rhs)
+        rh = None
+        if reuse is not None:
+            rh, reuse.h = reuse.h, None  # consumed
+        h = self.lib.rhip_pairwise_begin(self.h, OPS[op], A.h, B.h, lhs.size, lhs.ctypes.data, rhs.ctypes.data, rh)
+        if not h:
+            raise RoaringHipError(f"pairwise_begin {op} failed: " + self._err())
+        return Batch(self, h, (A, B))
+
     def pairwise_cardinality(self, op: str, A: "Pool", lhs, B: Optional["Pool"] = None, rhs=None) -> np.ndarray:
         """roaring_bitmap_{and,or,xor,andnot}_cardinality batched."""
         B = A if B is None else B
@@ -323,6 +338,33 @@ class PartialChunks:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+class Batch:
+    """A pairwise batch in flight (rhip_batch_t): `end()` waits for it and returns the result Pool."""
+
+    def __init__(self, engine: "Engine", handle, operands):
+        self.engine, self.h, self._operands = engine, handle, operands  # operands kept alive until the batch ends
+
+    def end(self) -> "Pool":
+        if self.h is None:
+            raise RoaringHipError("batch already ended")
+        h, self.h = self.h, None
+        r = self.engine.lib.rhip_pairwise_end(h)
+        self._operands = None
+        if not r:
+            raise RoaringHipError("pairwise_end failed: " + self.engine._err())
+        return Pool(self.engine, r)
+
+    def __del__(self):  # an abandoned batch still has to be ended: its slot and its result pool belong to it
+        try:
+            if self.h is not None and self.engine is not None and self.engine.h:
+                r = self.engine.lib.rhip_pairwise_end(self.h)
+                self.h = None
+                if r:
+                    self.engine.lib.rhip_pool_free(r)
         except Exception:
             pass
 

@@ -145,6 +145,19 @@ int rhip_pool_to_u64(rhip_pool_t *pool, uint64_t *out, size_t capacity, uint64_t
  * the returned pool replaces it). */
 rhip_pool_t *rhip_pairwise(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *A, rhip_pool_t *B, size_t npairs,
                            const uint32_t *lhs, const uint32_t *rhs, rhip_pool_t *reuse);
+/* The same call in two halves, so that the host side of batch i+1 (pair-list pass, staging, launches: the part of a
+ * small batch that the device waits for) runs while the kernels of batch i execute.  rhip_pairwise_begin enqueues
+ * everything and returns without waiting for the device; `lhs` / `rhs` are copied and may be freed at once.
+ * rhip_pairwise_end waits for that batch and returns its result pool (NULL on error; the handle is consumed either
+ * way).  Up to RHIP_MAX_BATCHES_IN_FLIGHT batches of one context may be in flight, ended in any order; they execute in
+ * begin order on the context's stream.  Until a batch has ended, its operand pools must not be freed or updated in
+ * place, its result cannot be an operand or the `reuse` of another batch (RHIP_ERR_ARG), and any other call on the
+ * context simply waits for the batches in flight.  rhip_pairwise == begin followed by end. */
+#define RHIP_MAX_BATCHES_IN_FLIGHT 4
+typedef struct rhip_batch_s rhip_batch_t;
+rhip_batch_t *rhip_pairwise_begin(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *A, rhip_pool_t *B, size_t npairs,
+                                  const uint32_t *lhs, const uint32_t *rhs, rhip_pool_t *reuse);
+rhip_pool_t *rhip_pairwise_end(rhip_batch_t *batch);
 /* roaring_bitmap_{and,or,xor,andnot}_cardinality (roaring.h:231,258,270,264;
  * src/roaring.c:3048-3107): nothing is materialised. */
 int rhip_pairwise_cardinality(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *A, rhip_pool_t *B, size_t npairs,

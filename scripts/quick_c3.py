@@ -21,6 +21,17 @@ for name in sys.argv[1:] or ["weather_sept_85", "census1881", "census-income", "
         st = eng.last_stats()
         row[op] = {"ms": round(min(ts[1:]) * 1e3, 4), "Mops": round(len(lhs) / min(ts[1:]) / 1e6, 2),
                    "TBps": round((st["bytes_in"] + st["bytes_out"]) / min(ts[1:]) / 1e12, 3)}
+        # two calls in flight (begin / end): per-call period over 30 calls
+        slots, prev = [res, None], None
+        t0 = time.perf_counter()
+        for it in range(30):
+            cur = eng.pairwise_begin(op, pool, lhs, pool, rhs, reuse=slots[it & 1])
+            slots[it & 1] = None
+            if prev is not None:
+                slots[(it - 1) & 1] = prev.end()
+            prev = cur
+        slots[1] = prev.end()
+        row[op]["ms_pipelined2"] = round((time.perf_counter() - t0) / 30 * 1e3, 4)
     t = []
     for _ in range(5):
         t0 = time.perf_counter(); eng.pairwise_cardinality("and", pool, lhs, pool, rhs); t.append(time.perf_counter() - t0)

@@ -220,3 +220,7 @@ def test_emu_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
         G.test_synth_every_type_pair(eng, oracle, synth, "andnot")
     finally:
         eng.close()
+
+
+def test_emu_batches_in_flight(emu, oracle, synth):
+    G.test_batches_in_flight(emu, oracle, synth)

@@ -573,3 +573,54 @@ def test_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
             test_synth_every_type_pair(eng, oracle, synth, op)
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_batches_in_flight(engine, oracle, synth):
+    """rhip_pairwise_begin / _end: four batches of different ops and pair lists in flight at once, ended out of order,
+    give byte-for-byte what the synchronous call gives; a fifth begin, a pending result as operand or as `reuse`, and a
+    double end are refused; the engine keeps working afterwards."""
+    from croaring_amd import RoaringHipError
+    bufs, _, _ = synth
+    pool = engine.pool_from_serialized(bufs)
+    n = len(bufs)
+    rng = np.random.default_rng(2024)
+    jobs = []
+    for op in OPS:
+        lhs = rng.integers(0, n, 300 + 50 * len(jobs)).astype(np.uint32)
+        rhs = rng.integers(0, n, lhs.size).astype(np.uint32)
+        jobs.append((op, lhs, rhs))
+    want = [engine.pairwise(op, pool, l, pool, r).serialize_many() for op, l, r in jobs]
+    batches = [engine.pairwise_begin(op, pool, l, pool, r) for op, l, r in jobs]
+    with pytest.raises(RoaringHipError):          # RHIP_MAX_BATCHES_IN_FLIGHT = 4
+        engine.pairwise_begin("and", pool, jobs[0][1], pool, jobs[0][2])
+    got = {}
+    for k in (2, 0, 3, 1):                        # any order
+        got[k] = batches[k].end()
+    with pytest.raises(RoaringHipError):
+        batches[0].end()
+    for k in range(4):
+        blob, offs = got[k].serialize_many()
+        assert np.array_equal(offs, want[k][1]) and np.array_equal(blob, want[k][0]), jobs[k][0]
+    # a result that is still in flight cannot be recycled by another batch; after its end it can
+    spare = engine.pairwise("and", pool, jobs[0][1], pool, jobs[0][2])
+    b = engine.pairwise_begin("or", pool, jobs[1][1], pool, jobs[1][2], reuse=spare)
+    r1 = b.end()
+    blob, offs = r1.serialize_many()
+    assert np.array_equal(blob, want[1][0]) and np.array_equal(offs, want[1][1])
+    # software pipeline: begin(i+1) before end(i), results recycled two batches later
+    res = [None, None]
+    prev = None
+    for it in range(6):
+        op, l, r = jobs[it % 4]
+        cur = engine.pairwise_begin(op, pool, l, pool, r, reuse=res[it & 1])
+        if prev is not None:
+            k, pb = prev
+            res[(it - 1) & 1] = pb.end()
+            blob, offs = res[(it - 1) & 1].serialize_many()
+            assert np.array_equal(blob, want[k][0]) and np.array_equal(offs, want[k][1]), (it, k)
+        prev = (it % 4, cur)
+    k, pb = prev
+    last = pb.end()
+    blob, offs = last.serialize_many()
+    assert np.array_equal(blob, want[k][0]) and np.array_equal(offs, want[k][1])
