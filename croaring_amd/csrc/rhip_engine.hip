@@ -129,6 +129,8 @@ struct rhip_ctx_s {
     // statistics area and completion word.  Device scratch is shared: the batches' kernels are ordered by the stream.
     static constexpr int N_SLOTS = RHIP_MAX_BATCHES_IN_FLIGHT;
     void* h_stage[N_SLOTS] = {};  // grow-only
+    void* h_stage_dev[N_SLOTS] = {};  // the same memory as the device addresses it
+    bool stage_kernel = true;  // small descriptions are pulled by k_stage_in (RHIP_STAGE_KERNEL=0: always a copy command)
     size_t h_stage_cap[N_SLOTS] = {};
     bool slot_busy[N_SLOTS] = {};
     void ensure_stage(int slot, size_t n);
@@ -168,6 +170,7 @@ void rhip_ctx_s::ensure_stage(int slot, size_t n) {
         throw (int)RHIP_ERR_ALLOC;
     }
     h_stage_cap[slot] = want;
+    if (hipHostGetDevicePointer(&h_stage_dev[slot], h_stage[slot], 0) != hipSuccess) h_stage_dev[slot] = nullptr;
 }
 int rhip_ctx_s::acquire_slot() {
     for (int k = 0; k < N_SLOTS; ++k) {
@@ -251,6 +254,7 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_NO_OVERLAP")) c->overlap = !(e[0] == '1');
         if (const char* e = getenv("RHIP_SPIN_WAIT")) c->spin_wait = !(e[0] == '0');
         if (const char* e = getenv("RHIP_EXPLICIT_UNITS")) c->explicit_units = atoi(e);
+        if (const char* e = getenv("RHIP_STAGE_KERNEL")) c->stage_kernel = !(e[0] == '0');
         memset(c->h_pinned, 0, 4096);
         return c;
     } catch (int) {
@@ -968,7 +972,13 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     P.d_rhs = (uint32_t*)(dp + o_rhs);
     P.d_upair = (uint32_t*)(dp + o_upair);
     P.d_utile = (uint32_t*)(dp + o_utile);
-    HIPCHK(hipMemcpyAsync(dp, hs, stage_bytes, hipMemcpyHostToDevice, s));
+    if (c->stage_kernel && c->h_stage_dev[slot] && stage_bytes <= (1u << 20)) {
+        const uint32_t n16 = (uint32_t)((stage_bytes + 15) >> 4);  // (staging and plan_in are 16 bytes longer than that)
+        hipLaunchKernelGGL(k_stage_in, dim3((n16 + 255) / 256), dim3(256), 0, s, (const uint4*)c->h_stage_dev[slot],
+                           (uint4*)dp, n16);
+    } else {
+        HIPCHK(hipMemcpyAsync(dp, hs, stage_bytes, hipMemcpyHostToDevice, s));
+    }
     if (clk) clk->lap(1);
     PoolView VA = A->view(), VB = B->view();
     UnitView UV{P.d_upair, P.d_utile, P.d_pair0, (uint32_t)NU, (uint32_t)npairs, implicit ? (btiles ? 2u : 1u) : 0u};

@@ -125,6 +125,14 @@ __global__ __launch_bounds__(256) void k_scan(const uint32_t* __restrict__ in, u
     }
 }
 
+// ------------------------------------------------------------------ batch description, host -> device
+// A small batch description (two index lists) is pulled from pinned host memory by a kernel on the compute queue:
+// fully coalesced 16-byte reads over PCIe, no dependent chain.  A copy command would run on the DMA engine, with one
+// cross-engine dependency behind the previous batch's last kernel and one in front of k_count.
+__global__ __launch_bounds__(256) void k_stage_in(const uint4* __restrict__ host_src, uint4* __restrict__ dst, uint32_t n16) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) dst[i] = host_src[i];
+}
+
 // ------------------------------------------------------------------ planning
 // Planning works on UNITS: one unit = one tile of up to 256 consecutive directory entries of the
 // left bitmap of a pair ("A-tile"), or -- for OR/XOR, whose result also carries the right bitmap's
