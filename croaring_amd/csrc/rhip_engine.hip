@@ -156,6 +156,10 @@ struct rhip_ctx_s {
     hipStream_t aux[N_AUX]{};
     hipEvent_t ev_fork = nullptr, ev_join[N_AUX]{}, ev_runs = nullptr;
     bool overlap = true;
+    // Class kernels are forked onto the auxiliary streams only when the batch is big enough for their concurrency to
+    // pay for the fork / join (two cross-queue dependencies, 40-50 us, and no overlap between consecutive batches):
+    // measured break-even on the realdata sets ~150 MB of result-slot bound (RHIP_FORK_MIN_MB overrides; 0 = always)
+    uint64_t fork_min_bytes = 144ull << 20;
 };
 
 void rhip_ctx_s::ensure_stage(int slot, size_t n) {
@@ -255,6 +259,7 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_SPIN_WAIT")) c->spin_wait = !(e[0] == '0');
         if (const char* e = getenv("RHIP_EXPLICIT_UNITS")) c->explicit_units = atoi(e);
         if (const char* e = getenv("RHIP_STAGE_KERNEL")) c->stage_kernel = !(e[0] == '0');
+        if (const char* e = getenv("RHIP_FORK_MIN_MB")) c->fork_min_bytes = (uint64_t)atoll(e) << 20;
         memset(c->h_pinned, 0, 4096);
         return c;
     } catch (int) {
@@ -800,7 +805,8 @@ struct PlanScratch {
 struct Plan {
     PlanScratch sc;
     size_t npairs = 0, NU = 0, S = 0;
-    uint64_t ub_match = 0, ub_cand = 0, arena_bound = 0;
+    uint64_t ub_match = 0, ub_cand = 0, arena_bound = 0, work_bound = 0;
+    uint32_t plan_group = 64;  // lanes per planning unit
     bool may_bb = true, may_filt = true, may_wave = true, may_runs = true, may_copy = true;
     // device pointers
     uint32_t *d_lhs = nullptr, *d_rhs = nullptr, *d_upair = nullptr, *d_utile = nullptr;
@@ -919,6 +925,7 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     P.ub_match = ub_match;
     P.ub_cand = cardmode ? 0 : ub;
     P.arena_bound = cardmode ? 0 : bound;
+    P.work_bound = bound;
     // which classes can occur at all (pool-level type census): a class that cannot is not launched
     auto has = [](const rhip_pool_t* X, int t) { return X->census[t] != 0; };
     const bool aB = has(A, 0), aA = has(A, 1), aR = has(A, 2), bB = has(B, 0), bA = has(B, 1), bR = has(B, 2);
@@ -984,9 +991,11 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     UnitView UV{P.d_upair, P.d_utile, P.d_pair0, (uint32_t)NU, (uint32_t)npairs, implicit ? (btiles ? 2u : 1u) : 0u};
     PlanZero Z{P.words, (uint32_t)P.sc.n_words, cardmode ? c->pair_acc.as<u64>() : nullptr};
     const size_t zero_threads = std::max<size_t>(P.sc.n_words, cardmode ? npairs : 0);
-    // planning waves: one unit per wave, or four when every unit is small (no bitmap above 64 containers)
-    const bool quad = implicit && A->max_n <= 64 && B->max_n <= 64 && c->explicit_units != 2;
-    const size_t plan_waves = quad ? (NU + 3) / 4 + 1 : NU;
+    // planning waves: one unit per wave, or two / four when every unit is small (no bitmap above 128 / 64 containers)
+    const uint32_t max_n = std::max(A->max_n, B->max_n);
+    const uint32_t G = (!implicit || c->explicit_units == 2 || max_n > 128) ? 64u : (max_n > 64 ? 32u : 16u);
+    P.plan_group = G;
+    const size_t plan_waves = G == 64 ? NU : (NU + 64 / G - 1) / (64 / G) + 1;
     unsigned gp = (unsigned)std::max<size_t>(1, (std::max<size_t>(plan_waves * 64, std::min<size_t>(zero_threads, 1 << 16)) + 255) / 256);
     const u64 n_scan = (u64)N_SEC * S;
     EmitQueues Q{c->q[CLS_BB].as<BBItem>(), c->q[CLS_GEN].as<GenItem>(), c->q[CLS_COPY].as<CopyItem>(),
@@ -994,19 +1003,14 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
                  c->q[CLS_PROBE].as<FatItem>(), c->q[CLS_BBA].as<BBItem>(), c->q[CLS_USMALL].as<FatItem>(),
                  c->q[CLS_RUNS16].as<GenItem>(), c->q[CLS_RUNS16W].as<GenItem>()};
     const unsigned ge = (unsigned)((plan_waves * 64 + 255) / 256);
-    if (quad)
-        hipLaunchKernelGGL(k_count<16>, dim3(gp), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, op, cardmode,
-                           c->cand.as<uint32_t>(), c->match.as<uint32_t>(), Z);
-    else
-        hipLaunchKernelGGL(k_count<64>, dim3(gp), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, op, cardmode,
-                           c->cand.as<uint32_t>(), c->match.as<uint32_t>(), Z);
+    auto count = G == 16 ? k_count<16> : G == 32 ? k_count<32> : k_count<64>;
+    auto emit = G == 16 ? k_emit<16> : G == 32 ? k_emit<32> : k_emit<64>;
+    hipLaunchKernelGGL(count, dim3(gp), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, op, cardmode,
+                       c->cand.as<uint32_t>(), c->match.as<uint32_t>(), Z);
     hipLaunchKernelGGL(k_scan, dim3((unsigned)((n_scan + SCAN_TILE - 1) / SCAN_TILE)), dim3(256), 0, s,
                        c->cand.as<uint32_t>(), c->cand_start.as<u64>(), n_scan, P.scan_lb(), P.ranges(), (u64)S);
-    if (NU && quad)
-        hipLaunchKernelGGL(k_emit<16>, dim3(ge), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, op, cardmode,
-                           c->cand_start.as<u64>(), c->match.as<uint32_t>(), P.CO, Q);
-    else if (NU)
-        hipLaunchKernelGGL(k_emit<64>, dim3(ge), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, op, cardmode,
+    if (NU)
+        hipLaunchKernelGGL(emit, dim3(ge), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, op, cardmode,
                            c->cand_start.as<u64>(), c->match.as<uint32_t>(), P.CO, Q);
     if (clk) clk->lap(2);
     return P;
@@ -1046,7 +1050,7 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
     const bool has_wave = P.may_wave && nm && !cardmode, has_copy = P.may_copy && P.ub_cand && !cardmode;
     const bool has_bba = has_bb && !cardmode && (op == OP_AND || op == OP_ANDNOT);
     const bool has_retry = !cardmode && ((has_bb && op != OP_OR) || has_runs);
-    const bool fork = c->overlap && (has_runs || has_filt || has_wave);
+    const bool fork = c->overlap && (has_runs || has_filt || has_wave) && P.work_bound >= c->fork_min_bytes;
     bool used[rhip_ctx_s::N_AUX] = {false, false, false};
     auto on = [&](int a) -> hipStream_t {
         if (!fork) return s;

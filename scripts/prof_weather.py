@@ -1,5 +1,5 @@
 """rocprofv3 target: all-pairs batches of one realdata set (argv[2], default weather_sept_85; "c5" = the roaring64
-configuration), one op per run (argv[1]), 12 timed batches."""
+configuration), one op per run (argv[1]), 12 timed batches; argv[3] == "pipe": two calls in flight (begin / end)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -20,6 +20,21 @@ else:
 lhs, rhs = all_pairs(len(bufs))
 res = None
 ts = []
+if len(sys.argv) > 3 and sys.argv[3] == "pipe":
+    slots, prev = [None, None], None
+    for it in range(8 + 24):
+        if it == 8:
+            eng.host_clock(True)
+            t0 = time.perf_counter()
+        cur = eng.pairwise_begin(op, pool, lhs, pool, rhs, reuse=slots[it & 1])
+        slots[it & 1] = None
+        if prev is not None:
+            slots[(it - 1) & 1] = prev.end()
+        prev = cur
+    slots[1] = prev.end()
+    dt = (time.perf_counter() - t0) / 24
+    print(op, name, "pipelined min ms", dt * 1e3, "host us/batch:", [round(x / 24, 1) for x in eng.host_clock()][:6])
+    sys.exit(0)
 for it in range(12):
     if it == 2:
         eng.host_clock(True)

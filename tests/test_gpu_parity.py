@@ -559,13 +559,17 @@ def test_tiny_interval_pairs(engine, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("mode", ["1", "2", "fork"])
 def test_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
-    """Small bitmaps plan on implicit units, four per wave up to 64 containers a bitmap.  RHIP_EXPLICIT_UNITS=1 forces
-    the staged unit arrays of the general path, =2 implicit units with one unit per wave, on the same inputs (larger
-    directories reach those paths by themselves)."""
+    """Paths the size of a batch selects, forced on the same small inputs (big batches reach them by themselves).
+    Small bitmaps plan on implicit units, four per wave up to 64 containers a bitmap: RHIP_EXPLICIT_UNITS=1 forces the
+    staged unit arrays of the general path, =2 implicit units with one unit per wave.  Small batches keep every class
+    kernel on one stream: RHIP_FORK_MIN_MB=0 forks them onto the auxiliary streams."""
     import croaring_amd
-    monkeypatch.setenv("RHIP_EXPLICIT_UNITS", mode)
+    if mode == "fork":
+        monkeypatch.setenv("RHIP_FORK_MIN_MB", "0")
+    else:
+        monkeypatch.setenv("RHIP_EXPLICIT_UNITS", mode)
     eng = croaring_amd.Engine()
     try:
         test_edge_cases(eng, oracle)
