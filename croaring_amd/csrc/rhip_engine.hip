@@ -981,8 +981,9 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     P.d_utile = (uint32_t*)(dp + o_utile);
     if (c->stage_kernel && c->h_stage_dev[slot] && stage_bytes <= (1u << 20)) {
         const uint32_t n16 = (uint32_t)((stage_bytes + 15) >> 4);  // (staging and plan_in are 16 bytes longer than that)
-        hipLaunchKernelGGL(k_stage_in, dim3((n16 + 255) / 256), dim3(256), 0, s, (const uint4*)c->h_stage_dev[slot],
-                           (uint4*)dp, n16);
+        if (n16)  // (an empty pair list has nothing to stage, and a zero-block launch is an error)
+            hipLaunchKernelGGL(k_stage_in, dim3((n16 + 255) / 256), dim3(256), 0, s, (const uint4*)c->h_stage_dev[slot],
+                               (uint4*)dp, n16);
     } else {
         HIPCHK(hipMemcpyAsync(dp, hs, stage_bytes, hipMemcpyHostToDevice, s));
     }
@@ -1236,6 +1237,7 @@ extern "C" rhip_batch_t* rhip_pairwise_begin(rhip_ctx_t* c, rhip_op op_, rhip_po
         hipLaunchKernelGGL(k_tail, dim3((unsigned)std::max<uint64_t>(1, (P.ub_cand + TAIL_TILE - 1) / TAIL_TILE)), dim3(256), 0,
                            s, P.ranges(), CO, O.meta, D, (uint32_t)npairs, P.tail_lb(), P.tail_part(),
                            (Stats*)c->slot_stats(slot), (u64*)c->done_flag(slot), (u64)seq);
+        HIPCHK(hipGetLastError());  // a refused launch anywhere above must not pass silently
         clk.lap(3);
         rhip_batch_t* b = new rhip_batch_s{c, R, seq, slot, P.may_bb};
         c->slot_busy[slot] = true;
