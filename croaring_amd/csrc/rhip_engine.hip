@@ -133,6 +133,19 @@ struct rhip_ctx_s {
     bool stage_kernel = true;  // small descriptions are pulled by k_stage_in (RHIP_STAGE_KERNEL=0: always a copy command)
     size_t h_stage_cap[N_SLOTS] = {};
     bool slot_busy[N_SLOTS] = {};
+    // device scratch of a pairwise batch (planning arrays, candidate directory, class queues, scan / tail words): one
+    // set per slot, so that the planning kernels of a batch can run while the class kernels of the previous one do
+    struct SlotScratch {
+        DBuf plan_in, match, cand, cand_start, o_key, o_meta, o_off, o_pair, q[N_CLS], misc;
+        void release() {
+            DBuf* all[] = {&plan_in, &match, &cand, &cand_start, &o_key, &o_meta, &o_off, &o_pair, &misc};
+            for (auto* b : all) b->release();
+            for (auto& b : q) b.release();
+        }
+    } ss[N_SLOTS];
+    hipEvent_t ev_plan[N_SLOTS] = {};
+    bool plan_overlap = true;  // RHIP_PLAN_OVERLAP=0: the planning kernels of a batch always run on the main stream
+    int in_flight() const { int n = 0; for (bool b : slot_busy) n += b ? 1 : 0; return n; }
     void ensure_stage(int slot, size_t n);
     int acquire_slot();
     DBuf many[20];
@@ -255,11 +268,13 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_runs, hipEventDisableTiming));
         for (auto& e : c->ev_join) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& e : c->ev_plan) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         if (const char* e = getenv("RHIP_NO_OVERLAP")) c->overlap = !(e[0] == '1');
         if (const char* e = getenv("RHIP_SPIN_WAIT")) c->spin_wait = !(e[0] == '0');
         if (const char* e = getenv("RHIP_EXPLICIT_UNITS")) c->explicit_units = atoi(e);
         if (const char* e = getenv("RHIP_STAGE_KERNEL")) c->stage_kernel = !(e[0] == '0');
         if (const char* e = getenv("RHIP_FORK_MIN_MB")) c->fork_min_bytes = (uint64_t)atoll(e) << 20;
+        if (const char* e = getenv("RHIP_PLAN_OVERLAP")) c->plan_overlap = !(e[0] == '0');
         memset(c->h_pinned, 0, 4096);
         return c;
     } catch (int) {
@@ -284,6 +299,8 @@ extern "C" void rhip_ctx_destroy(rhip_ctx_t* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_runs) (void)hipEventDestroy(c->ev_runs);
     for (auto& e : c->ev_join) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_plan) if (e) (void)hipEventDestroy(e);
+    for (auto& sc : c->ss) sc.release();
     (void)hipHostFree(c->h_pinned);
     (void)hipStreamDestroy(c->stream);
     if (sw_) (void)hipSetDevice(prev_dev_);
@@ -807,6 +824,7 @@ struct Plan {
     size_t npairs = 0, NU = 0, S = 0;
     uint64_t ub_match = 0, ub_cand = 0, arena_bound = 0, work_bound = 0;
     uint32_t plan_group = 64;  // lanes per planning unit
+    int slot = 0;
     bool may_bb = true, may_filt = true, may_wave = true, may_runs = true, may_copy = true;
     // device pointers
     uint32_t *d_lhs = nullptr, *d_rhs = nullptr, *d_upair = nullptr, *d_utile = nullptr;
@@ -833,8 +851,8 @@ void check_pair_args(rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32
 template <int OP>
 void launch_bb(rhip_ctx_t* c, unsigned grid, const PoolView& A, const PoolView& B, const OutView& O, const Plan& P,
                int cardmode) {
-    hipLaunchKernelGGL(k_bb<OP>, dim3(grid), dim3(256), 0, c->stream, A.arena, B.arena, O, c->q[CLS_BB].as<BBItem>(),
-                       P.ranges() + 2 * SEC_BB, cardmode, c->pair_acc.as<u64>(), c->q[CLS_RETRY].as<GenItem>(),
+    hipLaunchKernelGGL(k_bb<OP>, dim3(grid), dim3(256), 0, c->stream, A.arena, B.arena, O, c->ss[P.slot].q[CLS_BB].as<BBItem>(),
+                       P.ranges() + 2 * SEC_BB, cardmode, c->pair_acc.as<u64>(), c->ss[P.slot].q[CLS_RETRY].as<GenItem>(),
                        P.retry_count());
 }
 
@@ -858,10 +876,11 @@ struct HostClock {  // phase p accumulates the host time between the previous la
     }
 };
 Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs,
-          const uint32_t* rhs, int cardmode, int slot, HostClock* clk = nullptr) {
-    hipStream_t s = c->stream;
+          const uint32_t* rhs, int cardmode, int slot, hipStream_t s, HostClock* clk = nullptr) {
+    rhip_ctx_s::SlotScratch& SS = c->ss[slot];
     Plan P;
     P.npairs = npairs;
+    P.slot = slot;
     fetch_bounds(A);
     fetch_bounds(B);
     const bool btiles = !cardmode && (op == OP_OR || op == OP_XOR);
@@ -947,33 +966,33 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     // ---- device scratch
     const size_t S = P.S;
     P.sc.layout(N_SEC * S, P.ub_cand);
-    c->plan_in.ensure(stage_bytes + 16);
-    c->cand.ensure(4 * (N_SEC * S + 8));
-    c->cand_start.ensure(8 * (N_SEC * S + 8));
-    c->match.ensure(4 * 256 * (NU + 1));
-    c->misc.ensure(8 * P.sc.n_words + 64);
-    P.words = c->misc.as<u64>();
-    c->q[CLS_BB].ensure(sizeof(BBItem) * (ub_match + 1));
-    c->q[CLS_GEN].ensure(sizeof(GenItem) * (ub_match + 1));
-    c->q[CLS_FILT].ensure(sizeof(FatItem) * (ub_match + 1));
-    c->q[CLS_WAVE].ensure(sizeof(FatItem) * (ub_match + 1));
-    c->q[CLS_RUNS].ensure(sizeof(GenItem) * (ub_match + 1));
-    c->q[CLS_RETRY].ensure(sizeof(GenItem) * (ub_match + 1));
-    c->q[CLS_PROBE].ensure(sizeof(FatItem) * (ub_match + 1));
-    c->q[CLS_BBA].ensure(sizeof(BBItem) * (ub_match + 1));
-    c->q[CLS_USMALL].ensure(sizeof(FatItem) * (ub_match + 1));
-    c->q[CLS_RUNS16].ensure(sizeof(GenItem) * (ub_match + 1));
-    c->q[CLS_RUNS16W].ensure(sizeof(GenItem) * (ub_match + 1));
-    c->q[CLS_COPY].ensure(sizeof(CopyItem) * (P.ub_cand + 1));
+    SS.plan_in.ensure(stage_bytes + 16);
+    SS.cand.ensure(4 * (N_SEC * S + 8));
+    SS.cand_start.ensure(8 * (N_SEC * S + 8));
+    SS.match.ensure(4 * 256 * (NU + 1));
+    SS.misc.ensure(8 * P.sc.n_words + 64);
+    P.words = SS.misc.as<u64>();
+    SS.q[CLS_BB].ensure(sizeof(BBItem) * (ub_match + 1));
+    SS.q[CLS_GEN].ensure(sizeof(GenItem) * (ub_match + 1));
+    SS.q[CLS_FILT].ensure(sizeof(FatItem) * (ub_match + 1));
+    SS.q[CLS_WAVE].ensure(sizeof(FatItem) * (ub_match + 1));
+    SS.q[CLS_RUNS].ensure(sizeof(GenItem) * (ub_match + 1));
+    SS.q[CLS_RETRY].ensure(sizeof(GenItem) * (ub_match + 1));
+    SS.q[CLS_PROBE].ensure(sizeof(FatItem) * (ub_match + 1));
+    SS.q[CLS_BBA].ensure(sizeof(BBItem) * (ub_match + 1));
+    SS.q[CLS_USMALL].ensure(sizeof(FatItem) * (ub_match + 1));
+    SS.q[CLS_RUNS16].ensure(sizeof(GenItem) * (ub_match + 1));
+    SS.q[CLS_RUNS16W].ensure(sizeof(GenItem) * (ub_match + 1));
+    SS.q[CLS_COPY].ensure(sizeof(CopyItem) * (P.ub_cand + 1));
     if (cardmode) c->pair_acc.ensure(8 * (npairs + 1));
     if (!cardmode) {
-        c->o_key.ensure(8 * (ub + 1)); c->o_meta.ensure(8 * (ub + 1)); c->o_off.ensure(8 * (ub + 2));
-        c->o_pair.ensure(4 * (ub + 2));
-        P.CO = CandOut{c->o_key.as<u64>(), c->o_off.as<u64>(), c->o_pair.as<uint32_t>()};
+        SS.o_key.ensure(8 * (ub + 1)); SS.o_meta.ensure(8 * (ub + 1)); SS.o_off.ensure(8 * (ub + 2));
+        SS.o_pair.ensure(4 * (ub + 2));
+        P.CO = CandOut{SS.o_key.as<u64>(), SS.o_off.as<u64>(), SS.o_pair.as<uint32_t>()};
     }
     // (Letting the planning kernels read two short index lists in place from the pinned staging area was measured:
     // the PCIe round trips inside k_count / k_emit cost 25 us more per batch than the copy command they replace.)
-    char* dp = (char*)c->plan_in.p;
+    char* dp = (char*)SS.plan_in.p;
     P.d_pair0 = (u64*)(dp + o_pair0);
     P.d_lhs = (uint32_t*)(dp + o_lhs);
     P.d_rhs = (uint32_t*)(dp + o_rhs);
@@ -999,20 +1018,20 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     const size_t plan_waves = G == 64 ? NU : (NU + 64 / G - 1) / (64 / G) + 1;
     unsigned gp = (unsigned)std::max<size_t>(1, (std::max<size_t>(plan_waves * 64, std::min<size_t>(zero_threads, 1 << 16)) + 255) / 256);
     const u64 n_scan = (u64)N_SEC * S;
-    EmitQueues Q{c->q[CLS_BB].as<BBItem>(), c->q[CLS_GEN].as<GenItem>(), c->q[CLS_COPY].as<CopyItem>(),
-                 c->q[CLS_FILT].as<FatItem>(), c->q[CLS_WAVE].as<FatItem>(), c->q[CLS_RUNS].as<GenItem>(),
-                 c->q[CLS_PROBE].as<FatItem>(), c->q[CLS_BBA].as<BBItem>(), c->q[CLS_USMALL].as<FatItem>(),
-                 c->q[CLS_RUNS16].as<GenItem>(), c->q[CLS_RUNS16W].as<GenItem>()};
+    EmitQueues Q{SS.q[CLS_BB].as<BBItem>(), SS.q[CLS_GEN].as<GenItem>(), SS.q[CLS_COPY].as<CopyItem>(),
+                 SS.q[CLS_FILT].as<FatItem>(), SS.q[CLS_WAVE].as<FatItem>(), SS.q[CLS_RUNS].as<GenItem>(),
+                 SS.q[CLS_PROBE].as<FatItem>(), SS.q[CLS_BBA].as<BBItem>(), SS.q[CLS_USMALL].as<FatItem>(),
+                 SS.q[CLS_RUNS16].as<GenItem>(), SS.q[CLS_RUNS16W].as<GenItem>()};
     const unsigned ge = (unsigned)((plan_waves * 64 + 255) / 256);
     auto count = G == 16 ? k_count<16> : G == 32 ? k_count<32> : k_count<64>;
     auto emit = G == 16 ? k_emit<16> : G == 32 ? k_emit<32> : k_emit<64>;
     hipLaunchKernelGGL(count, dim3(gp), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, op, cardmode,
-                       c->cand.as<uint32_t>(), c->match.as<uint32_t>(), Z);
+                       SS.cand.as<uint32_t>(), SS.match.as<uint32_t>(), Z);
     hipLaunchKernelGGL(k_scan, dim3((unsigned)((n_scan + SCAN_TILE - 1) / SCAN_TILE)), dim3(256), 0, s,
-                       c->cand.as<uint32_t>(), c->cand_start.as<u64>(), n_scan, P.scan_lb(), P.ranges(), (u64)S);
+                       SS.cand.as<uint32_t>(), SS.cand_start.as<u64>(), n_scan, P.scan_lb(), P.ranges(), (u64)S);
     if (NU)
         hipLaunchKernelGGL(emit, dim3(ge), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, op, cardmode,
-                           c->cand_start.as<u64>(), c->match.as<uint32_t>(), P.CO, Q);
+                           SS.cand_start.as<u64>(), SS.match.as<uint32_t>(), P.CO, Q);
     if (clk) clk->lap(2);
     return P;
 }
@@ -1067,24 +1086,24 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
         // batch), long lists one pair per wave; then the general image class.  Few items as a rule, so few blocks (an
         // empty block of an LDS-heavy kernel still queues for a slot); many items simply loop.
         hipLaunchKernelGGL((k_ivl<16, R16_MAX_IV>), dim3(bounded_grid(nm, 4096)), dim3(256), 0, on(0), VA.arena, VB.arena,
-                           O, c->q[CLS_RUNS16].as<GenItem>(), ranges + 2 * SEC_RUNS16, op, cardmode,
-                           c->pair_acc.as<u64>(), c->q[CLS_RETRY].as<GenItem>(), retry_count);
+                           O, c->ss[P.slot].q[CLS_RUNS16].as<GenItem>(), ranges + 2 * SEC_RUNS16, op, cardmode,
+                           c->pair_acc.as<u64>(), c->ss[P.slot].q[CLS_RETRY].as<GenItem>(), retry_count);
         hipLaunchKernelGGL((k_ivl<16, R16W_MAX_IV>), dim3(bounded_grid(nm, 2048)), dim3(256), 0, on(0), VA.arena, VB.arena,
-                           O, c->q[CLS_RUNS16W].as<GenItem>(), ranges + 2 * SEC_RUNS16W, op, cardmode,
-                           c->pair_acc.as<u64>(), c->q[CLS_RETRY].as<GenItem>(), retry_count);
+                           O, c->ss[P.slot].q[CLS_RUNS16W].as<GenItem>(), ranges + 2 * SEC_RUNS16W, op, cardmode,
+                           c->pair_acc.as<u64>(), c->ss[P.slot].q[CLS_RETRY].as<GenItem>(), retry_count);
         hipLaunchKernelGGL((k_ivl<64, RUNS_MAX_INTERVALS>), dim3(bounded_grid(nm, 2048)), dim3(256), 0, on(0), VA.arena,
-                           VB.arena, O, c->q[CLS_RUNS].as<GenItem>(), ranges + 2 * SEC_RUNS, op, cardmode,
-                           c->pair_acc.as<u64>(), c->q[CLS_RETRY].as<GenItem>(), retry_count);
+                           VB.arena, O, c->ss[P.slot].q[CLS_RUNS].as<GenItem>(), ranges + 2 * SEC_RUNS, op, cardmode,
+                           c->pair_acc.as<u64>(), c->ss[P.slot].q[CLS_RETRY].as<GenItem>(), retry_count);
     }
     if (has_filt)
         hipLaunchKernelGGL(k_filter, dim3(bounded_grid(nm)), dim3(256), 0, on(1), VA.arena, VB.arena, O,
-                           c->q[CLS_FILT].as<FatItem>(), ranges + 2 * SEC_FILT, op, cardmode, c->pair_acc.as<u64>());
+                           c->ss[P.slot].q[CLS_FILT].as<FatItem>(), ranges + 2 * SEC_FILT, op, cardmode, c->pair_acc.as<u64>());
     if (has_wave)
         hipLaunchKernelGGL(k_wave, dim3(bounded_grid(nm)), dim3(256), 0, on(2), VA.arena, VB.arena, O,
-                           c->q[CLS_WAVE].as<FatItem>(), ranges + 2 * SEC_WAVE, op);
+                           c->ss[P.slot].q[CLS_WAVE].as<FatItem>(), ranges + 2 * SEC_WAVE, op);
     if (has_runs)  // the general image class, beside the interval chain: on the auxiliary stream this op leaves idle
         hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 512)), dim3(256), 0, on(!has_filt ? 1 : !has_wave ? 2 : 1),
-                           VA.arena, VB.arena, O, c->q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN,
+                           VA.arena, VB.arena, O, c->ss[P.slot].q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN,
                            (const uint32_t*)nullptr, op, cardmode, c->pair_acc.as<u64>());
     if (has_bb) {
         unsigned grid = persistent_grid(nm, 4, 256 * 32);
@@ -1104,25 +1123,25 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
         hipStream_t sr = has_runs ? on(0) : s;
         if (fork && has_runs && has_bb) HIPCHK(hipStreamWaitEvent(sr, c->ev_runs, 0));
         hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 512)), dim3(256), 0, sr, VA.arena, VB.arena, O,
-                           c->q[CLS_RETRY].as<GenItem>(), (const u64*)nullptr, retry_count, op, 0, c->pair_acc.as<u64>());
+                           c->ss[P.slot].q[CLS_RETRY].as<GenItem>(), (const u64*)nullptr, retry_count, op, 0, c->pair_acc.as<u64>());
     }
     if (has_wave && op != OP_ANDNOT)  // or / xor of a short array with a long one, by rank: light, beside k_wave
         hipLaunchKernelGGL(k_usmall, dim3(bounded_grid(nm)), dim3(256), 0, s, VA.arena, VB.arena, O,
-                           c->q[CLS_USMALL].as<FatItem>(), ranges + 2 * SEC_USMALL, op);
+                           c->ss[P.slot].q[CLS_USMALL].as<FatItem>(), ranges + 2 * SEC_USMALL, op);
     if (has_filt)  // short streamed arrays: no LDS, 8 waves per SIMD -- co-resides with the LDS-bound kernels
         hipLaunchKernelGGL(k_probe, dim3(bounded_grid(nm)), dim3(256), 0, s, VA.arena, VB.arena, O,
-                           c->q[CLS_PROBE].as<FatItem>(), ranges + 2 * SEC_PROBE, op, cardmode, c->pair_acc.as<u64>());
+                           c->ss[P.slot].q[CLS_PROBE].as<FatItem>(), ranges + 2 * SEC_PROBE, op, cardmode, c->pair_acc.as<u64>());
     if (has_bba) {  // bitset pairs expected to give arrays
         if (op == OP_AND)
             hipLaunchKernelGGL(k_bba<OP_AND>, dim3(bounded_grid(nm)), dim3(256), 0, s, VA.arena, VB.arena, O,
-                               c->q[CLS_BBA].as<BBItem>(), ranges + 2 * SEC_BBA);
+                               c->ss[P.slot].q[CLS_BBA].as<BBItem>(), ranges + 2 * SEC_BBA);
         else
             hipLaunchKernelGGL(k_bba<OP_ANDNOT>, dim3(bounded_grid(nm)), dim3(256), 0, s, VA.arena, VB.arena, O,
-                               c->q[CLS_BBA].as<BBItem>(), ranges + 2 * SEC_BBA);
+                               c->ss[P.slot].q[CLS_BBA].as<BBItem>(), ranges + 2 * SEC_BBA);
     }
     if (has_copy)
         hipLaunchKernelGGL(k_copy, dim3(bounded_grid(P.ub_cand)), dim3(256), 0, s, VA.arena, VB.arena, O,
-                           c->q[CLS_COPY].as<CopyItem>(), ranges + 2 * SEC_COPY);
+                           c->ss[P.slot].q[CLS_COPY].as<CopyItem>(), ranges + 2 * SEC_COPY);
     if (fork)
         for (int a = 0; a < rhip_ctx_s::N_AUX; ++a)
             if (used[a]) {
@@ -1212,7 +1231,17 @@ extern "C" rhip_batch_t* rhip_pairwise_begin(rhip_ctx_t* c, rhip_op op_, rhip_po
         hipStream_t s = c->stream;
         if (c->timing) HIPCHK(hipEventRecord(c->ev[0], s));
         HostClock clk(c);
-        Plan P = plan(c, op, A, B, npairs, lhs, rhs, 0, slot, &clk);
+        // With a batch already in flight, the planning kernels of this one go to an auxiliary stream (the one its op
+        // leaves idle when the class kernels are forked): they touch only this slot's scratch and read-only operands,
+        // so they run beside the class kernels of the previous batch; the main stream waits for them below.
+        hipStream_t ps = s;
+        if (c->plan_overlap && c->overlap && !c->timing && c->in_flight() > 0)
+            ps = c->aux[(op == OP_OR || op == OP_XOR) ? 1 : 2];
+        Plan P = plan(c, op, A, B, npairs, lhs, rhs, 0, slot, ps, &clk);
+        if (ps != s) {
+            HIPCHK(hipEventRecord(c->ev_plan[slot], ps));
+            HIPCHK(hipStreamWaitEvent(s, c->ev_plan[slot], 0));
+        }
         const CandOut& CO = P.CO;
         R = reuse ? reuse : new rhip_pool_s();
         reuse = nullptr;
@@ -1226,7 +1255,7 @@ extern "C" rhip_batch_t* rhip_pairwise_begin(rhip_ctx_t* c, rhip_op op_, rhip_po
         ensure_dir(R, (uint32_t)npairs, P.ub_cand);
         R->arena.ensure(P.arena_bound + 64);
         OutView O{};
-        O.key = CO.key; O.meta = c->o_meta.as<u64>(); O.off = CO.off; O.slot = nullptr;
+        O.key = CO.key; O.meta = c->ss[slot].o_meta.as<u64>(); O.off = CO.off; O.slot = nullptr;
         O.arena = R->arena.as<uint8_t>();
         PoolView VA = A->view(), VB = B->view();
         run_kernels(c, op, VA, VB, O, P, 0);
@@ -1305,7 +1334,7 @@ extern "C" int rhip_pairwise_cardinality(rhip_ctx_t* c, rhip_op op_, rhip_pool_t
             if ((e = rhip_pool_cardinalities(B, cB.data())) != 0) throw e;
         }
         if (c->timing) HIPCHK(hipEventRecord(c->ev[0], s));
-        Plan P = plan(c, OP_AND, A, B, npairs, lhs, rhs, 1, c->acquire_slot());
+        Plan P = plan(c, OP_AND, A, B, npairs, lhs, rhs, 1, c->acquire_slot(), s);
         OutView O{};
         PoolView VA = A->view(), VB = B->view();
         run_kernels(c, OP_AND, VA, VB, O, P, 1);
