@@ -437,14 +437,27 @@ def main():
     bb_ms, bb_pairs = [], []
 
     def step(i: int, timed: bool):
+        # the 2 x rounds calls of a step are issued with two in flight (rhip_pairwise_begin / _end): the planning of
+        # call k+1 runs under the bitset kernel of call k.  Every call of the step has ended when the step returns.
+        pending = None
+
+        def finish(p):
+            op, b = p
+            results[op] = b.end()
+            if timed:
+                st = eng.last_stats()
+                bb_ms.append(st["ms_bitset_kernel"])
+                bb_pairs.append(st["n_bitset_pairs"])
+
         for r in range(args.rounds):
             for j, op in enumerate(("and", "or")):
                 lhs, rhs = schedule(((i * args.rounds + r) * 2 + j) * args.pairs, args.pairs, args.pool)
-                results[op] = eng.pairwise(op, pool, lhs, pool, rhs, reuse=results[op])
-                if timed:
-                    st = eng.last_stats()
-                    bb_ms.append(st["ms_bitset_kernel"])
-                    bb_pairs.append(st["n_bitset_pairs"])
+                b = eng.pairwise_begin(op, pool, lhs, pool, rhs, reuse=results[op])
+                results[op] = None
+                if pending is not None:
+                    finish(pending)
+                pending = (op, b)
+        finish(pending)
 
     for i in range(args.warmup):
         step(i, False)
@@ -490,7 +503,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"C2 synthetic bitset-only: pool {args.pool} bitmaps x {args.containers} bitset "
                                f"containers (density 0.5), batched pairwise AND+OR, {args.pairs} pairs per call, "
-                               f"{args.rounds} x (AND call + OR call) per step",
+                               f"{args.rounds} x (AND call + OR call) per step, two calls in flight "
+                               f"(rhip_pairwise_begin / _end), every call ended inside its step",
                    "ops_per_step": ops_per_step,
                    "timed_region_s": dt,
                    "algorithmic_GBps": total_ops * args.containers * BB_BYTES_PER_PAIR / dt / 1e9,

@@ -163,7 +163,8 @@ struct rhip_ctx_s {
     double hclk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     rhip_stats_t stats{};
     bool timing = false;
-    hipEvent_t ev[4]{};
+    hipEvent_t evs[RHIP_MAX_BATCHES_IN_FLIGHT][4]{};  // timing events: [slot][call start, call end, k_bb start, k_bb end]
+    hipEvent_t* ev = evs[0];                          // (calls that are not batches use slot 0's)
     // independent class kernels of one batch run concurrently: fork after planning, join before compaction
     static constexpr int N_AUX = 3;
     hipStream_t aux[N_AUX]{};
@@ -263,7 +264,7 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         c->device = device;
         HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIPCHK(hipHostMalloc(&c->h_pinned, 4096, hipHostMallocDefault));
-        for (auto& e : c->ev) HIPCHK(hipEventCreate(&e));
+        for (auto& es : c->evs) for (auto& e : es) HIPCHK(hipEventCreate(&e));
         for (auto& a : c->aux) HIPCHK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_runs, hipEventDisableTiming));
@@ -294,7 +295,7 @@ extern "C" void rhip_ctx_destroy(rhip_ctx_t* c) {
     for (auto& b : c->many) b.release();
     for (auto& b : c->sel) b.release();
     for (auto& b : c->partial_cache) { (void)hipFree(b.keys); (void)hipFree(b.words); }
-    for (auto& e : c->ev) (void)hipEventDestroy(e);
+    for (auto& es : c->evs) for (auto& e : es) if (e) (void)hipEventDestroy(e);
     for (auto& a : c->aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_runs) (void)hipEventDestroy(c->ev_runs);
@@ -1107,14 +1108,14 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
                            (const uint32_t*)nullptr, op, cardmode, c->pair_acc.as<u64>());
     if (has_bb) {
         unsigned grid = persistent_grid(nm, 4, 256 * 32);
-        if (c->timing) HIPCHK(hipEventRecord(c->ev[2], s));
+        if (c->timing) HIPCHK(hipEventRecord(c->evs[P.slot][2], s));
         switch (op) {
             case OP_AND: launch_bb<OP_AND>(c, grid, VA, VB, O, P, cardmode); break;
             case OP_OR: launch_bb<OP_OR>(c, grid, VA, VB, O, P, cardmode); break;
             case OP_XOR: launch_bb<OP_XOR>(c, grid, VA, VB, O, P, cardmode); break;
             default: launch_bb<OP_ANDNOT>(c, grid, VA, VB, O, P, cardmode); break;
         }
-        if (c->timing) HIPCHK(hipEventRecord(c->ev[3], s));
+        if (c->timing) HIPCHK(hipEventRecord(c->evs[P.slot][3], s));
         if (fork && has_retry && has_runs) HIPCHK(hipEventRecord(c->ev_runs, s));  // "k_bb done" for the retry pass on aux0
     }
     if (has_retry) {
@@ -1162,8 +1163,9 @@ void finish_stats(rhip_ctx_t* c, const Stats* dstats, Stats* out, bool had_bb, u
     hipStream_t s = c->stream;
     // dstats == nullptr: the last kernel of the call already wrote the totals into the pinned area
     if (dstats) HIPCHK(hipMemcpyAsync(c->h_pinned, dstats, sizeof(Stats), hipMemcpyDeviceToHost, s));
-    if (c->timing) HIPCHK(hipEventRecord(c->ev[1], s));
-    if (wait_seq && c->spin_wait && !c->timing && !dstats) {
+    hipEvent_t* ev = c->evs[wait_seq ? slot : 0];
+    if (c->timing && !wait_seq) HIPCHK(hipEventRecord(ev[1], s));  // (a batch recorded its end when it was enqueued)
+    if (wait_seq && c->spin_wait && !dstats) {
         volatile uint64_t* flag = c->done_flag(slot);
         for (uint32_t spins = 0;; ++spins) {
             if (__atomic_load_n((const uint64_t*)flag, __ATOMIC_ACQUIRE) == wait_seq) break;
@@ -1193,8 +1195,9 @@ void finish_stats(rhip_ctx_t* c, const Stats* dstats, Stats* out, bool had_bb, u
     c->stats.ms_bitset_kernel = 0.f;
     c->stats.ms_total = 0.f;
     if (c->timing) {
-        (void)hipEventElapsedTime(&c->stats.ms_total, c->ev[0], c->ev[1]);
-        if (had_bb && st.n_bb) (void)hipEventElapsedTime(&c->stats.ms_bitset_kernel, c->ev[2], c->ev[3]);
+        if (wait_seq) HIPCHK(hipEventSynchronize(ev[1]));  // the completion word can be seen before the event signals
+        (void)hipEventElapsedTime(&c->stats.ms_total, ev[0], ev[1]);
+        if (had_bb && st.n_bb) (void)hipEventElapsedTime(&c->stats.ms_bitset_kernel, ev[2], ev[3]);
     }
 }
 }  // namespace
@@ -1229,13 +1232,13 @@ extern "C" rhip_batch_t* rhip_pairwise_begin(rhip_ctx_t* c, rhip_op op_, rhip_po
         }
         const int slot = c->acquire_slot();
         hipStream_t s = c->stream;
-        if (c->timing) HIPCHK(hipEventRecord(c->ev[0], s));
+        if (c->timing) HIPCHK(hipEventRecord(c->evs[slot][0], s));
         HostClock clk(c);
         // With a batch already in flight, the planning kernels of this one go to an auxiliary stream (the one its op
         // leaves idle when the class kernels are forked): they touch only this slot's scratch and read-only operands,
         // so they run beside the class kernels of the previous batch; the main stream waits for them below.
         hipStream_t ps = s;
-        if (c->plan_overlap && c->overlap && !c->timing && c->in_flight() > 0)
+        if (c->plan_overlap && c->overlap && c->in_flight() > 0)
             ps = c->aux[(op == OP_OR || op == OP_XOR) ? 1 : 2];
         Plan P = plan(c, op, A, B, npairs, lhs, rhs, 0, slot, ps, &clk);
         if (ps != s) {
@@ -1266,6 +1269,7 @@ extern "C" rhip_batch_t* rhip_pairwise_begin(rhip_ctx_t* c, rhip_op op_, rhip_po
         hipLaunchKernelGGL(k_tail, dim3((unsigned)std::max<uint64_t>(1, (P.ub_cand + TAIL_TILE - 1) / TAIL_TILE)), dim3(256), 0,
                            s, P.ranges(), CO, O.meta, D, (uint32_t)npairs, P.tail_lb(), P.tail_part(),
                            (Stats*)c->slot_stats(slot), (u64*)c->done_flag(slot), (u64)seq);
+        if (c->timing) HIPCHK(hipEventRecord(c->evs[slot][1], s));
         HIPCHK(hipGetLastError());  // a refused launch anywhere above must not pass silently
         clk.lap(3);
         rhip_batch_t* b = new rhip_batch_s{c, R, seq, slot, P.may_bb};
