@@ -145,6 +145,7 @@ struct rhip_ctx_s {
     } ss[N_SLOTS];
     hipEvent_t ev_plan[N_SLOTS] = {};
     bool plan_overlap = true;  // RHIP_PLAN_OVERLAP=0: the planning kernels of a batch always run on the main stream
+    uint64_t plan_overlap_max_bytes = 2ull << 30;
     int in_flight() const { int n = 0; for (bool b : slot_busy) n += b ? 1 : 0; return n; }
     void ensure_stage(int slot, size_t n);
     int acquire_slot();
@@ -826,6 +827,7 @@ struct Plan {
     uint64_t ub_match = 0, ub_cand = 0, arena_bound = 0, work_bound = 0;
     uint32_t plan_group = 64;  // lanes per planning unit
     int slot = 0;
+    hipStream_t plan_stream = nullptr;
     bool may_bb = true, may_filt = true, may_wave = true, may_runs = true, may_copy = true;
     // device pointers
     uint32_t *d_lhs = nullptr, *d_rhs = nullptr, *d_upair = nullptr, *d_utile = nullptr;
@@ -878,6 +880,7 @@ struct HostClock {  // phase p accumulates the host time between the previous la
 };
 Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs,
           const uint32_t* rhs, int cardmode, int slot, hipStream_t s, HostClock* clk = nullptr) {
+    // (s = the stream the planning kernels may use instead of the main one; taken below if the batch is not a huge one)
     rhip_ctx_s::SlotScratch& SS = c->ss[slot];
     Plan P;
     P.npairs = npairs;
@@ -939,6 +942,10 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
         }
         pair0[npairs] = NU;
     }
+    // beside an HBM-bound multi-gigabyte batch (C2: 24 GB per call) planning kernels cost the bitset kernel more
+    // bandwidth than the 3 % of the call they would hide: those batches plan on the main stream
+    if (bound >= c->plan_overlap_max_bytes) s = c->stream;
+    P.plan_stream = s;
     if (clk) clk->lap(0);
     P.NU = NU;
     P.S = NU + 1;
@@ -1241,8 +1248,8 @@ extern "C" rhip_batch_t* rhip_pairwise_begin(rhip_ctx_t* c, rhip_op op_, rhip_po
         if (c->plan_overlap && c->overlap && c->in_flight() > 0)
             ps = c->aux[(op == OP_OR || op == OP_XOR) ? 1 : 2];
         Plan P = plan(c, op, A, B, npairs, lhs, rhs, 0, slot, ps, &clk);
-        if (ps != s) {
-            HIPCHK(hipEventRecord(c->ev_plan[slot], ps));
+        if (P.plan_stream != s) {
+            HIPCHK(hipEventRecord(c->ev_plan[slot], P.plan_stream));
             HIPCHK(hipStreamWaitEvent(s, c->ev_plan[slot], 0));
         }
         const CandOut& CO = P.CO;
