@@ -124,7 +124,7 @@ struct rhip_ctx_s {
     }
     hipStream_t stream = nullptr;
     // scratch (grow-only): candidate directory + queues + scan temporaries
-    DBuf plan_in, match, cand, cand_start, o_key, o_meta, o_slot, o_off, o_pair, flag, newidx, q[N_CLS], misc, misc2, prim_tmp, pair_acc;
+    DBuf o_key, o_meta, o_slot, o_off, o_pair, flag, newidx, misc, misc2, prim_tmp, pair_acc;  // (pairwise batches: ss[] below)
     // Batches in flight (rhip_pairwise_begin .. _end): each has a slot = its own pinned staging of the batch description,
     // statistics area and completion word.  Device scratch is shared: the batches' kernels are ordered by the stream.
     static constexpr int N_SLOTS = RHIP_MAX_BATCHES_IN_FLIGHT;
@@ -288,11 +288,10 @@ extern "C" void rhip_ctx_destroy(rhip_ctx_t* c) {
     int prev_dev_ = -1;
     const bool sw_ = hipGetDevice(&prev_dev_) == hipSuccess && prev_dev_ != c->device && hipSetDevice(c->device) == hipSuccess;
     (void)hipStreamSynchronize(c->stream);
-    DBuf* all[] = {&c->plan_in, &c->match, &c->cand, &c->cand_start, &c->o_key, &c->o_meta, &c->o_slot, &c->o_off, &c->o_pair,
+    DBuf* all[] = {&c->o_key, &c->o_meta, &c->o_slot, &c->o_off, &c->o_pair,
                    &c->flag, &c->newidx, &c->misc, &c->misc2, &c->prim_tmp, &c->pair_acc};
     for (auto& hs : c->h_stage) if (hs) (void)hipHostFree(hs);
     for (auto* b : all) b->release();
-    for (auto& b : c->q) b.release();
     for (auto& b : c->many) b.release();
     for (auto& b : c->sel) b.release();
     for (auto& b : c->partial_cache) { (void)hipFree(b.keys); (void)hipFree(b.words); }

@@ -662,6 +662,7 @@ __global__ __launch_bounds__(256) void k_tail(const u64* __restrict__ ranges, Ca
         lb_store(&part[2 * (size_t)tile + 1], TAIL_READY | (u64)ty[0] | ((u64)ty[1] << 16) | ((u64)ty[2] << 32));
     }
     if (tile != n_tiles - 1) return;
+    __syncthreads();  // this block's own partial sums are published before any of its threads waits for them below
     // ---- the block of the last tile closes the call.  Every other tile has started (tickets are handed out in start
     // order), so its partial sums arrive; this block adds them up and hands the totals to the host in pinned memory:
     // no copy kernel after the tail.  (The directory stores of other blocks may still be in flight then -- whatever
