@@ -16,7 +16,20 @@ V16 = st.one_of(EDGE16, st.integers(0, 65535))
 @st.composite
 def chunk(draw):
     """Low-16 values of one container."""
-    kind = draw(st.sampled_from(["few", "range", "runs", "full", "stride", "boundary"]))
+    kind = draw(st.sampled_from(["few", "range", "runs", "full", "stride", "boundary", "manyruns", "midarray"]))
+    if kind == "manyruns":   # 8 .. 140 short runs: the interval kernel's size classes (31 / 127 / 255 intervals a side)
+        n = draw(st.sampled_from([8, 30, 31, 32, 33, 60, 126, 127, 128, 129, 140]))
+        gap = draw(st.sampled_from([3, 5, 40, 400]))
+        ln = draw(st.sampled_from([1, 2, 3, 9]))
+        s0 = draw(st.integers(0, 2000))
+        starts = s0 + np.arange(n, dtype=np.uint32) * np.uint32(gap + ln)
+        v = (starts[:, None] + np.arange(ln, dtype=np.uint32)[None, :]).ravel()
+        return np.unique(v[v < 65536]).astype(np.uint32)
+    if kind == "midarray":   # 100 .. 300 scattered values: the probe / rank-merge limits (128 / 255 / 256 values)
+        n = draw(st.sampled_from([100, 127, 128, 129, 200, 254, 255, 256, 257, 300]))
+        rng = np.random.default_rng(draw(st.integers(0, 2 ** 31)))
+        lo = draw(st.sampled_from([0, 30000, 65536 - 4 * 300]))
+        return np.sort(rng.choice(4 * 300, n, replace=False).astype(np.uint32) + np.uint32(lo))
     if kind == "few":
         return np.unique(np.array(draw(st.lists(V16, min_size=1, max_size=12)), dtype=np.uint32))
     if kind == "range":
@@ -57,7 +70,10 @@ def emu():
     eng.close()
 
 
-CFG = dict(max_examples=120, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
+# RHIP_HYP_EXAMPLES=n / RHIP_HYP_RANDOM=1: a longer, randomised hunt (offline); the committed default is deterministic
+_os = __import__("os")
+CFG = dict(max_examples=int(_os.environ.get("RHIP_HYP_EXAMPLES", "120")), deadline=None,
+           derandomize=_os.environ.get("RHIP_HYP_RANDOM") != "1", database=None, suppress_health_check=list(HealthCheck))
 
 
 @settings(**CFG)
@@ -105,3 +121,24 @@ def test_flip_convert_and_value_lists_match_the_oracle(emu, oracle, a, s, n):
     assert emu.pool_from_blob(blob, boffs).serialize(0) == pool.serialize(0)
     oracle.free(plain)
     oracle.free(h)
+
+
+@settings(**{**CFG, "max_examples": max(20, CFG["max_examples"] // 4)})
+@given(bms=st.lists(bitmap(), min_size=3, max_size=7), op=st.sampled_from(OPS))
+def test_batched_all_pairs_match_the_oracle(emu, oracle, bms, op):
+    """Several bitmaps, every ordered pair in ONE call: the sub-wave groups of the planning, interval and copy kernels
+    then hold different items (sizes, types, empty results) in one wave."""
+    hs = [oracle.from_sorted(v, run_optimize=r) for v, r in bms]
+    pool = emu.pool_from_serialized([oracle.serialize(h) for h in hs])
+    n = len(hs)
+    lhs = np.repeat(np.arange(n, dtype=np.uint32), n)
+    rhs = np.tile(np.arange(n, dtype=np.uint32), n)
+    res = emu.pairwise(op, pool, lhs, pool, rhs)
+    cards = emu.pairwise_cardinality(op, pool, lhs, pool, rhs)
+    for k in range(lhs.size):
+        want = oracle.op(op, hs[lhs[k]], hs[rhs[k]])
+        assert res.serialize(k) == oracle.serialize(want), (op, int(lhs[k]), int(rhs[k]))
+        assert cards[k] == oracle.cardinality(want)
+        oracle.free(want)
+    for h in hs:
+        oracle.free(h)
