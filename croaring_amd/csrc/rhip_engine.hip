@@ -1049,7 +1049,7 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
 // planning and joined before the tail -- four streams in all, one per hardware queue of the device (a fifth
 // stream shares a queue with another and serialises behind it):
 //     main : k_bb -> [ev_bb] -> k_usmall | k_probe -> k_bba -> k_copy -> [join] -> k_tail      streaming / light classes
-//     aux0 : k_ivl<16,31> -> k_ivl<16,127> -> k_ivl<64,255> -> [wait ev_bb] -> k_genw(retry)     interval algebra
+//     aux0 : k_ivl_all (<16,31> | <16,127> | <64,255> in one launch) -> [wait ev_bb] -> k_genw(retry)     interval algebra
 //     aux1 : k_filter                                                                and / andnot / cardinality
 //     aux2 : k_wave                                                                  or / xor / bitset \ array
 //     k_genw(general): on aux1 for or / xor, aux2 for and / cardinality (the stream the op leaves idle), else after k_filter
@@ -1089,18 +1089,15 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
     };
     if (fork) HIPCHK(hipEventRecord(c->ev_fork, s));
     if (has_runs) {
-        // interval algebra: short lists four pairs per wave in two size classes (most of a sparse run-compressed
-        // batch), long lists one pair per wave; then the general image class.  Few items as a rule, so few blocks (an
-        // empty block of an LDS-heavy kernel still queues for a slot); many items simply loop.
-        hipLaunchKernelGGL((k_ivl<16, R16_MAX_IV>), dim3(bounded_grid(nm, 4096)), dim3(256), 0, on(0), VA.arena, VB.arena,
-                           O, c->ss[P.slot].q[CLS_RUNS16].as<GenItem>(), ranges + 2 * SEC_RUNS16, op, cardmode,
-                           c->pair_acc.as<u64>(), c->ss[P.slot].q[CLS_RETRY].as<GenItem>(), retry_count);
-        hipLaunchKernelGGL((k_ivl<16, R16W_MAX_IV>), dim3(bounded_grid(nm, 2048)), dim3(256), 0, on(0), VA.arena, VB.arena,
-                           O, c->ss[P.slot].q[CLS_RUNS16W].as<GenItem>(), ranges + 2 * SEC_RUNS16W, op, cardmode,
-                           c->pair_acc.as<u64>(), c->ss[P.slot].q[CLS_RETRY].as<GenItem>(), retry_count);
-        hipLaunchKernelGGL((k_ivl<64, RUNS_MAX_INTERVALS>), dim3(bounded_grid(nm, 2048)), dim3(256), 0, on(0), VA.arena,
-                           VB.arena, O, c->ss[P.slot].q[CLS_RUNS].as<GenItem>(), ranges + 2 * SEC_RUNS, op, cardmode,
-                           c->pair_acc.as<u64>(), c->ss[P.slot].q[CLS_RETRY].as<GenItem>(), retry_count);
+        // interval algebra, three size classes in one launch: short lists four pairs per wave (most of a sparse
+        // run-compressed batch), long lists one pair per wave.  Few items as a rule, so few blocks (an empty block of an
+        // LDS-heavy kernel still queues for a slot); many items simply loop.
+        rhip_ctx_s::SlotScratch& SS = c->ss[P.slot];
+        const unsigned g1 = bounded_grid(nm, 4096), g2 = bounded_grid(nm, 2048), g3 = bounded_grid(nm, 2048);
+        IvlQueues IQ{{SS.q[CLS_RUNS16].as<GenItem>(), SS.q[CLS_RUNS16W].as<GenItem>(), SS.q[CLS_RUNS].as<GenItem>()},
+                     {ranges + 2 * SEC_RUNS16, ranges + 2 * SEC_RUNS16W, ranges + 2 * SEC_RUNS}};
+        hipLaunchKernelGGL(k_ivl_all, dim3(g1 + g2 + g3), dim3(256), 0, on(0), VA.arena, VB.arena, O, IQ, g1, g2, op,
+                           cardmode, c->pair_acc.as<u64>(), SS.q[CLS_RETRY].as<GenItem>(), retry_count);
     }
     if (has_filt)
         hipLaunchKernelGGL(k_filter, dim3(bounded_grid(nm)), dim3(256), 0, on(1), VA.arena, VB.arena, O,
@@ -1108,10 +1105,14 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
     if (has_wave)
         hipLaunchKernelGGL(k_wave, dim3(bounded_grid(nm)), dim3(256), 0, on(2), VA.arena, VB.arena, O,
                            c->ss[P.slot].q[CLS_WAVE].as<FatItem>(), ranges + 2 * SEC_WAVE, op);
-    if (has_runs)  // the general image class, beside the interval chain: on the auxiliary stream this op leaves idle
+    // the general image class: forked, beside the interval chain on the auxiliary stream this op leaves idle; on one
+    // stream it shares a launch with the retry pass further down
+    const bool genw_merged = !fork && has_runs && has_retry;
+    if (has_runs && !genw_merged)
         hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 512)), dim3(256), 0, on(!has_filt ? 1 : !has_wave ? 2 : 1),
                            VA.arena, VB.arena, O, c->ss[P.slot].q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN,
-                           (const uint32_t*)nullptr, op, cardmode, c->pair_acc.as<u64>());
+                           (const uint32_t*)nullptr, op, cardmode, c->pair_acc.as<u64>(), (const GenItem*)nullptr,
+                           (const uint32_t*)nullptr);
     if (has_bb) {
         unsigned grid = persistent_grid(nm, 4, 256 * 32);
         if (c->timing) HIPCHK(hipEventRecord(c->evs[P.slot][2], s));
@@ -1129,8 +1130,15 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
         // arrays (card <= 4096), interval results that must become bitsets
         hipStream_t sr = has_runs ? on(0) : s;
         if (fork && has_runs && has_bb) HIPCHK(hipStreamWaitEvent(sr, c->ev_runs, 0));
-        hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 512)), dim3(256), 0, sr, VA.arena, VB.arena, O,
-                           c->ss[P.slot].q[CLS_RETRY].as<GenItem>(), (const u64*)nullptr, retry_count, op, 0, c->pair_acc.as<u64>());
+        rhip_ctx_s::SlotScratch& SS = c->ss[P.slot];
+        if (genw_merged)  // one stream: the general class and the re-queued results in one launch, after their producers
+            hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 512)), dim3(256), 0, sr, VA.arena, VB.arena, O,
+                               SS.q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, 0,
+                               c->pair_acc.as<u64>(), (const GenItem*)SS.q[CLS_RETRY].as<GenItem>(), (const uint32_t*)retry_count);
+        else
+            hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 512)), dim3(256), 0, sr, VA.arena, VB.arena, O,
+                               SS.q[CLS_RETRY].as<GenItem>(), (const u64*)nullptr, retry_count, op, 0,
+                               c->pair_acc.as<u64>(), (const GenItem*)nullptr, (const uint32_t*)nullptr);
     }
     if (has_wave && op != OP_ANDNOT)  // or / xor of a short array with a long one, by rank: light, beside k_wave
         hipLaunchKernelGGL(k_usmall, dim3(bounded_grid(nm)), dim3(256), 0, s, VA.arena, VB.arena, O,

@@ -28,25 +28,33 @@
 // scans and sums by shuffles that never leave the group, group-private LDS -- and only long lists take the whole wave.
 // Control flow around the collectives stays wave-uniform: the groups of a wave walk their items in lockstep.
 template <uint32_t G, uint32_t MAXIV>
-__global__ __launch_bounds__(256) void k_ivl(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
-                                             OutView O, const GenItem* __restrict__ q,
-                                             const u64* __restrict__ qrange, int op, int cardmode, u64* pair_acc,
-                                             GenItem* retry_q, uint32_t* retry_count) {
-    constexpr uint32_t NG = 64 / G;                        // pairs per wave
-    constexpr uint32_t NB = 2 * MAXIV + 2;                 // >= result runs: (boundaries of both lists) / 2
-    constexpr uint32_t LBYTES = (4 * MAXIV + 15) & ~15u;   // staged payload of one operand, 16-byte padded
-    __shared__ __attribute__((aligned(16))) uint8_t lists_all[4 * NG][2][LBYTES];
-    __shared__ __attribute__((aligned(4))) uint16_t rse_all[4 * NG][2 * NB];  // result runs: start, end (inclusive)
+struct IvlShape {
+    static constexpr uint32_t NG = 64 / G;                        // pairs per wave
+    static constexpr uint32_t NB = 2 * MAXIV + 2;                 // >= result runs: (boundaries of both lists) / 2
+    static constexpr uint32_t LBYTES = (4 * MAXIV + 15) & ~15u;   // staged payload of one operand, 16-byte padded
+    static constexpr uint32_t LIST_BYTES = 4 * NG * 2 * LBYTES;   // per block
+    static constexpr uint32_t RSE_BYTES = 4 * NG * 2 * NB * 2;
+    static constexpr uint32_t LDS_BYTES = LIST_BYTES + RSE_BYTES;
+};
+// bid / nblk: this block's index and the number of blocks of ITS size class (k_ivl_all runs the three classes in one
+// launch); lds: the block's LDS, IvlShape<G, MAXIV>::LDS_BYTES of it
+template <uint32_t G, uint32_t MAXIV>
+__device__ __forceinline__ void ivl_body(uint8_t* lds, uint32_t bid, uint32_t nblk, const uint8_t* __restrict__ arenaA,
+                                         const uint8_t* __restrict__ arenaB, const OutView& O,
+                                         const GenItem* __restrict__ q, const u64* __restrict__ qrange, int op,
+                                         int cardmode, u64* pair_acc, GenItem* retry_q, uint32_t* retry_count) {
+    using SH = IvlShape<G, MAXIV>;
+    constexpr uint32_t NG = SH::NG, NB = SH::NB, LBYTES = SH::LBYTES;
     const Grp<G> gr;
     const uint32_t lane = gr.lane, gl = gr.gl;
     const uint32_t gslot = threadIdx.x / G;
-    uint8_t* lsA = lists_all[gslot][0];
-    uint8_t* lsB = lists_all[gslot][1];
-    uint16_t* RSE = rse_all[gslot];
+    uint8_t* lsA = lds + (size_t)gslot * 2 * LBYTES;   // this group's two lists, then (after all lists) its run table
+    uint8_t* lsB = lsA + LBYTES;
+    uint16_t* RSE = (uint16_t*)(lds + SH::LIST_BYTES) + (size_t)gslot * 2 * NB;
     const uint32_t* RUN = (const uint32_t*)RSE;  // run k = RUN[k]: start | end << 16
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    uint32_t wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t wi = (bid * blockDim.x + threadIdx.x) >> 6;
     GenItem tnext = {};
     if (NG * wi + gr.grp < n) tnext = q[NG * wi + gr.grp];
     for (; NG * wi < n; wi += nwaves) {
@@ -222,6 +230,31 @@ __global__ __launch_bounds__(256) void k_ivl(const uint8_t* __restrict__ arenaA,
     }
 }
 
+// The three size classes in ONE launch (a small batch is a chain of dependent launches: each one less is ~7 us):
+// blocks [0, g1) take the short lists, [g1, g1 + g2) the wide ones, the rest one pair per wave.  The block's LDS is
+// the largest of the three shapes (32 KiB); at ~100 VGPRs four blocks per CU fit either way.
+struct IvlQueues {
+    const GenItem* q[3];   // CLS_RUNS16, CLS_RUNS16W, CLS_RUNS
+    const u64* range[3];
+};
+__global__ __launch_bounds__(256) void k_ivl_all(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                                 OutView O, IvlQueues Q, uint32_t g1, uint32_t g2, int op, int cardmode,
+                                                 u64* pair_acc, GenItem* retry_q, uint32_t* retry_count) {
+    constexpr uint32_t LDS_A = IvlShape<16, R16_MAX_IV>::LDS_BYTES, LDS_B = IvlShape<16, R16W_MAX_IV>::LDS_BYTES,
+                       LDS_C = IvlShape<64, RUNS_MAX_INTERVALS>::LDS_BYTES;
+    constexpr uint32_t LDS_MAX = LDS_A > LDS_B ? (LDS_A > LDS_C ? LDS_A : LDS_C) : (LDS_B > LDS_C ? LDS_B : LDS_C);
+    __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_MAX];
+    const uint32_t b = blockIdx.x;
+    if (b < g1)
+        ivl_body<16, R16_MAX_IV>(lds, b, g1, arenaA, arenaB, O, Q.q[0], Q.range[0], op, cardmode, pair_acc, retry_q, retry_count);
+    else if (b < g1 + g2)
+        ivl_body<16, R16W_MAX_IV>(lds, b - g1, g2, arenaA, arenaB, O, Q.q[1], Q.range[1], op, cardmode, pair_acc, retry_q,
+                                  retry_count);
+    else
+        ivl_body<64, RUNS_MAX_INTERVALS>(lds, b - g1 - g2, gridDim.x - g1 - g2, arenaA, arenaB, O, Q.q[2], Q.range[2], op,
+                                         cardmode, pair_acc, retry_q, retry_count);
+}
+
 // ------------------------------------------------------------------ wave-level general pair kernel (K5, K7, K13-K16)
 // Every type pair the specialised kernels do not take (all pairs with a run container, plus
 // bitset x bitset results that must become arrays): ONE WAVE per container pair, two wave-private
@@ -301,7 +334,8 @@ __device__ void wimg_build(uint32_t* img, const uint8_t* __restrict__ p, uint32_
 __global__ __launch_bounds__(256) void k_genw(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                               OutView O, const GenItem* __restrict__ q,
                                               const u64* __restrict__ qrange, const uint32_t* __restrict__ qcount,
-                                              int op, int cardmode, u64* pair_acc) {
+                                              int op, int cardmode, u64* pair_acc,
+                                              const GenItem* __restrict__ q2, const uint32_t* __restrict__ q2count) {
     // ONE 8 KiB image per wave: operand A is rasterised, pulled into registers, then the same image is
     // reused for operand B and finally as the output staging buffer (16 waves per CU instead of 8)
     __shared__ __attribute__((aligned(16))) uint32_t img_all[4][2048];
@@ -309,9 +343,12 @@ __global__ __launch_bounds__(256) void k_genw(const uint8_t* __restrict__ arenaA
     uint32_t* ia = img_all[threadIdx.x >> 6];
     uint32_t* ib = ia;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t n = qrange ? (uint32_t)(qrange[1] - qrange[0]) : *qcount;
+    // items: queue q (its length from the section range, or from a counter), then -- when given -- the re-queued
+    // results in q2 (single-stream batches run both in one launch, after every kernel that re-queues)
+    const uint32_t n1 = qrange ? (uint32_t)(qrange[1] - qrange[0]) : *qcount;
+    const uint32_t n = n1 + (q2 ? *q2count : 0u);
     for (uint32_t wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wi < n; wi += nwaves) {
-        const GenItem t = q[wi];
+        const GenItem t = wi < n1 ? q[wi] : q2[wi - n1];
         const uint32_t ta = t.types & 0xFFu, tb = t.types >> 8;
         wimg_build(ia, arenaA + t.offa, ta, t.ca, t.nra);
         __builtin_amdgcn_wave_barrier();
