@@ -208,6 +208,7 @@ struct rhip_pool_s {
     DBuf bm_start, key, type, card, nruns, off, arena;
     uint64_t arena_used = 0;
     bool pending = false;       // result of a batch that has begun and not ended: not usable yet
+    int in_use = 0;             // batches in flight that read this pool as an operand: not recyclable yet
     uint64_t compact_mark = 0;  // arena_used right after the last compaction (0: never updated in place), see rhip_pairwise_inplace
     // host mirror of the directory (filled lazily for serialization); planning only needs bm_start
     bool host_dir = false;
@@ -1219,6 +1220,7 @@ void finish_stats(rhip_ctx_t* c, const Stats* dstats, Stats* out, bool had_bb, u
 struct rhip_batch_s {
     rhip_ctx_t* c;
     rhip_pool_t* R;
+    rhip_pool_t *A, *B;
     uint64_t seq;
     int slot;
     bool may_bb;
@@ -1233,9 +1235,9 @@ extern "C" rhip_batch_t* rhip_pairwise_begin(rhip_ctx_t* c, rhip_op op_, rhip_po
         int op = (int)op_;
         if (op < 0 || op > 3) { set_err("bad op"); throw (int)RHIP_ERR_ARG; }
         DeviceGuard dguard_(c->device);
-        if (reuse && reuse->pending) {
-            reuse = nullptr;  // still owned by its batch
-            set_err("`reuse` is the result of a batch still in flight");
+        if (reuse && (reuse->pending || reuse->in_use)) {
+            reuse = nullptr;  // still owned / read by a batch
+            set_err("`reuse` is the result or an operand of a batch still in flight");
             throw (int)RHIP_ERR_ARG;
         }
         check_pair_args(A, B, npairs, lhs, rhs);
@@ -1286,9 +1288,11 @@ extern "C" rhip_batch_t* rhip_pairwise_begin(rhip_ctx_t* c, rhip_op op_, rhip_po
         if (c->timing) HIPCHK(hipEventRecord(c->evs[slot][1], s));
         HIPCHK(hipGetLastError());  // a refused launch anywhere above must not pass silently
         clk.lap(3);
-        rhip_batch_t* b = new rhip_batch_s{c, R, seq, slot, P.may_bb};
+        rhip_batch_t* b = new rhip_batch_s{c, R, A, B, seq, slot, P.may_bb};
         c->slot_busy[slot] = true;
         R->pending = true;
+        ++A->in_use;
+        ++B->in_use;
         return b;
     } catch (int e) {
         last_status() = e;
@@ -1304,6 +1308,8 @@ extern "C" rhip_pool_t* rhip_pairwise_end(rhip_batch_t* b) {
     rhip_ctx_t* c = b->c;
     rhip_pool_t* R = b->R;
     const int slot = b->slot;
+    --b->A->in_use;
+    --b->B->in_use;
     try {
         DeviceGuard dguard_(c->device);
         HostClock clk(c);

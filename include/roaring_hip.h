@@ -151,7 +151,7 @@ rhip_pool_t *rhip_pairwise(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *A, rhip_poo
  * rhip_pairwise_end waits for that batch and returns its result pool (NULL on error; the handle is consumed either
  * way).  Up to RHIP_MAX_BATCHES_IN_FLIGHT batches of one context may be in flight, ended in any order; they execute in
  * begin order on the context's stream.  Until a batch has ended, its operand pools must not be freed or updated in
- * place, its result cannot be an operand or the `reuse` of another batch (RHIP_ERR_ARG), and any other call on the
+ * place (as `reuse` they are refused), its result cannot be an operand or the `reuse` of another batch (RHIP_ERR_ARG), and any other call on the
  * context simply waits for the batches in flight.  rhip_pairwise == begin followed by end. */
 #define RHIP_MAX_BATCHES_IN_FLIGHT 4
 typedef struct rhip_batch_s rhip_batch_t;

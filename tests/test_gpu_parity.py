@@ -606,6 +606,13 @@ def test_batches_in_flight(engine, oracle, synth):
     for k in range(4):
         blob, offs = got[k].serialize_many()
         assert np.array_equal(offs, want[k][1]) and np.array_equal(blob, want[k][0]), jobs[k][0]
+    # an operand of a batch in flight cannot be recycled as somebody's result buffer
+    opnd = engine.pairwise("and", pool, jobs[0][1], pool, jobs[0][2])
+    ids = np.arange(min(16, len(opnd)), dtype=np.uint32)
+    hold = engine.pairwise_begin("or", opnd, ids, opnd, ids)
+    with pytest.raises(RoaringHipError):
+        engine.pairwise_begin("and", pool, jobs[0][1], pool, jobs[0][2], reuse=opnd)
+    hold.end()
     # a result that is still in flight cannot be recycled by another batch; after its end it can
     spare = engine.pairwise("and", pool, jobs[0][1], pool, jobs[0][2])
     b = engine.pairwise_begin("or", pool, jobs[1][1], pool, jobs[1][2], reuse=spare)
