@@ -31,8 +31,7 @@ t.append("Per op on C2 (250 pairs per call, `profiles/r02_c2_ops.jsonl`):\n\n| o
 for o in map(json.loads, open(P("r02_c2_ops.jsonl"))):
     t.append(f"| {o['op']} | {o['ms_call']:.2f} | {o['ops_per_s']:,.0f} | {o['alg_GBps'] / 1e3:.2f} | {o['k_bb_GBps'] / 1e3:.2f} |")
 t.append("""
-(`and` trails the others by a few per cent: its array-typed results (card ≤ 4096) cannot store before the
-cardinality resolves; round 1 had it 7 % behind.)
+(`and` is bimodal from run to run on the same code — within 2 % of `or`, or 6 % behind: §10 item 7.)
 
 **Realdata, ALL unordered pairs in one batched call per op** (`bench.py` secondary block: wall time of the whole call
 incl. planning and the final wait, median of ≥ 10 calls; "2 in flight" = per-call period of 40 calls issued with
