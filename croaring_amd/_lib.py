@@ -71,11 +71,14 @@ SYMBOLS = [
     ("rhip_pool_run_optimize", _vp, [_vp, _vp]),
     ("rhip_pool_remove_run_compression", _vp, [_vp, _vp]),
     ("rhip_pool_flip", _vp, [_vp, _vp, _vp, _vp]),
+    ("rhip_pool_max_key", _i, [_vp, _vp]),
     ("rhip_or_many", _vp, [_vp, _vp, _sz, _vp]),
     ("rhip_xor_many", _vp, [_vp, _vp, _sz, _vp]),
     ("rhip_many_partials", _i, [_vp, _i, _vp, _sz, _vp, C.POINTER(Partials)]),
     ("rhip_partials_free", None, [_vp, C.POINTER(Partials)]),
     ("rhip_many_finalize", _vp, [_vp, _i, _i, _u64, _vp, _vp]),
+    ("rhip_many_partials_dense", _i, [_vp, _i, _vp, _sz, _vp, _u64, _u32, _vp]),
+    ("rhip_many_finalize_dense", _vp, [_vp, _i, _i, _u32, _u32, _u64, _vp]),
     ("rhip_last_stats", _i, [_vp, C.POINTER(Stats)]),
     ("rhip_ctx_set_timing", None, [_vp, _i]),
     ("rhip_debug_host_clock", _i, [_vp, C.POINTER(C.c_double), _i]),

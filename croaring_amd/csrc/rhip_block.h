@@ -41,76 +41,6 @@ __device__ __forceinline__ uint32_t blk_sum(uint32_t v, uint32_t* wsum) {
     return wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// Rasterise container c of pool V into the LDS image dst (K6 / K7 of SURVEY §2.2):
-//   bitset: straight 16-byte copy;
-//   array : zero + ds_or_b32 scatter (bitset_set_list, bitset_util.c:978-1141);
-//   run   : zero + toggle bits at every run start and end+1, then an inclusive prefix-XOR over
-//           the 65536 bits (in-word shifts + a cross-word parity carry obtained from one
-//           ballot per wave) -- O(1) work per word regardless of run lengths
-//           (replaces the serial bitset_set_lenrange loop, bitset_util.h:41-161).
-__device__ void lds_load(uint32_t* dst, const PoolView& V, uint32_t c, BlockScratch* sc) {
-    const uint32_t tid = threadIdx.x;
-    const uint8_t ty = V.type[c];
-    const uint8_t* p = V.arena + V.off[c];
-    if (ty == T_BITSET) {
-        const uint4* __restrict__ g = (const uint4*)p;
-        uint4 x0 = g[2 * tid], x1 = g[2 * tid + 1];
-        ((uint4*)dst)[2 * tid] = x0;
-        ((uint4*)dst)[2 * tid + 1] = x1;
-        __syncthreads();
-        return;
-    }
-    lds_zero(dst);
-    __syncthreads();
-    if (ty == T_ARRAY) {
-        const uint32_t n = V.card[c];
-        const uint32_t* __restrict__ a2 = (const uint32_t*)p;  // two values per dword, slot is 16-byte padded
-        for (uint32_t i = tid; 2 * i < n; i += 256) {
-            uint32_t v2 = a2[i];
-            uint32_t v = v2 & 0xFFFFu;
-            atomicOr(&dst[v >> 5], 1u << (v & 31));
-            if (2 * i + 1 < n) {
-                v = v2 >> 16;
-                atomicOr(&dst[v >> 5], 1u << (v & 31));
-            }
-        }
-        __syncthreads();
-        return;
-    }
-    {
-        const uint32_t n = V.nruns[c];
-        const uint32_t* __restrict__ r = (const uint32_t*)p;  // {u16 value, u16 length} little-endian
-        for (uint32_t i = tid; i < n; i += 256) {
-            uint32_t rl = r[i];
-            uint32_t s = rl & 0xFFFFu, e1 = s + (rl >> 16) + 1u;
-            atomicXor(&dst[s >> 5], 1u << (s & 31));
-            if (e1 < 65536u) atomicXor(&dst[e1 >> 5], 1u << (e1 & 31));
-        }
-        __syncthreads();
-        uint4 x0 = ((uint4*)dst)[2 * tid], x1 = ((uint4*)dst)[2 * tid + 1];
-        uint32_t w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-        uint32_t par = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) par ^= __popc(w[k]) & 1u;
-        const u64 m = __ballot(par != 0);
-        uint32_t carry = mbcnt(m) & 1u;
-        if (lane_id() == 0) sc->wsum[tid >> 6] = (uint32_t)__popcll(m) & 1u;
-        __syncthreads();
-        for (uint32_t wv = 0; wv < (tid >> 6); ++wv) carry ^= sc->wsum[wv];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            uint32_t x = w[k], y = x;
-            y ^= y << 1; y ^= y << 2; y ^= y << 4; y ^= y << 8; y ^= y << 16;
-            w[k] = carry ? ~y : y;
-            carry ^= __popc(x) & 1u;
-        }
-        ((uint4*)dst)[2 * tid] = make_uint4(w[0], w[1], w[2], w[3]);
-        ((uint4*)dst)[2 * tid + 1] = make_uint4(w[4], w[5], w[6], w[7]);
-        __syncthreads();
-    }
-}
-
-
 // Emit the LDS image `img` (result words also in r[8]) as a container of type ty into the
 // candidate slot.  stage is an 8 KiB LDS buffer for coalesced output of arrays / runs
 // (K5: bitset -> sorted u16 list by per-thread popcount + block prefix sum).

@@ -106,32 +106,20 @@ struct PartialBuf {  // chunk buffers of rhip_many_partials, recycled through th
 struct rhip_ctx_s {
     int device = 0;
     std::vector<PartialBuf> partial_cache;
-    PartialBuf take_partial_buf(uint64_t chunks) {
-        for (size_t i = 0; i < partial_cache.size(); ++i)
-            if (partial_cache[i].cap >= chunks) {
-                PartialBuf b = partial_cache[i];
-                partial_cache.erase(partial_cache.begin() + i);
-                return b;
-            }
-        PartialBuf b;
-        b.cap = chunks;
-        if (hipMalloc(&b.keys, 8 * chunks) != hipSuccess || hipMalloc(&b.words, 8192 * chunks) != hipSuccess) {
-            if (b.keys) (void)hipFree(b.keys);
-            set_err("hipMalloc of partial chunks failed");
-            throw (int)RHIP_ERR_ALLOC;
-        }
-        return b;
-    }
+    PartialBuf take_partial_buf(uint64_t chunks);
     hipStream_t stream = nullptr;
     // scratch (grow-only): candidate directory + queues + scan temporaries
     DBuf o_key, o_meta, o_slot, o_off, o_pair, flag, newidx, misc, misc2, prim_tmp, pair_acc;  // (pairwise batches: ss[] below)
     // Batches in flight (rhip_pairwise_begin .. _end): each has a slot = its own pinned staging of the batch description,
     // statistics area and completion word.  Device scratch is shared: the batches' kernels are ordered by the stream.
     static constexpr int N_SLOTS = RHIP_MAX_BATCHES_IN_FLIGHT;
-    void* h_stage[N_SLOTS] = {};  // grow-only
-    void* h_stage_dev[N_SLOTS] = {};  // the same memory as the device addresses it
+    // slot N_SLOTS belongs to the calls that are not batches (cardinality / predicate): they wait for their own
+    // completion, so they never find it busy and never touch the staging, scratch or timing events of a batch in flight
+    static constexpr int SYNC_SLOT = N_SLOTS;
+    void* h_stage[N_SLOTS + 1] = {};  // grow-only
+    void* h_stage_dev[N_SLOTS + 1] = {};  // the same memory as the device addresses it
     bool stage_kernel = true;  // small descriptions are pulled by k_stage_in (RHIP_STAGE_KERNEL=0: always a copy command)
-    size_t h_stage_cap[N_SLOTS] = {};
+    size_t h_stage_cap[N_SLOTS + 1] = {};
     bool slot_busy[N_SLOTS] = {};
     // device scratch of a pairwise batch (planning arrays, candidate directory, class queues, scan / tail words): one
     // set per slot, so that the planning kernels of a batch can run while the class kernels of the previous one do
@@ -142,7 +130,7 @@ struct rhip_ctx_s {
             for (auto* b : all) b->release();
             for (auto& b : q) b.release();
         }
-    } ss[N_SLOTS];
+    } ss[N_SLOTS + 1];
     hipEvent_t ev_plan[N_SLOTS] = {};
     bool plan_overlap = true;  // RHIP_PLAN_OVERLAP=0: the planning kernels of a batch always run on the main stream
     uint64_t plan_overlap_max_bytes = 2ull << 30;
@@ -150,6 +138,15 @@ struct rhip_ctx_s {
     void ensure_stage(int slot, size_t n);
     int acquire_slot();
     DBuf many[20];
+    // many-way path: pinned staging of the selection (ids + member prefix), the event that says the device has read
+    // it, totals / completion word / sticky error word inside h_pinned
+    void* h_many = nullptr;
+    size_t h_many_cap = 0;
+    hipEvent_t ev_many_stage = nullptr;
+    bool many_stage_pending = false;
+    int many_pf = 4;  // RHIP_MANY_PF: payload groups per lane k_many_l1 loads ahead (2 / 4 / 8)
+    int many_ch = 0;  // RHIP_MANY_CH: members per unit (tests of the multi-chunk / multi-unit paths on small inputs); 0 = by size
+    static constexpr size_t PINNED_MANY_FLAG_OFF = 2304, PINNED_MANY_TOT_OFF = 2560, PINNED_MANY_ERR_OFF = 2816;
     DBuf sel[5];  // pool_select / pool_convert scratch
     void* h_pinned = nullptr;  // small pinned readback area
     // completion word of the pairwise path (inside h_pinned): k_tail's last block writes the call's sequence number
@@ -164,8 +161,8 @@ struct rhip_ctx_s {
     double hclk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     rhip_stats_t stats{};
     bool timing = false;
-    hipEvent_t evs[RHIP_MAX_BATCHES_IN_FLIGHT][4]{};  // timing events: [slot][call start, call end, k_bb start, k_bb end]
-    hipEvent_t* ev = evs[0];                          // (calls that are not batches use slot 0's)
+    hipEvent_t evs[RHIP_MAX_BATCHES_IN_FLIGHT + 1][4]{};  // timing events: [slot][call start, call end, k_bb start, k_bb end]
+    hipEvent_t* ev = evs[RHIP_MAX_BATCHES_IN_FLIGHT];     // (calls that are not batches: the synchronous slot's)
     // independent class kernels of one batch run concurrently: fork after planning, join before compaction
     static constexpr int N_AUX = 3;
     hipStream_t aux[N_AUX]{};
@@ -209,6 +206,7 @@ struct rhip_pool_s {
     uint64_t arena_used = 0;
     bool pending = false;       // result of a batch that has begun and not ended: not usable yet
     int in_use = 0;             // batches in flight that read this pool as an operand: not recyclable yet
+    bool free_deferred = false; // rhip_pool_free arrived while in_use: the last batch to end frees it
     uint64_t compact_mark = 0;  // arena_used right after the last compaction (0: never updated in place), see rhip_pairwise_inplace
     // host mirror of the directory (filled lazily for serialization); planning only needs bm_start
     bool host_dir = false;
@@ -218,6 +216,10 @@ struct rhip_pool_s {
     std::vector<uint32_t> h_card, h_nruns;
     std::vector<uint64_t> h_cards;  // per-bitmap cardinalities cache
     std::vector<uint64_t> h_w;      // per-bitmap result-slot bound (k_bitmap_bounds), see fetch_bounds
+    std::vector<uint64_t> h_wm;     // the same bound as the many-way path needs it (runs by rounded cardinality)
+    uint64_t wm_total = 0;          // sum of h_wm
+    uint64_t n_keys_distinct = 0;   // 32-bit pools: distinct container keys in the pool (fetch_bounds)
+    uint64_t max_key = 0;           // largest container key in the pool
     std::vector<uint32_t> h_n;      // per-bitmap container count
     uint32_t max_n = 0;             // largest of them
     bool host_w = false;
@@ -272,12 +274,15 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         HIPCHK(hipEventCreateWithFlags(&c->ev_runs, hipEventDisableTiming));
         for (auto& e : c->ev_join) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto& e : c->ev_plan) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_many_stage, hipEventDisableTiming));
         if (const char* e = getenv("RHIP_NO_OVERLAP")) c->overlap = !(e[0] == '1');
         if (const char* e = getenv("RHIP_SPIN_WAIT")) c->spin_wait = !(e[0] == '0');
         if (const char* e = getenv("RHIP_EXPLICIT_UNITS")) c->explicit_units = atoi(e);
         if (const char* e = getenv("RHIP_STAGE_KERNEL")) c->stage_kernel = !(e[0] == '0');
         if (const char* e = getenv("RHIP_FORK_MIN_MB")) c->fork_min_bytes = (uint64_t)atoll(e) << 20;
         if (const char* e = getenv("RHIP_PLAN_OVERLAP")) c->plan_overlap = !(e[0] == '0');
+        if (const char* e = getenv("RHIP_MANY_PF")) c->many_pf = atoi(e);
+        if (const char* e = getenv("RHIP_MANY_CH")) c->many_ch = std::max(1, std::min(1024, atoi(e)));
         memset(c->h_pinned, 0, 4096);
         return c;
     } catch (int) {
@@ -302,6 +307,8 @@ extern "C" void rhip_ctx_destroy(rhip_ctx_t* c) {
     if (c->ev_runs) (void)hipEventDestroy(c->ev_runs);
     for (auto& e : c->ev_join) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_plan) if (e) (void)hipEventDestroy(e);
+    if (c->ev_many_stage) (void)hipEventDestroy(c->ev_many_stage);
+    if (c->h_many) (void)hipHostFree(c->h_many);
     for (auto& sc : c->ss) sc.release();
     (void)hipHostFree(c->h_pinned);
     (void)hipStreamDestroy(c->stream);
@@ -530,12 +537,27 @@ extern "C" rhip_pool_t* rhip_pool_from_portable64(rhip_ctx_t* ctx, size_t n, con
 
 extern "C" void rhip_pool_free(rhip_pool_t* P) {
     if (!P) return;
+    if (P->in_use > 0) {  // an operand of batches in flight: released by the last of them (rhip_pairwise_end)
+        P->free_deferred = true;
+        return;
+    }
     P->release();  // hipFree synchronises with the device; the context may already be gone
     delete P;
 }
 extern "C" uint32_t rhip_pool_size(const rhip_pool_t* P) { return P->n_bitmaps; }
 extern "C" uint64_t rhip_pool_containers(const rhip_pool_t* P) { return P->n_cont; }
 extern "C" int rhip_pool_is64(const rhip_pool_t* P) { return P->is64 ? 1 : 0; }
+namespace { static void fetch_bounds(rhip_pool_t* P); }
+extern "C" int rhip_pool_max_key(rhip_pool_t* P, uint64_t* out) {
+    try {
+        if (!P || !out) { set_err("null argument"); throw (int)RHIP_ERR_ARG; }
+        if (P->pending) { set_err("pool is the result of a batch still in flight"); throw (int)RHIP_ERR_ARG; }
+        DeviceGuard dguard_(P->ctx->device);
+        fetch_bounds(P);
+        *out = P->max_key;
+        return RHIP_OK;
+    } catch (int e) { return e; }
+}
 
 static void pool_payload_stats(rhip_pool_t* P, uint64_t out[4]) {
     rhip_ctx_t* c = P->ctx;
@@ -779,18 +801,38 @@ static void fetch_bounds(rhip_pool_t* P) {
     if (P->host_w) return;
     rhip_ctx_t* c = P->ctx;
     P->h_w.assign((size_t)P->n_bitmaps, 0);
+    P->h_wm.assign((size_t)P->n_bitmaps, 0);
     uint32_t census[3] = {0, 0, 0};
+    uint64_t nkeys = P->n_cont;
     if (P->n_bitmaps && P->n_cont) {
-        c->misc2.ensure(8 * (size_t)P->n_bitmaps + 64);
-        uint32_t* dcensus = (uint32_t*)((char*)c->misc2.p + 8 * (size_t)P->n_bitmaps);
-        HIPCHK(hipMemsetAsync(dcensus, 0, 12, c->stream));
-        hipLaunchKernelGGL(k_bitmap_bounds, dim3((unsigned)(((size_t)P->n_bitmaps * 64 + 255) / 256)), dim3(256), 0, c->stream,
-                           P->view(), P->n_bitmaps, c->misc2.as<u64>(), dcensus);
-        HIPCHK(hipMemcpyAsync(P->h_w.data(), c->misc2.p, 8 * (size_t)P->n_bitmaps, hipMemcpyDeviceToHost, c->stream));
+        const size_t nb = (size_t)P->n_bitmaps;
+        // misc2: W[nb] | Wmany[nb] | census (3 x u32, padded to 16 bytes) | distinct-key count, largest key (u64 each) |
+        // key bits (2048 x u32)
+        c->misc2.ensure(16 * nb + 32 + 8192 + 64);
+        u64* dw = c->misc2.as<u64>();
+        u64* dwm = dw + nb;
+        uint32_t* dcensus = (uint32_t*)(dwm + nb);
+        u64* dnk = (u64*)(dcensus + 4);
+        uint32_t* dbits = (uint32_t*)(dnk + 2);
+        HIPCHK(hipMemsetAsync(dcensus, 0, 32 + 8192, c->stream));
+        hipLaunchKernelGGL(k_bitmap_bounds, dim3((unsigned)((nb * 64 + 255) / 256)), dim3(256), 0, c->stream,
+                           P->view(), P->n_bitmaps, dw, dwm, dcensus, dnk + 1);
+        if (!P->is64) {
+            hipLaunchKernelGGL(k_key_mark, dim3((unsigned)std::min<uint64_t>((P->n_cont + 255) / 256, 2048)), dim3(256), 0,
+                               c->stream, P->key.as<u64>(), (u64)P->n_cont, dbits);
+            hipLaunchKernelGGL(k_key_count, dim3(1), dim3(256), 0, c->stream, dbits, dnk);
+            HIPCHK(hipMemcpyAsync(&nkeys, dnk, 8, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(hipMemcpyAsync(P->h_w.data(), dw, 8 * nb, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(P->h_wm.data(), dwm, 8 * nb, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(census, dcensus, 12, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(&P->max_key, dnk + 1, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     for (int t = 0; t < 3; ++t) P->census[t] = census[t] ? 1 : 0;
+    P->n_keys_distinct = nkeys;
+    P->wm_total = 0;
+    for (uint64_t w : P->h_wm) P->wm_total += w;
     P->h_n.resize((size_t)P->n_bitmaps);
     P->max_n = 0;
     for (uint32_t b = 0; b < P->n_bitmaps; ++b) {
@@ -977,7 +1019,6 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     SS.plan_in.ensure(stage_bytes + 16);
     SS.cand.ensure(4 * (N_SEC * S + 8));
     SS.cand_start.ensure(8 * (N_SEC * S + 8));
-    SS.match.ensure(4 * 256 * (NU + 1));
     SS.misc.ensure(8 * P.sc.n_words + 64);
     P.words = SS.misc.as<u64>();
     SS.q[CLS_BB].ensure(sizeof(BBItem) * (ub_match + 1));
@@ -1023,6 +1064,7 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     const uint32_t max_n = std::max(A->max_n, B->max_n);
     const uint32_t G = (!implicit || c->explicit_units == 2 || max_n > 128) ? 64u : (max_n > 64 ? 32u : 16u);
     P.plan_group = G;
+    SS.match.ensure(4 * (size_t)(4 * G) * (NU + 1));  // one word per directory entry of a unit (<= 4 G of them)
     const size_t plan_waves = G == 64 ? NU : (NU + 64 / G - 1) / (64 / G) + 1;
     unsigned gp = (unsigned)std::max<size_t>(1, (std::max<size_t>(plan_waves * 64, std::min<size_t>(zero_threads, 1 << 16)) + 255) / 256);
     const u64 n_scan = (u64)N_SEC * S;
@@ -1166,6 +1208,30 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
             }
 }
 
+// Wait until the last kernel of a call has published `seq` in its completion word (pinned memory): the host polls the
+// word (and the stream's state now and then, so that a device fault still surfaces) instead of blocking on the
+// stream, whose completion signal costs an interrupt and a wake-up.  RHIP_SPIN_WAIT=0: block on the stream.
+void wait_word(rhip_ctx_t* c, volatile uint64_t* flag, uint64_t seq) {
+    hipStream_t s = c->stream;
+    if (!c->spin_wait) {
+        HIPCHK(hipStreamSynchronize(s));
+        return;
+    }
+    for (uint32_t spins = 0;; ++spins) {
+        if (__atomic_load_n((const uint64_t*)flag, __ATOMIC_ACQUIRE) == seq) break;
+        if ((spins & 0x3FFFu) == 0x3FFFu) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipSuccess) {  // stream drained: the word is there now, or the kernel never ran
+                if (__atomic_load_n((const uint64_t*)flag, __ATOMIC_ACQUIRE) == seq) break;
+                set_err("the last kernel of the call finished without publishing its completion word");
+                throw (int)RHIP_ERR_DEVICE;
+            }
+            if (q != hipErrorNotReady) { set_err("device error while waiting: %s", hipGetErrorString(q)); throw (int)RHIP_ERR_DEVICE; }
+        }
+        __builtin_ia32_pause();
+    }
+}
+
 // many-way / flip paths: their statistics live at a fixed offset of ctx->misc (cleared by the caller)
 constexpr size_t MISC_STATS_OFF = 192;
 void finish_stats(rhip_ctx_t* c, const Stats* dstats, Stats* out, bool had_bb, uint64_t wait_seq = 0, int slot = 0);
@@ -1178,23 +1244,10 @@ void finish_stats(rhip_ctx_t* c, const Stats* dstats, Stats* out, bool had_bb, u
     hipStream_t s = c->stream;
     // dstats == nullptr: the last kernel of the call already wrote the totals into the pinned area
     if (dstats) HIPCHK(hipMemcpyAsync(c->h_pinned, dstats, sizeof(Stats), hipMemcpyDeviceToHost, s));
-    hipEvent_t* ev = c->evs[wait_seq ? slot : 0];
+    hipEvent_t* ev = c->evs[wait_seq ? slot : rhip_ctx_s::SYNC_SLOT];
     if (c->timing && !wait_seq) HIPCHK(hipEventRecord(ev[1], s));  // (a batch recorded its end when it was enqueued)
-    if (wait_seq && c->spin_wait && !dstats) {
-        volatile uint64_t* flag = c->done_flag(slot);
-        for (uint32_t spins = 0;; ++spins) {
-            if (__atomic_load_n((const uint64_t*)flag, __ATOMIC_ACQUIRE) == wait_seq) break;
-            if ((spins & 0x3FFFu) == 0x3FFFu) {
-                const hipError_t q = hipStreamQuery(s);
-                if (q == hipSuccess) {  // stream drained: the word is there now, or the kernel never ran
-                    if (__atomic_load_n((const uint64_t*)flag, __ATOMIC_ACQUIRE) == wait_seq) break;
-                    set_err("tail kernel finished without publishing its completion word");
-                    throw (int)RHIP_ERR_DEVICE;
-                }
-                if (q != hipErrorNotReady) { set_err("device error while waiting: %s", hipGetErrorString(q)); throw (int)RHIP_ERR_DEVICE; }
-            }
-            __builtin_ia32_pause();
-        }
+    if (wait_seq && !dstats) {
+        wait_word(c, c->done_flag(slot), wait_seq);
     } else {
         HIPCHK(hipStreamSynchronize(s));
     }
@@ -1310,6 +1363,9 @@ extern "C" rhip_pool_t* rhip_pairwise_end(rhip_batch_t* b) {
     const int slot = b->slot;
     --b->A->in_use;
     --b->B->in_use;
+    auto drop_deferred = [](rhip_pool_t* X) {
+        if (X->free_deferred && X->in_use == 0) { X->release(); delete X; }
+    };
     try {
         DeviceGuard dguard_(c->device);
         HostClock clk(c);
@@ -1321,15 +1377,22 @@ extern "C" rhip_pool_t* rhip_pairwise_end(rhip_batch_t* b) {
         for (int t = 0; t < 3; ++t) R->census[t] = st.n_type[t] ? 1 : 0;
         R->pending = false;
         c->slot_busy[slot] = false;
+        rhip_pool_t *A = b->A, *B = b->B;
         delete b;
+        drop_deferred(A);  // (the batch has completed: nothing reads the operands any more)
+        if (B != A) drop_deferred(B);
         clk.lap(5);
         return R;
     } catch (int e) {
         last_status() = e;
         c->slot_busy[slot] = false;
+        (void)hipStreamSynchronize(c->stream);
+        rhip_pool_t *A = b->A, *B = b->B;
         R->release();
         delete R;
         delete b;
+        drop_deferred(A);
+        if (B != A) drop_deferred(B);
         return nullptr;
     }
 }
@@ -1358,7 +1421,7 @@ extern "C" int rhip_pairwise_cardinality(rhip_ctx_t* c, rhip_op op_, rhip_pool_t
             if ((e = rhip_pool_cardinalities(B, cB.data())) != 0) throw e;
         }
         if (c->timing) HIPCHK(hipEventRecord(c->ev[0], s));
-        Plan P = plan(c, OP_AND, A, B, npairs, lhs, rhs, 1, c->acquire_slot(), s);
+        Plan P = plan(c, OP_AND, A, B, npairs, lhs, rhs, 1, rhip_ctx_s::SYNC_SLOT, s);
         OutView O{};
         PoolView VA = A->view(), VB = B->view();
         run_kernels(c, OP_AND, VA, VB, O, P, 1);

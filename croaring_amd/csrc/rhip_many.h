@@ -3,68 +3,271 @@
 //
 // The reference folds bitmap after bitmap into a growing answer ("for every key, OR all
 // containers with that key into one 8 KiB accumulator, then canonicalise",
-// roaring.c:2600-2682 + 2845-2856).  Here the same computation is a group-by-key:
-//   1. gather (key, container) members of the selected bitmaps, stable radix sort by key;
-//   2. split each key group into units of <= CH members;
-//   3. k_many_l1: one workgroup per unit accumulates its members into an LDS bitset
-//      (arrays: ds_or/ds_xor scatter by all four waves; bitsets: owner-thread word OR;
-//      runs: toggle + prefix-xor rasterisation into a second LDS image, then word OR);
-//   4. groups with one unit are canonicalised straight from LDS; groups with several units
-//      write 8 KiB partial chunks that k_many_l2 combines (same shape as the multi-GPU
-//      exchange: partial chunks -> owner -> combine -> canonicalise).
+// roaring.c:2600-2682 + 2845-2856).  Here the same computation is a group-by-key with ONE host wait at the end:
+//   k_many_gather   every member container of the selected bitmaps becomes (key, 64-bit DESCRIPTOR): payload offset,
+//                   type, size -- everything the accumulation needs, so nothing gathers from the pool directory later;
+//                   also clears the scan / totals scratch of the call
+//   (stable radix sort by key: members of one key stay in input-bitmap order)
+//   k_many_groups   ONE look-back pass: group heads, group starts / keys, per-group cardinality bound (a second
+//                   look-back sum, read off at the heads), positions of the last full-run / bitset member of a group
+//   k_many_units    ONE look-back pass over the groups: units of <= ch members per group, result-slot offsets
+//   k_many_l1       one workgroup per unit: the array members of the unit are ONE flattened stream of 16-byte payload
+//                   groups (every lane holds eight values whatever the cardinalities), four loads per lane in flight
+//                   while the previous four feed the LDS atomics; bitset members: owner-thread word OR; run members:
+//                   toggle + prefix-xor rasterisation.  Groups with one unit are canonicalised straight from LDS,
+//                   groups with several write 8 KiB partial chunks
+//   k_many_l2       combines the partial chunks of multi-unit groups (same shape as the multi-GPU exchange)
+//   k_many_copy     single-member groups keep their container unchanged
+//   k_many_tail     ONE look-back pass: drops empty (xor) results, writes the result directory, totals and the
+//                   completion word into pinned host memory
+// Every buffer is sized on the host from upper bounds (members, distinct keys of the pool, per-bitmap payload bounds);
+// every kernel takes its counts from device memory.
 #pragma once
 #include "rhip_kernels.h"
 
+// ------------------------------------------------------------------ member descriptors
+// bits 0..34  payload offset / 16 (arenas up to 512 GiB)
+// bits 35..36 container type
+// bit  37     cardinality == 65536
+// bits 38..53 n: array = cardinality (1..4096), bitset = cardinality - 1, run = number of runs (1..32768)
+// bits 54..62 run only: ceil(cardinality / 256) (1..256) -- an upper bound is all the slot sizing needs
+__device__ __forceinline__ u64 md_pack(u64 off, uint32_t ty, uint32_t card, uint32_t nruns) {
+    const uint32_t n = ty == T_ARRAY ? card : (ty == T_BITSET ? card - 1u : nruns);
+    const uint32_t rq = ty == T_RUN ? (card + 255u) >> 8 : 0u;
+    return (off >> 4) | ((u64)ty << 35) | ((u64)(card == 65536u ? 1u : 0u) << 37) | ((u64)n << 38) | ((u64)rq << 54);
+}
+__device__ __forceinline__ u64 md_off(u64 d) { return (d & ((1ull << 35) - 1ull)) << 4; }
+__device__ __forceinline__ uint32_t md_type(u64 d) { return (uint32_t)(d >> 35) & 3u; }
+__device__ __forceinline__ bool md_full(u64 d) { return ((d >> 37) & 1ull) != 0; }
+__device__ __forceinline__ uint32_t md_n(u64 d) { return (uint32_t)(d >> 38) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t md_card_ub(u64 d) {  // >= the cardinality, exact for arrays and bitsets
+    const uint32_t ty = md_type(d);
+    return ty == T_ARRAY ? md_n(d) : (ty == T_BITSET ? md_n(d) + 1u : ((uint32_t)(d >> 54) & 0x1FFu) << 8);
+}
+__device__ __forceinline__ uint32_t md_payload(u64 d) {
+    const uint32_t ty = md_type(d);
+    return ty == T_BITSET ? 8192u : (ty == T_ARRAY ? 2u * md_n(d) : 4u * md_n(d));
+}
+
+// device-side totals of one call (inside the zeroed scratch words); the last kernel copies them to pinned memory
+struct ManyTotals {
+    u64 n_groups, n_units, slot_bytes, kept, bytes_in, bytes_out, n_type[3], max_key, err;
+};
+#define MANY_ERR_KEYSPACE 1ull
+
 struct ManyView {
     const u64* skey;        // [M] sorted member keys
-    const uint32_t* sval;   // [M] member container index (into the pool directory)
+    const u64* sdesc;       // [M] member descriptors, same order
     const u64* gstart;      // [G+1] first member of each group
     const u64* ustart;      // [G+1] first unit of each group
-    const uint32_t* n_groups;  // device scalar
-    uint32_t ch;            // members per unit
+    const u64* pstart;      // [G+1] first partial-chunk slot of each group (groups with several units)
+    const ManyTotals* tot;  // n_groups / n_units live here
+    uint32_t ch;            // members per unit (upper bound, <= 1024)
+};
+struct ManyZero {   // scratch the first kernel of a call clears for the later ones
+    u64* words; u64 n_words;
+    uint32_t* glast; u64 n_glast;
+    u64* table; u64 n_table;   // dense stage-1 table of the sharded form (u64 words), may be null
 };
 
-// wave per selected bitmap: append its (key, container index) members
+// members of the selected bitmaps -> (key, descriptor).  ids == null: every bitmap of the pool, one thread per container.
 __global__ __launch_bounds__(256) void k_many_gather(PoolView P, const uint32_t* __restrict__ ids,
-                                                     const u64* __restrict__ sel_start, uint32_t nsel,
-                                                     u64* __restrict__ mkey, uint32_t* __restrict__ mval) {
-    uint32_t s = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (s >= nsel) return;
-    const uint32_t b = ids[s];
-    const u64 c0 = P.bm_start[b], c1 = P.bm_start[b + 1], d0 = sel_start[s];
-    for (u64 i = c0 + lane_id(); i < c1; i += 64) {
-        mkey[d0 + (i - c0)] = P.key[i];
-        mval[d0 + (i - c0)] = (uint32_t)i;
+                                                     const u64* __restrict__ sel_start, uint32_t nsel, u64 M,
+                                                     u64* __restrict__ mkey, u64* __restrict__ mdesc, ManyZero Z) {
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x, nth = (u64)gridDim.x * blockDim.x;
+    for (u64 i = gid; i < Z.n_words; i += nth) Z.words[i] = 0;
+    for (u64 i = gid; i < Z.n_glast; i += nth) Z.glast[i] = 0;
+    for (u64 i = gid; i < Z.n_table; i += nth) Z.table[i] = 0;
+    if (!ids) {
+        for (u64 i = gid; i < M; i += nth) {
+            mkey[i] = P.key[i];
+            mdesc[i] = md_pack(P.off[i], P.type[i], P.card[i], P.nruns[i]);
+        }
+        return;
+    }
+    const u64 nw = nth >> 6;
+    for (u64 s = gid >> 6; s < nsel; s += nw) {
+        const uint32_t b = ids[s];
+        const u64 c0 = P.bm_start[b], c1 = P.bm_start[b + 1], d0 = sel_start[s];
+        for (u64 i = c0 + lane_id(); i < c1; i += 64) {
+            mkey[d0 + (i - c0)] = P.key[i];
+            mdesc[d0 + (i - c0)] = md_pack(P.off[i], P.type[i], P.card[i], P.nruns[i]);
+        }
     }
 }
 
-__global__ void k_many_heads(const u64* __restrict__ skey, u64 M, uint32_t* __restrict__ flag) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < M) flag[i] = (i == 0 || skey[i] != skey[i - 1]) ? 1u : 0u;
-    if (i == M) flag[i] = 0;
-}
-// gid = exclusive scan of flag (so head i belongs to group gid[i]); gid[M] = number of groups
-__global__ void k_many_gstart(const uint32_t* __restrict__ flag, const u64* __restrict__ gid, u64 M,
-                              u64* __restrict__ gstart, uint32_t* __restrict__ n_groups) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < M && flag[i]) gstart[gid[i]] = i;
-    if (i == M) {
-        gstart[gid[M]] = M;
-        *n_groups = (uint32_t)gid[M];
+constexpr uint32_t MANY_TILE = 2048;  // elements per block of the look-back passes: 256 threads x 8, lane-contiguous
+struct ManyLb {
+    u64* status_a;      // first look-back chain
+    u64* status_b;      // second chain (same tile numbering)
+    uint32_t* ticket;
+};
+// exclusive prefixes of the block's 32 (k, wave) partial sums in sa / sb (LDS) and the tile's two global prefixes:
+// wave 0 walks chain a, wave 1 chain b.  On return sa / sb hold the exclusive prefixes inside the tile, *pa / *pb
+// (LDS) the prefixes in front of the tile; returns the tile totals through ta / tb (LDS).
+__device__ __forceinline__ void many_two_scans(uint32_t* sa, uint32_t* sb, const ManyLb& lb, uint32_t tile, u64* pa,
+                                               u64* pb, u64* ta, u64* tb) {
+    const uint32_t wv = threadIdx.x >> 6, lane = lane_id();
+    __syncthreads();
+    if (wv < 2) {
+        uint32_t* s = wv ? sb : sa;
+        const uint32_t v = lane < 32 ? s[lane] : 0u;
+        const uint32_t inc = wave_incl_scan(v);
+        if (lane < 32) s[lane] = inc - v;
+        const u64 tot = __shfl(inc, 63);
+        const u64 pfx = lb_exclusive_prefix(wv ? lb.status_b : lb.status_a, tile, tot);
+        if (lane == 0) { *(wv ? pb : pa) = pfx; *(wv ? tb : ta) = tot; }
     }
+    __syncthreads();
 }
-// per group: number of units; also the group's key
-__global__ void k_many_units(const u64* __restrict__ gstart, const u64* __restrict__ skey,
-                             const uint32_t* __restrict__ n_groups, uint32_t ch, uint32_t* __restrict__ nunits,
-                             u64* __restrict__ gkey, u64 maxg) {
-    u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u64 G = *n_groups;
-    if (g < G) {
-        u64 cnt = gstart[g + 1] - gstart[g];
-        nunits[g] = (uint32_t)((cnt + ch - 1) / ch);
-        gkey[g] = skey[gstart[g]];
-    } else if (g <= maxg) {
-        nunits[g] = 0;
+
+// group heads -> group ids; gstart / gkey / cardinality-bound prefix at the heads; glast[2g], glast[2g+1] = member
+// index + 1 of the group's LAST full-run member and LAST bitset member (0 = none) for the replay of
+// roaring_bitmap_or_many's full-union typing (full_union_is_run below).  A key present in every bitmap of a
+// 100 000-bitmap set has 100 000 members (BASELINE config C4's key 0): nothing here is per-group serial.
+__global__ __launch_bounds__(256) void k_many_groups(const u64* __restrict__ skey, const u64* __restrict__ sdesc, u64 M,
+                                                     ManyLb lb, u64* __restrict__ gstart, u64* __restrict__ gcs,
+                                                     u64* __restrict__ gkey, uint32_t* __restrict__ glast,
+                                                     ManyTotals* __restrict__ tot) {
+    __shared__ uint32_t s_h[32], s_c[32];
+    __shared__ uint32_t s_tile;
+    __shared__ u64 s_ph, s_pc, s_th, s_tc;
+    __shared__ u64 s_bytes[4];
+    if (threadIdx.x == 0) s_tile = atomicAdd(lb.ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    if ((u64)tile * MANY_TILE >= M) return;
+    const uint32_t wv = threadIdx.x >> 6, lane = lane_id();
+    const u64 tbase = (u64)tile * MANY_TILE + threadIdx.x;
+    u64 key[8], d[8];
+    bool head[8];
+    uint32_t rankh[8], cex[8], cu[8];
+    u64 bytes = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const u64 i = tbase + 256ull * k;
+        const bool in = i < M;
+        key[k] = in ? skey[i] : 0;
+        const u64 prev = (in && i) ? skey[i - 1] : 0;
+        d[k] = in ? sdesc[i] : 0;
+        head[k] = in && (i == 0 || key[k] != prev);
+        cu[k] = in ? md_card_ub(d[k]) : 0u;
+        bytes += in ? md_payload(d[k]) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const u64 bal = __ballot(head[k]);
+        rankh[k] = mbcnt(bal);
+        const uint32_t inc = wave_incl_scan(cu[k]);
+        cex[k] = inc - cu[k];
+        const uint32_t wtot = __shfl(inc, 63);
+        if (lane == 0) { s_h[4 * k + wv] = (uint32_t)__popcll(bal); s_c[4 * k + wv] = wtot; }
+    }
+    many_two_scans(s_h, s_c, lb, tile, &s_ph, &s_pc, &s_th, &s_tc);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const u64 i = tbase + 256ull * k;
+        const bool in = i < M;
+        const u64 hex = s_ph + s_h[4 * k + wv] + rankh[k];  // heads strictly before i
+        const u64 g = hex + (head[k] ? 1u : 0u) - 1u;       // (i in => at least one head at or before i)
+        const u64 cpre = s_pc + s_c[4 * k + wv] + cex[k];
+        if (head[k]) { gstart[g] = i; gkey[g] = key[k]; gcs[g] = cpre; }
+        if (in && i == M - 1) {
+            gstart[g + 1] = M; gcs[g + 1] = cpre + cu[k];
+            tot->n_groups = g + 1; tot->max_key = key[k];
+        }
+        // last full-run / last bitset member of the group.  At a fixed k the wave's members are consecutive, so when
+        // the flagged ones share a group only the highest lane needs to publish.
+        const uint32_t ty = md_type(d[k]);
+        const bool frf = in && ty == T_RUN && md_full(d[k]), fb = in && ty == T_BITSET;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const bool f = x ? fb : frf;
+            const u64 m = __ballot(f);
+            if (m) {
+                const int top = 63 - __clzll((long long)m);
+                const u64 gtop = (u64)__shfl((uint32_t)g, top) | ((u64)__shfl((uint32_t)(g >> 32), top) << 32);
+                const bool same = __ballot(f && g != gtop) == 0;
+                if (same ? (int)lane == top : f) atomicMax(&glast[2 * g + x], (uint32_t)i + 1u);
+            }
+        }
+    }
+    bytes = wave_sum64(bytes);
+    if (lane == 0) s_bytes[wv] = bytes;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&tot->bytes_in, s_bytes[0] + s_bytes[1] + s_bytes[2] + s_bytes[3]);
+}
+
+// per group: number of units, partial-chunk slots (the units of a group that has several) and the result-slot size
+// (upper bound on the canonical result payload); look-back sums give the first unit / first partial slot of the group
+// and the byte offset of its result slot.  Element G (one past the last group) carries the totals.
+// Chain a carries units and partial slots packed in one word (units < 2^33, partial slots < 2^29).
+__global__ __launch_bounds__(256) void k_many_units(const u64* __restrict__ sdesc, const u64* __restrict__ gstart,
+                                                    const u64* __restrict__ gcs, uint32_t ch, int force_typed, ManyLb lb,
+                                                    u64* __restrict__ ustart, u64* __restrict__ pstart,
+                                                    u64* __restrict__ off, ManyTotals* __restrict__ tot) {
+    __shared__ uint32_t s_u[32], s_s[32], s_p[32];
+    __shared__ uint32_t s_tile;
+    __shared__ u64 s_pu, s_pp, s_ps;
+    if (threadIdx.x == 0) s_tile = atomicAdd(lb.ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const u64 G = tot->n_groups;
+    if ((u64)tile * MANY_TILE > G) return;  // (element G is the sentinel)
+    const uint32_t wv = threadIdx.x >> 6, lane = lane_id();
+    const u64 tbase = (u64)tile * MANY_TILE + threadIdx.x;
+    uint32_t nun[8], sl[8], uex[8], sex[8], pex[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const u64 g = tbase + 256ull * k;
+        nun[k] = 0; sl[k] = 0;
+        if (g < G) {
+            const u64 gs = gstart[g], cnt = gstart[g + 1] - gs;
+            nun[k] = (uint32_t)((cnt + ch - 1) / ch);
+            uint32_t sz;
+            if (cnt == 1 && !force_typed) {
+                sz = align16(md_payload(sdesc[gs]));
+            } else {
+                const u64 c = gcs[g + 1] - gcs[g];
+                sz = c >= 4096ull ? 8192u : align16(2u * (uint32_t)c);
+            }
+            sl[k] = (sz < 16u ? 16u : sz) >> 4;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t np = nun[k] > 1u ? nun[k] : 0u;
+        const uint32_t iu = wave_incl_scan(nun[k]), is = wave_incl_scan(sl[k]), ip = wave_incl_scan(np);
+        uex[k] = iu - nun[k]; sex[k] = is - sl[k]; pex[k] = ip - np;
+        const uint32_t tu = __shfl(iu, 63), ts = __shfl(is, 63), tp = __shfl(ip, 63);
+        if (lane == 0) { s_u[4 * k + wv] = tu; s_s[4 * k + wv] = ts; s_p[4 * k + wv] = tp; }
+    }
+    __syncthreads();
+    if (wv == 0) {
+        const uint32_t vu = lane < 32 ? s_u[lane] : 0u, vp = lane < 32 ? s_p[lane] : 0u;
+        const uint32_t iu = wave_incl_scan(vu), ip = wave_incl_scan(vp);
+        if (lane < 32) { s_u[lane] = iu - vu; s_p[lane] = ip - vp; }
+        const u64 agg = ((u64)__shfl(iu, 63) << 29) | (u64)__shfl(ip, 63);
+        const u64 pfx = lb_exclusive_prefix(lb.status_a, tile, agg);
+        if (lane == 0) { s_pu = pfx >> 29; s_pp = pfx & ((1ull << 29) - 1ull); }
+    } else if (wv == 1) {
+        const uint32_t vs = lane < 32 ? s_s[lane] : 0u;
+        const uint32_t is = wave_incl_scan(vs);
+        if (lane < 32) s_s[lane] = is - vs;
+        const u64 pfx = lb_exclusive_prefix(lb.status_b, tile, (u64)__shfl(is, 63));
+        if (lane == 0) s_ps = pfx;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const u64 g = tbase + 256ull * k;
+        if (g <= G) {
+            const u64 pu = s_pu + s_u[4 * k + wv] + uex[k], ps = 16ull * (s_ps + s_s[4 * k + wv] + sex[k]);
+            ustart[g] = pu;
+            pstart[g] = s_pp + s_p[4 * k + wv] + pex[k];
+            off[g] = ps;
+            if (g == G) { tot->n_units = pu; tot->slot_bytes = ps; }
+        }
     }
 }
 
@@ -79,78 +282,16 @@ __device__ __forceinline__ uint32_t unit_group(const u64* __restrict__ ustart, u
     return (uint32_t)lo;
 }
 
-// wave per unit: sum of member cardinalities -> gcard[group]; single-member groups also
-// record their payload size (pass-through slot)
-// ... and, for the replay of roaring_bitmap_or_many's full-union typing (full_union_is_run), where the group's LAST
-// full-run member and LAST bitset member sit (position relative to the group start, +1; 0 = none): glast[2g],
-// glast[2g+1].  A key present in every bitmap of a 100 000-bitmap set has 100 000 members (BASELINE config C4's key
-// 0): finding these two positions inside the finalising workgroup cost it 0.3 ms of dependent loads.
-__global__ __launch_bounds__(256) void k_many_cardsum(PoolView P, ManyView V, const u64* __restrict__ n_units,
-                                                      u64* __restrict__ gcard, uint32_t* __restrict__ glast) {
-    const u64 u = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (u >= *n_units) return;
-    const uint32_t G = *V.n_groups;
-    const uint32_t g = unit_group(V.ustart, G, u);
-    const u64 m0 = V.gstart[g] + (u - V.ustart[g]) * V.ch;
-    const u64 m1 = (m0 + V.ch < V.gstart[g + 1]) ? m0 + V.ch : V.gstart[g + 1];
-    u64 s = 0;
-    uint32_t lrf = 0, lb = 0;
-    const u64 gs = V.gstart[g];
-    for (u64 m = m0 + lane_id(); m < m1; m += 64) {
-        const uint32_t c = V.sval[m];
-        const uint32_t cd = P.card[c];
-        const uint8_t ty = P.type[c];
-        s += cd;
-        if (ty == T_RUN && cd == 65536u) lrf = (uint32_t)(m - gs) + 1u;
-        if (ty == T_BITSET) lb = (uint32_t)(m - gs) + 1u;
-    }
-    s = wave_sum64(s);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t a = __shfl_xor(lrf, o), b = __shfl_xor(lb, o);
-        lrf = a > lrf ? a : lrf;
-        lb = b > lb ? b : lb;
-    }
-    if (lane_id() == 0) {
-        atomicAdd(&gcard[g], s);
-        if (lrf) atomicMax(&glast[2 * (u64)g], lrf);
-        if (lb) atomicMax(&glast[2 * (u64)g + 1], lb);
-    }
-}
-
-// slot size of every group (upper bound on the canonical result payload)
-__global__ void k_many_slots(PoolView P, ManyView V, const u64* __restrict__ gcard, int force_typed,
-                             uint32_t* __restrict__ slot, u64 maxg) {
-    u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u64 G = *V.n_groups;
-    if (g < G) {
-        u64 cnt = V.gstart[g + 1] - V.gstart[g];
-        uint32_t sz;
-        if (cnt == 1 && !force_typed) {
-            uint32_t c = V.sval[V.gstart[g]];
-            sz = align16(payload_bytes(P.type[c], P.card[c], P.nruns[c]));
-        } else {
-            u64 ub = gcard[g] > 65536ull ? 65536ull : gcard[g];
-            sz = align16((uint32_t)(2 * ub > 8192 ? 8192 : 2 * ub));
-        }
-        slot[g] = sz < 16u ? 16u : sz;
-    } else if (g <= maxg) {
-        slot[g] = 0;
-    }
-}
-
-// Accumulate the members [m0, m1) into the LDS image acc (zeroed by the caller).
-// Member lists built during phase A (relative member indices; a unit has at most 1024 members)
-struct ManyLists {
-    uint32_t n_bitset, n_run;
-    uint16_t bitset[1024], run[1024];
+// ------------------------------------------------------------------ accumulation of one unit into an LDS image
+constexpr uint32_t MANY_CHUNK = 512;  // members staged at a time (a unit has at most 1024)
+struct ManyLists {  // bitset / run members of the chunk (relative member indices), listed by the staging pass
+    uint32_t n_bitset, n_run, n_g16, pad;
+    uint16_t bitset[MANY_CHUNK], run[MANY_CHUNK];
 };
 // During the array scatter the image is addressed through an XOR swizzle of the low 5 word-index bits:
-// arrays whose values are spaced by a multiple of 1024 (any regular stride, e.g. the stratified C4 data)
-// would otherwise put every lane of a ds_or on the same LDS bank.  (On C4 itself the kernel is bound by
-// the random 512-byte member gathers -- ~2 TB/s incl. directory sectors -- so this is insurance, not a
-// measured win.)  The swizzle is an involution inside each aligned 32-word block: one pass converts
-// either way.
+// arrays whose values are spaced by a multiple of 1024 (any regular stride, e.g. stratified data)
+// would otherwise put every lane of a ds_or on the same LDS bank.  The swizzle is an involution inside each
+// aligned 32-word block: one pass converts either way.
 __device__ __forceinline__ uint32_t mswz(uint32_t w) { return w ^ ((w >> 5) & 31u); }
 __device__ __forceinline__ void many_swizzle_pass(uint32_t* acc) {
     const uint32_t tid = threadIdx.x;
@@ -163,90 +304,168 @@ __device__ __forceinline__ void many_swizzle_pass(uint32_t* acc) {
     __syncthreads();
 }
 
-__device__ void many_accumulate_chunk(uint32_t* acc, uint32_t* tmp, const PoolView& P, const ManyView& V, u64 m0,
-                                      u64 m1, int op, BlockScratch* sc, ManyLists* ml) {
+// Rasterise a run container (toggle bits at every run start and end + 1, then an inclusive prefix-XOR over the 65536
+// bits, see lds_load in rhip_block.h) given by its descriptor into dst.
+__device__ void many_raster_runs(uint32_t* dst, const uint8_t* __restrict__ arena, u64 d, BlockScratch* sc) {
+    const uint32_t tid = threadIdx.x;
+    lds_zero(dst);
+    __syncthreads();
+    const uint32_t n = md_n(d);
+    const uint32_t* __restrict__ r = (const uint32_t*)(arena + md_off(d));
+    for (uint32_t i = tid; i < n; i += 256) {
+        const uint32_t rl = r[i];
+        const uint32_t s = rl & 0xFFFFu, e1 = s + (rl >> 16) + 1u;
+        atomicXor(&dst[s >> 5], 1u << (s & 31));
+        if (e1 < 65536u) atomicXor(&dst[e1 >> 5], 1u << (e1 & 31));
+    }
+    __syncthreads();
+    uint4 x0 = ((uint4*)dst)[2 * tid], x1 = ((uint4*)dst)[2 * tid + 1];
+    uint32_t w[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    uint32_t par = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) par ^= __popc(w[k]) & 1u;
+    const u64 m = __ballot(par != 0);
+    uint32_t carry = mbcnt(m) & 1u;
+    if (lane_id() == 0) sc->wsum[tid >> 6] = (uint32_t)__popcll(m) & 1u;
+    __syncthreads();
+    for (uint32_t wv = 0; wv < (tid >> 6); ++wv) carry ^= sc->wsum[wv];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        uint32_t x = w[k], y = x;
+        y ^= y << 1; y ^= y << 2; y ^= y << 4; y ^= y << 8; y ^= y << 16;
+        w[k] = carry ? ~y : y;
+        carry ^= __popc(x) & 1u;
+    }
+    ((uint4*)dst)[2 * tid] = make_uint4(w[0], w[1], w[2], w[3]);
+    ((uint4*)dst)[2 * tid + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+    __syncthreads();
+}
+
+// Accumulate the members [m0, m1) (at most MANY_CHUNK of them) into the LDS image acc.
+// `tmp` (8 KiB) first holds the staging tables of the array stream -- g16[j] = number of 16-byte payload groups of the
+// chunk's array members in front of member j, and the members' descriptors -- and later the rasterised run members.
+template <int PF>
+__device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* tmp, const uint8_t* __restrict__ arena,
+                                      const u64* __restrict__ sdesc, u64 m0, u64 m1, int op, BlockScratch* sc,
+                                      ManyLists* ml) {
     const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const uint32_t nm = (uint32_t)(m1 - m0);
+    uint32_t* g16 = tmp;                          // [MANY_CHUNK + 1]
+    u64* mdl = (u64*)(tmp + MANY_CHUNK + 2);      // [MANY_CHUNK] (8-byte aligned: MANY_CHUNK + 2 is even)
     __syncthreads();
     if (tid == 0) { ml->n_bitset = 0; ml->n_run = 0; }
     many_swizzle_pass(acc);  // linear -> swizzled (ends with a barrier)
-    // phase A: array members, LDS atomics (commutative: no ordering needed).  Each wave takes 64
-    // members at a time: their directory entries are fetched lane-parallel (one member per lane) and
-    // broadcast with shuffles, and members are consumed four at a time so that four independent
-    // 16-byte payload loads per lane are in flight before the first LDS atomic needs one of them
-    // (a member is a few hundred bytes at a random arena offset: this loop is latency-, not
-    // bandwidth-limited unless loads overlap).
-    for (u64 mb = m0 + 64ull * wave; mb < m1; mb += 256) {
-        const u64 mi = mb + lane;
-        uint32_t cd = 0, of_lo = 0, of_hi = 0;
-        if (mi < m1) {
-            const uint32_t c = V.sval[mi];
-            const uint8_t ty = P.type[c];
-            if (ty == T_ARRAY) {
-                cd = P.card[c];
-                const u64 of = P.off[c];
-                of_lo = (uint32_t)of; of_hi = (uint32_t)(of >> 32);
-            } else if (ty == T_BITSET) {
-                ml->bitset[atomicAdd(&ml->n_bitset, 1u)] = (uint16_t)(mi - m0);
-            } else {
-                ml->run[atomicAdd(&ml->n_run, 1u)] = (uint16_t)(mi - m0);
-            }
+    // ---- staging: descriptors, lists of the bitset / run members, prefix of the array members' 16-byte groups
+    uint32_t carry = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < MANY_CHUNK / 256; ++r) {
+        const uint32_t j = 256u * r + tid;
+        uint32_t ng = 0;
+        if (j < nm) {
+            const u64 d = sdesc[m0 + j];
+            mdl[j] = d;
+            const uint32_t ty = md_type(d);
+            if (ty == T_ARRAY) ng = (md_n(d) + 7u) >> 3;
+            else if (ty == T_BITSET) ml->bitset[atomicAdd(&ml->n_bitset, 1u)] = (uint16_t)j;
+            else ml->run[atomicAdd(&ml->n_run, 1u)] = (uint16_t)j;
         }
-        const uint32_t cnt = (uint32_t)((m1 - mb) < 64 ? (m1 - mb) : 64);
-        for (uint32_t k = 0; k < cnt; k += 4) {
-            uint4 q4[4];
-            uint32_t cdk[4];
-            const uint4* pk[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t src = (k + u < cnt) ? k + u : k;
-                cdk[u] = (k + u < cnt) ? __shfl(cd, src) : 0u;
-                const u64 of = (u64)__shfl(of_lo, src) | ((u64)__shfl(of_hi, src) << 32);
-                pk[u] = (const uint4*)(P.arena + of);
-                q4[u] = (8 * lane < cdk[u]) ? pk[u][lane] : make_uint4(0, 0, 0, 0);
+        uint32_t tot;
+        const uint32_t ex = blk_exscan(ng, sc->wsum, &tot);
+        if (j < nm) g16[j] = carry + ex;
+        carry += tot;
+    }
+    if (tid == 0) { g16[nm] = carry; ml->n_g16 = carry; }
+    __syncthreads();
+    // ---- phase A: the array members as one flattened stream of 16-byte groups, LDS atomics (commutative: no ordering
+    // needed).  Wave w takes a contiguous quarter of the stream, 64 groups (1 KiB) per step, every lane eight values
+    // whatever the members' cardinalities; the member of a group is found by advancing a per-lane cursor over g16[]
+    // (consecutive steps are 64 groups apart: a couple of members).  FOUR steps are loaded ahead while the previous
+    // four feed the atomics: a member is a few hundred bytes at a random arena offset, so this loop is latency-bound
+    // unless enough loads overlap (one load round trip per four members and wave held k_many_l1 at 1.8 TB/s on the
+    // 100 000 sparse bitmaps of BASELINE config C4).
+    {
+        const uint32_t T = carry;
+        const uint32_t nc = (T + 63u) >> 6;
+        const uint32_t c0 = wave * nc / 4u, c1 = (wave + 1u) * nc / 4u;
+        uint32_t m = 0;
+        if (c0 < c1) {  // cursor: largest member index with g16[m] <= first group of this lane
+            const uint32_t q = 64u * c0 + lane < T ? 64u * c0 + lane : T - 1u;
+            uint32_t lo = 0, hi = nm;
+            while (lo + 1u < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (g16[mid] <= q) lo = mid;
+                else hi = mid;
             }
+            m = lo;
+        }
+        uint4 cur[PF], nxt[PF];
+        uint32_t cn[PF], nn[PF];
+        auto fetch = [&](uint32_t c, uint4& x, uint32_t& nv) {
+            const uint32_t q = 64u * c + lane;
+            nv = 0;
+            x = make_uint4(0, 0, 0, 0);
+            if (c < c1 && q < T) {
+                while (g16[m + 1u] <= q) ++m;  // (members without array payload span no groups and are stepped over)
+                const u64 d = mdl[m];
+                const uint32_t j = q - g16[m], card = md_n(d);
+                nv = card - 8u * j < 8u ? card - 8u * j : 8u;
+                x = ((const uint4*)(arena + md_off(d)))[j];
+            }
+        };
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                for (uint32_t i = lane; 8 * i < cdk[u]; i += 64) {
-                    const uint4 x = (i == lane) ? q4[u] : pk[u][i];
-                    const uint32_t d[4] = {x.x, x.y, x.z, x.w};
+        for (int p = 0; p < PF; ++p) fetch(c0 + p, cur[p], cn[p]);
+        for (uint32_t c = c0; c < c1; c += PF) {
 #pragma unroll
-                    for (int h = 0; h < 8; ++h) {
-                        if (8 * i + h < cdk[u]) {
-                            const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
-                            if (op == OP_OR) atomicOr(&acc[mswz(v >> 5)], 1u << (v & 31));
-                            else atomicXor(&acc[mswz(v >> 5)], 1u << (v & 31));
-                        }
+            for (int p = 0; p < PF; ++p) fetch(c + PF + p, nxt[p], nn[p]);
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                const uint32_t dd[4] = {cur[p].x, cur[p].y, cur[p].z, cur[p].w};
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    if ((uint32_t)h < cn[p]) {
+                        const uint32_t v = (dd[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                        if (op == OP_OR) atomicOr(&acc[mswz(v >> 5)], 1u << (v & 31));
+                        else atomicXor(&acc[mswz(v >> 5)], 1u << (v & 31));
                     }
                 }
             }
+#pragma unroll
+            for (int p = 0; p < PF; ++p) { cur[p] = nxt[p]; cn[p] = nn[p]; }
         }
     }
     __syncthreads();
     many_swizzle_pass(acc);  // swizzled -> linear
     __syncthreads();
-    // phase B: bitset members (listed by phase A), thread-owned words.  XOR/OR are commutative, so the
-    // arbitrary list order is fine.
+    // ---- phase B: bitset members, thread-owned words, four members' loads in flight.  XOR / OR are commutative, so
+    // the arbitrary list order is fine.
     {
         const uint32_t nb = ml->n_bitset;
         if (nb) {
             uint4 r0 = ((uint4*)acc)[2 * tid], r1 = ((uint4*)acc)[2 * tid + 1];
-            for (uint32_t k = 0; k < nb; ++k) {
-                const uint32_t c = V.sval[m0 + ml->bitset[k]];
-                const uint4* __restrict__ g = (const uint4*)(P.arena + P.off[c]);
-                r0 = op4(op, r0, g[2 * tid]);
-                r1 = op4(op, r1, g[2 * tid + 1]);
+            for (uint32_t k = 0; k < nb; k += 4) {
+                uint4 a[4], b[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) {
+                    a[u] = make_uint4(0, 0, 0, 0); b[u] = a[u];
+                    if (k + u < nb) {
+                        const uint4* __restrict__ g = (const uint4*)(arena + md_off(sdesc[m0 + ml->bitset[k + u]]));
+                        a[u] = g[2 * tid];
+                        b[u] = g[2 * tid + 1];
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) { r0 = op4(op, r0, a[u]); r1 = op4(op, r1, b[u]); }  // (x op 0 = x for or / xor)
             }
             ((uint4*)acc)[2 * tid] = r0;
             ((uint4*)acc)[2 * tid + 1] = r1;
         }
     }
     __syncthreads();
-    // phase C: run members, rasterised one at a time into tmp
+    // ---- phase C: run members, rasterised one at a time into tmp (the staging tables are dead by now)
     {
         const uint32_t nr = ml->n_run;
         for (uint32_t k = 0; k < nr; ++k) {
-            const uint32_t c = V.sval[m0 + ml->run[k]];
-            lds_load(tmp, P, c, sc);
+            many_raster_runs(tmp, arena, sdesc[m0 + ml->run[k]], sc);
             uint4 r0 = ((uint4*)acc)[2 * tid], r1 = ((uint4*)acc)[2 * tid + 1];
             uint4 x0 = ((uint4*)tmp)[2 * tid], x1 = ((uint4*)tmp)[2 * tid + 1];
             ((uint4*)acc)[2 * tid] = op4(op, r0, x0);
@@ -256,120 +475,174 @@ __device__ void many_accumulate_chunk(uint32_t* acc, uint32_t* tmp, const PoolVi
     }
 }
 
-// Accumulate the members [m0, m1) into the LDS image acc (zeroed by the caller), 1024 members at a time.
-__device__ void many_accumulate(uint32_t* acc, uint32_t* tmp, const PoolView& P, const ManyView& V, u64 m0, u64 m1,
-                                int op, BlockScratch* sc, ManyLists* ml) {
-    for (u64 c0 = m0; c0 < m1; c0 += 1024) many_accumulate_chunk(acc, tmp, P, V, c0, (c0 + 1024 < m1) ? c0 + 1024 : m1, op, sc, ml);
+// Accumulate the members [m0, m1) into the LDS image acc (zeroed by the caller), MANY_CHUNK members at a time.
+template <int PF>
+__device__ __forceinline__ void many_accumulate(uint32_t* acc, uint32_t* tmp, const uint8_t* __restrict__ arena,
+                                const u64* __restrict__ sdesc, u64 m0, u64 m1, int op, BlockScratch* sc, ManyLists* ml) {
+    for (u64 c0 = m0; c0 < m1; c0 += MANY_CHUNK)
+        many_accumulate_chunk<PF>(acc, tmp, arena, sdesc, c0, (c0 + MANY_CHUNK < m1) ? c0 + MANY_CHUNK : m1, op, sc, ml);
 }
 
 struct ManyOut {
-    OutView O;          // candidate directory indexed by group
+    OutView O;          // candidate directory indexed by group (O.key = group keys)
     u64* partial;       // [n_units][1024] scratch chunks (multi-unit groups)
-    u64* chunk_out;     // partial_mode: [G][1024] final uncompressed chunks
-    int partial_mode;   // 1: write uncompressed chunks instead of canonical containers
+    u64* chunk_out;     // partial modes: the uncompressed chunks
+    int partial_mode;   // 0: canonical containers; 1: chunk of group g at row g; 2: dense table of the sharded form,
+                        //    chunk of key k at row (k % world) * dense_b + k / world
     int force_typed;    // 1: single-member groups are typed by cardinality too
     int exact_or_many;  // 1: reproduce roaring_bitmap_or_many's run-vs-bitset choice for FULL containers
-    const uint32_t* glast;  // [2 G] last full-run / last bitset member of every group (k_many_cardsum)
+    uint32_t world, dense_b;
+    u64 key_space;
+    const uint32_t* glast;  // [2 G] last full-run / last bitset member of every group (k_many_groups)
     u64 first_lo, first_hi, second_lo, second_hi;  // container index ranges of ids[0] and ids[1]
+    ManyTotals* tot;
 };
+// row of group g's chunk in a partial mode; ~0 = the key does not fit the dense table (error recorded)
+__device__ __forceinline__ u64 many_chunk_row(const ManyOut& MO, uint32_t g) {
+    if (MO.partial_mode == 1) return g;
+    const u64 k = MO.O.key[g];
+    if (k >= MO.key_space) {
+        if (threadIdx.x == 0) atomicOr(&MO.tot->err, MANY_ERR_KEYSPACE);
+        return ~0ull;
+    }
+    return (k % MO.world) * (u64)MO.dense_b + k / MO.world;
+}
 
+__device__ __forceinline__ bool many_key_in(const PoolView& P, u64 lo, u64 hi, u64 key) {
+    const u64 j = lower_bound(P.key, lo, hi, key);
+    return j < hi && P.key[j] == key;
+}
 // A union that fills the whole chunk is the one place where roaring_bitmap_or_many's result type
 // depends on the fold order (SURVEY G11 / Appendix A "or_many"): the accumulator is a lazy bitset
 // whose cardinality is only computed by bitset x bitset steps (container_lazy_ior, containers.h:
 // 1343-1352, which turn a full result into a full RUN), a full run operand replaces it by a full run
 // (containers.h:1407-1412), and a known-full accumulator short-circuits later steps (roaring.c:2621).
 // Given that the final union IS full, the outcome follows from member metadata plus ONE question:
-// "is the union already full after the last bitset member?" -- answered by re-accumulating that prefix.
-// Returns true for a full run, false for a (full) bitset.
-__device__ bool full_union_is_run(uint32_t* acc2, uint32_t* tmp, const PoolView& P, const ManyView& V,
-                                  const ManyOut& MO, uint32_t g, u64 gs, u64 ge, BlockScratch* sc, ManyLists* ml) {
-    const uint32_t c0 = V.sval[gs], c1 = V.sval[gs + 1];
-    const bool first = c0 >= MO.first_lo && c0 < MO.first_hi && c1 >= MO.second_lo && c1 < MO.second_hi;
-    auto isB = [&](uint32_t c) { return P.type[c] == T_BITSET; };
-    auto isRF = [&](uint32_t c) { return P.type[c] == T_RUN && P.card[c] == 65536u; };
+// "is the union already full after the last bitset member?" -- answered by re-accumulating that prefix (the caller
+// does that, through the same accumulation code as everything else: the answer "2" below).
+// Returns 1 for a full run, 0 for a (full) bitset, 2: full run iff the union of members [gs, *replay_end) is full.
+__device__ __forceinline__ int full_union_decide(const PoolView& P, const ManyView& V, const ManyOut& MO, uint32_t g,
+                                                 u64 gs, u64* replay_end) {
+    const u64 d0 = V.sdesc[gs], d1 = V.sdesc[gs + 1];
+    // the first two members come from ids[0] and ids[1] iff both of those bitmaps hold the key (the sort is stable)
+    const u64 key = MO.O.key[g];
+    const bool first = many_key_in(P, MO.first_lo, MO.first_hi, key) && many_key_in(P, MO.second_lo, MO.second_hi, key);
+    auto isB = [&](u64 d) { return md_type(d) == T_BITSET; };
+    auto isRF = [&](u64 d) { return md_type(d) == T_RUN && md_full(d); };
     u64 start;  // first member handled by the generic lazy_or_inplace step
     if (first) {  // roaring_bitmap_lazy_or(x0, x1), roaring.c:2529-2548
-        if (isB(c0) || isB(c1)) { if (isRF(c0) || isRF(c1)) return true; }
-        else if (isRF(c1)) return true;
+        if (isB(d0) || isB(d1)) { if (isRF(d0) || isRF(d1)) return 1; }
+        else if (isRF(d1)) return 1;
         start = gs + 2;
     } else {
-        if (isRF(c0)) return true;                          // container_is_full -> every step skipped
-        if (isB(c0) && P.card[c0] == 65536u) return false;  // known-full bitset: skipped, repair keeps a bitset
+        if (isRF(d0)) return 1;                       // container_is_full -> every step skipped
+        if (isB(d0) && md_full(d0)) return 0;         // known-full bitset: skipped, repair keeps a bitset
         start = gs + 1;
     }
     // Any full run among the members [start, ge) wins (it is never skipped: the accumulator's cardinality is unknown
     // or below 65536 when it arrives); otherwise the LAST bitset member decides.  Both positions were recorded by
-    // k_many_cardsum (relative to gs, +1).
+    // k_many_groups (member index + 1).
     const uint32_t lrf = MO.glast[2 * (u64)g], lb_all = MO.glast[2 * (u64)g + 1];
-    if (lrf && gs + lrf - 1u >= start) return true;
-    const uint32_t lb = (lb_all && gs + lb_all - 1u >= start) ? lb_all : 0u;
-    if (!lb) return false;
-    const u64 last_b = gs + lb - 1u;
-    // union of members [gs, last_b] full?
-    __syncthreads();
-    lds_zero(acc2);
-    __syncthreads();
-    many_accumulate(acc2, tmp, P, V, gs, last_b + 1, OP_OR, sc, ml);
-    uint4 r0 = ((uint4*)acc2)[2 * threadIdx.x], r1 = ((uint4*)acc2)[2 * threadIdx.x + 1];
-    return blk_sum(popc4(r0) + popc4(r1), sc->wsum) == 65536u;
+    if (lrf && (u64)lrf - 1u >= start) return 1;
+    const uint32_t lb = (lb_all && (u64)lb_all - 1u >= start) ? lb_all : 0u;
+    if (!lb) return 0;
+    *replay_end = (u64)lb;  // union of members [gs, last bitset member] full?
+    return 2;
 }
-
-// canonicalise the LDS image of a finished group: card <= 4096 -> array, else bitset
-// (container_repair_after_lazy, containers.h:344-371); empty -> dropped by compaction
-__device__ void many_finalize(uint32_t* acc, uint16_t* stage, const ManyOut& MO, uint32_t g, BlockScratch* sc,
-                              uint32_t* acc2, uint32_t* tmp, const PoolView& P, const ManyView& V, u64 gs, u64 ge,
-                              ManyLists* ml) {
+// the result of a group whose union is full: one run {0, 0xFFFF}, or the all-ones bitset
+__device__ __forceinline__ void many_emit_full(const ManyOut& MO, uint32_t g, bool as_run) {
     const uint32_t tid = threadIdx.x;
-    uint4 r0 = ((uint4*)acc)[2 * tid], r1 = ((uint4*)acc)[2 * tid + 1];
-    if (MO.partial_mode) {
-        uint4* po = (uint4*)(MO.chunk_out + (u64)g * 1024ull);
-        po[2 * tid] = r0;
-        po[2 * tid + 1] = r1;
-        return;
-    }
-    uint32_t r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-    const uint32_t rc = blk_sum(popc4(r0) + popc4(r1), sc->wsum);
-    int ty = T_ARRAY;
-    if (rc == 65536u && MO.exact_or_many && ge - gs >= 2 && full_union_is_run(acc2, tmp, P, V, MO, g, gs, ge, sc, ml)) {
+    uint8_t* out = MO.O.arena + MO.O.off[g];
+    if (as_run) {
         if (tid == 0) {
-            *(uint32_t*)(MO.O.arena + MO.O.off[g]) = 0xFFFF0000u;  // one run {value 0, length 0xFFFF}
+            *(uint32_t*)out = 0xFFFF0000u;  // {value 0, length 0xFFFF}
             MO.O.meta[g] = pack_meta(T_RUN, 65536u, 1u);
         }
         return;
     }
+    const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u);
+    ((uint4*)out)[2 * tid] = ones;
+    ((uint4*)out)[2 * tid + 1] = ones;
+    if (tid == 0) MO.O.meta[g] = pack_meta(T_BITSET, 65536u, 0u);
+}
+
+// What to do with the finished LDS image of group g (members [gs, ge)): partial modes store the chunk; otherwise it is
+// canonicalised -- card <= 4096 -> array, else bitset (container_repair_after_lazy, containers.h:344-371); empty ->
+// dropped by the tail.  Returns true when the caller must first answer full_union_decide's question by accumulating
+// the members [gs, *replay_end) and calling many_emit_full(.., union is full).
+__device__ __forceinline__ bool many_finalize(uint32_t* acc, uint16_t* stage, const ManyOut& MO, uint32_t g,
+                                              BlockScratch* sc, const PoolView& P, const ManyView& V, u64 gs, u64 ge,
+                                              u64* replay_end) {
+    const uint32_t tid = threadIdx.x;
+    uint4 r0 = ((uint4*)acc)[2 * tid], r1 = ((uint4*)acc)[2 * tid + 1];
+    if (MO.partial_mode) {
+        const u64 row = many_chunk_row(MO, g);
+        if (row == ~0ull) return false;
+        uint4* po = (uint4*)(MO.chunk_out + row * 1024ull);
+        po[2 * tid] = r0;
+        po[2 * tid + 1] = r1;
+        return false;
+    }
+    uint32_t r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    const uint32_t rc = blk_sum(popc4(r0) + popc4(r1), sc->wsum);
+    if (rc == 65536u && MO.exact_or_many && ge - gs >= 2) {
+        const int dec = full_union_decide(P, V, MO, g, gs, replay_end);  // (block-uniform: metadata only)
+        if (dec == 2) return true;
+        many_emit_full(MO, g, dec == 1);
+        return false;
+    }
+    int ty = T_ARRAY;
     if (rc) {
         ty = type_ba(rc);
         lds_emit(acc, r, ty, rc, 0, stage, MO.O.arena + MO.O.off[g], sc);
     }
     if (tid == 0) MO.O.meta[g] = pack_meta(ty, rc, 0);
+    return false;
+}
+__device__ __forceinline__ bool many_image_full(const uint32_t* acc, BlockScratch* sc) {
+    const uint4 r0 = ((const uint4*)acc)[2 * threadIdx.x], r1 = ((const uint4*)acc)[2 * threadIdx.x + 1];
+    return blk_sum(popc4(r0) + popc4(r1), sc->wsum) == 65536u;
 }
 
-__global__ __launch_bounds__(256) void k_many_l1(PoolView P, ManyView V, ManyOut MO, const u64* __restrict__ n_units,
-                                                 int op) {
+// PF = 16-byte payload groups per lane loaded ahead of the LDS atomics (RHIP_MANY_PF selects 2 / 4 / 8; default 4)
+template <int PF>
+__global__ __launch_bounds__(256) void k_many_l1(PoolView P, ManyView V, ManyOut MO, int op) {
     __shared__ __attribute__((aligned(16))) uint32_t acc[2048];
     __shared__ __attribute__((aligned(16))) uint32_t tmp[2048];
-    __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];  // doubles as the replay image (8 KiB)
+    __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];
     __shared__ BlockScratch sc;
     __shared__ ManyLists ml;
-    const uint32_t G = *V.n_groups;
-    const u64 U = *n_units;
+    const uint32_t G = (uint32_t)V.tot->n_groups;
+    const u64 U = V.tot->n_units;
     for (u64 u = blockIdx.x; u < U; u += gridDim.x) {
         const uint32_t g = unit_group(V.ustart, G, u);
         const u64 gs = V.gstart[g], ge = V.gstart[g + 1];
         const u64 nu = V.ustart[g + 1] - V.ustart[g];
         if (nu == 1 && (ge - gs) == 1 && !MO.force_typed && !MO.partial_mode) continue;  // pass-through copy path
-        const u64 m0 = gs + (u - V.ustart[g]) * V.ch;
-        const u64 m1 = (m0 + V.ch < ge) ? m0 + V.ch : ge;
-        __syncthreads();
-        lds_zero(acc);
-        __syncthreads();
-        many_accumulate(acc, tmp, P, V, m0, m1, op, &sc, &ml);
-        if (nu == 1) {
-            many_finalize(acc, stage, MO, g, &sc, (uint32_t*)stage, tmp, P, V, gs, ge, &ml);
-        } else {
-            uint4* po = (uint4*)(MO.partial + u * 1024ull);
-            po[2 * threadIdx.x] = ((uint4*)acc)[2 * threadIdx.x];
-            po[2 * threadIdx.x + 1] = ((uint4*)acc)[2 * threadIdx.x + 1];
+        const u64 per = (ge - gs + nu - 1) / nu;  // the group's members in nu equal shares (<= ch each)
+        u64 a0 = gs + (u - V.ustart[g]) * per;
+        u64 a1 = (a0 + per < ge) ? a0 + per : ge;
+        // One accumulation site for the unit's members and -- rarely -- for the replay of a full union's prefix
+        for (bool replay = false;;) {
+            __syncthreads();
+            lds_zero(acc);
+            __syncthreads();
+            many_accumulate<PF>(acc, tmp, P.arena, V.sdesc, a0, a1, replay ? (int)OP_OR : op, &sc, &ml);
+            if (replay) {
+                many_emit_full(MO, g, many_image_full(acc, &sc));
+                break;
+            }
+            if (nu != 1) {
+                uint4* po = (uint4*)(MO.partial + (V.pstart[g] + (u - V.ustart[g])) * 1024ull);
+                po[2 * threadIdx.x] = ((uint4*)acc)[2 * threadIdx.x];
+                po[2 * threadIdx.x + 1] = ((uint4*)acc)[2 * threadIdx.x + 1];
+                break;
+            }
+            u64 rend = 0;
+            if (!many_finalize(acc, stage, MO, g, &sc, P, V, gs, ge, &rend)) break;
+            replay = true;
+            a0 = gs;
+            a1 = rend;
         }
     }
 }
@@ -381,14 +654,16 @@ __global__ __launch_bounds__(256) void k_many_l2(PoolView P, ManyView V, ManyOut
     __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];
     __shared__ BlockScratch sc;
     __shared__ ManyLists ml;
-    const uint32_t G = *V.n_groups;
+    const uint32_t G = (uint32_t)V.tot->n_groups;
     const uint32_t tid = threadIdx.x;
+    if (V.tot->n_units == (u64)G) return;  // no group has more than one unit
     for (uint32_t g = blockIdx.x; g < G; g += gridDim.x) {
         const u64 u0 = V.ustart[g], u1 = V.ustart[g + 1];
         if (u1 - u0 < 2) continue;
         uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
-        for (u64 u = u0; u < u1; ++u) {
-            const uint4* __restrict__ p = (const uint4*)(MO.partial + u * 1024ull);
+        const u64 p0 = V.pstart[g];
+        for (u64 u = 0; u < u1 - u0; ++u) {
+            const uint4* __restrict__ p = (const uint4*)(MO.partial + (p0 + u) * 1024ull);
             r0 = op4(op, r0, p[2 * tid]);
             r1 = op4(op, r1, p[2 * tid + 1]);
         }
@@ -396,37 +671,229 @@ __global__ __launch_bounds__(256) void k_many_l2(PoolView P, ManyView V, ManyOut
         ((uint4*)acc)[2 * tid] = r0;
         ((uint4*)acc)[2 * tid + 1] = r1;
         __syncthreads();
-        many_finalize(acc, stage, MO, g, &sc, (uint32_t*)stage, tmp, P, V, V.gstart[g], V.gstart[g + 1], &ml);
+        const u64 gs = V.gstart[g];
+        u64 rend = 0;
+        if (many_finalize(acc, stage, MO, g, &sc, P, V, gs, V.gstart[g + 1], &rend)) {
+            __syncthreads();
+            lds_zero(acc);
+            __syncthreads();
+            many_accumulate<2>(acc, tmp, P.arena, V.sdesc, gs, rend, OP_OR, &sc, &ml);
+            many_emit_full(MO, g, many_image_full(acc, &sc));
+        }
     }
 }
 
 // single-member groups keep their container unchanged (type included): roaring.c:2660-2676
 __global__ __launch_bounds__(256) void k_many_copy(PoolView P, ManyView V, ManyOut MO) {
-    const uint32_t G = *V.n_groups;
+    const uint32_t G = (uint32_t)V.tot->n_groups;
     const uint32_t lane = lane_id();
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; g < G; g += nwaves) {
         if (V.gstart[g + 1] - V.gstart[g] != 1) continue;
-        const uint32_t c = V.sval[V.gstart[g]];
-        const uint8_t ty = P.type[c];
-        const uint32_t card = P.card[c], nr = P.nruns[c];
-        const uint32_t n16 = (payload_bytes(ty, card, nr) + 15u) >> 4;
-        const uint4* __restrict__ ps = (const uint4*)(P.arena + P.off[c]);
+        const u64 d = V.sdesc[V.gstart[g]];
+        const uint32_t ty = md_type(d), n = md_n(d);
+        const uint32_t n16 = (md_payload(d) + 15u) >> 4;
+        const uint4* __restrict__ ps = (const uint4*)(P.arena + md_off(d));
         uint4* __restrict__ po = (uint4*)(MO.O.arena + MO.O.off[g]);
-        for (uint32_t i = lane; i < n16; i += 64) po[i] = ps[i];
-        if (lane == 0) MO.O.meta[g] = pack_meta(ty, card, nr);
+        uint32_t card = 0;  // runs: the descriptor has no exact cardinality, the runs do (sum of length + 1)
+        for (uint32_t i = lane; i < n16; i += 64) {
+            const uint4 x = ps[i];
+            po[i] = x;
+            if (ty == T_RUN) {
+                const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k)
+                    if (4u * i + k < n) card += (w[k] >> 16) + 1u;
+            }
+        }
+        if (ty == T_RUN) card = wave_sum(card);
+        else card = ty == T_ARRAY ? n : n + 1u;
+        if (lane == 0) MO.O.meta[g] = pack_meta(ty, card, ty == T_RUN ? n : 0u);
     }
 }
 
+// Stage 3 of the sharded form, dense exchange: the table holds `world` rows per owned key, row s * B + j = source
+// rank s's chunk (all zero if s never saw the key) of key rank + world * j.  One workgroup per key combines the rows
+// and canonicalises (card <= 4096 -> array, else bitset); slots are fixed (8 KiB per key), empty keys are dropped by
+// the tail.  No gather, no sort: the table's shape IS the grouping.
+__global__ __launch_bounds__(256) void k_many_dense_finalize(const u64* __restrict__ table, uint32_t world, uint32_t B,
+                                                             uint32_t rank, int op, OutView O, u64* __restrict__ zwords,
+                                                             u64 n_zwords) {
+    __shared__ __attribute__((aligned(16))) uint32_t acc[2048];
+    __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];
+    __shared__ BlockScratch sc;
+    const uint32_t tid = threadIdx.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + tid; i < n_zwords; i += (u64)gridDim.x * blockDim.x) zwords[i] = 0;  // the tail's scratch
+    for (uint32_t j = blockIdx.x; j < B; j += gridDim.x) {
+        uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
+        for (uint32_t s = 0; s < world; s += 4) {
+            uint4 a[4], b[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                a[u] = make_uint4(0, 0, 0, 0); b[u] = a[u];
+                if (s + u < world) {
+                    const uint4* __restrict__ p = (const uint4*)(table + ((u64)(s + u) * B + j) * 1024ull);
+                    a[u] = p[2 * tid];
+                    b[u] = p[2 * tid + 1];
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) { r0 = op4(op, r0, a[u]); r1 = op4(op, r1, b[u]); }
+        }
+        const uint32_t r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        const uint32_t rc = blk_sum(popc4(r0) + popc4(r1), sc.wsum);
+        int ty = T_ARRAY;
+        if (rc) {
+            ty = type_ba(rc);
+            __syncthreads();
+            ((uint4*)acc)[2 * tid] = r0;
+            ((uint4*)acc)[2 * tid + 1] = r1;
+            __syncthreads();
+            lds_emit(acc, r, ty, rc, 0, stage, O.arena + (u64)j * 8192ull, &sc);
+        }
+        if (tid == 0) {
+            O.meta[j] = pack_meta(ty, rc, 0);
+            O.key[j] = (u64)rank + (u64)world * j;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ tail: compaction + directory + totals
+// One look-back pass over the n candidate groups: keep = non-empty, prefix -> position in the result directory of the
+// ONE result bitmap.  The block of the last tile adds up the per-tile sums and hands the totals (and the completion
+// word) to the host in pinned memory.  n comes from device memory (tot->n_groups) unless n_fixed is given.
+__global__ __launch_bounds__(256) void k_many_tail(const u64* __restrict__ key, const u64* __restrict__ meta,
+                                                   const u64* __restrict__ off, u64 off_stride, DirOut R, u64 n_fixed,
+                                                   int use_fixed, LbState lb, u64* __restrict__ part,
+                                                   ManyTotals* __restrict__ tot, ManyTotals* __restrict__ host_tot,
+                                                   u64* host_flag, u64 seq, u64* host_err) {
+    __shared__ uint32_t s_cnt[32];
+    __shared__ uint32_t s_tile;
+    __shared__ u64 s_prefix, s_total;
+    __shared__ u64 s_bytes[4];
+    __shared__ uint32_t s_types[4][3];
+    __shared__ u64 s_tot[4][4];
+    const u64 n = use_fixed ? n_fixed : tot->n_groups;
+    if (threadIdx.x == 0) s_tile = atomicAdd(lb.ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const u64 n_tiles = n ? (n + MANY_TILE - 1) / MANY_TILE : 1;
+    if (tile >= n_tiles) return;
+    const u64 tbase = (u64)tile * MANY_TILE + threadIdx.x;
+    const uint32_t wv = threadIdx.x >> 6, lane = lane_id();
+    u64 m[8];
+    uint32_t rank[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const u64 i = tbase + 256ull * k;
+        m[k] = i < n ? meta[i] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const u64 bal = __ballot(meta_card(m[k]) != 0);
+        rank[k] = mbcnt(bal);
+        if (lane == 0) s_cnt[4 * k + wv] = (uint32_t)__popcll(bal);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const uint32_t v = lane < 32 ? s_cnt[lane] : 0u;
+        const uint32_t inc = wave_incl_scan(v);
+        if (lane < 32) s_cnt[lane] = inc - v;
+        const u64 t = __shfl(inc, 63);
+        const u64 pfx = lb_exclusive_prefix(lb.status, tile, t);
+        if (lane == 0) { s_prefix = pfx; s_total = t; }
+    }
+    __syncthreads();
+    u64 bytes = 0;
+    uint32_t nty[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const u64 i = tbase + 256ull * k;
+        if (i < n && meta_card(m[k])) {
+            const u64 ex = s_prefix + s_cnt[4 * k + wv] + rank[k];
+            const uint32_t ty = meta_type(m[k]);
+            R.key[ex] = key[i];
+            R.type[ex] = (uint8_t)ty;
+            R.card[ex] = meta_card(m[k]);
+            R.nruns[ex] = meta_nruns(m[k]);
+            R.off[ex] = off ? off[i] : i * off_stride;
+            bytes += payload_bytes((uint8_t)ty, meta_card(m[k]), meta_nruns(m[k]));
+            nty[ty - 1]++;
+        }
+    }
+    bytes = wave_sum64(bytes);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) nty[t] = wave_sum(nty[t]);
+    if (lane == 0) {
+        s_bytes[wv] = bytes;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) s_types[wv][t] = nty[t];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 b = 0;
+        uint32_t ty[3] = {0, 0, 0};
+        for (int w = 0; w < 4; ++w) {
+            b += s_bytes[w];
+            for (int t = 0; t < 3; ++t) ty[t] += s_types[w][t];
+        }
+        lb_store(&part[2 * (size_t)tile], TAIL_READY | b);
+        lb_store(&part[2 * (size_t)tile + 1], TAIL_READY | (u64)ty[0] | ((u64)ty[1] << 16) | ((u64)ty[2] << 32));
+    }
+    if (tile != n_tiles - 1) return;
+    __syncthreads();
+    const u64 kept = s_prefix + s_total;
+    u64 tb = 0, t0 = 0, t1 = 0, t2 = 0;
+    for (u64 t = threadIdx.x; t < n_tiles; t += 256) {
+        u64 pb, pk;
+        while (!((pb = lb_load(&part[2 * t])) & TAIL_READY)) {}
+        while (!((pk = lb_load(&part[2 * t + 1])) & TAIL_READY)) {}
+        tb += pb & ~TAIL_READY;
+        t0 += pk & 0xFFFFu; t1 += (pk >> 16) & 0xFFFFu; t2 += (pk >> 32) & 0xFFFFu;
+    }
+    tb = wave_sum64(tb); t0 = wave_sum64(t0); t1 = wave_sum64(t1); t2 = wave_sum64(t2);
+    if (lane == 0) { s_tot[wv][0] = tb; s_tot[wv][1] = t0; s_tot[wv][2] = t1; s_tot[wv][3] = t2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ManyTotals T = *tot;
+        if (use_fixed) T.n_groups = n;
+        T.kept = kept;
+        T.bytes_out = 0; T.n_type[0] = T.n_type[1] = T.n_type[2] = 0;
+        for (int w = 0; w < 4; ++w) {
+            T.bytes_out += s_tot[w][0];
+            for (int t = 0; t < 3; ++t) T.n_type[t] += s_tot[w][t + 1];
+        }
+        R.bm_start[0] = 0;
+        R.bm_start[1] = kept;
+        const u64* lv = (const u64*)&T;
+        u64* hv = (u64*)host_tot;
+        for (uint32_t k = 0; k < sizeof(ManyTotals) / 8; ++k) hv[k] = lv[k];
+        if (T.err) atomicOr(host_err, T.err);
+        __threadfence_system();
+        __atomic_store_n(host_flag, seq, __ATOMIC_RELEASE);
+    }
+}
+// partial modes have no tail: the totals (number of groups, largest key, error word) alone
+__global__ void k_many_publish(const ManyTotals* __restrict__ tot, ManyTotals* __restrict__ host_tot, u64* host_flag, u64 seq,
+                               u64* host_err) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const u64* lv = (const u64*)tot;
+        u64* hv = (u64*)host_tot;
+        for (uint32_t k = 0; k < sizeof(ManyTotals) / 8; ++k) hv[k] = lv[k];
+        if (tot->err) atomicOr(host_err, tot->err);  // sticky: read (and cleared) by the call that ends the pipeline
+        __threadfence_system();
+        __atomic_store_n(host_flag, seq, __ATOMIC_RELEASE);
+    }
+}
+
+// directory of rhip_many_finalize's pseudo pool: chunk i is a "bitset container" at byte offset 8192 i
+__global__ void k_pseudo_dir(u64* __restrict__ off, uint32_t* __restrict__ card, uint32_t* __restrict__ nruns,
+                             uint8_t* __restrict__ type, u64 n) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { off[i] = 8192ull * i; card[i] = 65536u; nruns[i] = 0u; type[i] = (uint8_t)T_BITSET; }
+}
 __global__ void k_iota64(u64* p, u64 n, u64 mul) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = i * mul;
-}
-__global__ void k_fill8(uint8_t* p, u64 n, uint8_t v) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-__global__ void k_fill32(uint32_t* p, u64 n, uint32_t v) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
 }

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const bool found = act[t] && j[t] < l1 && LV.key[j[t]] == k[t];
-        if (act[t]) match[(size_t)u * 256 + G * t + lane] = (uint32_t)(j[t] - l0) | (found ? MATCH_FOUND : 0u);
+        if (act[t]) match[(size_t)u * (4 * G) + G * t + lane] = (uint32_t)(j[t] - l0) | (found ? MATCH_FOUND : 0u);
         int cls = -1;
         if (act[t] && (bside ? !found : (found || keep_unmatched))) {
             const u64 si = s0 + G * t + lane;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
         for (int t = 0; t < 4; ++t) {
             const u64 ai = s0 + G * t + lane;
             const bool act = ai < a1;
-            const uint32_t mt = act ? match[(size_t)u * 256 + G * t + lane] : 0u;
+            const uint32_t mt = act ? match[(size_t)u * (4 * G) + G * t + lane] : 0u;
             const bool found = (mt & MATCH_FOUND) != 0;
             const uint32_t lbcount = mt & ~MATCH_FOUND;
             const u64 bj = b0 + lbcount;
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
         for (int t = 0; t < 4; ++t) {
             const u64 bi = s0 + G * t + lane;
             const bool act = bi < b1;
-            const uint32_t mt = act ? match[(size_t)u * 256 + G * t + lane] : 0u;
+            const uint32_t mt = act ? match[(size_t)u * (4 * G) + G * t + lane] : 0u;
             const bool found = (mt & MATCH_FOUND) != 0;
             const u64 fm = gr.ballot(found);
             const uint32_t mb = mbefore + gr.rank(fm);
@@ -549,6 +549,15 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
             qcopy += __popcll(mcp);
         }
     }
+}
+
+// matched container pairs of a batch = the items of the class queues (the SEC_M section also counts the matched keys
+// of B-tiles, which k_emit needs for ranking: under or / xor it is twice this)
+__device__ __forceinline__ u64 matched_total(const u64* __restrict__ ranges) {
+    const int secs[] = {SEC_BB, SEC_GEN, SEC_FILT, SEC_WAVE, SEC_RUNS, SEC_PROBE, SEC_BBA, SEC_USMALL, SEC_RUNS16, SEC_RUNS16W};
+    u64 m = 0;
+    for (int k = 0; k < 10; ++k) m += ranges[2 * secs[k] + 1] - ranges[2 * secs[k]];
+    return m;
 }
 
 // ------------------------------------------------------------------ fused tail: compaction + directory + statistics
@@ -691,7 +700,7 @@ __global__ __launch_bounds__(256) void k_tail(const u64* __restrict__ ranges, Ca
         Stats st = {};
         st.result_containers = kept;
         st.n_cand = n;
-        st.matched_pairs = ranges[2 * SEC_M + 1] - ranges[2 * SEC_M];
+        st.matched_pairs = matched_total(ranges);
         st.passthrough = ranges[2 * SEC_COPY + 1] - ranges[2 * SEC_COPY];
         st.n_bb = ranges[2 * SEC_BB + 1] - ranges[2 * SEC_BB] + ranges[2 * SEC_BBA + 1] - ranges[2 * SEC_BBA];
         st.bytes_in = ranges[2 * SEC_BYTES + 1] - ranges[2 * SEC_BYTES];
@@ -712,7 +721,7 @@ __global__ __launch_bounds__(256) void k_tail(const u64* __restrict__ ranges, Ca
 __global__ void k_card_stats(const u64* __restrict__ ranges, Stats* __restrict__ host_stats) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         Stats st = {};
-        st.matched_pairs = ranges[2 * SEC_M + 1] - ranges[2 * SEC_M];
+        st.matched_pairs = matched_total(ranges);
         st.n_bb = ranges[2 * SEC_BB + 1] - ranges[2 * SEC_BB];
         st.bytes_in = ranges[2 * SEC_BYTES + 1] - ranges[2 * SEC_BYTES];
         *host_stats = st;
@@ -794,25 +803,50 @@ __device__ __forceinline__ uint32_t slot_bound(uint8_t type, uint32_t card, uint
     const uint32_t w = p > c ? p : c;
     return w < 16u ? 16u : w;
 }
+// wmany: the same bound for the many-way path, whose member descriptors (rhip_many.h) carry a run container's
+// cardinality rounded up to a multiple of 256
 __global__ __launch_bounds__(256) void k_bitmap_bounds(PoolView P, uint32_t nbm, u64* __restrict__ wout,
-                                                       uint32_t* __restrict__ census /* [3] bitset, array, run */) {
+                                                       u64* __restrict__ wmany,
+                                                       uint32_t* __restrict__ census /* [3] bitset, array, run */,
+                                                       u64* __restrict__ maxkey) {
     uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (b >= nbm) return;
-    u64 s = 0;
+    u64 s = 0, sm = 0;
     uint32_t seen = 0;
     for (u64 i = P.bm_start[b] + lane_id(); i < P.bm_start[b + 1]; i += 64) {
         const uint8_t t = P.type[i];
-        s += slot_bound(t, P.card[i], P.nruns[i]);
+        const uint32_t cd = P.card[i], nr = P.nruns[i];
+        s += slot_bound(t, cd, nr);
+        sm += slot_bound(t, t == T_RUN ? ((cd + 255u) & ~255u) : cd, nr);
         seen |= 1u << (t - 1);
     }
     s = wave_sum64(s);
+    sm = wave_sum64(sm);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) seen |= __shfl_xor(seen, o);
     if (lane_id() == 0) {
         wout[b] = s;
+        wmany[b] = sm;
+        if (P.bm_start[b + 1] > P.bm_start[b]) atomicMax(maxkey, P.key[P.bm_start[b + 1] - 1]);  // keys ascend inside a bitmap
         for (int t = 0; t < 3; ++t)
             if ((seen >> t) & 1u) census[t] = 1u;  // benign race: every writer stores the same value
     }
+}
+// distinct 16-bit keys of a 32-bit pool: mark (bits = 2048 zeroed words), then count
+__global__ void k_key_mark(const u64* __restrict__ key, u64 n, uint32_t* __restrict__ bits) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const uint32_t k = (uint32_t)key[i] & 0xFFFFu, bit = 1u << (k & 31u);
+        if (!(bits[k >> 5] & bit)) atomicOr(&bits[k >> 5], bit);
+    }
+}
+__global__ __launch_bounds__(256) void k_key_count(const uint32_t* __restrict__ bits, u64* __restrict__ out) {
+    __shared__ uint32_t sw[4];
+    uint32_t s = 0;
+    for (uint32_t i = threadIdx.x; i < 2048u; i += 256u) s += (uint32_t)__popc(bits[i]);
+    s = wave_sum(s);
+    if (lane_id() == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (u64)sw[0] + sw[1] + sw[2] + sw[3];
 }
 __global__ __launch_bounds__(256) void k_payload_stats(const uint8_t* type, const uint32_t* card,
                                                        const uint32_t* nruns, u64 n, u64* out /*[4]*/) {

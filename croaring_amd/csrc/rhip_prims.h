@@ -13,3 +13,6 @@ hipError_t prim_exscan_u32_u64(void* tmp, size_t& tmp_bytes, const uint32_t* in,
 // stable LSD radix sort of (key, value) pairs on key bits [0, end_bit)
 hipError_t prim_sort_pairs_u64_u32(void* tmp, size_t& tmp_bytes, const unsigned long long* kin, unsigned long long* kout,
                                    const uint32_t* vin, uint32_t* vout, size_t n, int end_bit, hipStream_t s);
+hipError_t prim_sort_pairs_u64_u64(void* tmp, size_t& tmp_bytes, const unsigned long long* kin, unsigned long long* kout,
+                                   const unsigned long long* vin, unsigned long long* vout, size_t n, int end_bit,
+                                   hipStream_t s);

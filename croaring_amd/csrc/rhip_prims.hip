@@ -20,3 +20,8 @@ hipError_t prim_sort_pairs_u64_u32(void* tmp, size_t& tmp_bytes, const unsigned 
                                    const uint32_t* vin, uint32_t* vout, size_t n, int end_bit, hipStream_t s) {
     return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, (unsigned)end_bit, s);
 }
+hipError_t prim_sort_pairs_u64_u64(void* tmp, size_t& tmp_bytes, const unsigned long long* kin, unsigned long long* kout,
+                                   const unsigned long long* vin, unsigned long long* vout, size_t n, int end_bit,
+                                   hipStream_t s) {
+    return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, n, 0, (unsigned)end_bit, s);
+}

@@ -126,34 +126,52 @@ class _DevArray:
                                          "version": 2, "strides": None}
 
 
-def many_sharded(engine, local_pool, op: str = "or", ids=None, group=None, key_space: Optional[int] = None):
+def many_sharded(engine, local_pool, op: str = "or", ids=None, group=None, key_space: Optional[int] = None,
+                 force_collective: bool = False):
     """or_many / xor_many over the union of every rank's `local_pool[ids]`.
 
     Returns this rank's share of the result: a one-bitmap Pool holding the container keys with
     key % world == rank.  Must be called by every rank of the group, all with the same `key_space`.
     key_space = an exclusive upper bound of the container keys on EVERY rank (e.g. 4096) selects the dense
-    fixed-shape exchange; None selects the sparse one."""
-    parts = engine.many_partials(op, local_pool, ids)
-    n = parts.n_keys
+    fixed-shape exchange; None selects the sparse one.
+
+    Dense form: stage 1 (rhip_many_partials_dense) writes the chunks straight into the zero-filled send table and
+    returns without waiting, the all_to_all_single is enqueued on the engine's stream, stage 3
+    (rhip_many_finalize_dense) combines the `world` rows of every owned key -- ONE host wait, at its end."""
     dev = engine.torch_device()
     # test configuration: ranks without RCCL between them (two ranks sharing one GPU) stage chunks through the host
     staged = dist.get_backend(group) == "gloo" and dev.type != "cpu"
-    # torch work is issued on the ENGINE's stream: stage 1, the table scatter, the collective's input/output
-    # dependencies and stage 3 are then ordered by the stream itself, with no host synchronisation in between
+    if key_space is not None:
+        world = dist.get_world_size(group)
+        rank = dist.get_rank(group)
+        B = dense_block(key_space, world)
+        if len(local_pool) and local_pool.max_key() >= key_space:  # (a host value, cached on the pool: no device round trip)
+            raise ValueError(f"key {local_pool.max_key()} >= key_space {key_space}: use the sparse exchange")
+        # torch work is issued on the ENGINE's stream: stage 1, the collective and stage 3 are ordered by the stream
+        with engine.torch_stream():
+            table, recv = _dense_tables(engine, world * B, dev)
+            engine.many_partials_dense(op, local_pool, ids, int(key_space), world, table.data_ptr())
+            if staged:
+                hsend = table.cpu()
+                hrecv = torch.empty_like(hsend)
+                dist.all_to_all_single(hrecv, hsend, group=group)
+                recv.copy_(hrecv)
+            elif world == 1 and not force_collective:
+                recv = table  # (a one-rank all-to-all is the identity; force_collective: issue it anyway, to time it)
+            else:
+                dist.all_to_all_single(recv, table, group=group)
+            return engine.many_finalize_dense(op, local_pool.is64, world, rank, B, recv.data_ptr())
+    parts = engine.many_partials(op, local_pool, ids)
+    n = parts.n_keys
     with engine.torch_stream():
         if n:
             keys, words = engine.as_tensor(parts.d_keys, (n,)), engine.as_tensor(parts.d_words, (n, WORDS))
         else:
             keys = torch.empty(0, dtype=torch.int64, device=dev)
             words = torch.empty((0, WORDS), dtype=torch.int64, device=dev)
-        if key_space is not None and n and parts.max_key >= key_space:
-            raise ValueError(f"key {parts.max_key} >= key_space {key_space}: use the sparse exchange")
         if staged:
             keys, words = keys.cpu(), words.cpu()
-        if key_space is not None:
-            rk, rw = exchange_dense(keys, words, key_space, group)
-        else:
-            rk, rw = exchange_chunks(keys, words, group)
+        rk, rw = exchange_chunks(keys, words, group)
         if staged:
             rk, rw = rk.to(dev), rw.to(dev)
         rk, rw = rk.contiguous(), rw.contiguous()
@@ -161,6 +179,17 @@ def many_sharded(engine, local_pool, op: str = "or", ids=None, group=None, key_s
         out = engine.many_finalize(op, local_pool.is64, nk, rk.data_ptr() if nk else 0, rw.data_ptr() if nk else 0)
     parts.free()  # buffers go back to the context's cache; their next writer is on the same stream
     return out
+
+
+def _dense_tables(engine, rows: int, dev):
+    """Send / receive tables of the dense exchange, kept on the engine between calls (a fresh 32 MiB torch
+    allocation per call would cost more than the exchange)."""
+    cache = getattr(engine, "_dense_cache", None)
+    if cache is None or cache[0].shape[0] != rows or cache[0].device != dev:
+        cache = (torch.empty((rows, WORDS), dtype=torch.int64, device=dev),
+                 torch.empty((rows, WORDS), dtype=torch.int64, device=dev))
+        engine._dense_cache = cache
+    return cache
 
 
 def gather_serialized(engine, owned_pool, dst: int = 0, group=None) -> Optional[bytes]:

@@ -176,7 +176,10 @@ class Engine:
             rh, reuse.h = reuse.h, None  # consumed
         h = self.lib.rhip_pairwise(self.h, OPS[op], A.h, B.h, lhs.size, lhs.ctypes.data, rhs.ctypes.data, rh)
         if not h:
-            raise RoaringHipError(f"pairwise {op} failed: " + self._err())
+            err = self._err()
+            if reuse is not None and "still in flight" in err:
+                reuse.h = rh  # refused, not consumed (include/roaring_hip.h): the caller's Pool stays valid
+            raise RoaringHipError(f"pairwise {op} failed: " + err)
         return Pool(self, h)
 
     def pairwise_begin(self, op: str, A: "Pool", lhs, B: Optional["Pool"] = None, rhs=None,
@@ -191,7 +194,10 @@ class Engine:
             rh, reuse.h = reuse.h, None  # consumed
         h = self.lib.rhip_pairwise_begin(self.h, OPS[op], A.h, B.h, lhs.size, lhs.ctypes.data, rhs.ctypes.data, rh)
         if not h:
-            raise RoaringHipError(f"pairwise_begin {op} failed: " + self._err())
+            err = self._err()
+            if reuse is not None and "still in flight" in err:
+                reuse.h = rh  # refused, not consumed: the caller's Pool stays valid
+            raise RoaringHipError(f"pairwise_begin {op} failed: " + err)
         return Batch(self, h, (A, B))
 
     def pairwise_cardinality(self, op: str, A: "Pool", lhs, B: Optional["Pool"] = None, rhs=None) -> np.ndarray:
@@ -296,6 +302,26 @@ class Engine:
         h = self.lib.rhip_many_finalize(self.h, OPS[op], 1 if is64 else 0, n_chunks, d_keys, d_words)
         if not h:
             raise RoaringHipError("many_finalize failed: " + self._err())
+        return Pool(self, h)
+
+    def many_partials_dense(self, op: str, P: "Pool", ids, key_space: int, world: int, d_table: int) -> None:
+        """Stage 1, dense exchange: ENQUEUES the reduction of P[ids] into the zero-filled table at device address
+        d_table (world * ceil(key_space / world) rows of 1024 words; the chunk of key k at row (k % world) * B + k //
+        world) and returns without waiting for the device."""
+        if ids is None:
+            rc = self.lib.rhip_many_partials_dense(self.h, OPS[op], P.h, 0, None, key_space, world, d_table)
+        else:
+            ids = _u32(ids)
+            rc = self.lib.rhip_many_partials_dense(self.h, OPS[op], P.h, ids.size, ids.ctypes.data, key_space, world, d_table)
+        if rc != 0:
+            raise RoaringHipError("many_partials_dense failed: " + self._err())
+
+    def many_finalize_dense(self, op: str, is64: bool, world: int, rank: int, keys_per_rank: int, d_table: int) -> "Pool":
+        """Stage 3, dense exchange: row s * keys_per_rank + j of the received table = source rank s's chunk of key
+        rank + world * j.  The one host wait of the sharded pipeline."""
+        h = self.lib.rhip_many_finalize_dense(self.h, OPS[op], 1 if is64 else 0, world, rank, keys_per_rank, d_table)
+        if not h:
+            raise RoaringHipError("many_finalize_dense failed: " + self._err())
         return Pool(self, h)
 
 
@@ -405,6 +431,13 @@ class Pool:
         if self.eng.lib.rhip_pool_type_counts(self.h, out) != 0:
             raise RoaringHipError(self.eng._err())
         return tuple(int(x) for x in out)  # (bitset, array, run)
+
+    def max_key(self) -> int:
+        """Largest container key of the pool (cached on the pool after the first call)."""
+        out = C.c_uint64(0)
+        if self.eng.lib.rhip_pool_max_key(self.h, C.byref(out)) != 0:
+            raise RoaringHipError("pool_max_key failed: " + self.eng._err())
+        return int(out.value)
 
     def cardinalities(self) -> np.ndarray:
         """roaring_bitmap_get_cardinality of every bitmap."""

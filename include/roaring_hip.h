@@ -107,6 +107,9 @@ void rhip_pool_free(rhip_pool_t *pool); /* roaring_bitmap_free, roaring.h:365 */
 uint32_t rhip_pool_size(const rhip_pool_t *pool);          /* number of bitmaps */
 uint64_t rhip_pool_containers(const rhip_pool_t *pool);    /* total containers */
 int rhip_pool_is64(const rhip_pool_t *pool);
+/* largest container key of the pool (high 16 bits of a value; high 48 for 64-bit pools), 0 for an empty pool;
+ * computed once per pool and cached */
+int rhip_pool_max_key(rhip_pool_t *pool, uint64_t *out);
 /* payload bytes (bitset 8192, array 2*card, run 4*n_runs) of all containers */
 uint64_t rhip_pool_payload_bytes(rhip_pool_t *pool);
 /* per-type container counts out[0]=bitset out[1]=array out[2]=run */
@@ -226,6 +229,10 @@ typedef struct rhip_partials_s {
 } rhip_partials_t;
 int rhip_many_partials(rhip_ctx_t *ctx, rhip_op op /* RHIP_OR | RHIP_XOR */, rhip_pool_t *pool, size_t n,
                        const uint32_t *ids, rhip_partials_t *out);
+/* Returns the chunk buffers to the context, which keeps the largest pair for its next rhip_many_partials instead of
+ * freeing it.  Reuse is protected by STREAM ORDER only: whatever read d_keys / d_words must have been enqueued on the
+ * context's stream (rhip_ctx_stream) -- or have completed -- before this call; a consumer on another stream must be
+ * synchronised first. */
 void rhip_partials_free(rhip_ctx_t *ctx, rhip_partials_t *p);
 /* Stage 2: n_chunks (key, 1024-word chunk) records in device memory, any order,
  * duplicates allowed: chunks with equal keys are combined with op, then every
@@ -233,6 +240,22 @@ void rhip_partials_free(rhip_ctx_t *ctx, rhip_partials_t *p);
  * a pool holding ONE bitmap. */
 rhip_pool_t *rhip_many_finalize(rhip_ctx_t *ctx, rhip_op op, int is64, uint64_t n_chunks, const uint64_t *d_keys,
                                 const uint64_t *d_words);
+
+/* The same two stages for the DENSE exchange (every rank sees most keys and the key space is small, e.g. the 4096
+ * keys of BASELINE config C4), with NO host wait between the start of stage 1 and the end of stage 3:
+ *  - rhip_many_partials_dense enqueues stage 1 and returns at once.  d_table (caller-owned device memory,
+ *    world * B * 1024 words, B = ceil(key_space / world)) is zero-filled and the chunk of key k is written to row
+ *    (k % world) * B + k / world: block d of the table (rows [d B, (d + 1) B)) is what rank d must receive, so ONE
+ *    fixed-shape all-to-all (enqueued on the context's stream) is the whole exchange.  A key >= key_space is an
+ *    error that the owner's rhip_many_finalize_dense on this context reports (RHIP_ERR_ARG).
+ *  - rhip_many_finalize_dense: d_table now holds world blocks of keys_per_rank rows, block s = what source rank s
+ *    sent (all-zero rows where it never saw the key); row s * keys_per_rank + j belongs to key rank + world * j.  The
+ *    rows of a key are combined with op and canonicalised (card <= 4096 -> array, else bitset; empty dropped) -- no
+ *    gather, no sort: the table's shape is the grouping.  The ONE host wait of the pipeline is at the end of this call. */
+int rhip_many_partials_dense(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *pool, size_t n, const uint32_t *ids,
+                             uint64_t key_space, uint32_t world, uint64_t *d_table);
+rhip_pool_t *rhip_many_finalize_dense(rhip_ctx_t *ctx, rhip_op op, int is64, uint32_t world, uint32_t rank,
+                                      uint64_t keys_per_rank, const uint64_t *d_table);
 
 /* ---- measurement hooks (bench.py) --------------------------------------- */
 /* algorithmic bytes and matched container pairs of the last

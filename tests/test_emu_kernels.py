@@ -192,6 +192,27 @@ def test_emu_sharded_many_partials_and_finalize(emu, oracle, op):
         oracle.free(h)
 
 
+def test_emu_sparse_many_and_dense_shards(emu, oracle):
+    G.sparse_many_body(emu, oracle, n=400, worlds=(1, 3))
+
+
+@pytest.mark.parametrize("ch", ["1024", "3"])
+def test_emu_many_unit_shapes(oracle, synth, monkeypatch, ch):
+    """RHIP_MANY_CH forces the unit size of the many-way path: 1024 = units of more than one 512-member staging
+    chunk (key 0 of the sparse set has one member per bitmap), 3 = nearly every group split over partial chunks."""
+    from emu import build_emu, emu_engine
+    if not __import__("os").path.exists(build_emu.CXX):
+        pytest.skip("hipemu needs the ROCm clang++ to compile the kernels for the host")
+    monkeypatch.setenv("RHIP_MANY_CH", ch)
+    eng = emu_engine()
+    try:
+        G.sparse_many_body(eng, oracle, n=700 if ch == "1024" else 150, worlds=(2,))
+        G.test_synth_many(eng, oracle, synth)
+        G.test_or_many_full_container_typing(eng, oracle)
+    finally:
+        eng.close()
+
+
 def test_emu_array_filter_probe_boundaries(emu, oracle):
     G.test_array_filter_probe_boundaries(emu, oracle)
 

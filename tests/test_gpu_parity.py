@@ -113,6 +113,66 @@ def test_synth_many(engine, oracle, synth):
             oracle.free(h)
 
 
+def sparse_many_body(eng, oracle, n=600, worlds=(1, 3)):
+    """The C4 generator at test size (32 array containers of 1..512 values per bitmap, key 0 in every
+    bitmap): or_many byte-identical to the oracle, xor_many set-equal, and the DENSE sharded pipeline on `world`
+    logical shards -- rhip_many_partials_dense per shard, the all-to-all done by hand, rhip_many_finalize_dense per
+    owner -- reproduces the union.  Device tables are torch tensors on the engine's device."""
+    import torch
+    import croaring_amd
+    from croaring_amd.distributed import dense_block, shard_ids
+    blob, offs = croaring_amd.synth_sparse_portable(0, 1, n)
+    bufs = [bytes(blob[int(offs[i]):int(offs[i + 1])]) for i in range(n)]
+    hs = [oracle.deserialize(b) for b in bufs]
+    pool = eng.pool_from_blob(blob, offs)
+    want_or, want_xor = oracle.or_many(hs), oracle.xor_many(hs)
+    got = eng.or_many(pool).serialize(0)
+    assert got == oracle.serialize(want_or), "sparse or_many: bytes differ from the oracle"
+    assert eng.last_stats()["bytes_in"] == pool.payload_bytes()
+    hx = oracle.deserialize(eng.xor_many(pool).serialize(0))
+    assert oracle.validate(hx) and np.array_equal(oracle.to_array(hx), oracle.to_array(want_xor))
+    oracle.free(hx)
+    sub = np.arange(5, n, 7, dtype=np.uint32)  # a selection: same through ids
+    ws = oracle.or_many([hs[i] for i in sub])
+    assert eng.or_many(pool, sub).serialize(0) == oracle.serialize(ws)
+    oracle.free(ws)
+    dev = eng.torch_device()
+    for op, want in (("or", want_or), ("xor", want_xor)):
+        wv = oracle.to_array(want)
+        for world in worlds:
+            B = dense_block(4096, world)
+            with eng.torch_stream():
+                sends = []
+                for r in range(world):
+                    t = torch.empty((world * B, 1024), dtype=torch.int64, device=dev)
+                    eng.many_partials_dense(op, pool, shard_ids(n, r, world) if world > 1 else None, 4096, world, t.data_ptr())
+                    sends.append(t)
+                vals = []
+                for owner in range(world):  # the all-to-all: owner receives block `owner` of every source's table
+                    recv = torch.cat([sends[s][owner * B:(owner + 1) * B] for s in range(world)]).contiguous()
+                    res = eng.many_finalize_dense(op, False, world, owner, B, recv.data_ptr())
+                    h = oracle.deserialize(res.serialize(0))
+                    assert oracle.validate(h)
+                    v = oracle.to_array(h)
+                    assert np.all((v >> 16) % world == owner)
+                    vals.append(v)
+                    oracle.free(h)
+            assert np.array_equal(np.sort(np.concatenate(vals)), wv), (op, world)
+    # a key beyond the table is refused by the owner's finalize
+    with eng.torch_stream():
+        t = torch.empty((16, 1024), dtype=torch.int64, device=dev)
+        eng.many_partials_dense("or", pool, None, 16, 1, t.data_ptr())
+        with pytest.raises(Exception):
+            eng.many_finalize_dense("or", False, 1, 0, 16, t.data_ptr())
+    for h in hs + [want_or, want_xor]:
+        oracle.free(h)
+
+
+@pytest.mark.gpu
+def test_sparse_many_and_dense_shards(engine, oracle):
+    sparse_many_body(engine, oracle, n=3000, worlds=(1, 2, 8))
+
+
 def test_bitset_only_synthetic_pool(engine, oracle):
     """SURVEY §8d C2 at test size: device-generated splitmix64 pool == host restatement, and
     pairwise results on it are byte-identical to the oracle."""
@@ -612,7 +672,30 @@ def test_batches_in_flight(engine, oracle, synth):
     hold = engine.pairwise_begin("or", opnd, ids, opnd, ids)
     with pytest.raises(RoaringHipError):
         engine.pairwise_begin("and", pool, jobs[0][1], pool, jobs[0][2], reuse=opnd)
-    hold.end()
+    assert opnd.h is not None and len(opnd) == jobs[0][1].size, "a refused `reuse` pool must stay the caller's"
+    with pytest.raises(RoaringHipError):          # nor can it be updated in place
+        engine.pairwise_inplace("or", opnd, ids, opnd, ids)
+    # synchronous calls do not need a batch slot: cardinalities with four batches in flight
+    more = [engine.pairwise_begin(op, pool, l, pool, r) for op, l, r in jobs[:3]]
+    cards = engine.pairwise_cardinality("and", pool, jobs[0][1], pool, jobs[0][2])
+    assert cards.size == jobs[0][1].size
+    # freeing an operand of a batch in flight is deferred to the end of that batch
+    opnd_cards = opnd.cardinalities()[:ids.size].copy()
+    opnd.free()
+    got_hold = hold.end()
+    assert np.array_equal(got_hold.cardinalities(), opnd_cards)
+    for k, bt in enumerate(more):
+        blob, offs = bt.end().serialize_many()
+        assert np.array_equal(blob, want[k][0]) and np.array_equal(offs, want[k][1])
+    assert np.array_equal(cards, engine.pairwise("and", pool, jobs[0][1], pool, jobs[0][2]).cardinalities())
+    # matched container pairs are a property of the pair list, not of the op (or / xor also plan B-side tiles)
+    mp = {}
+    for op in OPS:
+        engine.pairwise(op, pool, jobs[0][1], pool, jobs[0][2])
+        mp[op] = engine.last_stats()["matched_pairs"]
+    engine.pairwise_cardinality("and", pool, jobs[0][1], pool, jobs[0][2])
+    mp["card"] = engine.last_stats()["matched_pairs"]
+    assert len(set(mp.values())) == 1 and mp["and"] > 0, mp
     # a result that is still in flight cannot be recycled by another batch; after its end it can
     spare = engine.pairwise("and", pool, jobs[0][1], pool, jobs[0][2])
     b = engine.pairwise_begin("or", pool, jobs[1][1], pool, jobs[1][2], reuse=spare)
