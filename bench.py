@@ -68,7 +68,7 @@ def parse_args():
     ap.add_argument("--bitmaps", type=int, default=100000, help="C4: total sparse bitmaps over all ranks")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-secondary", action="store_true", help="skip config.secondary (realdata, C4, C5)")
-    ap.add_argument("--cpu-seconds", type=float, default=16.0)
+    ap.add_argument("--cpu-seconds", type=float, default=24.0)
     return ap.parse_args()
 
 
@@ -424,9 +424,20 @@ def run_ormany(args, eng, D: Dist, steps: int, warmup: int, chk=None):
 
 
 # ----------------------------------------------------------------------------- main
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner when a
+    communicator is created), so file descriptor 1 is pointed at stderr for the whole run and the line goes to a
+    private duplicate of the original stdout."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def main():
     args = parse_args()
     maybe_spawn(args)
+    real_stdout = claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -457,7 +468,7 @@ def main():
                "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                "config": {"workload": f"C4 or_many over {args.bitmaps} sparse bitmaps x 32 array containers", **row}}
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            print(json.dumps(out), file=real_stdout, flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -561,7 +572,7 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -385,6 +385,93 @@ __global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ aren
     PH_FLUSH(0);
 }
 
+// ------------------------------------------------------------------ bitset (op) array -> (mostly) bitset (K6)
+// or / xor of a bitset with an array (either order) and bitset \ array: bitset_set_list_withcard /
+// bitset_flip_list_withcard / bitset_clear_list (bitset_util.c:978-1141) behind array_bitset_container_union,
+// array_bitset_container_xor and bitset_array_container_andnot (mixed_union.c:22-31, mixed_xor.c:23-39,
+// mixed_andnot.c:54-72).  The BITSET never goes through LDS: its 32 words per lane stay in registers, laid out as in
+// k_bb (lane l holds the 16-byte groups i * 64 + l).  Only the array is rasterised -- into a wave-private image,
+// with plain (non-returning) ds_or while the bitset's loads are still in flight -- then every lane reads ITS groups of
+// the image back (conflict-free 16-byte reads), combines, popcounts, and the result leaves from registers.  The
+// cardinality comes from the popcount, so no returning atomics; the result is a bitset for or (containers.h:
+// 1030-1045) and when xor / andnot leave more than 4096 values (mixed_xor.c:32-37, mixed_andnot.c:64-70), else the
+// (rare) array result is re-queued for k_genw's extraction path, as k_bb does.
+template <int OP>
+__global__ __launch_bounds__(256) void k_ba(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                            OutView O, const FatItem* __restrict__ q, const u64* __restrict__ qrange,
+                                            GenItem* retry_q, uint32_t* retry_count) {
+    __shared__ __attribute__((aligned(16))) uint32_t img_all[4][2048];
+    const uint32_t lane = lane_id();
+    uint32_t* img = img_all[threadIdx.x >> 6];
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
+    uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    FatItem tnext;
+    if (w < n) tnext = q[w];
+    for (; w < n; w += nwaves) {
+        const FatItem t = tnext;
+        if (w + nwaves < n) tnext = q[w + nwaves];  // next work item in flight while this one is processed
+        const bool x_is_a = (uint8_t)(t.types & 0xFF) == T_BITSET;  // (andnot: always)
+        const u32x4* __restrict__ px = (const u32x4*)(x_is_a ? arenaA + t.offa : arenaB + t.offb);
+        const uint4* __restrict__ y4 = (const uint4*)(x_is_a ? arenaB + t.offb : arenaA + t.offa);
+        const uint32_t cy = x_is_a ? t.cb : t.ca;
+        u32x4 va[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) va[i] = px[i * 64 + lane];
+        uint4 yfirst = make_uint4(0, 0, 0, 0);
+        if (8 * lane < cy) yfirst = y4[lane];
+        {
+            const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ((uint4*)img)[i * 64 + lane] = z;
+        }
+        __builtin_amdgcn_wave_barrier();  // every lane's slice is zero before any lane scatters into it
+        for (uint32_t i = lane; 8 * i < cy; i += 64) {
+            const uint4 q4 = i == lane ? yfirst : y4[i];
+            const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
+            const uint32_t nval = cy - 8 * i < 8u ? cy - 8 * i : 8u;
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                if ((uint32_t)h < nval) {
+                    const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                    atomicOr(&img[v >> 5], 1u << (v & 31));
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t tot = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint4 m4 = ((const uint4*)img)[i * 64 + lane];
+            u32x4 m;
+            m.x = m4.x; m.y = m4.y; m.z = m4.z; m.w = m4.w;
+            va[i] = vop<OP>(va[i], m);
+            tot += vpopc(va[i]);
+        }
+        const uint32_t card = wave_sum(tot);
+        uint8_t* outp = O.arena + t.offo;
+        if (OP == OP_OR || card > 4096u) {
+            u32x4* __restrict__ po = (u32x4*)outp;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) po[i * 64 + lane] = va[i];
+            if (lane == 0) O.meta[t.out] = pack_meta(T_BITSET, card, 0);
+            __builtin_amdgcn_wave_barrier();  // the image is zeroed again by the next item
+            continue;
+        }
+        if (card == 0) {
+            if (lane == 0) O.meta[t.out] = pack_meta(T_ARRAY, 0, 0);
+        } else if (lane == 0) {
+            // rare (the bitset held little more than the array took away): the result is an array -> re-queued for the
+            // extraction path of k_genw, like k_bb's array results
+            GenItem g;
+            g.offa = t.offa; g.offb = t.offb; g.out = t.out; g.ca = t.ca; g.cb = t.cb; g.types = t.types;
+            g.nra = 0; g.nrb = 0; g.offo = t.offo;
+            retry_q[atomicAdd(retry_count, 1u)] = g;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ------------------------------------------------------------------ wave-private LDS image kernel (K6, K10, K11)
 // One WAVE per container pair for {array,bitset} x {array,bitset} pairs with at least one array under
 // or / xor, and bitset \ array.  The wave owns an 8 KiB LDS image: X is loaded into it (bitset: 8

@@ -8,7 +8,7 @@ typedef unsigned long long u64;
 
 enum { T_BITSET = 1, T_ARRAY = 2, T_RUN = 3 };
 enum { OP_AND = 0, OP_OR = 1, OP_XOR = 2, OP_ANDNOT = 3 };
-enum { CLS_BB = 0, CLS_GEN = 1, CLS_COPY = 2, CLS_RETRY = 3, CLS_FILT = 4, CLS_WAVE = 5, CLS_RUNS = 6, CLS_PROBE = 7, CLS_BBA = 8, CLS_USMALL = 9, CLS_RUNS16 = 10, CLS_RUNS16W = 11, N_CLS = 12 };
+enum { CLS_BB = 0, CLS_GEN = 1, CLS_COPY = 2, CLS_RETRY = 3, CLS_FILT = 4, CLS_WAVE = 5, CLS_RUNS = 6, CLS_PROBE = 7, CLS_BBA = 8, CLS_USMALL = 9, CLS_RUNS16 = 10, CLS_RUNS16W = 11, CLS_BA = 12, N_CLS = 13 };
 // interval pairs that run four to a wave (k_ivl<16, .>): at most that many intervals per operand and values in both
 // operands together; two size classes, because the four pairs of a wave advance in lockstep
 #define R16_MAX_IV 31u

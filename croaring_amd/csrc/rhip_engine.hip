@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -144,6 +146,7 @@ struct rhip_ctx_s {
     size_t h_many_cap = 0;
     hipEvent_t ev_many_stage = nullptr;
     bool many_stage_pending = false;
+    std::vector<rhip_pool_t*> many_free;  // retired results of rhip_or_many / rhip_xor_many: their buffers are recycled
     int many_pf = 4;  // RHIP_MANY_PF: payload groups per lane k_many_l1 loads ahead (2 / 4 / 8)
     int many_ch = 0;  // RHIP_MANY_CH: members per unit (tests of the multi-chunk / multi-unit paths on small inputs); 0 = by size
     static constexpr size_t PINNED_MANY_FLAG_OFF = 2304, PINNED_MANY_TOT_OFF = 2560, PINNED_MANY_ERR_OFF = 2816;
@@ -166,7 +169,7 @@ struct rhip_ctx_s {
     // independent class kernels of one batch run concurrently: fork after planning, join before compaction
     static constexpr int N_AUX = 3;
     hipStream_t aux[N_AUX]{};
-    hipEvent_t ev_fork = nullptr, ev_join[N_AUX]{}, ev_runs = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join[N_AUX]{}, ev_runs = nullptr, ev_ba = nullptr;
     bool overlap = true;
     // Class kernels are forked onto the auxiliary streams only when the batch is big enough for their concurrency to
     // pay for the fork / join (two cross-queue dependencies, 40-50 us, and no overlap between consecutive batches):
@@ -207,6 +210,7 @@ struct rhip_pool_s {
     bool pending = false;       // result of a batch that has begun and not ended: not usable yet
     int in_use = 0;             // batches in flight that read this pool as an operand: not recyclable yet
     bool free_deferred = false; // rhip_pool_free arrived while in_use: the last batch to end frees it
+    bool from_many = false;     // result of the many-way path: rhip_pool_free hands its buffers back to the context
     uint64_t compact_mark = 0;  // arena_used right after the last compaction (0: never updated in place), see rhip_pairwise_inplace
     // host mirror of the directory (filled lazily for serialization); planning only needs bm_start
     bool host_dir = false;
@@ -251,6 +255,13 @@ static void ensure_dir(rhip_pool_t* P, uint32_t n_bitmaps, uint64_t n_cont) {
 }
 
 // ------------------------------------------------------------------ context
+// contexts that exist: a pool may outlive its context (rhip_pool_free then must not touch it)
+static std::mutex g_ctx_mu;
+static std::set<rhip_ctx_t*> g_live_ctx;
+static bool ctx_alive(rhip_ctx_t* c) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    return g_live_ctx.count(c) != 0;
+}
 extern "C" const char* rhip_last_error(void) { return g_err.c_str(); }
 extern "C" const char* rhip_version(void) { return "roaring-hip 0.1 (gfx950)"; }
 
@@ -272,6 +283,7 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         for (auto& a : c->aux) HIPCHK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_runs, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_ba, hipEventDisableTiming));
         for (auto& e : c->ev_join) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto& e : c->ev_plan) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_many_stage, hipEventDisableTiming));
@@ -284,6 +296,10 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_MANY_PF")) c->many_pf = atoi(e);
         if (const char* e = getenv("RHIP_MANY_CH")) c->many_ch = std::max(1, std::min(1024, atoi(e)));
         memset(c->h_pinned, 0, 4096);
+        {
+            std::lock_guard<std::mutex> lk(g_ctx_mu);
+            g_live_ctx.insert(c);
+        }
         return c;
     } catch (int) {
         return nullptr;
@@ -291,6 +307,10 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
 }
 extern "C" void rhip_ctx_destroy(rhip_ctx_t* c) {
     if (!c) return;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        g_live_ctx.erase(c);
+    }
     int prev_dev_ = -1;
     const bool sw_ = hipGetDevice(&prev_dev_) == hipSuccess && prev_dev_ != c->device && hipSetDevice(c->device) == hipSuccess;
     (void)hipStreamSynchronize(c->stream);
@@ -301,10 +321,13 @@ extern "C" void rhip_ctx_destroy(rhip_ctx_t* c) {
     for (auto& b : c->many) b.release();
     for (auto& b : c->sel) b.release();
     for (auto& b : c->partial_cache) { (void)hipFree(b.keys); (void)hipFree(b.words); }
+    for (rhip_pool_t* R : c->many_free) { R->release(); delete R; }
+    c->many_free.clear();
     for (auto& es : c->evs) for (auto& e : es) if (e) (void)hipEventDestroy(e);
     for (auto& a : c->aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_runs) (void)hipEventDestroy(c->ev_runs);
+    if (c->ev_ba) (void)hipEventDestroy(c->ev_ba);
     for (auto& e : c->ev_join) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_plan) if (e) (void)hipEventDestroy(e);
     if (c->ev_many_stage) (void)hipEventDestroy(c->ev_many_stage);
@@ -539,6 +562,12 @@ extern "C" void rhip_pool_free(rhip_pool_t* P) {
     if (!P) return;
     if (P->in_use > 0) {  // an operand of batches in flight: released by the last of them (rhip_pairwise_end)
         P->free_deferred = true;
+        return;
+    }
+    // A many-way result goes back to its context, buffers and all: hipFree synchronises with the device and hipMalloc of
+    // the next result costs as much again -- together more than the aggregation of a small bitmap set itself.
+    if (P->from_many && ctx_alive(P->ctx) && P->ctx->many_free.size() < 2) {
+        P->ctx->many_free.push_back(P);
         return;
     }
     P->release();  // hipFree synchronises with the device; the context may already be gone
@@ -870,7 +899,7 @@ struct Plan {
     uint32_t plan_group = 64;  // lanes per planning unit
     int slot = 0;
     hipStream_t plan_stream = nullptr;
-    bool may_bb = true, may_filt = true, may_wave = true, may_runs = true, may_copy = true;
+    bool may_bb = true, may_filt = true, may_wave = true, may_runs = true, may_copy = true, may_ba = true;
     // device pointers
     uint32_t *d_lhs = nullptr, *d_rhs = nullptr, *d_upair = nullptr, *d_utile = nullptr;
     u64* d_pair0 = nullptr;
@@ -1003,14 +1032,17 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     if (cardmode || op == OP_AND) {
         P.may_filt = (aA && (bA || bB)) || (bA && (aA || aB));
         P.may_wave = false;
+        P.may_ba = false;
         P.may_copy = false;
     } else if (op == OP_ANDNOT) {
         P.may_filt = aA && (bA || bB);
-        P.may_wave = aB && bA;
+        P.may_wave = false;
+        P.may_ba = aB && bA;       // bitset \ array
         P.may_copy = true;
     } else {
         P.may_filt = false;
-        P.may_wave = (aA && (bA || bB)) || (aB && bA);
+        P.may_wave = aA && bA;     // two arrays through the image (k_usmall takes the short-operand ones)
+        P.may_ba = (aA && bB) || (aB && bA);
         P.may_copy = true;
     }
     // ---- device scratch
@@ -1025,6 +1057,7 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     SS.q[CLS_GEN].ensure(sizeof(GenItem) * (ub_match + 1));
     SS.q[CLS_FILT].ensure(sizeof(FatItem) * (ub_match + 1));
     SS.q[CLS_WAVE].ensure(sizeof(FatItem) * (ub_match + 1));
+    SS.q[CLS_BA].ensure(sizeof(FatItem) * (ub_match + 1));
     SS.q[CLS_RUNS].ensure(sizeof(GenItem) * (ub_match + 1));
     SS.q[CLS_RETRY].ensure(sizeof(GenItem) * (ub_match + 1));
     SS.q[CLS_PROBE].ensure(sizeof(FatItem) * (ub_match + 1));
@@ -1071,7 +1104,7 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     EmitQueues Q{SS.q[CLS_BB].as<BBItem>(), SS.q[CLS_GEN].as<GenItem>(), SS.q[CLS_COPY].as<CopyItem>(),
                  SS.q[CLS_FILT].as<FatItem>(), SS.q[CLS_WAVE].as<FatItem>(), SS.q[CLS_RUNS].as<GenItem>(),
                  SS.q[CLS_PROBE].as<FatItem>(), SS.q[CLS_BBA].as<BBItem>(), SS.q[CLS_USMALL].as<FatItem>(),
-                 SS.q[CLS_RUNS16].as<GenItem>(), SS.q[CLS_RUNS16W].as<GenItem>()};
+                 SS.q[CLS_RUNS16].as<GenItem>(), SS.q[CLS_RUNS16W].as<GenItem>(), SS.q[CLS_BA].as<FatItem>()};
     const unsigned ge = (unsigned)((plan_waves * 64 + 255) / 256);
     auto count = G == 16 ? k_count<16> : G == 32 ? k_count<32> : k_count<64>;
     auto emit = G == 16 ? k_emit<16> : G == 32 ? k_emit<32> : k_emit<64>;
@@ -1119,8 +1152,9 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
     const bool has_bb = P.may_bb && nm, has_runs = P.may_runs && nm, has_filt = P.may_filt && nm;
     const bool has_wave = P.may_wave && nm && !cardmode, has_copy = P.may_copy && P.ub_cand && !cardmode;
     const bool has_bba = has_bb && !cardmode && (op == OP_AND || op == OP_ANDNOT);
-    const bool has_retry = !cardmode && ((has_bb && op != OP_OR) || has_runs);
-    const bool fork = c->overlap && (has_runs || has_filt || has_wave) && P.work_bound >= c->fork_min_bytes;
+    const bool has_retry = !cardmode && ((has_bb && op != OP_OR) || has_runs || (P.may_ba && nm && op != OP_OR));
+    const bool has_ba = P.may_ba && nm && !cardmode;
+    const bool fork = c->overlap && (has_runs || has_filt || has_wave || has_ba) && P.work_bound >= c->fork_min_bytes;
     bool used[rhip_ctx_s::N_AUX] = {false, false, false};
     auto on = [&](int a) -> hipStream_t {
         if (!fork) return s;
@@ -1148,6 +1182,16 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
     if (has_wave)
         hipLaunchKernelGGL(k_wave, dim3(bounded_grid(nm)), dim3(256), 0, on(2), VA.arena, VB.arena, O,
                            c->ss[P.slot].q[CLS_WAVE].as<FatItem>(), ranges + 2 * SEC_WAVE, op);
+    if (has_ba) {  // bitset (op) array: andnot has no k_wave items, so its stream is free; or / xor: the filter's stream
+        hipStream_t sb = on(op == OP_ANDNOT ? 2 : 1);
+        const FatItem* qb = c->ss[P.slot].q[CLS_BA].as<FatItem>();
+        const unsigned gb = bounded_grid(nm);
+        GenItem* rq = c->ss[P.slot].q[CLS_RETRY].as<GenItem>();
+        if (op == OP_OR) hipLaunchKernelGGL(k_ba<OP_OR>, dim3(gb), dim3(256), 0, sb, VA.arena, VB.arena, O, qb, ranges + 2 * SEC_BA, rq, retry_count);
+        else if (op == OP_XOR) hipLaunchKernelGGL(k_ba<OP_XOR>, dim3(gb), dim3(256), 0, sb, VA.arena, VB.arena, O, qb, ranges + 2 * SEC_BA, rq, retry_count);
+        else hipLaunchKernelGGL(k_ba<OP_ANDNOT>, dim3(gb), dim3(256), 0, sb, VA.arena, VB.arena, O, qb, ranges + 2 * SEC_BA, rq, retry_count);
+        if (fork && op != OP_OR) HIPCHK(hipEventRecord(c->ev_ba, sb));  // "k_ba done" for the retry pass
+    }
     // the general image class: forked, beside the interval chain on the auxiliary stream this op leaves idle; on one
     // stream it shares a launch with the retry pass further down
     const bool genw_merged = !fork && has_runs && has_retry;
@@ -1173,6 +1217,7 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
         // arrays (card <= 4096), interval results that must become bitsets
         hipStream_t sr = has_runs ? on(0) : s;
         if (fork && has_runs && has_bb) HIPCHK(hipStreamWaitEvent(sr, c->ev_runs, 0));
+        if (fork && has_ba && op != OP_OR) HIPCHK(hipStreamWaitEvent(sr, c->ev_ba, 0));  // k_ba re-queues its rare array results
         rhip_ctx_s::SlotScratch& SS = c->ss[P.slot];
         if (genw_merged)  // one stream: the general class and the re-queued results in one launch, after their producers
             hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 512)), dim3(256), 0, sr, VA.arena, VB.arena, O,

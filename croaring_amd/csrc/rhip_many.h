@@ -566,6 +566,37 @@ __device__ __forceinline__ void many_emit_full(const ManyOut& MO, uint32_t g, bo
     if (tid == 0) MO.O.meta[g] = pack_meta(T_BITSET, 65536u, 0u);
 }
 
+// Emit the image words r[8] of this thread (words [8 tid, 8 tid + 8)) as a bitset or as a sorted array: the many-way
+// results are never runs (container_repair_after_lazy), so this is lds_emit without its run extraction.
+__device__ __forceinline__ void many_emit(const uint32_t r[8], int ty, uint32_t rc, uint16_t* stage, uint8_t* out,
+                                          BlockScratch* sc) {
+    const uint32_t tid = threadIdx.x;
+    if (ty == T_BITSET) {
+        uint4* __restrict__ po = (uint4*)out;
+        po[2 * tid] = make_uint4(r[0], r[1], r[2], r[3]);
+        po[2 * tid + 1] = make_uint4(r[4], r[5], r[6], r[7]);
+        return;
+    }
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cnt += __popc(r[k]);
+    uint32_t tot;
+    uint32_t base = blk_exscan(cnt, sc->wsum, &tot);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        uint32_t x = r[k];
+        const uint32_t vbase = (8u * tid + k) * 32u;
+        while (x) {
+            stage[base++] = (uint16_t)(vbase + (__ffs((int)x) - 1));
+            x &= x - 1;
+        }
+    }
+    __syncthreads();
+    const uint32_t n16 = (2u * rc + 15u) >> 4;
+    uint4* __restrict__ po = (uint4*)out;
+    for (uint32_t i = tid; i < n16; i += 256) po[i] = ((const uint4*)stage)[i];
+}
+
 // What to do with the finished LDS image of group g (members [gs, ge)): partial modes store the chunk; otherwise it is
 // canonicalised -- card <= 4096 -> array, else bitset (container_repair_after_lazy, containers.h:344-371); empty ->
 // dropped by the tail.  Returns true when the caller must first answer full_union_decide's question by accumulating
@@ -594,7 +625,7 @@ __device__ __forceinline__ bool many_finalize(uint32_t* acc, uint16_t* stage, co
     int ty = T_ARRAY;
     if (rc) {
         ty = type_ba(rc);
-        lds_emit(acc, r, ty, rc, 0, stage, MO.O.arena + MO.O.off[g], sc);
+        many_emit(r, ty, rc, stage, MO.O.arena + MO.O.off[g], sc);
     }
     if (tid == 0) MO.O.meta[g] = pack_meta(ty, rc, 0);
     return false;
@@ -661,11 +692,20 @@ __global__ __launch_bounds__(256) void k_many_l2(PoolView P, ManyView V, ManyOut
         const u64 u0 = V.ustart[g], u1 = V.ustart[g + 1];
         if (u1 - u0 < 2) continue;
         uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
-        const u64 p0 = V.pstart[g];
-        for (u64 u = 0; u < u1 - u0; ++u) {
-            const uint4* __restrict__ p = (const uint4*)(MO.partial + (p0 + u) * 1024ull);
-            r0 = op4(op, r0, p[2 * tid]);
-            r1 = op4(op, r1, p[2 * tid + 1]);
+        const u64 p0 = V.pstart[g], np = u1 - u0;
+        for (u64 u = 0; u < np; u += 8) {  // eight chunks' loads in flight (one at a time: 15 GB/s for the one block)
+            uint4 a[8], b[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+                a[k] = make_uint4(0, 0, 0, 0); b[k] = a[k];
+                if (u + k < np) {
+                    const uint4* __restrict__ p = (const uint4*)(MO.partial + (p0 + u + k) * 1024ull);
+                    a[k] = p[2 * tid];
+                    b[k] = p[2 * tid + 1];
+                }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) { r0 = op4(op, r0, a[k]); r1 = op4(op, r1, b[k]); }  // (x op 0 = x for or / xor)
         }
         __syncthreads();
         ((uint4*)acc)[2 * tid] = r0;
@@ -749,7 +789,7 @@ __global__ __launch_bounds__(256) void k_many_dense_finalize(const u64* __restri
             ((uint4*)acc)[2 * tid] = r0;
             ((uint4*)acc)[2 * tid + 1] = r1;
             __syncthreads();
-            lds_emit(acc, r, ty, rc, 0, stage, O.arena + (u64)j * 8192ull, &sc);
+            many_emit(r, ty, rc, stage, O.arena + (u64)j * 8192ull, &sc);
         }
         if (tid == 0) {
             O.meta[j] = pack_meta(ty, rc, 0);

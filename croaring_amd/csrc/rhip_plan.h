@@ -147,7 +147,8 @@ enum { SEC_CAND = 0, SEC_M = 1, SEC_BB = 2, SEC_GEN = 3, SEC_COPY = 4, SEC_FILT 
        SEC_USMALL = 12,
        SEC_RUNS16 = 13,
        SEC_RUNS16W = 14,
-       N_SEC = 15 };
+       SEC_BA = 15,
+       N_SEC = 16 };
 // work class of a matched container pair
 // ia / ib = number of intervals of the operand when it is read as an interval list (runs: n_runs, arrays: card)
 // ca / cb = cardinalities
@@ -178,12 +179,13 @@ __device__ __forceinline__ int classify(int op, int cardmode, uint8_t ta, uint8_
         }
     } else if (op == OP_ANDNOT) {
         if (ta == T_ARRAY && tb != T_RUN) return ia <= PROBE_MAX ? CLS_PROBE : CLS_FILT;
-        if (ta == T_BITSET && tb == T_ARRAY) return CLS_WAVE;  // bitset \ array: clear-list in LDS
+        if (ta == T_BITSET && tb == T_ARRAY) return CLS_BA;  // bitset \\ array: the bitset stays in registers
     } else {
         // or / xor of two arrays, one of them short and the sum small enough that the result is an array whatever its
         // cardinality (mixed_union.c:162-191, mixed_xor.c:196-219): the short one is merged INTO the long one by rank
         if (ta == T_ARRAY && tb == T_ARRAY && (ia < ib ? ia : ib) <= USMALL_MAX && ia + ib <= 4096u) return CLS_USMALL;
-        if (ta != T_RUN && tb != T_RUN) return CLS_WAVE;       // or / xor with an array operand
+        if ((ta == T_BITSET && tb == T_ARRAY) || (ta == T_ARRAY && tb == T_BITSET)) return CLS_BA;  // bitset | ^ array
+        if (ta != T_RUN && tb != T_RUN) return CLS_WAVE;       // or / xor of two arrays through the image
     }
     return CLS_GEN;
 }
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         k[t] = act[t] ? SV.key[s0 + G * t + lane] : 0;
     }
     lower_bound4(LV.key, l0, l1, k, act, j);
-    uint32_t matched = 0, nbb = 0, nfilt = 0, nwave = 0, nruns_cls = 0, nprobe = 0, nbba = 0, nusm = 0, nr16 = 0, nr16w = 0, slot16 = 0, bytes = 0;
+    uint32_t matched = 0, nbb = 0, nfilt = 0, nwave = 0, nruns_cls = 0, nprobe = 0, nbba = 0, nusm = 0, nr16 = 0, nr16w = 0, nba = 0, slot16 = 0, bytes = 0;
     const bool keep_unmatched = bside || !(cardmode || op == OP_AND);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -333,6 +335,7 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         nusm += (uint32_t)__popcll(gr.ballot(cls == CLS_USMALL));
         nr16 += (uint32_t)__popcll(gr.ballot(cls == CLS_RUNS16));
         nr16w += (uint32_t)__popcll(gr.ballot(cls == CLS_RUNS16W));
+        nba += (uint32_t)__popcll(gr.ballot(cls == CLS_BA));
     }
     slot16 = gr.sum(slot16);
     bytes = gr.sum(bytes);
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         counts[SEC_CAND * S + u] = bside ? ncopy : matched + ncopy;
         counts[SEC_M * S + u] = matched;
         counts[SEC_BB * S + u] = nbb;
-        counts[SEC_GEN * S + u] = bside ? 0u : matched - nbb - nfilt - nwave - nruns_cls - nprobe - nbba - nusm - nr16 - nr16w;
+        counts[SEC_GEN * S + u] = bside ? 0u : matched - nbb - nfilt - nwave - nruns_cls - nprobe - nbba - nusm - nr16 - nr16w - nba;
         counts[SEC_PROBE * S + u] = nprobe;
         counts[SEC_BBA * S + u] = nbba;
         counts[SEC_USMALL * S + u] = nusm;
@@ -353,6 +356,7 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         counts[SEC_RUNS * S + u] = nruns_cls;
         counts[SEC_FILT * S + u] = nfilt;
         counts[SEC_WAVE * S + u] = nwave;
+        counts[SEC_BA * S + u] = nba;
         counts[SEC_COPY * S + u] = ncopy;
         counts[SEC_SLOT * S + u] = slot16;
         counts[SEC_BYTES * S + u] = bytes;
@@ -379,6 +383,7 @@ struct EmitQueues {
     FatItem* usmall; // section SEC_USMALL
     GenItem* runs16; // section SEC_RUNS16
     GenItem* runs16w; // section SEC_RUNS16W
+    FatItem* ba;      // section SEC_BA
 };
 struct CandOut {     // candidate (pre-compaction) result directory
     u64* key;        // [cand]
@@ -414,6 +419,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
     u64 qusm = starts[SEC_USMALL * S + u] - starts[SEC_USMALL * S];
     u64 qr16 = starts[SEC_RUNS16 * S + u] - starts[SEC_RUNS16 * S];
     u64 qr16w = starts[SEC_RUNS16W * S + u] - starts[SEC_RUNS16W * S];
+    u64 qba = starts[SEC_BA * S + u] - starts[SEC_BA * S];
     u64 slot_run = 16ull * (starts[SEC_SLOT * S + u] - starts[SEC_SLOT * S]);  // arena offset of the unit's first slot
     if (!bside) {
         const u64 s0 = a0 + tile * (4 * G);
@@ -473,10 +479,11 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
             const bool isr16 = cls == CLS_RUNS16;
             const bool isr16w = cls == CLS_RUNS16W;
             const bool isprobe = cls == CLS_PROBE;
+            const bool isba = cls == CLS_BA;
             const bool iscopy = emit && !found;
             const u64 mbb = gr.ballot(isbb), mgen = gr.ballot(isgen), mcp = gr.ballot(iscopy), mfl = gr.ballot(isfilt);
             const u64 mwv = gr.ballot(iswave), mrn = gr.ballot(isruns), mpr = gr.ballot(isprobe), mba = gr.ballot(isbba);
-            const u64 mus = gr.ballot(isusm), mr16 = gr.ballot(isr16), mr16w = gr.ballot(isr16w);
+            const u64 mus = gr.ballot(isusm), mr16 = gr.ballot(isr16), mr16w = gr.ballot(isr16w), mbar = gr.ballot(isba);
             if (isbb || isbba) {
                 BBItem it;
                 it.offa = A.off[ai]; it.offb = B.off[bj]; it.offo = offo; it.out = outidx; it.slot = sl;
@@ -493,7 +500,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 else if (isr16) Q.runs16[qr16 + gr.rank(mr16)] = it;
                 else Q.runs16w[qr16w + gr.rank(mr16w)] = it;
             }
-            if (isfilt || iswave || isprobe || isusm) {
+            if (isfilt || iswave || isprobe || isusm || isba) {
                 FatItem it;
                 it.offa = A.off[ai]; it.offb = B.off[bj]; it.offo = offo;
                 it.out = outidx; it.ca = ca; it.cb = cb; it.types = (uint32_t)ta | ((uint32_t)tb << 8);
@@ -501,6 +508,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 if (isfilt) Q.filt[qfilt + gr.rank(mfl)] = it;
                 else if (iswave) Q.wave[qwave + gr.rank(mwv)] = it;
                 else if (isprobe) Q.probe[qprobe + gr.rank(mpr)] = it;
+                else if (isba) Q.ba[qba + gr.rank(mbar)] = it;
                 else Q.usmall[qusm + gr.rank(mus)] = it;
             }
             if (iscopy) {
@@ -509,7 +517,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 it.out = outidx; it.n16 = (pa + 15u) >> 4;
                 Q.copy[qcopy + gr.rank(mcp)] = it;
             }
-            qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv); qruns += __popcll(mrn); qprobe += __popcll(mpr); qbba += __popcll(mba); qusm += __popcll(mus); qr16 += __popcll(mr16); qr16w += __popcll(mr16w);
+            qbb += __popcll(mbb); qgen += __popcll(mgen); qcopy += __popcll(mcp); qfilt += __popcll(mfl); qwave += __popcll(mwv); qruns += __popcll(mrn); qprobe += __popcll(mpr); qbba += __popcll(mba); qusm += __popcll(mus); qr16 += __popcll(mr16); qr16w += __popcll(mr16w); qba += __popcll(mbar);
         }
     } else {
         const u64 nAt = U.implicit ? 1 : (a1 - a0 + 255) / 256;  // A-tiles of the pair in front of its B-tiles
@@ -554,9 +562,9 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
 // matched container pairs of a batch = the items of the class queues (the SEC_M section also counts the matched keys
 // of B-tiles, which k_emit needs for ranking: under or / xor it is twice this)
 __device__ __forceinline__ u64 matched_total(const u64* __restrict__ ranges) {
-    const int secs[] = {SEC_BB, SEC_GEN, SEC_FILT, SEC_WAVE, SEC_RUNS, SEC_PROBE, SEC_BBA, SEC_USMALL, SEC_RUNS16, SEC_RUNS16W};
+    const int secs[] = {SEC_BB, SEC_GEN, SEC_FILT, SEC_WAVE, SEC_RUNS, SEC_PROBE, SEC_BBA, SEC_USMALL, SEC_RUNS16, SEC_RUNS16W, SEC_BA};
     u64 m = 0;
-    for (int k = 0; k < 10; ++k) m += ranges[2 * secs[k] + 1] - ranges[2 * secs[k]];
+    for (int k = 0; k < 11; ++k) m += ranges[2 * secs[k] + 1] - ranges[2 * secs[k]];
     return m;
 }
 
@@ -827,7 +835,10 @@ __global__ __launch_bounds__(256) void k_bitmap_bounds(PoolView P, uint32_t nbm,
     if (lane_id() == 0) {
         wout[b] = s;
         wmany[b] = sm;
-        if (P.bm_start[b + 1] > P.bm_start[b]) atomicMax(maxkey, P.key[P.bm_start[b + 1] - 1]);  // keys ascend inside a bitmap
+        if (P.bm_start[b + 1] > P.bm_start[b]) {  // keys ascend inside a bitmap: its last key is its largest
+            const u64 k = P.key[P.bm_start[b + 1] - 1];
+            if (k > __atomic_load_n(maxkey, __ATOMIC_RELAXED)) atomicMax(maxkey, k);  // (100 000 same-address atomics cost 4 ms)
+        }
         for (int t = 0; t < 3; ++t)
             if ((seen >> t) & 1u) census[t] = 1u;  // benign race: every writer stores the same value
     }
