@@ -16,6 +16,10 @@ class RoaringHipError(RuntimeError):
     pass
 
 
+class ClassStats(C.Structure):
+    _fields_ = [("kernel", C.c_char_p), ("items", C.c_uint64), ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64)]
+
+
 class Stats(C.Structure):
     _fields_ = [("matched_pairs", C.c_uint64), ("passthrough", C.c_uint64), ("bytes_in", C.c_uint64),
                 ("bytes_out", C.c_uint64), ("n_bitset_pairs", C.c_uint64), ("result_containers", C.c_uint64),
@@ -81,6 +85,8 @@ SYMBOLS = [
     ("rhip_many_finalize_dense", _vp, [_vp, _i, _i, _u32, _u32, _u64, _vp]),
     ("rhip_last_stats", _i, [_vp, C.POINTER(Stats)]),
     ("rhip_ctx_set_timing", None, [_vp, _i]),
+    ("rhip_ctx_set_class_stats", None, [_vp, _i]),
+    ("rhip_last_class_stats", _i, [_vp, C.POINTER(ClassStats), _i]),
     ("rhip_debug_host_clock", _i, [_vp, C.POINTER(C.c_double), _i]),
 ]
 

@@ -164,6 +164,8 @@ struct rhip_ctx_s {
     double hclk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     rhip_stats_t stats{};
     bool timing = false;
+    bool class_stats = false;                     // rhip_ctx_set_class_stats: one more kernel + wait per batch
+    uint64_t cls_stats[3 * N_CLS] = {};           // items / bytes in / bytes out per work class of the last batch
     hipEvent_t evs[RHIP_MAX_BATCHES_IN_FLIGHT + 1][4]{};  // timing events: [slot][call start, call end, k_bb start, k_bb end]
     hipEvent_t* ev = evs[RHIP_MAX_BATCHES_IN_FLIGHT];     // (calls that are not batches: the synchronous slot's)
     // independent class kernels of one batch run concurrently: fork after planning, join before compaction
@@ -348,6 +350,24 @@ extern "C" int rhip_ctx_synchronize(rhip_ctx_t* c) {
     return RHIP_OK;
 }
 extern "C" void rhip_ctx_set_timing(rhip_ctx_t* c, int enabled) { c->timing = enabled != 0; }
+extern "C" void rhip_ctx_set_class_stats(rhip_ctx_t* c, int enabled) { c->class_stats = enabled != 0; }
+static const char* const k_class_names[N_CLS] = {"k_bb", "k_genw", "k_copy", "(retry)", "k_filter", "k_wave", "k_ivl<64,255>", "k_probe",
+                                                 "k_bba", "k_usmall", "k_ivl<16,31>", "k_ivl<16,127>", "k_ba"};
+extern "C" int rhip_last_class_stats(rhip_ctx_t* c, rhip_class_stats_t* out, int capacity) {
+    if (!c || (!out && capacity > 0)) return RHIP_ERR_ARG;
+    int n = 0;
+    for (int k = 0; k < N_CLS; ++k) {
+        if (k == CLS_RETRY) continue;  // (re-queued items are counted under the class that produced them)
+        if (n < capacity) {
+            out[n].kernel = k_class_names[k];
+            out[n].items = c->cls_stats[3 * k];
+            out[n].bytes_in = c->cls_stats[3 * k + 1];
+            out[n].bytes_out = c->cls_stats[3 * k + 2];
+        }
+        ++n;
+    }
+    return n;
+}
 extern "C" int rhip_last_stats(rhip_ctx_t* c, rhip_stats_t* out) {
     *out = c->stats;
     return RHIP_OK;
@@ -1322,6 +1342,7 @@ struct rhip_batch_s {
     uint64_t seq;
     int slot;
     bool may_bb;
+    const u64* ranges;  // the batch's section ranges (device)
 };
 
 // Everything of a pairwise call up to and including the launch of k_tail: nothing here waits for the device.
@@ -1386,7 +1407,7 @@ extern "C" rhip_batch_t* rhip_pairwise_begin(rhip_ctx_t* c, rhip_op op_, rhip_po
         if (c->timing) HIPCHK(hipEventRecord(c->evs[slot][1], s));
         HIPCHK(hipGetLastError());  // a refused launch anywhere above must not pass silently
         clk.lap(3);
-        rhip_batch_t* b = new rhip_batch_s{c, R, A, B, seq, slot, P.may_bb};
+        rhip_batch_t* b = new rhip_batch_s{c, R, A, B, seq, slot, P.may_bb, P.ranges()};
         c->slot_busy[slot] = true;
         R->pending = true;
         ++A->in_use;
@@ -1416,6 +1437,20 @@ extern "C" rhip_pool_t* rhip_pairwise_end(rhip_batch_t* b) {
         HostClock clk(c);
         Stats st;
         finish_stats(c, nullptr, &st, b->may_bb, b->seq, slot);
+        if (c->class_stats) {  // (diagnostics: the slot's queues and meta words are intact until its next batch)
+            rhip_ctx_s::SlotScratch& SS = c->ss[slot];
+            ClassQueues CQ{SS.q[CLS_BB].as<BBItem>(), SS.q[CLS_BBA].as<BBItem>(),
+                           {SS.q[CLS_FILT].as<FatItem>(), SS.q[CLS_WAVE].as<FatItem>(), SS.q[CLS_PROBE].as<FatItem>(),
+                            SS.q[CLS_USMALL].as<FatItem>(), SS.q[CLS_BA].as<FatItem>()},
+                           {SS.q[CLS_GEN].as<GenItem>(), SS.q[CLS_RUNS].as<GenItem>(), SS.q[CLS_RUNS16].as<GenItem>(),
+                            SS.q[CLS_RUNS16W].as<GenItem>()},
+                           SS.q[CLS_COPY].as<CopyItem>()};
+            c->misc.ensure(8 * 3 * N_CLS + 64);
+            hipLaunchKernelGGL(k_class_stats, dim3(N_CLS), dim3(256), 0, c->stream, (const u64*)b->ranges, CQ,
+                               (const u64*)SS.o_meta.as<u64>(), c->misc.as<u64>());
+            HIPCHK(hipMemcpyAsync(c->cls_stats, c->misc.p, 8 * 3 * N_CLS, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
         clk.lap(4);
         R->n_cont = st.result_containers;
         R->arena_used = st.slot_bytes + 64;

@@ -736,6 +736,59 @@ __global__ void k_card_stats(const u64* __restrict__ ranges, Stats* __restrict__
     }
 }
 
+// ------------------------------------------------------------------ per-class statistics (opt-in, rhip_ctx_set_class_stats)
+// One block per work class walks that class's queue after the batch has run: items, payload bytes of the operands
+// (from the item) and of the results (from the candidate meta words the class kernels wrote) -- SURVEY §8d's algorithmic
+// bytes, split by the kernel that moved them.  out[3 * cls + {0, 1, 2}] = items, bytes in, bytes out.
+struct ClassQueues {
+    const BBItem* bb; const BBItem* bba;
+    const FatItem* fat[5];   // filt, wave, probe, usmall, ba
+    const GenItem* gen[4];   // gen, runs, runs16, runs16w
+    const CopyItem* copy;
+};
+__device__ __forceinline__ uint32_t meta_payload(u64 m) {
+    return meta_card(m) ? payload_bytes((uint8_t)meta_type(m), meta_card(m), meta_nruns(m)) : 0u;
+}
+__global__ __launch_bounds__(256) void k_class_stats(const u64* __restrict__ ranges, ClassQueues Q,
+                                                     const u64* __restrict__ meta, u64* __restrict__ out) {
+    __shared__ u64 sb[4][2];
+    const int secs[N_CLS] = {SEC_BB, SEC_GEN, SEC_COPY, -1, SEC_FILT, SEC_WAVE, SEC_RUNS, SEC_PROBE, SEC_BBA, SEC_USMALL,
+                             SEC_RUNS16, SEC_RUNS16W, SEC_BA};
+    const int cls = blockIdx.x;
+    const int sec = secs[cls];
+    u64 n = 0, bin = 0, bout = 0;
+    if (sec >= 0) {
+        n = ranges[2 * sec + 1] - ranges[2 * sec];
+        for (u64 i = threadIdx.x; i < n; i += 256) {
+            uint32_t o = 0;
+            if (cls == CLS_BB || cls == CLS_BBA) {
+                const BBItem& t = (cls == CLS_BB ? Q.bb : Q.bba)[i];
+                bin += 16384u; o = t.out;
+            } else if (cls == CLS_COPY) {
+                const CopyItem& t = Q.copy[i];
+                bin += meta_payload(t.meta); o = t.out;
+            } else if (cls == CLS_GEN || cls == CLS_RUNS || cls == CLS_RUNS16 || cls == CLS_RUNS16W) {
+                const GenItem& t = Q.gen[cls == CLS_GEN ? 0 : cls == CLS_RUNS ? 1 : cls == CLS_RUNS16 ? 2 : 3][i];
+                bin += payload_bytes((uint8_t)(t.types & 0xFF), t.ca, t.nra) + payload_bytes((uint8_t)(t.types >> 8), t.cb, t.nrb);
+                o = t.out;
+            } else {
+                const FatItem& t = Q.fat[cls == CLS_FILT ? 0 : cls == CLS_WAVE ? 1 : cls == CLS_PROBE ? 2 : cls == CLS_USMALL ? 3 : 4][i];
+                bin += payload_bytes((uint8_t)(t.types & 0xFF), t.ca, 0) + payload_bytes((uint8_t)(t.types >> 8), t.cb, 0);
+                o = t.out;
+            }
+            bout += meta_payload(meta[o]);
+        }
+    }
+    bin = wave_sum64(bin); bout = wave_sum64(bout);
+    if (lane_id() == 0) { sb[threadIdx.x >> 6][0] = bin; sb[threadIdx.x >> 6][1] = bout; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[3 * cls] = n;
+        out[3 * cls + 1] = sb[0][0] + sb[1][0] + sb[2][0] + sb[3][0];
+        out[3 * cls + 2] = sb[0][1] + sb[1][1] + sb[2][1] + sb[3][1];
+    }
+}
+
 // ------------------------------------------------------------------ directory compaction (flip / many-way paths)
 __global__ __launch_bounds__(1024) void k_sum_u64(const u64* __restrict__ v, u64 n, u64* __restrict__ out) {
     __shared__ u64 sb[16];

@@ -13,7 +13,7 @@ from typing import Iterable, Optional, Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import RoaringHipError, Stats, Partials
+from ._lib import ClassStats, RoaringHipError, Stats, Partials
 
 OPS = {"and": 0, "or": 1, "xor": 2, "andnot": 3}
 PREDS = {"intersect": 0, "is_subset": 1, "is_strict_subset": 2, "equals": 3}
@@ -85,6 +85,17 @@ class Engine:
 
     def set_timing(self, on: bool):
         self.lib.rhip_ctx_set_timing(self.h, 1 if on else 0)
+
+    def set_class_stats(self, on: bool):
+        """Per-kernel algorithmic bytes of every pairwise batch (one more kernel + wait per batch while on)."""
+        self.lib.rhip_ctx_set_class_stats(self.h, 1 if on else 0)
+
+    def last_class_stats(self) -> dict:
+        """{kernel: {"items", "bytes_in", "bytes_out"}} of the last pairwise batch ended (set_class_stats(True))."""
+        buf = (ClassStats * 16)()
+        n = self.lib.rhip_last_class_stats(self.h, buf, 16)
+        return {buf[k].kernel.decode(): {"items": int(buf[k].items), "bytes_in": int(buf[k].bytes_in),
+                                         "bytes_out": int(buf[k].bytes_out)} for k in range(min(n, 16))}
 
     def last_stats(self) -> dict:
         s = Stats()

@@ -273,6 +273,18 @@ typedef struct rhip_stats_s {
 int rhip_last_stats(rhip_ctx_t *ctx, rhip_stats_t *out);
 /* enable/disable HIP-event timing of kernel launches (adds two event records per call) */
 void rhip_ctx_set_timing(rhip_ctx_t *ctx, int enabled);
+/* Per-kernel split of a pairwise batch's algorithmic bytes (the vocabulary of roaring_bitmap_statistics,
+ * src/roaring.c:381-419, applied to the work instead of to a bitmap): for every class kernel, the container pairs
+ * (pass-through containers for k_copy) it processed, the payload bytes of their operands and of their results.
+ * Opt-in (rhip_ctx_set_class_stats): costs one more kernel and one more wait per rhip_pairwise / rhip_pairwise_end.
+ * rhip_last_class_stats fills out[0 .. min(capacity, n)) for the last batch ended and returns n, the number of
+ * classes. */
+typedef struct rhip_class_stats_s {
+    const char *kernel;  /* static string, e.g. "k_filter" */
+    uint64_t items, bytes_in, bytes_out;
+} rhip_class_stats_t;
+void rhip_ctx_set_class_stats(rhip_ctx_t *ctx, int enabled);
+int rhip_last_class_stats(rhip_ctx_t *ctx, rhip_class_stats_t *out, int capacity);
 /* Diagnostics: host time of rhip_pairwise by phase, microseconds accumulated since the last reset:
  * [0] passes over the pair list, [1] scratch sizing + host-to-device copy of the batch description,
  * [2] planning launches, [3] class + tail launches, [4] wait for completion, [5] result bookkeeping.

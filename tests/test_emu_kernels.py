@@ -192,6 +192,10 @@ def test_emu_sharded_many_partials_and_finalize(emu, oracle, op):
         oracle.free(h)
 
 
+def test_emu_class_stats(emu, oracle, synth):
+    G.test_class_stats(emu, oracle, synth)
+
+
 def test_emu_sparse_many_and_dense_shards(emu, oracle):
     G.sparse_many_body(emu, oracle, n=400, worlds=(1, 3))
 

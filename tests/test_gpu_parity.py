@@ -113,6 +113,28 @@ def test_synth_many(engine, oracle, synth):
             oracle.free(h)
 
 
+def test_class_stats(engine, oracle, synth):
+    """rhip_last_class_stats: the per-kernel split adds up to the batch totals of rhip_last_stats (SURVEY §8d
+    algorithmic bytes), for every op."""
+    bufs, _, _ = synth
+    pool = engine.pool_from_serialized(bufs)
+    n = len(bufs)
+    rng = np.random.default_rng(77)
+    lhs = rng.integers(0, n, 400).astype(np.uint32)
+    rhs = rng.integers(0, n, 400).astype(np.uint32)
+    engine.set_class_stats(True)
+    try:
+        for op in OPS:
+            engine.pairwise(op, pool, lhs, pool, rhs)
+            st, cs = engine.last_stats(), engine.last_class_stats()
+            assert sum(v["bytes_in"] for v in cs.values()) == st["bytes_in"], (op, cs, st)
+            assert sum(v["bytes_out"] for v in cs.values()) == st["bytes_out"], (op, cs, st)
+            assert sum(v["items"] for k, v in cs.items() if k != "k_copy") == st["matched_pairs"], (op, cs, st)
+            assert cs["k_copy"]["items"] == st["passthrough"]
+    finally:
+        engine.set_class_stats(False)
+
+
 def sparse_many_body(eng, oracle, n=600, worlds=(1, 3)):
     """The C4 generator at test size (32 array containers of 1..512 values per bitmap, key 0 in every
     bitmap): or_many byte-identical to the oracle, xor_many set-equal, and the DENSE sharded pipeline on `world`
