@@ -1202,7 +1202,16 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
     if (has_wave)
         hipLaunchKernelGGL(k_wave, dim3(bounded_grid(nm)), dim3(256), 0, on(2), VA.arena, VB.arena, O,
                            c->ss[P.slot].q[CLS_WAVE].as<FatItem>(), ranges + 2 * SEC_WAVE, op);
-    if (has_ba) {  // bitset (op) array: andnot has no k_wave items, so its stream is free; or / xor: the filter's stream
+    // the general image class: forked, beside the interval chain on the auxiliary stream this op leaves idle; on one
+    // stream it shares a launch with the retry pass further down
+    const bool genw_merged = !fork && has_runs && has_retry;
+    if (has_runs && !genw_merged)
+        hipLaunchKernelGGL(k_genw, dim3(4 * bounded_grid(nm, 512)), dim3(64), 0, on(!has_filt ? 1 : !has_wave ? 2 : 1),
+                           VA.arena, VB.arena, O, c->ss[P.slot].q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN,
+                           (const uint32_t*)nullptr, op, cardmode, c->pair_acc.as<u64>(), (const GenItem*)nullptr,
+                           (const uint32_t*)nullptr);
+    if (has_ba) {  // bitset (op) array, behind the few general items of its stream: andnot has no k_wave items, so that
+                   // stream is free; or / xor: the filter's stream
         hipStream_t sb = on(op == OP_ANDNOT ? 2 : 1);
         const FatItem* qb = c->ss[P.slot].q[CLS_BA].as<FatItem>();
         const unsigned gb = bounded_grid(nm);
@@ -1212,14 +1221,6 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
         else hipLaunchKernelGGL(k_ba<OP_ANDNOT>, dim3(gb), dim3(256), 0, sb, VA.arena, VB.arena, O, qb, ranges + 2 * SEC_BA, rq, retry_count);
         if (fork && op != OP_OR) HIPCHK(hipEventRecord(c->ev_ba, sb));  // "k_ba done" for the retry pass
     }
-    // the general image class: forked, beside the interval chain on the auxiliary stream this op leaves idle; on one
-    // stream it shares a launch with the retry pass further down
-    const bool genw_merged = !fork && has_runs && has_retry;
-    if (has_runs && !genw_merged)
-        hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 512)), dim3(256), 0, on(!has_filt ? 1 : !has_wave ? 2 : 1),
-                           VA.arena, VB.arena, O, c->ss[P.slot].q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN,
-                           (const uint32_t*)nullptr, op, cardmode, c->pair_acc.as<u64>(), (const GenItem*)nullptr,
-                           (const uint32_t*)nullptr);
     if (has_bb) {
         unsigned grid = persistent_grid(nm, 4, 256 * 32);
         if (c->timing) HIPCHK(hipEventRecord(c->evs[P.slot][2], s));
@@ -1240,11 +1241,11 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
         if (fork && has_ba && op != OP_OR) HIPCHK(hipStreamWaitEvent(sr, c->ev_ba, 0));  // k_ba re-queues its rare array results
         rhip_ctx_s::SlotScratch& SS = c->ss[P.slot];
         if (genw_merged)  // one stream: the general class and the re-queued results in one launch, after their producers
-            hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 512)), dim3(256), 0, sr, VA.arena, VB.arena, O,
+            hipLaunchKernelGGL(k_genw, dim3(4 * bounded_grid(nm, 512)), dim3(64), 0, sr, VA.arena, VB.arena, O,
                                SS.q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, 0,
                                c->pair_acc.as<u64>(), (const GenItem*)SS.q[CLS_RETRY].as<GenItem>(), (const uint32_t*)retry_count);
         else
-            hipLaunchKernelGGL(k_genw, dim3(bounded_grid(nm, 512)), dim3(256), 0, sr, VA.arena, VB.arena, O,
+            hipLaunchKernelGGL(k_genw, dim3(4 * bounded_grid(nm, 512)), dim3(64), 0, sr, VA.arena, VB.arena, O,
                                SS.q[CLS_RETRY].as<GenItem>(), (const u64*)nullptr, retry_count, op, 0,
                                c->pair_acc.as<u64>(), (const GenItem*)nullptr, (const uint32_t*)nullptr);
     }

@@ -331,16 +331,20 @@ __device__ void wimg_build(uint32_t* img, const uint8_t* __restrict__ p, uint32_
     }
 }
 
-__global__ __launch_bounds__(256) void k_genw(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
-                                              OutView O, const GenItem* __restrict__ q,
-                                              const u64* __restrict__ qrange, const uint32_t* __restrict__ qcount,
-                                              int op, int cardmode, u64* pair_acc,
-                                              const GenItem* __restrict__ q2, const uint32_t* __restrict__ q2count) {
+// ONE-WAVE workgroups (launch with 64 threads per block): at 248 VGPRs a wave needs half a SIMD's register file, and a
+// four-wave workgroup needs that on all four SIMDs of one CU at once -- next to a machine-filling k_filter / k_wave
+// (whose freed slots go to whoever fits first) such a workgroup waited for the big kernel's grid to drain: 216 us for
+// the 1 173 run pairs of a weather_sept_85 batch that take 47 us alone.  A single wave fits wherever two slots free up.
+__global__ __launch_bounds__(64) void k_genw(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                             OutView O, const GenItem* __restrict__ q,
+                                             const u64* __restrict__ qrange, const uint32_t* __restrict__ qcount,
+                                             int op, int cardmode, u64* pair_acc,
+                                             const GenItem* __restrict__ q2, const uint32_t* __restrict__ q2count) {
     // ONE 8 KiB image per wave: operand A is rasterised, pulled into registers, then the same image is
-    // reused for operand B and finally as the output staging buffer (16 waves per CU instead of 8)
-    __shared__ __attribute__((aligned(16))) uint32_t img_all[4][2048];
+    // reused for operand B and finally as the output staging buffer
+    __shared__ __attribute__((aligned(16))) uint32_t img_all[1][2048];
     const uint32_t lane = lane_id();
-    uint32_t* ia = img_all[threadIdx.x >> 6];
+    uint32_t* ia = img_all[0];
     uint32_t* ib = ia;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     // items: queue q (its length from the section range, or from a counter), then -- when given -- the re-queued
