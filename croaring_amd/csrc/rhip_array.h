@@ -183,17 +183,20 @@ __global__ __launch_bounds__(256) void k_usmall(const uint8_t* __restrict__ aren
                                                 const u64* __restrict__ qrange, int op) {
     // per wave: D = one byte counter per X index 0..nx (new values by rank), DEL = one bit per X index (xor: value
     // in both), GP = deleted-before count of every 8-index group
-    constexpr uint32_t D_WORDS = 1032, DEL_WORDS = 136, GP_WORDS = 264;
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[4][D_WORDS + DEL_WORDS + GP_WORDS];
+    // ST = output window of one step: <= 7 carried + 512 of X + 255 new values
+    constexpr uint32_t D_WORDS = 1032, DEL_WORDS = 136, GP_WORDS = 264, ST_WORDS = 392;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[4][D_WORDS + DEL_WORDS + GP_WORDS + ST_WORDS];
     const uint32_t lane = lane_id();
     uint32_t* D32 = lds_all[threadIdx.x >> 6];
     uint32_t* DEL = D32 + D_WORDS;
     uint16_t* GP = (uint16_t*)(DEL + DEL_WORDS);
+    uint16_t* ST = (uint16_t*)(DEL + DEL_WORDS + GP_WORDS);
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
     uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     FatItem tnext;
     if (w < n) tnext = q[w];
+    PH_BEGIN();
     for (; w < n; w += nwaves) {
         const FatItem t = tnext;
         if (w + nwaves < n) tnext = q[w + nwaves];
@@ -221,6 +224,7 @@ __global__ __launch_bounds__(256) void k_usmall(const uint8_t* __restrict__ aren
         if (op == OP_XOR)
             for (uint32_t i = lane; i < ndl; i += 64) DEL[i] = 0u;
         __builtin_amdgcn_wave_barrier();
+        PH(0);
         bool isnew[R];
         uint32_t rk[R], before[R];
         u64 m[R];
@@ -239,10 +243,22 @@ __global__ __launch_bounds__(256) void k_usmall(const uint8_t* __restrict__ aren
             ndel += (uint32_t)__popcll(__ballot(del));
         }
         __builtin_amdgcn_wave_barrier();
-        uint16_t* __restrict__ o16 = (uint16_t*)(O.arena + t.offo);
-        // ---- X, 16 bytes (8 values) per lane and step
+        PH(1);
+        uint4* __restrict__ po4 = (uint4*)(O.arena + t.offo);
+        // ---- X, 16 bytes (8 values) per lane and step.  The outputs of a step -- its X values and the new values of Y
+        // whose rank falls into it -- are one contiguous stretch of the result: they are placed in the LDS window ST
+        // (ST[0] = result index out_base, a multiple of 8) and leave as whole 16-byte groups, the incomplete last
+        // group staying behind for the next step.  (Written straight to global they were 2-byte stores 16 bytes
+        // apart, eight instructions per step for the same kilobyte: 40 % of the kernel.)
         const uint32_t ngroups = (nx + 7u) >> 3;
-        uint32_t run_new = 0, run_del = 0;
+        auto del_below = [&](uint32_t r) -> uint32_t {
+            if (op != OP_XOR) return 0u;
+            const uint32_t g = r >> 3;
+            if (g >= ngroups) return ndel;
+            const uint32_t byte = (DEL[g >> 2] >> (8u * (g & 3u))) & 0xFFu;
+            return (uint32_t)GP[g] + (uint32_t)__popc(byte & ((1u << (r & 7u)) - 1u));
+        };
+        uint32_t run_new = 0, run_del = 0, out_base = 0, carry = 0;
         for (uint32_t g0 = 0; g0 < ngroups; g0 += 64) {
             const uint32_t g = g0 + lane;
             const bool act = g < ngroups;
@@ -269,26 +285,40 @@ __global__ __launch_bounds__(256) void k_usmall(const uint8_t* __restrict__ aren
                 if ((uint32_t)h < nval) {
                     newc += ((h < 4 ? c0 : c1) >> (8 * (h & 3))) & 0xFFu;
                     const uint32_t dl = (delb >> h) & 1u;
-                    if (!dl) o16[8u * g + h + newc - delc] = (uint16_t)((d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu);
+                    if (!dl) ST[8u * g + h + newc - delc - out_base] = (uint16_t)((d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu);
                     delc += dl;
                 }
             }
-        }
-        __builtin_amdgcn_wave_barrier();  // GP complete
-        // ---- the new values of Y
-        auto del_below = [&](uint32_t r) -> uint32_t {
-            if (op != OP_XOR) return 0u;
-            const uint32_t g = r >> 3;
-            if (g >= ngroups) return ndel;
-            const uint32_t byte = (DEL[g >> 2] >> (8u * (g & 3u))) & 0xFFu;
-            return (uint32_t)GP[g] + (uint32_t)__popc(byte & ((1u << (r & 7u)) - 1u));
-        };
+            __builtin_amdgcn_wave_barrier();  // GP of this step's groups is complete
+            // the new values of Y whose rank is an X index of this step (the last step also takes rank == nx)
+            const uint32_t rlo = 8u * g0, rhi = g0 + 64u < ngroups ? 8u * (g0 + 64u) : 0xFFFFFFFFu;
+            uint32_t ynew = 0;
 #pragma unroll
-        for (uint32_t r = 0; r < R; ++r)
-            if (isnew[r]) o16[rk[r] - del_below(rk[r]) + before[r] + mbcnt(m[r])] = (uint16_t)v[r];
+            for (uint32_t r = 0; r < R; ++r) {
+                const bool here = isnew[r] && rk[r] >= rlo && rk[r] < rhi;
+                if (here) ST[rk[r] - del_below(rk[r]) + before[r] + mbcnt(m[r]) - out_base] = (uint16_t)v[r];
+                ynew += (uint32_t)__popcll(__ballot(here));
+            }
+            const uint32_t nxs = nx - 8u * g0 < 512u ? nx - 8u * g0 : 512u;  // X values of this step
+            const uint32_t cnt = carry + nxs - (tot >> 16) + ynew;         // values in the window now
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t nfull = cnt >> 3;
+            for (uint32_t j = lane; j < nfull; j += 64) po4[(out_base >> 3) + j] = ((const uint4*)ST)[j];
+            carry = cnt & 7u;
+            uint16_t keep = 0;
+            if (lane < carry) keep = ST[8u * nfull + lane];
+            __builtin_amdgcn_wave_barrier();  // the window has been read
+            if (lane < carry) ST[lane] = keep;
+            out_base += 8u * nfull;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (carry && lane == 0) po4[out_base >> 3] = ((const uint4*)ST)[0];  // (the slot is padded to 16 bytes)
+        PH(2);
         if (lane == 0) O.meta[t.out] = pack_meta(T_ARRAY, nx + nnew - ndel, 0);
         __builtin_amdgcn_wave_barrier();  // LDS is reused by the next item
+        PH(3);
     }
+    PH_FLUSH(16);
 }
 
 // ------------------------------------------------------------------ array filter (K8, K12)
