@@ -323,6 +323,26 @@ def run_realdata(eng, D: Dist, name: str, tag: str, chk, is64=False, ops=("and",
             row["cpu1_ops_per_s"] = cpu_pairs_rate(chk, hs, L, R, op, is64=is64)
             row["cpu_kind"] = chk.name
         out[f"{tag}_{op}"] = row
+    # the ops of this configuration over the pair list in ONE batch (rhip_pairwise_multi): planned once
+    if len(ops) > 1:
+        res = [None]
+
+        def mcall():
+            res[0] = eng.pairwise_multi(list(ops), pool, lhs, pool, rhs, reuse=res[0])
+        tmin, tmed = timed_calls(D, mcall)
+        st = eng.last_stats()
+        alg = D.sum(float(st["bytes_in"] + st["bytes_out"]))
+        csum = D.sum(float(res[0].cardinalities().sum()))
+        want = sum(out[f"{tag}_{op}"]["checksum"] for op in ops)
+        sep = sum(out[f"{tag}_{op}"]["ms_batch_median"] for op in ops)
+        if D.rank == 0:
+            assert int(csum) == want, f"{name} multi: checksum {int(csum)} != sum of the single-op checksums {want}"
+        out[f"{tag}_multi{len(ops)}"] = {"ops": list(ops), "pairs": int(L.size), "set_ops": int(L.size) * len(ops),
+                                        "ms_batch_median": tmed * 1e3, "ms_batch_min": tmin * 1e3,
+                                        "ms_sum_of_single_op_batches": sep, "ops_per_s": L.size * len(ops) / tmed,
+                                        "alg_GBps": alg / tmed / 1e9, "frac": alg / tmed / 1e9 / HBM_PEAK_GBS,
+                                        "checksum": int(csum), "checksum_ok": int(csum) == want}
+        res[0] = None
     tmin, tmed = timed_calls(D, lambda: eng.pairwise_cardinality("and", pool, lhs, pool, rhs))
     out[f"{tag}_and_cardinality"] = {"pairs": int(L.size), "ops_per_s": L.size / tmed, "ms_batch_median": tmed * 1e3,
                                      "ms_batch_min": tmin * 1e3}

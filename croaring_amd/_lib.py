@@ -68,6 +68,8 @@ SYMBOLS = [
     ("rhip_pairwise", _vp, [_vp, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     ("rhip_pairwise_begin", _vp, [_vp, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     ("rhip_pairwise_end", _vp, [_vp]),
+    ("rhip_pairwise_multi", _vp, [_vp, _sz, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    ("rhip_pairwise_multi_begin", _vp, [_vp, _sz, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     ("rhip_pairwise_cardinality", _i, [_vp, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     ("rhip_pairwise_predicate", _i, [_vp, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     ("rhip_pairwise_inplace", _i, [_vp, _i, _vp, _vp, _sz, _vp, _vp]),

@@ -42,7 +42,7 @@ __device__ __forceinline__ bool probe_sorted(const uint16_t* __restrict__ x16, u
 }
 __global__ __launch_bounds__(256) void k_probe(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                                OutView O, const FatItem* __restrict__ q,
-                                               const u64* __restrict__ qrange, int op, int cardmode, u64* pair_acc) {
+                                               const u64* __restrict__ qrange, int kop, int cardmode, u64* pair_acc) {
     const uint32_t lane = lane_id();
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void k_probe(const uint8_t* __restrict__ arena
     for (; w < n; w += nwaves) {
         const FatItem t = tnext;
         if (w + nwaves < n) tnext = q[w + nwaves];
+        const int op = item_op(kop, t.types);
         const uint8_t ta = (uint8_t)(t.types & 0xFF), tb = (uint8_t)(t.types >> 8);
         bool y_is_a = true;
         if (op == OP_AND) y_is_a = (ta == T_ARRAY) && (tb != T_ARRAY || t.ca <= t.cb);
@@ -180,7 +181,7 @@ __device__ __forceinline__ uint32_t probe_rank(const uint16_t* __restrict__ x16,
 }
 __global__ __launch_bounds__(256) void k_usmall(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                                 OutView O, const FatItem* __restrict__ q,
-                                                const u64* __restrict__ qrange, int op) {
+                                                const u64* __restrict__ qrange, int kop) {
     // per wave: D = one byte counter per X index 0..nx (new values by rank), DEL = one bit per X index (xor: value
     // in both), GP = deleted-before count of every 8-index group
     // ST = output window of one step: <= 7 carried + 512 of X + 255 new values
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(256) void k_usmall(const uint8_t* __restrict__ aren
     for (; w < n; w += nwaves) {
         const FatItem t = tnext;
         if (w + nwaves < n) tnext = q[w + nwaves];
+        const int op = item_op(kop, t.types);
         const bool x_is_a = t.ca >= t.cb;
         const uint8_t* xp = x_is_a ? arenaA + t.offa : arenaB + t.offb;
         const uint8_t* yp = x_is_a ? arenaB + t.offb : arenaA + t.offa;
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(256) void k_usmall(const uint8_t* __restrict__ aren
 // (containers.h:741-746, 1799-1803).
 __global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                                 OutView O, const FatItem* __restrict__ q,
-                                                const u64* __restrict__ qrange, int op, int cardmode,
+                                                const u64* __restrict__ qrange, int kop, int cardmode,
                                                 u64* pair_acc) {
     __shared__ __attribute__((aligned(16))) uint32_t img_all[4][2048];
     const uint32_t lane = lane_id();
@@ -345,6 +347,7 @@ __global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ aren
     for (; w < n; w += nwaves) {
         const FatItem t = tnext;
         if (w + nwaves < n) tnext = q[w + nwaves];  // next work item in flight while this one is processed
+        const int op = item_op(kop, t.types);
         const uint8_t ta = (uint8_t)(t.types & 0xFF), tb = (uint8_t)(t.types >> 8);
         const uint32_t ca = t.ca, cb = t.cb;
         PH(0);
@@ -441,6 +444,7 @@ __global__ __launch_bounds__(256) void k_ba(const uint8_t* __restrict__ arenaA, 
     for (; w < n; w += nwaves) {
         const FatItem t = tnext;
         if (w + nwaves < n) tnext = q[w + nwaves];  // next work item in flight while this one is processed
+        const int op = item_op(OP, t.types);
         const bool x_is_a = (uint8_t)(t.types & 0xFF) == T_BITSET;  // (andnot: always)
         const u32x4* __restrict__ px = (const u32x4*)(x_is_a ? arenaA + t.offa : arenaB + t.offb);
         const uint4* __restrict__ y4 = (const uint4*)(x_is_a ? arenaB + t.offb : arenaA + t.offa);
@@ -475,12 +479,12 @@ __global__ __launch_bounds__(256) void k_ba(const uint8_t* __restrict__ arenaA, 
             const uint4 m4 = ((const uint4*)img)[i * 64 + lane];
             u32x4 m;
             m.x = m4.x; m.y = m4.y; m.z = m4.z; m.w = m4.w;
-            va[i] = vop<OP>(va[i], m);
+            va[i] = x_is_a ? vop_any<OP>(op, va[i], m) : vop_any<OP>(op, m, va[i]);
             tot += vpopc(va[i]);
         }
         const uint32_t card = wave_sum(tot);
         uint8_t* outp = O.arena + t.offo;
-        if (OP == OP_OR || card > 4096u) {
+        if ((OP == OP_ITEM ? op == OP_OR : OP == OP_OR) || card > 4096u) {
             u32x4* __restrict__ po = (u32x4*)outp;
 #pragma unroll
             for (int i = 0; i < 8; ++i) po[i * 64 + lane] = va[i];
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(256) void k_ba(const uint8_t* __restrict__ arenaA, 
 // compacted into the (by then dead) image and leave with coalesced 16-byte stores.  No workgroup barrier anywhere.
 __global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                               OutView O, const FatItem* __restrict__ q,
-                                              const u64* __restrict__ qrange, int op) {
+                                              const u64* __restrict__ qrange, int kop) {
     __shared__ __attribute__((aligned(16))) uint32_t img_all[4][2048];
     const uint32_t lane = lane_id();
     uint32_t* img = img_all[threadIdx.x >> 6];
@@ -527,6 +531,7 @@ __global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA
     for (; w < n; w += nwaves) {
         const FatItem t = tnext;
         if (w + nwaves < n) tnext = q[w + nwaves];  // next work item in flight while this one is processed
+        const int op = item_op(kop, t.types);
         const uint8_t ta = (uint8_t)(t.types & 0xFF), tb = (uint8_t)(t.types >> 8);
         const uint32_t ca = t.ca, cb = t.cb;
         PH(0);

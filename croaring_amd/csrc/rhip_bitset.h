@@ -29,6 +29,11 @@ __device__ __forceinline__ u32x4 vop(u32x4 a, u32x4 b) {
     if (OP == OP_XOR) return a ^ b;
     return a & ~b;
 }
+__device__ __forceinline__ u32x4 vop_rt(int op, u32x4 a, u32x4 b) {  // op known per item only (multi-op batches)
+    return op == OP_AND ? (a & b) : op == OP_OR ? (a | b) : op == OP_XOR ? (a ^ b) : (a & ~b);
+}
+template <int OP>
+__device__ __forceinline__ u32x4 vop_any(int op, u32x4 a, u32x4 b) { return OP == OP_ITEM ? vop_rt(op, a, b) : vop<OP>(a, b); }
 __device__ __forceinline__ uint32_t vpopc(u32x4 v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
 
 template <int OP>
@@ -40,6 +45,9 @@ __global__ __launch_bounds__(256) void k_bb(const uint8_t* __restrict__ arenaA, 
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
     for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
         const BBItem t = q[w];
+        const int op = item_op(OP, t.slot);            // (OP_ITEM: the item's own op, wave-uniform)
+        const uint32_t slot = t.slot & 0xFFFFu;
+        const bool is_or = OP == OP_ITEM ? op == OP_OR : OP == OP_OR;
         const u32x4* __restrict__ pa = (const u32x4*)(arenaA + t.offa);
         const u32x4* __restrict__ pb = (const u32x4*)(arenaB + t.offb);
         u32x4 va[8], vb[8];
@@ -50,14 +58,14 @@ __global__ __launch_bounds__(256) void k_bb(const uint8_t* __restrict__ arenaA, 
         uint32_t cnt = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            va[i] = vop<OP>(va[i], vb[i]);
+            va[i] = vop_any<OP>(op, va[i], vb[i]);
             cnt += vpopc(va[i]);
         }
         // The result words leave as soon as they exist: whenever the slot can hold a bitset (8192 bytes: always for
         // OR; for and / xor / andnot unless the operands are too sparse for a result above 4096 values) the eight
         // stores are issued BEFORE the cardinality reduction resolves, so they overlap it.  If the result then turns
         // out to be an array (card <= 4096) the retry pass rewrites the slot; a smaller slot can never need a bitset.
-        if (!cardmode && (OP == OP_OR || t.slot >= 8192u)) {
+        if (!cardmode && (is_or || slot >= 8192u)) {
             u32x4* __restrict__ po = (u32x4*)(O.arena + t.offo);
 #pragma unroll
             for (int i = 0; i < 8; ++i) __builtin_nontemporal_store(va[i], po + i * 64 + lane);
@@ -70,7 +78,7 @@ __global__ __launch_bounds__(256) void k_bb(const uint8_t* __restrict__ arenaA, 
         // result typing: OR is always a bitset (containers.h:1015-1020); and/xor/andnot are a
         // bitset iff card > 4096 (mixed_intersection.c:305-325, mixed_xor.c:260-273,
         // mixed_andnot.c:482-497)
-        if (OP == OP_OR || card > 4096u) {
+        if (is_or || card > 4096u) {
             if (lane == 0) O.meta[t.out] = pack_meta(T_BITSET, card, 0);
         } else if (card == 0) {
             if (lane == 0) O.meta[t.out] = pack_meta(T_ARRAY, 0, 0);
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(256) void k_bb(const uint8_t* __restrict__ arenaA, 
             if (lane == 0) {
                 GenItem g;
                 g.offa = t.offa; g.offb = t.offb; g.out = t.out; g.ca = 65536u; g.cb = 65536u;
-                g.types = (uint32_t)T_BITSET | ((uint32_t)T_BITSET << 8);
+                g.types = (uint32_t)T_BITSET | ((uint32_t)T_BITSET << 8) | ((uint32_t)op << ITEM_OP_SHIFT);
                 g.nra = 0; g.nrb = 0; g.offo = t.offo;
                 retry_q[atomicAdd(retry_count, 1u)] = g;
             }
@@ -105,6 +113,7 @@ __global__ __launch_bounds__(256) void k_bba(const uint8_t* __restrict__ arenaA,
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
     for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
         const BBItem t = q[w];
+        const int op = item_op(OP, t.slot);
         const u32x4* __restrict__ pa = (const u32x4*)(arenaA + t.offa);
         const u32x4* __restrict__ pb = (const u32x4*)(arenaB + t.offb);
         u32x4 va[8], vb[8];
@@ -115,7 +124,7 @@ __global__ __launch_bounds__(256) void k_bba(const uint8_t* __restrict__ arenaA,
         uint32_t cnt[8], tot = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            va[i] = vop<OP>(va[i], vb[i]);
+            va[i] = vop_any<OP>(op, va[i], vb[i]);
             cnt[i] = vpopc(va[i]);
             tot += cnt[i];
         }

@@ -7,7 +7,11 @@
 typedef unsigned long long u64;
 
 enum { T_BITSET = 1, T_ARRAY = 2, T_RUN = 3 };
-enum { OP_AND = 0, OP_OR = 1, OP_XOR = 2, OP_ANDNOT = 3 };
+enum { OP_AND = 0, OP_OR = 1, OP_XOR = 2, OP_ANDNOT = 3,
+       OP_ITEM = 4 };  // kernel argument of a multi-op batch (rhip_pairwise_multi): every work item carries its own op
+// the op of an item: bits 16..17 of FatItem / GenItem `types`, of BBItem `slot` (written by k_emit)
+#define ITEM_OP_SHIFT 16
+__device__ __forceinline__ int item_op(int kop, uint32_t field) { return kop < OP_ITEM ? kop : (int)((field >> ITEM_OP_SHIFT) & 3u); }
 enum { CLS_BB = 0, CLS_GEN = 1, CLS_COPY = 2, CLS_RETRY = 3, CLS_FILT = 4, CLS_WAVE = 5, CLS_RUNS = 6, CLS_PROBE = 7, CLS_BBA = 8, CLS_USMALL = 9, CLS_RUNS16 = 10, CLS_RUNS16W = 11, CLS_BA = 12, N_CLS = 13 };
 // interval pairs that run four to a wave (k_ivl<16, .>): at most that many intervals per operand and values in both
 // operands together; two size classes, because the four pairs of a wave advance in lockstep

@@ -969,7 +969,16 @@ struct HostClock {  // phase p accumulates the host time between the previous la
         t = n;
     }
 };
-Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs,
+// the ops of one batch: one for rhip_pairwise, up to four for rhip_pairwise_multi (result bitmap o * npairs + k =
+// op[o] of pair k; on the device such a batch is n x npairs VIRTUAL pairs, see UnitView)
+struct OpSet {
+    int n = 1;
+    int op[4] = {0, 0, 0, 0};
+    uint32_t packed() const { uint32_t v = 0; for (int i = 0; i < n; ++i) v |= (uint32_t)op[i] << (2 * i); return v; }
+    bool has(int o) const { for (int i = 0; i < n; ++i) if (op[i] == o) return true; return false; }
+    int kop() const { return n == 1 ? op[0] : (int)OP_ITEM; }  // kernel argument: the op, or "read it from the item"
+};
+Plan plan(rhip_ctx_t* c, const OpSet& ops, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs,
           const uint32_t* rhs, int cardmode, int slot, hipStream_t s, HostClock* clk = nullptr) {
     // (s = the stream the planning kernels may use instead of the main one; taken below if the batch is not a huge one)
     rhip_ctx_s::SlotScratch& SS = c->ss[slot];
@@ -978,8 +987,18 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     P.slot = slot;
     fetch_bounds(A);
     fetch_bounds(B);
-    const bool btiles = !cardmode && (op == OP_OR || op == OP_XOR);
-    const int bmode = (cardmode || op == OP_AND) ? 0 : (op == OP_ANDNOT ? 1 : 2);
+    const size_t nvirt = npairs * (size_t)ops.n;  // virtual pairs = result bitmaps
+    if (nvirt >= 0x3FFFFFF0ull) { set_err("too many result bitmaps"); throw (int)RHIP_ERR_ARG; }
+    // per op: does the result carry B's unmatched containers (B-side tiles), and which bound formula applies
+    bool any_btiles = false;
+    int n_b0 = 0, n_b1 = 0, n_b2 = 0;  // ops by bound mode: and-like, andnot, or / xor
+    for (int o = 0; o < ops.n; ++o) {
+        const int op = ops.op[o];
+        if (cardmode || op == OP_AND) ++n_b0;
+        else if (op == OP_ANDNOT) ++n_b1;
+        else { ++n_b2; any_btiles = true; }
+    }
+    const bool btiles = any_btiles;  // (a multi-op batch gives EVERY virtual pair its B-side units; dead ones count nothing)
     // ---- pass 1 over the pair list: range check, units and every upper bound (directory mirrors only)
     // No bitmap of either pool above 256 containers (one tile): the units are implicit -- unit = pair (and / andnot /
     // cardinality) or 2 pair + side (or / xor) -- and only the two index lists travel to the device.
@@ -992,25 +1011,30 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
         const uint64_t* wAv = A->h_w.data();
         const uint64_t* wBv = B->h_w.data();
         const uint32_t nbmA = A->n_bitmaps, nbmB = B->n_bitmaps;
+        uint64_t nu_a = 0, nu_b = 0, s_mn = 0, s_na = 0, s_nb = 0, s_wmin = 0, s_wa = 0, s_wb = 0;
         for (size_t i = 0; i < npairs; ++i) {
             const uint32_t l = lhs[i], r = rhs[i];
             if (l >= nbmA || r >= nbmB) { set_err("pair %zu: bitmap index out of range", i); throw (int)RHIP_ERR_ARG; }
             const uint64_t nA = nAv[l], nB = nBv[r], wA = wAv[l], wB = wBv[r];
-            NU += (nA + 255) / 256 + (btiles ? (nB + 255) / 256 : 0);
-            const uint64_t mn = nA < nB ? nA : nB;
-            ub_match += mn;
-            if (bmode == 0) { ub += mn; bound += wA < wB ? wA : wB; }
-            else if (bmode == 1) { ub += nA; bound += wA; }
-            else { ub += nA + nB; bound += wA + wB; }
+            nu_a += (nA + 255) / 256;
+            nu_b += (nB + 255) / 256;
+            s_mn += nA < nB ? nA : nB;
+            s_na += nA; s_nb += nB;
+            s_wmin += wA < wB ? wA : wB;
+            s_wa += wA; s_wb += wB;
         }
+        NU = (size_t)(ops.n * (nu_a + (btiles ? nu_b : 0)));
+        ub_match = (uint64_t)ops.n * s_mn;
+        ub = n_b0 * s_mn + n_b1 * s_na + n_b2 * (s_na + s_nb);
+        bound = n_b0 * s_wmin + n_b1 * s_wa + n_b2 * (s_wa + s_wb);
     }
-    if (implicit) NU = npairs * (btiles ? 2 : 1);
+    if (implicit) NU = nvirt * (btiles ? 2 : 1);
     if (NU >= 0x7FFFFFF0ull) { set_err("batch too large: %zu planning units", NU); throw (int)RHIP_ERR_ARG; }
     if (ub >= 0xFFFFFFF0ull) { set_err("batch too large: %llu candidate containers", (unsigned long long)ub); throw (int)RHIP_ERR_ARG; }
-    // staging layout (host pinned == device): lhs | rhs (u32 each) and, with explicit units, pair0[npairs+1] u64 |
+    // staging layout (host pinned == device): lhs | rhs (u32 each) and, with explicit units, pair0[nvirt+1] u64 |
     // upair | utile (u32 each)
     const size_t o_lhs = 0, o_rhs = o_lhs + 4 * npairs, o_pair0 = (o_rhs + 4 * npairs + 7) & ~(size_t)7,
-                 o_upair = o_pair0 + (implicit ? 0 : 8 * (npairs + 1)), o_utile = o_upair + (implicit ? 0 : 4 * NU),
+                 o_upair = o_pair0 + (implicit ? 0 : 8 * (nvirt + 1)), o_utile = o_upair + (implicit ? 0 : 4 * NU),
                  stage_bytes = o_utile + (implicit ? 0 : 4 * NU);
     c->ensure_stage(slot, stage_bytes + 16);
     char* hs = (char*)c->h_stage[slot];
@@ -1018,20 +1042,23 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
         memcpy(hs + o_lhs, lhs, 4 * npairs);
         memcpy(hs + o_rhs, rhs, 4 * npairs);
     }
-    if (!implicit) {   // ---- pass 2: the units
+    if (!implicit) {   // ---- pass 2: the units, virtual pair by virtual pair
         uint64_t* pair0 = (uint64_t*)(hs + o_pair0);
         uint32_t* upair = (uint32_t*)(hs + o_upair);
         uint32_t* utile = (uint32_t*)(hs + o_utile);
         const uint32_t* nAv = A->h_n.data();
         const uint32_t* nBv = B->h_n.data();
         size_t u = 0;
-        for (size_t i = 0; i < npairs; ++i) {
-            const uint32_t tA = (nAv[lhs[i]] + 255u) >> 8, tB = btiles ? (nBv[rhs[i]] + 255u) >> 8 : 0u;
-            pair0[i] = u;
-            for (uint32_t t = 0; t < tA; ++t) { upair[u] = (uint32_t)i; utile[u] = t; ++u; }
-            for (uint32_t t = 0; t < tB; ++t) { upair[u] = (uint32_t)i; utile[u] = t | UNIT_B; ++u; }
+        for (int o = 0; o < ops.n; ++o) {
+            for (size_t i = 0; i < npairs; ++i) {
+                const size_t v = (size_t)o * npairs + i;
+                const uint32_t tA = (nAv[lhs[i]] + 255u) >> 8, tB = btiles ? (nBv[rhs[i]] + 255u) >> 8 : 0u;
+                pair0[v] = u;
+                for (uint32_t t = 0; t < tA; ++t) { upair[u] = (uint32_t)v; utile[u] = t; ++u; }
+                for (uint32_t t = 0; t < tB; ++t) { upair[u] = (uint32_t)v; utile[u] = t | UNIT_B; ++u; }
+            }
         }
-        pair0[npairs] = NU;
+        pair0[nvirt] = NU;
     }
     // beside an HBM-bound multi-gigabyte batch (C2: 24 GB per call) planning kernels cost the bitset kernel more
     // bandwidth than the 3 % of the call they would hide: those batches plan on the main stream
@@ -1049,21 +1076,20 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     const bool aB = has(A, 0), aA = has(A, 1), aR = has(A, 2), bB = has(B, 0), bA = has(B, 1), bR = has(B, 2);
     P.may_bb = aB && bB;
     P.may_runs = aR || bR;  // interval class and the general image class
-    if (cardmode || op == OP_AND) {
-        P.may_filt = (aA && (bA || bB)) || (bA && (aA || aB));
-        P.may_wave = false;
-        P.may_ba = false;
-        P.may_copy = false;
-    } else if (op == OP_ANDNOT) {
-        P.may_filt = aA && (bA || bB);
-        P.may_wave = false;
-        P.may_ba = aB && bA;       // bitset \ array
-        P.may_copy = true;
-    } else {
-        P.may_filt = false;
-        P.may_wave = aA && bA;     // two arrays through the image (k_usmall takes the short-operand ones)
-        P.may_ba = (aA && bB) || (aB && bA);
-        P.may_copy = true;
+    P.may_filt = P.may_wave = P.may_ba = P.may_copy = false;
+    for (int o = 0; o < ops.n; ++o) {
+        const int op = ops.op[o];
+        if (cardmode || op == OP_AND) {
+            P.may_filt |= (aA && (bA || bB)) || (bA && (aA || aB));
+        } else if (op == OP_ANDNOT) {
+            P.may_filt |= aA && (bA || bB);
+            P.may_ba |= aB && bA;       // bitset \ array
+            P.may_copy = true;
+        } else {
+            P.may_wave |= aA && bA;     // two arrays through the image (k_usmall takes the short-operand ones)
+            P.may_ba |= (aA && bB) || (aB && bA);
+            P.may_copy = true;
+        }
     }
     // ---- device scratch
     const size_t S = P.S;
@@ -1110,7 +1136,8 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     }
     if (clk) clk->lap(1);
     PoolView VA = A->view(), VB = B->view();
-    UnitView UV{P.d_upair, P.d_utile, P.d_pair0, (uint32_t)NU, (uint32_t)npairs, implicit ? (btiles ? 2u : 1u) : 0u};
+    UnitView UV{P.d_upair, P.d_utile, P.d_pair0, (uint32_t)NU, (uint32_t)nvirt, implicit ? (btiles ? 2u : 1u) : 0u,
+                (uint32_t)std::max<size_t>(npairs, 1), ops.packed()};
     PlanZero Z{P.words, (uint32_t)P.sc.n_words, cardmode ? c->pair_acc.as<u64>() : nullptr};
     const size_t zero_threads = std::max<size_t>(P.sc.n_words, cardmode ? npairs : 0);
     // planning waves: one unit per wave, or two / four when every unit is small (no bitmap above 128 / 64 containers)
@@ -1128,12 +1155,12 @@ Plan plan(rhip_ctx_t* c, int op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, 
     const unsigned ge = (unsigned)((plan_waves * 64 + 255) / 256);
     auto count = G == 16 ? k_count<16> : G == 32 ? k_count<32> : k_count<64>;
     auto emit = G == 16 ? k_emit<16> : G == 32 ? k_emit<32> : k_emit<64>;
-    hipLaunchKernelGGL(count, dim3(gp), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, op, cardmode,
+    hipLaunchKernelGGL(count, dim3(gp), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, cardmode,
                        SS.cand.as<uint32_t>(), SS.match.as<uint32_t>(), Z);
     hipLaunchKernelGGL(k_scan, dim3((unsigned)((n_scan + SCAN_TILE - 1) / SCAN_TILE)), dim3(256), 0, s,
                        SS.cand.as<uint32_t>(), SS.cand_start.as<u64>(), n_scan, P.scan_lb(), P.ranges(), (u64)S);
     if (NU)
-        hipLaunchKernelGGL(emit, dim3(ge), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, op, cardmode,
+        hipLaunchKernelGGL(emit, dim3(ge), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, cardmode,
                            SS.cand_start.as<u64>(), SS.match.as<uint32_t>(), P.CO, Q);
     if (clk) clk->lap(2);
     return P;
@@ -1163,16 +1190,20 @@ unsigned bounded_grid(uint64_t ub_items, unsigned max_blocks = 1u << 16) {
     const uint64_t need = (ub_items + 4 * ITEMS_PER_WAVE - 1) / (4 * ITEMS_PER_WAVE);
     return (unsigned)std::min<uint64_t>(std::max<uint64_t>(need, 1), max_blocks);
 }
-void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, const OutView& O, const Plan& P,
+void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const PoolView& VB, const OutView& O, const Plan& P,
                  int cardmode) {
     hipStream_t s = c->stream;
+    const int op = ops.kop();  // the batch's op, or OP_ITEM: a multi-op batch, every work item carries its own
+    const bool multi = ops.n > 1;
+    const bool any_and_like = ops.has(OP_AND) || ops.has(OP_ANDNOT), any_not_or = ops.n > 1 || ops.op[0] != OP_OR;
+    const bool any_union = ops.has(OP_OR) || ops.has(OP_XOR);
     const u64* ranges = P.ranges();
     uint32_t* retry_count = P.retry_count();
     const uint64_t nm = P.ub_match;
     const bool has_bb = P.may_bb && nm, has_runs = P.may_runs && nm, has_filt = P.may_filt && nm;
     const bool has_wave = P.may_wave && nm && !cardmode, has_copy = P.may_copy && P.ub_cand && !cardmode;
-    const bool has_bba = has_bb && !cardmode && (op == OP_AND || op == OP_ANDNOT);
-    const bool has_retry = !cardmode && ((has_bb && op != OP_OR) || has_runs || (P.may_ba && nm && op != OP_OR));
+    const bool has_bba = has_bb && !cardmode && any_and_like;
+    const bool has_retry = !cardmode && ((has_bb && any_not_or) || has_runs || (P.may_ba && nm && any_not_or));
     const bool has_ba = P.may_ba && nm && !cardmode;
     const bool fork = c->overlap && (has_runs || has_filt || has_wave || has_ba) && P.work_bound >= c->fork_min_bytes;
     bool used[rhip_ctx_s::N_AUX] = {false, false, false};
@@ -1212,11 +1243,12 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
                            (const uint32_t*)nullptr);
     if (has_ba) {  // bitset (op) array, behind the few general items of its stream: andnot has no k_wave items, so that
                    // stream is free; or / xor: the filter's stream
-        hipStream_t sb = on(op == OP_ANDNOT ? 2 : 1);
+        hipStream_t sb = on((op == OP_ANDNOT || (multi && has_filt)) ? 2 : 1);
         const FatItem* qb = c->ss[P.slot].q[CLS_BA].as<FatItem>();
         const unsigned gb = bounded_grid(nm);
         GenItem* rq = c->ss[P.slot].q[CLS_RETRY].as<GenItem>();
-        if (op == OP_OR) hipLaunchKernelGGL(k_ba<OP_OR>, dim3(gb), dim3(256), 0, sb, VA.arena, VB.arena, O, qb, ranges + 2 * SEC_BA, rq, retry_count);
+        if (multi) hipLaunchKernelGGL(k_ba<OP_ITEM>, dim3(gb), dim3(256), 0, sb, VA.arena, VB.arena, O, qb, ranges + 2 * SEC_BA, rq, retry_count);
+        else if (op == OP_OR) hipLaunchKernelGGL(k_ba<OP_OR>, dim3(gb), dim3(256), 0, sb, VA.arena, VB.arena, O, qb, ranges + 2 * SEC_BA, rq, retry_count);
         else if (op == OP_XOR) hipLaunchKernelGGL(k_ba<OP_XOR>, dim3(gb), dim3(256), 0, sb, VA.arena, VB.arena, O, qb, ranges + 2 * SEC_BA, rq, retry_count);
         else hipLaunchKernelGGL(k_ba<OP_ANDNOT>, dim3(gb), dim3(256), 0, sb, VA.arena, VB.arena, O, qb, ranges + 2 * SEC_BA, rq, retry_count);
         if (fork && op != OP_OR) HIPCHK(hipEventRecord(c->ev_ba, sb));  // "k_ba done" for the retry pass
@@ -1225,6 +1257,7 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
         unsigned grid = persistent_grid(nm, 4, 256 * 32);
         if (c->timing) HIPCHK(hipEventRecord(c->evs[P.slot][2], s));
         switch (op) {
+            case OP_ITEM: launch_bb<OP_ITEM>(c, grid, VA, VB, O, P, cardmode); break;
             case OP_AND: launch_bb<OP_AND>(c, grid, VA, VB, O, P, cardmode); break;
             case OP_OR: launch_bb<OP_OR>(c, grid, VA, VB, O, P, cardmode); break;
             case OP_XOR: launch_bb<OP_XOR>(c, grid, VA, VB, O, P, cardmode); break;
@@ -1249,14 +1282,17 @@ void run_kernels(rhip_ctx_t* c, int op, const PoolView& VA, const PoolView& VB, 
                                SS.q[CLS_RETRY].as<GenItem>(), (const u64*)nullptr, retry_count, op, 0,
                                c->pair_acc.as<u64>(), (const GenItem*)nullptr, (const uint32_t*)nullptr);
     }
-    if (has_wave && op != OP_ANDNOT)  // or / xor of a short array with a long one, by rank: light, beside k_wave
+    if (has_wave && any_union)  // or / xor of a short array with a long one, by rank: light, beside k_wave
         hipLaunchKernelGGL(k_usmall, dim3(bounded_grid(nm)), dim3(256), 0, s, VA.arena, VB.arena, O,
                            c->ss[P.slot].q[CLS_USMALL].as<FatItem>(), ranges + 2 * SEC_USMALL, op);
     if (has_filt)  // short streamed arrays: no LDS, 8 waves per SIMD -- co-resides with the LDS-bound kernels
         hipLaunchKernelGGL(k_probe, dim3(bounded_grid(nm)), dim3(256), 0, s, VA.arena, VB.arena, O,
                            c->ss[P.slot].q[CLS_PROBE].as<FatItem>(), ranges + 2 * SEC_PROBE, op, cardmode, c->pair_acc.as<u64>());
     if (has_bba) {  // bitset pairs expected to give arrays
-        if (op == OP_AND)
+        if (multi)
+            hipLaunchKernelGGL(k_bba<OP_ITEM>, dim3(bounded_grid(nm)), dim3(256), 0, s, VA.arena, VB.arena, O,
+                               c->ss[P.slot].q[CLS_BBA].as<BBItem>(), ranges + 2 * SEC_BBA);
+        else if (op == OP_AND)
             hipLaunchKernelGGL(k_bba<OP_AND>, dim3(bounded_grid(nm)), dim3(256), 0, s, VA.arena, VB.arena, O,
                                c->ss[P.slot].q[CLS_BBA].as<BBItem>(), ranges + 2 * SEC_BBA);
         else
@@ -1347,13 +1383,19 @@ struct rhip_batch_s {
 };
 
 // Everything of a pairwise call up to and including the launch of k_tail: nothing here waits for the device.
-extern "C" rhip_batch_t* rhip_pairwise_begin(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A, rhip_pool_t* B, size_t npairs,
-                                            const uint32_t* lhs, const uint32_t* rhs, rhip_pool_t* reuse) {
+static rhip_batch_t* pairwise_begin_ops(rhip_ctx_t* c, size_t n_ops, const rhip_op* ops_, rhip_pool_t* A, rhip_pool_t* B,
+                                        size_t npairs, const uint32_t* lhs, const uint32_t* rhs, rhip_pool_t* reuse) {
     rhip_pool_t* R = nullptr;
     try {
         if (!c) { set_err("null context"); throw (int)RHIP_ERR_ARG; }
-        int op = (int)op_;
-        if (op < 0 || op > 3) { set_err("bad op"); throw (int)RHIP_ERR_ARG; }
+        if (n_ops < 1 || n_ops > 4 || !ops_) { set_err("a batch takes one to four ops"); throw (int)RHIP_ERR_ARG; }
+        OpSet ops;
+        ops.n = (int)n_ops;
+        for (size_t o = 0; o < n_ops; ++o) {
+            ops.op[o] = (int)ops_[o];
+            if (ops.op[o] < 0 || ops.op[o] > 3) { set_err("bad op"); throw (int)RHIP_ERR_ARG; }
+        }
+        const int op = ops.op[0];
         DeviceGuard dguard_(c->device);
         if (reuse && (reuse->pending || reuse->in_use)) {
             reuse = nullptr;  // still owned / read by a batch
@@ -1375,8 +1417,8 @@ extern "C" rhip_batch_t* rhip_pairwise_begin(rhip_ctx_t* c, rhip_op op_, rhip_po
         // so they run beside the class kernels of the previous batch; the main stream waits for them below.
         hipStream_t ps = s;
         if (c->plan_overlap && c->overlap && c->in_flight() > 0)
-            ps = c->aux[(op == OP_OR || op == OP_XOR) ? 1 : 2];
-        Plan P = plan(c, op, A, B, npairs, lhs, rhs, 0, slot, ps, &clk);
+            ps = c->aux[(ops.n == 1 && (op == OP_OR || op == OP_XOR)) ? 1 : 2];
+        Plan P = plan(c, ops, A, B, npairs, lhs, rhs, 0, slot, ps, &clk);
         if (P.plan_stream != s) {
             HIPCHK(hipEventRecord(c->ev_plan[slot], P.plan_stream));
             HIPCHK(hipStreamWaitEvent(s, c->ev_plan[slot], 0));
@@ -1385,25 +1427,25 @@ extern "C" rhip_batch_t* rhip_pairwise_begin(rhip_ctx_t* c, rhip_op op_, rhip_po
         R = reuse ? reuse : new rhip_pool_s();
         reuse = nullptr;
         R->ctx = c;
-        R->n_bitmaps = (uint32_t)npairs;
+        R->n_bitmaps = (uint32_t)(npairs * n_ops);
         R->is64 = A->is64;
         R->host_dir = false;
         R->host_bm = false;
         R->host_w = false;
         R->h_cards.clear();
-        ensure_dir(R, (uint32_t)npairs, P.ub_cand);
+        ensure_dir(R, (uint32_t)(npairs * n_ops), P.ub_cand);
         R->arena.ensure(P.arena_bound + 64);
         OutView O{};
         O.key = CO.key; O.meta = c->ss[slot].o_meta.as<u64>(); O.off = CO.off; O.slot = nullptr;
         O.arena = R->arena.as<uint8_t>();
         PoolView VA = A->view(), VB = B->view();
-        run_kernels(c, op, VA, VB, O, P, 0);
+        run_kernels(c, ops, VA, VB, O, P, 0);
         // drop empty results, build the result directory, totals
         DirOut D{R->bm_start.as<u64>(), R->key.as<u64>(), R->type.as<uint8_t>(), R->card.as<uint32_t>(),
                  R->nruns.as<uint32_t>(), R->off.as<u64>()};
         const uint64_t seq = ++c->seq;
         hipLaunchKernelGGL(k_tail, dim3((unsigned)std::max<uint64_t>(1, (P.ub_cand + TAIL_TILE - 1) / TAIL_TILE)), dim3(256), 0,
-                           s, P.ranges(), CO, O.meta, D, (uint32_t)npairs, P.tail_lb(), P.tail_part(),
+                           s, P.ranges(), CO, O.meta, D, (uint32_t)(npairs * n_ops), P.tail_lb(), P.tail_part(),
                            (Stats*)c->slot_stats(slot), (u64*)c->done_flag(slot), (u64)seq);
         if (c->timing) HIPCHK(hipEventRecord(c->evs[slot][1], s));
         HIPCHK(hipGetLastError());  // a refused launch anywhere above must not pass silently
@@ -1420,6 +1462,21 @@ extern "C" rhip_batch_t* rhip_pairwise_begin(rhip_ctx_t* c, rhip_op op_, rhip_po
         if (reuse) { reuse->release(); delete reuse; }
         return nullptr;
     }
+}
+
+extern "C" rhip_batch_t* rhip_pairwise_begin(rhip_ctx_t* c, rhip_op op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs,
+                                            const uint32_t* lhs, const uint32_t* rhs, rhip_pool_t* reuse) {
+    return pairwise_begin_ops(c, 1, &op, A, B, npairs, lhs, rhs, reuse);
+}
+extern "C" rhip_batch_t* rhip_pairwise_multi_begin(rhip_ctx_t* c, size_t n_ops, const rhip_op* ops, rhip_pool_t* A,
+                                                  rhip_pool_t* B, size_t npairs, const uint32_t* lhs, const uint32_t* rhs,
+                                                  rhip_pool_t* reuse) {
+    return pairwise_begin_ops(c, n_ops, ops, A, B, npairs, lhs, rhs, reuse);
+}
+extern "C" rhip_pool_t* rhip_pairwise_multi(rhip_ctx_t* c, size_t n_ops, const rhip_op* ops, rhip_pool_t* A, rhip_pool_t* B,
+                                            size_t npairs, const uint32_t* lhs, const uint32_t* rhs, rhip_pool_t* reuse) {
+    rhip_batch_t* b = pairwise_begin_ops(c, n_ops, ops, A, B, npairs, lhs, rhs, reuse);
+    return b ? rhip_pairwise_end(b) : nullptr;
 }
 
 // The ONE host wait of the call; the result pool becomes usable.  Batches may be ended in any order.
@@ -1502,10 +1559,10 @@ extern "C" int rhip_pairwise_cardinality(rhip_ctx_t* c, rhip_op op_, rhip_pool_t
             if ((e = rhip_pool_cardinalities(B, cB.data())) != 0) throw e;
         }
         if (c->timing) HIPCHK(hipEventRecord(c->ev[0], s));
-        Plan P = plan(c, OP_AND, A, B, npairs, lhs, rhs, 1, rhip_ctx_s::SYNC_SLOT, s);
+        Plan P = plan(c, OpSet{}, A, B, npairs, lhs, rhs, 1, rhip_ctx_s::SYNC_SLOT, s);
         OutView O{};
         PoolView VA = A->view(), VB = B->view();
-        run_kernels(c, OP_AND, VA, VB, O, P, 1);
+        run_kernels(c, OpSet{}, VA, VB, O, P, 1);
         hipLaunchKernelGGL(k_card_stats, dim3(1), dim3(64), 0, s, P.ranges(), (Stats*)c->h_pinned);
         if (npairs) HIPCHK(hipMemcpyAsync(out, c->pair_acc.p, 8 * npairs, hipMemcpyDeviceToHost, s));
         finish_stats(c, nullptr, nullptr, P.may_bb);

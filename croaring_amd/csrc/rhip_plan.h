@@ -199,7 +199,13 @@ struct UnitView {
     uint32_t n_pairs;
     uint32_t implicit;      // 0: the arrays above; 1 / 2: every pair has exactly that many one-tile units (A, then B)
                             //    and the arrays are not there (no bitmap of the batch has more than 256 containers)
+    // Multi-op batches (rhip_pairwise_multi): n_pairs = n_ops x n_real VIRTUAL pairs, virtual pair v = op index
+    // v / n_real over real pair v % n_real (the index into lhs / rhs); ops = the ops, two bits each.  A plain batch has
+    // n_real = n_pairs and its one op in bits 0..1.
+    uint32_t n_real;
+    uint32_t ops;
 };
+__device__ __forceinline__ int unit_op(const UnitView& U, uint32_t vpair) { return (int)((U.ops >> (2u * (vpair / U.n_real))) & 3u); }
 struct UnitId { uint32_t pair; bool bside; u64 tile; u64 unit0; };
 __device__ __forceinline__ UnitId unit_id(const UnitView& U, uint32_t u) {
     UnitId r;
@@ -268,7 +274,7 @@ __device__ __forceinline__ uint32_t unit_of_group(const UnitView& U, uint32_t w,
 // match positions are kept for k_emit.
 template <uint32_t G>
 __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uint32_t* __restrict__ lhs,
-                                               const uint32_t* __restrict__ rhs, UnitView U, int op, int cardmode,
+                                               const uint32_t* __restrict__ rhs, UnitView U, int cardmode,
                                                uint32_t* __restrict__ counts, uint32_t* __restrict__ match, PlanZero Z) {
     const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 nthreads = (u64)gridDim.x * blockDim.x;
@@ -282,7 +288,8 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
     if (u >= U.n_units) return;
     const uint32_t lane = gr.gl;
     const UnitId uid = unit_id(U, u);
-    const uint32_t p = uid.pair;
+    const uint32_t p = uid.pair % U.n_real;
+    const int op = unit_op(U, uid.pair);
     const bool bside = uid.bside;
     const u64 tile = uid.tile;
     const u64 a0 = A.bm_start[lhs[p]], a1 = A.bm_start[lhs[p] + 1];
@@ -290,7 +297,9 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
     // s* = the side this tile walks, l* = the side it searches
     const PoolView& SV = bside ? B : A;
     const PoolView& LV = bside ? A : B;
-    const u64 s0 = (bside ? b0 : a0) + tile * (4 * G), sEnd = bside ? b1 : a1;
+    // (a multi-op batch gives every virtual pair a B-side unit; under and / andnot it has nothing to contribute)
+    const bool dead = bside && !(op == OP_OR || op == OP_XOR);
+    const u64 s0 = (bside ? b0 : a0) + tile * (4 * G), sEnd = dead ? s0 : (bside ? b1 : a1);
     const u64 s1 = s0 + 4 * G < sEnd ? s0 + 4 * G : sEnd;
     const u64 l0 = bside ? a0 : b0, l1 = bside ? a1 : b1;
     u64 k[4], j[4];
@@ -392,7 +401,7 @@ struct CandOut {     // candidate (pre-compaction) result directory
 };
 template <uint32_t G>
 __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint32_t* __restrict__ lhs,
-                                              const uint32_t* __restrict__ rhs, UnitView U, int op, int cardmode,
+                                              const uint32_t* __restrict__ rhs, UnitView U, int cardmode,
                                               const u64* __restrict__ starts, const uint32_t* __restrict__ match,
                                               CandOut O, EmitQueues Q) {
     const Grp<G> gr;
@@ -401,11 +410,15 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
     const uint32_t lane = gr.gl;
     const size_t S = (size_t)U.n_units + 1;
     const UnitId uid = unit_id(U, u);
-    const uint32_t p = uid.pair;
+    const uint32_t p = uid.pair;               // result bitmap (virtual pair)
+    const uint32_t pr = uid.pair % U.n_real;   // index into the pair list
+    const int op = unit_op(U, uid.pair);
+    const uint32_t opbits = (uint32_t)op << ITEM_OP_SHIFT;
     const bool bside = uid.bside;
     const u64 tile = uid.tile;
-    const u64 a0 = A.bm_start[lhs[p]], a1 = A.bm_start[lhs[p] + 1];
-    const u64 b0 = B.bm_start[rhs[p]], b1 = B.bm_start[rhs[p] + 1];
+    const u64 a0 = A.bm_start[lhs[pr]], a1 = A.bm_start[lhs[pr] + 1];
+    const u64 b0 = B.bm_start[rhs[pr]], b1 = B.bm_start[rhs[pr] + 1];
+    if (bside && !(op == OP_OR || op == OP_XOR)) return;  // (multi-op batches: the B-side unit of an and / andnot pair)
     const u64 u0 = uid.unit0;
     const u64 base = starts[SEC_CAND * S + u0];
     u64 qbb = starts[SEC_BB * S + u] - starts[SEC_BB * S];
@@ -486,14 +499,14 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
             const u64 mus = gr.ballot(isusm), mr16 = gr.ballot(isr16), mr16w = gr.ballot(isr16w), mbar = gr.ballot(isba);
             if (isbb || isbba) {
                 BBItem it;
-                it.offa = A.off[ai]; it.offb = B.off[bj]; it.offo = offo; it.out = outidx; it.slot = sl;
+                it.offa = A.off[ai]; it.offb = B.off[bj]; it.offo = offo; it.out = outidx; it.slot = sl | opbits;
                 if (isbb) Q.bb[qbb + gr.rank(mbb)] = it;
                 else Q.bba[qbba + gr.rank(mba)] = it;
             }
             if (isgen || isruns || isr16 || isr16w) {
                 GenItem it;
                 it.offa = A.off[ai]; it.offb = B.off[bj];
-                it.out = outidx; it.ca = ca; it.cb = cb; it.types = (uint32_t)ta | ((uint32_t)tb << 8);
+                it.out = outidx; it.ca = ca; it.cb = cb; it.types = (uint32_t)ta | ((uint32_t)tb << 8) | opbits;
                 it.nra = nra; it.nrb = nrb; it.offo = offo;
                 if (isgen) Q.gen[qgen + gr.rank(mgen)] = it;
                 else if (isruns) Q.runs[qruns + gr.rank(mrn)] = it;
@@ -503,7 +516,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
             if (isfilt || iswave || isprobe || isusm || isba) {
                 FatItem it;
                 it.offa = A.off[ai]; it.offb = B.off[bj]; it.offo = offo;
-                it.out = outidx; it.ca = ca; it.cb = cb; it.types = (uint32_t)ta | ((uint32_t)tb << 8);
+                it.out = outidx; it.ca = ca; it.cb = cb; it.types = (uint32_t)ta | ((uint32_t)tb << 8) | opbits;
                 it.pad0 = 0; it.pad1 = 0;
                 if (isfilt) Q.filt[qfilt + gr.rank(mfl)] = it;
                 else if (iswave) Q.wave[qwave + gr.rank(mwv)] = it;

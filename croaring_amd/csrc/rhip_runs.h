@@ -41,7 +41,7 @@ struct IvlShape {
 template <uint32_t G, uint32_t MAXIV>
 __device__ __forceinline__ void ivl_body(uint8_t* lds, uint32_t bid, uint32_t nblk, const uint8_t* __restrict__ arenaA,
                                          const uint8_t* __restrict__ arenaB, const OutView& O,
-                                         const GenItem* __restrict__ q, const u64* __restrict__ qrange, int op,
+                                         const GenItem* __restrict__ q, const u64* __restrict__ qrange, int kop,
                                          int cardmode, u64* pair_acc, GenItem* retry_q, uint32_t* retry_count) {
     using SH = IvlShape<G, MAXIV>;
     constexpr uint32_t NG = SH::NG, NB = SH::NB, LBYTES = SH::LBYTES;
@@ -61,7 +61,8 @@ __device__ __forceinline__ void ivl_body(uint8_t* lds, uint32_t bid, uint32_t nb
         const bool have = NG * wi + gr.grp < n;
         const GenItem t = tnext;
         if (NG * (wi + nwaves) + gr.grp < n) tnext = q[NG * (wi + nwaves) + gr.grp];  // next item in flight meanwhile
-        const uint32_t ta = t.types & 0xFFu, tb = t.types >> 8;
+        const uint32_t ta = t.types & 0xFFu, tb = (t.types >> 8) & 0xFFu;
+        const int op = item_op(kop, t.types);  // (multi-op batches: the groups of a wave may hold different ops)
         // boundary counts (2 x intervals); an absent item is a pair of empty lists
         const uint32_t nA = have ? 2u * (ta == T_RUN ? t.nra : t.ca) : 0u;
         const uint32_t nB2 = have ? 2u * (tb == T_RUN ? t.nrb : t.cb) : 0u;
@@ -338,7 +339,7 @@ __device__ void wimg_build(uint32_t* img, const uint8_t* __restrict__ p, uint32_
 __global__ __launch_bounds__(64) void k_genw(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                              OutView O, const GenItem* __restrict__ q,
                                              const u64* __restrict__ qrange, const uint32_t* __restrict__ qcount,
-                                             int op, int cardmode, u64* pair_acc,
+                                             int kop, int cardmode, u64* pair_acc,
                                              const GenItem* __restrict__ q2, const uint32_t* __restrict__ q2count) {
     // ONE 8 KiB image per wave: operand A is rasterised, pulled into registers, then the same image is
     // reused for operand B and finally as the output staging buffer
@@ -353,7 +354,8 @@ __global__ __launch_bounds__(64) void k_genw(const uint8_t* __restrict__ arenaA,
     const uint32_t n = n1 + (q2 ? *q2count : 0u);
     for (uint32_t wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wi < n; wi += nwaves) {
         const GenItem t = wi < n1 ? q[wi] : q2[wi - n1];
-        const uint32_t ta = t.types & 0xFFu, tb = t.types >> 8;
+        const uint32_t ta = t.types & 0xFFu, tb = (t.types >> 8) & 0xFFu;
+        const int op = item_op(kop, t.types);
         wimg_build(ia, arenaA + t.offa, ta, t.ca, t.nra);
         __builtin_amdgcn_wave_barrier();
         uint32_t r[32];

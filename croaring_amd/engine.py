@@ -193,6 +193,24 @@ class Engine:
             raise RoaringHipError(f"pairwise {op} failed: " + err)
         return Pool(self, h)
 
+    def pairwise_multi(self, ops: Sequence[str], A: "Pool", lhs, B: Optional["Pool"] = None, rhs=None,
+                       reuse: Optional["Pool"] = None) -> "Pool":
+        """Several ops over ONE pair list in one batch (rhip_pairwise_multi): result bitmap o * len(lhs) + k =
+        ops[o](A[lhs[k]], B[rhs[k]]) -- the and / or / xor / andnot sweep of the reference benchmark planned once."""
+        B = A if B is None else B
+        lhs, rhs = _pair_ids(lhs, rhs)
+        codes = (C.c_int * len(ops))(*[OPS[o] for o in ops])
+        rh = None
+        if reuse is not None:
+            rh, reuse.h = reuse.h, None  # consumed
+        h = self.lib.rhip_pairwise_multi(self.h, len(ops), codes, A.h, B.h, lhs.size, lhs.ctypes.data, rhs.ctypes.data, rh)
+        if not h:
+            err = self._err()
+            if reuse is not None and "still in flight" in err:
+                reuse.h = rh
+            raise RoaringHipError(f"pairwise_multi {list(ops)} failed: " + err)
+        return Pool(self, h)
+
     def pairwise_begin(self, op: str, A: "Pool", lhs, B: Optional["Pool"] = None, rhs=None,
                        reuse: Optional["Pool"] = None) -> "Batch":
         """First half of `pairwise`: enqueue the batch and return without waiting for the device (rhip_pairwise_begin).

@@ -161,6 +161,17 @@ typedef struct rhip_batch_s rhip_batch_t;
 rhip_batch_t *rhip_pairwise_begin(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *A, rhip_pool_t *B, size_t npairs,
                                   const uint32_t *lhs, const uint32_t *rhs, rhip_pool_t *reuse);
 rhip_pool_t *rhip_pairwise_end(rhip_batch_t *batch);
+/* Several ops over ONE pair list in one batch -- the reference's benchmark loop issues exactly that, and / or / xor /
+ * andnot of every pair one after the other (benchmarks/benchmark.cpp:2035-2091).  The batch is planned once: one
+ * staging copy of the pair list, one key-merge launch, one scan, one emit, class kernels whose queues hold the items
+ * of all the ops (every item carries its op), one tail.  Result: a pool of n_ops x npairs bitmaps, bitmap
+ * o * npairs + k = ops[o](A[lhs[k]], B[rhs[k]]), each byte-identical to what rhip_pairwise gives for that op.
+ * 1 <= n_ops <= 4; ops may repeat.  _begin / rhip_pairwise_end as for rhip_pairwise. */
+rhip_pool_t *rhip_pairwise_multi(rhip_ctx_t *ctx, size_t n_ops, const rhip_op *ops, rhip_pool_t *A, rhip_pool_t *B,
+                                 size_t npairs, const uint32_t *lhs, const uint32_t *rhs, rhip_pool_t *reuse);
+rhip_batch_t *rhip_pairwise_multi_begin(rhip_ctx_t *ctx, size_t n_ops, const rhip_op *ops, rhip_pool_t *A,
+                                        rhip_pool_t *B, size_t npairs, const uint32_t *lhs, const uint32_t *rhs,
+                                        rhip_pool_t *reuse);
 /* roaring_bitmap_{and,or,xor,andnot}_cardinality (roaring.h:231,258,270,264;
  * src/roaring.c:3048-3107): nothing is materialised. */
 int rhip_pairwise_cardinality(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *A, rhip_pool_t *B, size_t npairs,

@@ -23,3 +23,8 @@ for name in sys.argv[1:] or ["weather_sept_85", "census1881", "census-income", "
             t = time.perf_counter(); res = eng.pairwise(op, pool, lhs, pool, rhs, reuse=res); ts.append(time.perf_counter() - t)
         row[op] = round(min(ts[2:]) * 1e3, 4)
     print(tag, name, json.dumps(row), flush=True)
+    if os.environ.get("MULTI", "1") == "1":
+        res, ts = None, []
+        for _ in range(9):
+            t = time.perf_counter(); res = eng.pairwise_multi(list(OPS), pool, lhs, pool, rhs, reuse=res); ts.append(time.perf_counter() - t)
+        print(tag, name, "multi4 ms", round(min(ts[2:]) * 1e3, 4), "sum of singles", round(sum(row.values()), 4), flush=True)

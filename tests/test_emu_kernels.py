@@ -192,6 +192,23 @@ def test_emu_sharded_many_partials_and_finalize(emu, oracle, op):
         oracle.free(h)
 
 
+def test_emu_pairwise_multi(emu, oracle, synth):
+    G.test_pairwise_multi(emu, oracle, synth)
+
+
+@pytest.mark.parametrize("mode", ["1"])
+def test_emu_pairwise_multi_explicit_units(oracle, synth, monkeypatch, mode):
+    from emu import build_emu, emu_engine
+    if not __import__("os").path.exists(build_emu.CXX):
+        pytest.skip("hipemu needs the ROCm clang++ to compile the kernels for the host")
+    monkeypatch.setenv("RHIP_EXPLICIT_UNITS", mode)
+    eng = emu_engine()
+    try:
+        G.test_pairwise_multi(eng, oracle, synth)
+    finally:
+        eng.close()
+
+
 def test_emu_class_stats(emu, oracle, synth):
     G.test_class_stats(emu, oracle, synth)
 

@@ -113,6 +113,32 @@ def test_synth_many(engine, oracle, synth):
             oracle.free(h)
 
 
+def test_pairwise_multi(engine, oracle, synth):
+    """rhip_pairwise_multi: several ops over one pair list planned as ONE batch; bitmap o * npairs + k of the result
+    is byte-identical to rhip_pairwise(ops[o]) -- every class kernel reads the op from its work items."""
+    bufs, _, _ = synth
+    pool = engine.pool_from_serialized(bufs)
+    n = len(bufs)
+    rng = np.random.default_rng(99)
+    lhs = rng.integers(0, n, 500).astype(np.uint32)
+    rhs = rng.integers(0, n, 500).astype(np.uint32)
+    single = {op: engine.pairwise(op, pool, lhs, pool, rhs) for op in OPS}
+    for ops in (list(OPS), ["or", "and"], ["andnot", "xor", "andnot"], ["xor"]):
+        res = engine.pairwise_multi(ops, pool, lhs, pool, rhs)
+        assert len(res) == len(ops) * lhs.size
+        blob, offs = res.serialize_many()
+        for o, op in enumerate(ops):
+            wb, wo = single[op].serialize_many()
+            lo, hi = int(offs[o * lhs.size]), int(offs[(o + 1) * lhs.size])
+            assert hi - lo == wb.size and np.array_equal(blob[lo:hi], wb), (ops, op)
+            assert np.array_equal(offs[o * lhs.size:(o + 1) * lhs.size + 1] - offs[o * lhs.size], wo), (ops, op)
+    # the result is an ordinary pool: chained on the device
+    res = engine.pairwise_multi(["and", "or"], pool, lhs, pool, rhs)
+    k = np.arange(lhs.size, dtype=np.uint32)
+    back = engine.pairwise("and", res, k + lhs.size, res, k)  # (a | b) & (a & b) == a & b
+    assert np.array_equal(back.serialize_many()[0], single["and"].serialize_many()[0])
+
+
 def test_class_stats(engine, oracle, synth):
     """rhip_last_class_stats: the per-kernel split adds up to the batch totals of rhip_last_stats (SURVEY §8d
     algorithmic bytes), for every op."""
