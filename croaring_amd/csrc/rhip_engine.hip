@@ -1227,23 +1227,26 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
         hipLaunchKernelGGL(k_ivl_all, dim3(g1 + g2 + g3), dim3(256), 0, on(0), VA.arena, VB.arena, O, IQ, g1, g2, op,
                            cardmode, c->pair_acc.as<u64>(), SS.q[CLS_RETRY].as<GenItem>(), retry_count);
     }
+    // the general image class: forked, beside the interval chain on the auxiliary stream this op leaves idle (a multi-op
+    // batch leaves none idle: ahead of k_filter -- its one-wave blocks slip in wherever two slots are free); on one
+    // stream it shares a launch with the retry pass further down
+    const bool genw_merged = !fork && has_runs && has_retry;
+    auto launch_genw_general = [&](hipStream_t sg) {
+        hipLaunchKernelGGL(k_genw, dim3(4 * bounded_grid(nm, 512)), dim3(64), 0, sg, VA.arena, VB.arena, O,
+                           c->ss[P.slot].q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op,
+                           cardmode, c->pair_acc.as<u64>(), (const GenItem*)nullptr, (const uint32_t*)nullptr);
+    };
+    if (multi && has_runs && !genw_merged) launch_genw_general(on(1));
     if (has_filt)
         hipLaunchKernelGGL(k_filter, dim3(bounded_grid(nm)), dim3(256), 0, on(1), VA.arena, VB.arena, O,
                            c->ss[P.slot].q[CLS_FILT].as<FatItem>(), ranges + 2 * SEC_FILT, op, cardmode, c->pair_acc.as<u64>());
     if (has_wave)
         hipLaunchKernelGGL(k_wave, dim3(bounded_grid(nm)), dim3(256), 0, on(2), VA.arena, VB.arena, O,
                            c->ss[P.slot].q[CLS_WAVE].as<FatItem>(), ranges + 2 * SEC_WAVE, op);
-    // the general image class: forked, beside the interval chain on the auxiliary stream this op leaves idle; on one
-    // stream it shares a launch with the retry pass further down
-    const bool genw_merged = !fork && has_runs && has_retry;
-    if (has_runs && !genw_merged)
-        hipLaunchKernelGGL(k_genw, dim3(4 * bounded_grid(nm, 512)), dim3(64), 0, on(!has_filt ? 1 : !has_wave ? 2 : 1),
-                           VA.arena, VB.arena, O, c->ss[P.slot].q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN,
-                           (const uint32_t*)nullptr, op, cardmode, c->pair_acc.as<u64>(), (const GenItem*)nullptr,
-                           (const uint32_t*)nullptr);
+    if (!multi && has_runs && !genw_merged) launch_genw_general(on(!has_filt ? 1 : !has_wave ? 2 : 1));
     if (has_ba) {  // bitset (op) array, behind the few general items of its stream: andnot has no k_wave items, so that
                    // stream is free; or / xor: the filter's stream
-        hipStream_t sb = on((op == OP_ANDNOT || (multi && has_filt)) ? 2 : 1);
+        hipStream_t sb = on(multi ? 0 : (op == OP_ANDNOT ? 2 : 1));  // (multi-op: behind the interval kernel)
         const FatItem* qb = c->ss[P.slot].q[CLS_BA].as<FatItem>();
         const unsigned gb = bounded_grid(nm);
         GenItem* rq = c->ss[P.slot].q[CLS_RETRY].as<GenItem>();
