@@ -1,11 +1,12 @@
-"""Copy what profiles/ cites out of gpurun_out/final_r2 (scratch) after `gpurun -- 'bash scripts/gpu_final_r2.sh'`:
+"""Copy what profiles/ cites out of gpurun_out/final_rN (scratch) after `gpurun -- 'bash scripts/gpu_final_rN.sh'`
+(argv[1] = tag, default r03):
 kernel-stats CSVs, the bench line, JSON-lines tables, the kernel timelines of one batch per workload, and the PMC
 summaries (scripts/summarize_pmc.py, scripts/summarize_sq.py)."""
 import csv, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "final_r2")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+SRC = os.path.join(ROOT, "gpurun_out", "final_" + TAG.replace("0", "", 1))
 DST = os.path.join(ROOT, "profiles")
-TAG = "r02"
 
 def cp(src, dst):
     if os.path.exists(src):
@@ -14,8 +15,10 @@ def cp(src, dst):
 
 cp(os.path.join(SRC, "bench.json"), f"{TAG}_bench.json")
 for f, d in (("c2_ops.jsonl", "c2_ops"), ("quick_c3.jsonl", "quick_c3"), ("class_throughput.jsonl", "class_throughput"),
-             ("poolops.jsonl", "poolops")):
-    cp(os.path.join(SRC, f), f"{TAG}_{d}.jsonl")
+             ("poolops.jsonl", "poolops"), ("per_kernel_c3.jsonl", "per_kernel_c3"), ("multi.txt", "multi_ops")):
+    cp(os.path.join(SRC, f), f"{TAG}_{d}" + (".txt" if f.endswith(".txt") else ".jsonl"))
+for f in ("pmc_c4_sq.md",):
+    cp(os.path.join(SRC, f), f"{TAG}_{f}")
 for d in sorted(glob.glob(os.path.join(SRC, "prof_*"))):
     if not os.path.isdir(d):
         continue
@@ -32,7 +35,7 @@ for d in sorted(glob.glob(os.path.join(SRC, "prof_*"))):
     if not tr:
         continue
     rows = sorted(csv.DictReader(open(tr[0])), key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_count")]
+    idx = [i for i, r in enumerate(rows) if "k_count" in r["Kernel_Name"] or "k_many_gather" in r["Kernel_Name"]]
     if len(idx) < 2:
         continue
     i0, i1 = idx[-2], idx[-1]
@@ -42,7 +45,7 @@ for d in sorted(glob.glob(os.path.join(SRC, "prof_*"))):
     lines.append(f"== {os.path.basename(d)[5:]}   ({ms[0].strip() if ms else ''})")
     for r in rows[i0:i1]:
         s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
-        lines.append(f"  {r['Kernel_Name'].split('(')[0][:28]:28s} start {s / 1e3:8.1f}  end {e / 1e3:8.1f}  dur {(e - s) / 1e3:7.1f}")
+        lines.append(f"  {r['Kernel_Name'].split('(')[0].replace('void ', '')[:28]:28s} start {s / 1e3:8.1f}  end {e / 1e3:8.1f}  dur {(e - s) / 1e3:7.1f}")
     lines.append(f"  call-to-call period {(int(rows[i1]['Start_Timestamp']) - t0) / 1e3:.1f} us")
     lines.append("")
 open(os.path.join(DST, f"{TAG}_timelines.txt"), "w").write("\n".join(lines))

@@ -4,7 +4,6 @@ import collections, csv, glob, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]
 tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
-ITEMS = {"and": {"k_filter": None, "k_probe": None}, "or": {"k_wave": 223255}}
 out = [f"# SQ counters of the class kernels, C3 weather_sept_85 all-pairs ({tag})", "",
        "`rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS "
        "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace` on `scripts/prof_weather.py {and,or}` (12 batches each).",
