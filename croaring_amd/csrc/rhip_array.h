@@ -40,13 +40,13 @@ __device__ __forceinline__ bool probe_sorted(const uint16_t* __restrict__ x16, u
     }
     return pos != 0u && last == v;
 }
-__global__ __launch_bounds__(256) void k_probe(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+__device__ __forceinline__ void probe_body(uint32_t* __restrict__ lds, uint32_t bid, uint32_t nblk, const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                                OutView O, const FatItem* __restrict__ q,
                                                const u64* __restrict__ qrange, int kop, int cardmode, u64* pair_acc) {
     const uint32_t lane = lane_id();
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t w = (bid * blockDim.x + threadIdx.x) >> 6;
     FatItem tnext;
     if (w < n) tnext = q[w];
     for (; w < n; w += nwaves) {
@@ -104,6 +104,13 @@ __global__ __launch_bounds__(256) void k_probe(const uint8_t* __restrict__ arena
         }
     }
 }
+__global__ __launch_bounds__(256) void k_probe(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                               OutView O, const FatItem* __restrict__ q,
+                                               const u64* __restrict__ qrange, int kop, int cardmode, u64* pair_acc) {
+    uint32_t* lds = nullptr;
+    probe_body(lds, blockIdx.x, gridDim.x, arenaA, arenaB, O, q, qrange, kop, cardmode, pair_acc);
+}
+
 
 __device__ __forceinline__ void wave_scatter_or(uint32_t* img, const uint4* __restrict__ x4, uint32_t nx, uint32_t lane) {
     const uint32_t nfull = nx >> 3;   // whole 8-value groups: no per-value bound checks
@@ -179,22 +186,22 @@ __device__ __forceinline__ uint32_t probe_rank(const uint16_t* __restrict__ x16,
     *present = pos != 0u && last == v;
     return pos == 0u ? 0u : (last == v ? idx : idx + 1u);
 }
-__global__ __launch_bounds__(256) void k_usmall(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+constexpr uint32_t D_WORDS = 1032, DEL_WORDS = 136, GP_WORDS = 264, ST_WORDS = 392;  // k_usmall's LDS per wave, words
+constexpr uint32_t USMALL_LDS_WORDS = 4 * (D_WORDS + DEL_WORDS + GP_WORDS + ST_WORDS);
+__device__ __forceinline__ void usmall_body(uint32_t* __restrict__ lds, uint32_t bid, uint32_t nblk, const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                                 OutView O, const FatItem* __restrict__ q,
                                                 const u64* __restrict__ qrange, int kop) {
     // per wave: D = one byte counter per X index 0..nx (new values by rank), DEL = one bit per X index (xor: value
     // in both), GP = deleted-before count of every 8-index group
     // ST = output window of one step: <= 7 carried + 512 of X + 255 new values
-    constexpr uint32_t D_WORDS = 1032, DEL_WORDS = 136, GP_WORDS = 264, ST_WORDS = 392;
-    __shared__ __attribute__((aligned(16))) uint32_t lds_all[4][D_WORDS + DEL_WORDS + GP_WORDS + ST_WORDS];
     const uint32_t lane = lane_id();
-    uint32_t* D32 = lds_all[threadIdx.x >> 6];
+    uint32_t* D32 = lds + (threadIdx.x >> 6) * (D_WORDS + DEL_WORDS + GP_WORDS + ST_WORDS);
     uint32_t* DEL = D32 + D_WORDS;
     uint16_t* GP = (uint16_t*)(DEL + DEL_WORDS);
     uint16_t* ST = (uint16_t*)(DEL + DEL_WORDS + GP_WORDS);
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t w = (bid * blockDim.x + threadIdx.x) >> 6;
     FatItem tnext;
     if (w < n) tnext = q[w];
     PH_BEGIN();
@@ -322,6 +329,13 @@ __global__ __launch_bounds__(256) void k_usmall(const uint8_t* __restrict__ aren
     }
     PH_FLUSH(16);
 }
+__global__ __launch_bounds__(256) void k_usmall(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                                OutView O, const FatItem* __restrict__ q,
+                                                const u64* __restrict__ qrange, int kop) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[USMALL_LDS_WORDS];
+    usmall_body(lds, blockIdx.x, gridDim.x, arenaA, arenaB, O, q, qrange, kop);
+}
+
 
 // ------------------------------------------------------------------ array filter (K8, K12)
 // One WAVE per container pair, no workgroup barriers: the membership side X is brought into a wave-private 8 KiB LDS
@@ -331,16 +345,15 @@ __global__ __launch_bounds__(256) void k_usmall(const uint8_t* __restrict__ aren
 // (array_util.c:385-459) and array_bitset_container_intersection / _andnot (mixed_intersection.c:19-46,
 // mixed_andnot.c:24-39); short streamed arrays take k_probe instead.  The result is always an array
 // (containers.h:741-746, 1799-1803).
-__global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+__device__ __forceinline__ void filter_body(uint32_t* __restrict__ lds, uint32_t bid, uint32_t nblk, const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                                 OutView O, const FatItem* __restrict__ q,
                                                 const u64* __restrict__ qrange, int kop, int cardmode,
                                                 u64* pair_acc) {
-    __shared__ __attribute__((aligned(16))) uint32_t img_all[4][2048];
     const uint32_t lane = lane_id();
-    uint32_t* img = img_all[threadIdx.x >> 6];
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    uint32_t* img = lds + (threadIdx.x >> 6) * 2048u;
+    const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t w = (bid * blockDim.x + threadIdx.x) >> 6;
     FatItem tnext;
     if (w < n) tnext = q[w];
     PH_BEGIN();
@@ -417,6 +430,14 @@ __global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ aren
     }
     PH_FLUSH(0);
 }
+__global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                                OutView O, const FatItem* __restrict__ q,
+                                                const u64* __restrict__ qrange, int kop, int cardmode,
+                                                u64* pair_acc) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[8192];
+    filter_body(lds, blockIdx.x, gridDim.x, arenaA, arenaB, O, q, qrange, kop, cardmode, pair_acc);
+}
+
 
 // ------------------------------------------------------------------ bitset (op) array -> (mostly) bitset (K6)
 // or / xor of a bitset with an array (either order) and bitset \ array: bitset_set_list_withcard /
@@ -430,15 +451,14 @@ __global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ aren
 // 1030-1045) and when xor / andnot leave more than 4096 values (mixed_xor.c:32-37, mixed_andnot.c:64-70), else the
 // (rare) array result is re-queued for k_genw's extraction path, as k_bb does.
 template <int OP>
-__global__ __launch_bounds__(256) void k_ba(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+__device__ __forceinline__ void ba_body(uint32_t* __restrict__ lds, uint32_t bid, uint32_t nblk, const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                             OutView O, const FatItem* __restrict__ q, const u64* __restrict__ qrange,
                                             GenItem* retry_q, uint32_t* retry_count) {
-    __shared__ __attribute__((aligned(16))) uint32_t img_all[4][2048];
     const uint32_t lane = lane_id();
-    uint32_t* img = img_all[threadIdx.x >> 6];
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    uint32_t* img = lds + (threadIdx.x >> 6) * 2048u;
+    const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t w = (bid * blockDim.x + threadIdx.x) >> 6;
     FatItem tnext;
     if (w < n) tnext = q[w];
     for (; w < n; w += nwaves) {
@@ -505,6 +525,14 @@ __global__ __launch_bounds__(256) void k_ba(const uint8_t* __restrict__ arenaA, 
         __builtin_amdgcn_wave_barrier();
     }
 }
+template <int OP>
+__global__ __launch_bounds__(256) void k_ba(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                            OutView O, const FatItem* __restrict__ q, const u64* __restrict__ qrange,
+                                            GenItem* retry_q, uint32_t* retry_count) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[8192];
+    ba_body<OP>(lds, blockIdx.x, gridDim.x, arenaA, arenaB, O, q, qrange, retry_q, retry_count);
+}
+
 
 // ------------------------------------------------------------------ wave-private LDS image kernel (K6, K10, K11)
 // One WAVE per container pair for {array,bitset} x {array,bitset} pairs with at least one array under
@@ -516,15 +544,14 @@ __global__ __launch_bounds__(256) void k_ba(const uint8_t* __restrict__ arenaA, 
 // rules and either streamed out as a bitset or extracted as a sorted array: words are owned strided
 // (balanced under clustering), a two-level popcount prefix gives every word its output position, values are
 // compacted into the (by then dead) image and leave with coalesced 16-byte stores.  No workgroup barrier anywhere.
-__global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+__device__ __forceinline__ void wave_body(uint32_t* __restrict__ lds, uint32_t bid, uint32_t nblk, const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                               OutView O, const FatItem* __restrict__ q,
                                               const u64* __restrict__ qrange, int kop) {
-    __shared__ __attribute__((aligned(16))) uint32_t img_all[4][2048];
     const uint32_t lane = lane_id();
-    uint32_t* img = img_all[threadIdx.x >> 6];
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    uint32_t* img = lds + (threadIdx.x >> 6) * 2048u;
+    const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t w = (bid * blockDim.x + threadIdx.x) >> 6;
     FatItem tnext;
     if (w < n) tnext = q[w];
     PH_BEGIN();
@@ -668,3 +695,10 @@ __global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA
     }
     PH_FLUSH(8);
 }
+__global__ __launch_bounds__(256) void k_wave(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                              OutView O, const FatItem* __restrict__ q,
+                                              const u64* __restrict__ qrange, int kop) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[8192];
+    wave_body(lds, blockIdx.x, gridDim.x, arenaA, arenaB, O, q, qrange, kop);
+}
+

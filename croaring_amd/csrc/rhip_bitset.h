@@ -37,13 +37,13 @@ __device__ __forceinline__ u32x4 vop_any(int op, u32x4 a, u32x4 b) { return OP =
 __device__ __forceinline__ uint32_t vpopc(u32x4 v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
 
 template <int OP>
-__global__ __launch_bounds__(256) void k_bb(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+__device__ __forceinline__ void bb_body(uint32_t* __restrict__ lds, uint32_t bid, uint32_t nblk, const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                             OutView O, const BBItem* __restrict__ q, const u64* __restrict__ qrange,
                                             int cardmode, u64* pair_acc, GenItem* retry_q, uint32_t* retry_count) {
     const uint32_t lane = lane_id();
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
+    for (uint32_t w = (bid * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
         const BBItem t = q[w];
         const int op = item_op(OP, t.slot);            // (OP_ITEM: the item's own op, wave-uniform)
         const uint32_t slot = t.slot & 0xFFFFu;
@@ -94,6 +94,14 @@ __global__ __launch_bounds__(256) void k_bb(const uint8_t* __restrict__ arenaA, 
         }
     }
 }
+template <int OP>
+__global__ __launch_bounds__(256) void k_bb(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                            OutView O, const BBItem* __restrict__ q, const u64* __restrict__ qrange,
+                                            int cardmode, u64* pair_acc, GenItem* retry_q, uint32_t* retry_count) {
+    uint32_t* lds = nullptr;
+    bb_body<OP>(lds, blockIdx.x, gridDim.x, arenaA, arenaB, O, q, qrange, cardmode, pair_acc, retry_q, retry_count);
+}
+
 
 // ------------------------------------------------------------------ bitset x bitset -> (mostly) array
 // and / andnot of two bitsets whose result is expected to hold at most 4096 values (three quarters of the bitset pairs
@@ -104,14 +112,13 @@ __global__ __launch_bounds__(256) void k_bb(const uint8_t* __restrict__ arenaA, 
 // sorted output is segment by segment, inside a segment lane by lane (wave prefix of popcounts), inside a lane bit by
 // bit; values are compacted into a wave-private 8 KiB LDS buffer and leave with coalesced 16-byte stores.
 template <int OP>
-__global__ __launch_bounds__(256) void k_bba(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+__device__ __forceinline__ void bba_body(uint32_t* __restrict__ lds, uint32_t bid, uint32_t nblk, const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                              OutView O, const BBItem* __restrict__ q, const u64* __restrict__ qrange) {
-    __shared__ __attribute__((aligned(16))) uint16_t stage_all[4][4096];
     const uint32_t lane = lane_id();
-    uint16_t* st16 = stage_all[threadIdx.x >> 6];
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    uint16_t* st16 = (uint16_t*)(lds + (threadIdx.x >> 6) * 2048u);
+    const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    for (uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
+    for (uint32_t w = (bid * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
         const BBItem t = q[w];
         const int op = item_op(OP, t.slot);
         const u32x4* __restrict__ pa = (const u32x4*)(arenaA + t.offa);
@@ -164,18 +171,25 @@ __global__ __launch_bounds__(256) void k_bba(const uint8_t* __restrict__ arenaA,
         __builtin_amdgcn_wave_barrier();  // the staging buffer is reused by the next item
     }
 }
+template <int OP>
+__global__ __launch_bounds__(256) void k_bba(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                             OutView O, const BBItem* __restrict__ q, const u64* __restrict__ qrange) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[8192];
+    bba_body<OP>(lds, blockIdx.x, gridDim.x, arenaA, arenaB, O, q, qrange);
+}
+
 
 // ------------------------------------------------------------------ pass-through copy
 // The item says where from, where to, how much -- no directory loads.  A wave takes FOUR items at a time: when all
 // of them are short (<= 256 bytes, the pass-through containers of sparse data) each quarter-wave copies one, 16 bytes
 // per lane; otherwise the whole wave copies them one after the other.
-__global__ __launch_bounds__(256) void k_copy(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+__device__ __forceinline__ void copy_body(uint32_t* __restrict__ lds, uint32_t bid, uint32_t nblk, const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                               OutView O, const CopyItem* __restrict__ q,
                                               const u64* __restrict__ qrange) {
     const uint32_t lane = lane_id(), grp = lane >> 4, gl = lane & 15u;
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t w = (bid * blockDim.x + threadIdx.x) >> 6;
     CopyItem tn;
     if (4 * w + grp < n) tn = q[4 * w + grp];
     for (; 4 * w < n; w += nwaves) {
@@ -203,6 +217,13 @@ __global__ __launch_bounds__(256) void k_copy(const uint8_t* __restrict__ arenaA
         }
     }
 }
+__global__ __launch_bounds__(256) void k_copy(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                              OutView O, const CopyItem* __restrict__ q,
+                                              const u64* __restrict__ qrange) {
+    uint32_t* lds = nullptr;
+    copy_body(lds, blockIdx.x, gridDim.x, arenaA, arenaB, O, q, qrange);
+}
+
 
 
 // ------------------------------------------------------------------ synthetic C2 pool

@@ -34,4 +34,5 @@
 #include "rhip_bitset.h"
 #include "rhip_array.h"
 #include "rhip_runs.h"
+#include "rhip_classes.h"
 #include "rhip_block.h"

@@ -246,7 +246,7 @@ def test_emu_tiny_interval_pairs(emu, oracle):
     G.test_tiny_interval_pairs(emu, oracle)
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("mode", ["1", "2", "fork", "nomerge"])
 def test_emu_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
     """Batches whose bitmaps all have <= 256 containers plan on implicit units (unit = pair / 2 pair + side), four
     units per wave up to 64 containers; RHIP_EXPLICIT_UNITS=1 forces the staged unit arrays that larger bitmaps need,
@@ -254,12 +254,21 @@ def test_emu_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
     from emu import build_emu, emu_engine
     if not __import__("os").path.exists(build_emu.CXX):
         pytest.skip("hipemu needs the ROCm clang++ to compile the kernels for the host")
-    monkeypatch.setenv("RHIP_EXPLICIT_UNITS", mode)
+    if mode == "fork":       # the stand-alone class kernels (a small batch otherwise runs them as ONE launch, k_classes)
+        monkeypatch.setenv("RHIP_FORK_MIN_MB", "0")
+    elif mode == "nomerge":
+        monkeypatch.setenv("RHIP_MERGE_CLASSES", "0")
+    else:
+        monkeypatch.setenv("RHIP_EXPLICIT_UNITS", mode)
     eng = emu_engine()
     try:
         G.test_edge_cases(eng, oracle)
         G.test_synth_every_type_pair(eng, oracle, synth, "xor")
         G.test_synth_every_type_pair(eng, oracle, synth, "andnot")
+        if mode in ("fork", "nomerge"):
+            G.test_synth_every_type_pair(eng, oracle, synth, "and")
+            G.test_synth_every_type_pair(eng, oracle, synth, "or")
+            G.test_pairwise_multi(eng, oracle, synth)
     finally:
         eng.close()
 

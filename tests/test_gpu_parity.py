@@ -667,15 +667,18 @@ def test_tiny_interval_pairs(engine, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["1", "2", "fork"])
+@pytest.mark.parametrize("mode", ["1", "2", "fork", "nomerge"])
 def test_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
     """Paths the size of a batch selects, forced on the same small inputs (big batches reach them by themselves).
     Small bitmaps plan on implicit units, four per wave up to 64 containers a bitmap: RHIP_EXPLICIT_UNITS=1 forces the
     staged unit arrays of the general path, =2 implicit units with one unit per wave.  Small batches keep every class
-    kernel on one stream: RHIP_FORK_MIN_MB=0 forks them onto the auxiliary streams."""
+    kernel in ONE launch (k_classes): RHIP_FORK_MIN_MB=0 forks the stand-alone kernels onto the auxiliary streams,
+    RHIP_MERGE_CLASSES=0 launches them one by one on the main stream."""
     import croaring_amd
     if mode == "fork":
         monkeypatch.setenv("RHIP_FORK_MIN_MB", "0")
+    elif mode == "nomerge":
+        monkeypatch.setenv("RHIP_MERGE_CLASSES", "0")
     else:
         monkeypatch.setenv("RHIP_EXPLICIT_UNITS", mode)
     eng = croaring_amd.Engine()
