@@ -490,8 +490,18 @@ size_t parse_portable32(const char* buf, size_t len, uint64_t key_hi, HostDir& D
     return (size_t)(p - buf);
 }
 
-rhip_pool_t* upload(rhip_ctx_t* ctx, HostDir& D, uint32_t n_bitmaps, bool is64) {
-    rhip_pool_t* P = new rhip_pool_s();
+// `into`: a pool that no batch reads any more, to be refilled -- its device buffers are kept (grown when needed), every
+// cached host-side fact about the old content is dropped.  A per-call caller (roaring_compat.inc) then pays no
+// hipMalloc / hipFree pair per buffer and call.  On failure `into` is destroyed like a fresh pool would be.
+rhip_pool_t* upload(rhip_ctx_t* ctx, HostDir& D, uint32_t n_bitmaps, bool is64, rhip_pool_t* into = nullptr) {
+    rhip_pool_t* P = into ? into : new rhip_pool_s();
+    if (into) {
+        rhip_pool_s fresh;
+        std::swap(fresh.bm_start, P->bm_start); std::swap(fresh.key, P->key); std::swap(fresh.type, P->type);
+        std::swap(fresh.card, P->card); std::swap(fresh.nruns, P->nruns); std::swap(fresh.off, P->off);
+        std::swap(fresh.arena, P->arena);
+        *P = std::move(fresh);
+    }
     try {
         DeviceGuard dguard_(ctx->device);
         P->ctx = ctx;
@@ -507,6 +517,28 @@ rhip_pool_t* upload(rhip_ctx_t* ctx, HostDir& D, uint32_t n_bitmaps, bool is64) 
         P->arena.ensure(D.arena.size());
         P->arena_used = D.arena.size();
         hipStream_t s = ctx->stream;
+        const size_t small_total = 8 * D.bm_start.size() + 29 * D.key.size() + D.arena.size() + 7 * 16;
+        if (small_total <= (1u << 20)) {
+            // A small pool (the per-call drop-ins upload two bitmaps a call): seven copy commands from pageable memory
+            // are seven synchronous staging round trips inside the runtime.  Pack the seven arrays into the context's
+            // pinned staging buffer (free between synchronous calls) and issue seven asynchronous copies from there.
+            ctx->ensure_stage(rhip_ctx_s::SYNC_SLOT, small_total);
+            char* hs = (char*)ctx->h_stage[rhip_ctx_s::SYNC_SLOT];
+            size_t at = 0;
+            auto put = [&](void* dst, const void* src, size_t n) {
+                if (!n) return;
+                memcpy(hs + at, src, n);
+                HIPCHK(hipMemcpyAsync(dst, hs + at, n, hipMemcpyHostToDevice, s));
+                at += (n + 15) & ~(size_t)15;
+            };
+            put(P->bm_start.p, D.bm_start.data(), 8 * D.bm_start.size());
+            put(P->key.p, D.key.data(), 8 * D.key.size());
+            put(P->type.p, D.type.data(), D.type.size());
+            put(P->card.p, D.card.data(), 4 * D.card.size());
+            put(P->nruns.p, D.nruns.data(), 4 * D.nruns.size());
+            put(P->off.p, D.off.data(), 8 * D.off.size());
+            put(P->arena.p, D.arena.data(), D.arena.size());
+        } else {
         HIPCHK(hipMemcpyAsync(P->bm_start.p, D.bm_start.data(), 8 * D.bm_start.size(), hipMemcpyHostToDevice, s));
         if (P->n_cont) {
             HIPCHK(hipMemcpyAsync(P->key.p, D.key.data(), 8 * D.key.size(), hipMemcpyHostToDevice, s));
@@ -516,6 +548,7 @@ rhip_pool_t* upload(rhip_ctx_t* ctx, HostDir& D, uint32_t n_bitmaps, bool is64) 
             HIPCHK(hipMemcpyAsync(P->off.p, D.off.data(), 8 * D.off.size(), hipMemcpyHostToDevice, s));
         }
         HIPCHK(hipMemcpyAsync(P->arena.p, D.arena.data(), D.arena.size(), hipMemcpyHostToDevice, s));
+        }
         HIPCHK(hipStreamSynchronize(s));
         // keep the host mirror of the directory: it is already here
         P->h_bm_start.swap(D.bm_start); P->h_key.swap(D.key); P->h_off.swap(D.off);
@@ -681,12 +714,46 @@ static void fetch_bm_start(rhip_pool_t* P) {
     HIPCHK(hipStreamSynchronize(P->ctx->stream));
     P->host_bm = true;
 }
+// Device -> host reads of a few small arrays (a per-call result's directory and payload): a copy command into
+// pageable memory is a synchronous staging round trip each, so they land in the context's pinned staging buffer
+// (free between synchronous calls) with ONE wait, and are copied out from there.
+struct SmallReads {
+    rhip_ctx_t* c;
+    struct Rd { void* dst; size_t at, n; };
+    std::vector<Rd> rds;
+    size_t at = 0;
+    static constexpr size_t LIMIT = 1u << 20;
+    explicit SmallReads(rhip_ctx_t* ctx, size_t total) : c(ctx) { c->ensure_stage(rhip_ctx_s::SYNC_SLOT, total + 16 * 8); }
+    void get(void* dst, const void* src, size_t n) {
+        if (!n) return;
+        HIPCHK(hipMemcpyAsync((char*)c->h_stage[rhip_ctx_s::SYNC_SLOT] + at, src, n, hipMemcpyDeviceToHost, c->stream));
+        rds.push_back(Rd{dst, at, n});
+        at += (n + 15) & ~(size_t)15;
+    }
+    void finish() {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (const Rd& r : rds) memcpy(r.dst, (char*)c->h_stage[rhip_ctx_s::SYNC_SLOT] + r.at, r.n);
+    }
+};
 static void fetch_dir(rhip_pool_t* P) {
     if (P->host_dir) return;
     hipStream_t s = P->ctx->stream;
     P->h_bm_start.resize((size_t)P->n_bitmaps + 1);
     P->h_key.resize(P->n_cont); P->h_off.resize(P->n_cont); P->h_type.resize(P->n_cont);
     P->h_card.resize(P->n_cont); P->h_nruns.resize(P->n_cont);
+    const size_t total = 8 * P->h_bm_start.size() + 29 * (size_t)P->n_cont;
+    if (total <= SmallReads::LIMIT) {
+        SmallReads R(P->ctx, total);
+        R.get(P->h_bm_start.data(), P->bm_start.p, 8 * P->h_bm_start.size());
+        R.get(P->h_key.data(), P->key.p, 8 * P->n_cont);
+        R.get(P->h_off.data(), P->off.p, 8 * P->n_cont);
+        R.get(P->h_type.data(), P->type.p, P->n_cont);
+        R.get(P->h_card.data(), P->card.p, 4 * P->n_cont);
+        R.get(P->h_nruns.data(), P->nruns.p, 4 * P->n_cont);
+        R.finish();
+        P->host_dir = true;
+        return;
+    }
     HIPCHK(hipMemcpyAsync(P->h_bm_start.data(), P->bm_start.p, 8 * P->h_bm_start.size(), hipMemcpyDeviceToHost, s));
     if (P->n_cont) {
         HIPCHK(hipMemcpyAsync(P->h_key.data(), P->key.p, 8 * P->n_cont, hipMemcpyDeviceToHost, s));
