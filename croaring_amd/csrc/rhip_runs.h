@@ -51,7 +51,6 @@ __device__ __forceinline__ void ivl_body(uint8_t* lds, uint32_t bid, uint32_t nb
     uint8_t* lsA = lds + (size_t)gslot * 2 * LBYTES;   // this group's two lists, then (after all lists) its run table
     uint8_t* lsB = lsA + LBYTES;
     uint16_t* RSE = (uint16_t*)(lds + SH::LIST_BYTES) + (size_t)gslot * 2 * NB;
-    const uint32_t* RUN = (const uint32_t*)RSE;  // run k = RUN[k]: start | end << 16
     const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
     uint32_t wi = (bid * blockDim.x + threadIdx.x) >> 6;
@@ -117,32 +116,45 @@ __device__ __forceinline__ void ivl_body(uint8_t* lds, uint32_t bid, uint32_t nb
         const uint32_t tt = op == OP_AND ? 0x8u : op == OP_OR ? 0xEu : op == OP_XOR ? 0x6u : 0x2u;
         // Walk the chunk, branch-free: fn(p, eff, g) for every event at position p; eff = it is the LAST event at that
         // position (the only kind that counts), g = op state after it.
+        // The next boundary of each list is read ONE EVENT AHEAD (pa1 / pb1): the step that consumes a boundary only
+        // selects registers, and the LDS read it issues is for the event after next -- off the dependent chain unless
+        // the same list advances twice in a row.
         auto walk = [&](auto&& fn) {
             uint32_t ia = ia0, ib = ib0, inA = ia0 & 1u, inB = ib0 & 1u;
             uint32_t pa = ia < nA ? bnd(0, ia) : SENT, pb = ib < nB2 ? bnd(HALF, ib) : SENT;
+            uint32_t pa1 = ia + 1u < nA ? bnd(0, ia + 1u) : SENT, pb1 = ib + 1u < nB2 ? bnd(HALF, ib + 1u) : SENT;
             for (uint32_t sidx = 0; sidx < steps; ++sidx) {
                 const bool tA = pa <= pb;
                 const uint32_t pcur = tA ? pa : pb;
                 inA ^= tA ? 1u : 0u; inB ^= tA ? 0u : 1u;
                 ia += tA ? 1u : 0u; ib += tA ? 0u : 1u;
-                const uint32_t idx = tA ? ia : ib, lim = tA ? nA : nB2;
-                const uint32_t raw = bnd(tA ? 0u : HALF, idx);  // (a slot past the list is inside the staging area)
+                const uint32_t idx = (tA ? ia : ib) + 1u, lim = tA ? nA : nB2;
+                const uint32_t raw = bnd(tA ? 0u : HALF, idx);  // (two slots past the list are inside the staging area)
                 const uint32_t val = idx < lim ? raw : SENT;
-                pa = tA ? val : pa; pb = tA ? pb : val;
+                pa = tA ? pa1 : pa; pb = tA ? pb : pb1;
+                pa1 = tA ? val : pa1; pb1 = tA ? pb1 : val;
                 const uint32_t pnext = pa < pb ? pa : pb;
                 fn(pcur, pnext != pcur, ((tt >> (inA + 2u * inB)) & 1u) != 0u);
             }
         };
-        // walk 1: first / last effective state of the chunk and its run starts / ends, counted as if the state before
-        // the chunk were 0; the true state (a ballot pair and a count-leading-zeros) only changes the first event
+        // ONE walk: the lane's transitions (start / end values, alternating) go to a lane-private slice of the run table
+        // as if the state before the chunk were 0; the true state (a ballot pair and a count-leading-zeros) only changes
+        // the FIRST effective event: its start is dropped (the run began in an earlier chunk) or an end is put in front
+        // of it.  The slices are then compacted to their scanned positions -- independent LDS copies, into the staging
+        // area of the two lists, which is dead by now.  (A second walk to write them cost as much as the first: a chain
+        // of dependent LDS reads.)
         bool has_eff = false, g_first = false, g_last = false;
-        uint32_t ns = 0, ne = 0;
+        uint32_t ns = 0, ne = 0, p_first = 0;
+        uint16_t* TMP = RSE + gl * per;
         {
             bool gp = false;
-            walk([&](uint32_t, bool eff, bool g) {
+            uint32_t k = 0;
+            walk([&](uint32_t pcur, bool eff, bool g) {
                 g_first = (eff && !has_eff) ? g : g_first;
+                p_first = (eff && !has_eff) ? pcur : p_first;
                 has_eff = has_eff || eff;
                 g_last = eff ? g : g_last;
+                if (eff && g != gp) TMP[k++] = (uint16_t)(g ? pcur : pcur - 1u);
                 ns += (eff && g && !gp) ? 1u : 0u; ne += (eff && !g && gp) ? 1u : 0u;
                 gp = eff ? g : gp;
             });
@@ -153,21 +165,22 @@ __device__ __forceinline__ void ivl_body(uint8_t* lds, uint32_t bid, uint32_t nb
             const u64 below = mh & ((1ull << gl) - 1ull);
             if (below) gprev = (mg >> (63 - __clzll((long long)below))) & 1ull;
         }
-        if (gprev && has_eff) {
-            if (g_first) ns -= 1u;  // no start: the state was 1 already
-            else ne += 1u;          // the first event ends a run begun in an earlier chunk
-        }
+        const uint32_t nrec = ns + ne;
+        const bool drop_first = gprev && has_eff && g_first;   // no start: the state was 1 already
+        const bool add_end = gprev && has_eff && !g_first;     // the first event ends a run begun in an earlier chunk
+        ns -= drop_first ? 1u : 0u;
+        ne += add_end ? 1u : 0u;
         const uint32_t incs = gr.incl_scan(ns), ince = gr.incl_scan(ne);
         const uint32_t rn = __shfl(incs, gr.glast);  // == total ends: every run that starts also ends (both states end at 0)
-        // walk 2: write the transitions; they alternate start, end, start, ... over the whole sequence
+        uint16_t* OUT = (uint16_t*)lsA;
+        __builtin_amdgcn_wave_barrier();  // every lane is done reading the lists
         {
             uint32_t kt = (incs - ns) + (ince - ne);
-            bool gp = gprev;
-            walk([&](uint32_t pcur, bool eff, bool g) {
-                if (eff && g != gp) RSE[kt++] = (uint16_t)(g ? pcur : pcur - 1u);
-                gp = eff ? g : gp;
-            });
+            if (add_end) OUT[kt++] = (uint16_t)(p_first - 1u);
+            const uint32_t skip = drop_first ? 1u : 0u;
+            for (uint32_t j = skip; j < nrec; ++j) OUT[kt + j - skip] = TMP[j];
         }
+        const uint32_t* RUN = (const uint32_t*)OUT;  // run k = RUN[k]: start | end << 16
         __builtin_amdgcn_wave_barrier();
         // ---- cardinality, typing
         uint32_t cnt = 0;

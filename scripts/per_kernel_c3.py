@@ -12,7 +12,11 @@ import croaring_amd
 from util import load_bundle, all_pairs, OPS
 name = sys.argv[1] if len(sys.argv) > 1 else "weather_sept_85"
 eng = croaring_amd.Engine(0)
-pool = eng.pool_from_serialized(load_bundle(name))
+if name == "c5":
+    from util import c5_inputs
+    pool = eng.pool_from_serialized64(c5_inputs())
+else:
+    pool = eng.pool_from_serialized(load_bundle(name))
 lhs, rhs = all_pairs(len(pool))
 for op in OPS:
     res = None
