@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_classes(ClassLaunch L) {
     const u64* R = L.ranges;
     switch (seg) {
         case CSEG_IVL16:
-            ivl_body<16, R16_MAX_IV>((uint8_t*)lds, b, nblk, L.arenaA, L.arenaB, L.O, L.q_r16, R + 2 * SEC_RUNS16, L.kop, L.cardmode,
+            ivl_body<R16_G, R16_MAX_IV>((uint8_t*)lds, b, nblk, L.arenaA, L.arenaB, L.O, L.q_r16, R + 2 * SEC_RUNS16, L.kop, L.cardmode,
                                      L.pair_acc, L.retry_q, L.retry_count);
             break;
         case CSEG_IVL16W:

@@ -16,6 +16,7 @@ enum { CLS_BB = 0, CLS_GEN = 1, CLS_COPY = 2, CLS_RETRY = 3, CLS_FILT = 4, CLS_W
 // interval pairs that run four to a wave (k_ivl<16, .>): at most that many intervals per operand and values in both
 // operands together; two size classes, because the four pairs of a wave advance in lockstep
 #define R16_MAX_IV 31u
+#define R16_G 8u  // lanes per pair of that class (eight pairs per wave)
 #define R16_MAX_CARD 1024u
 #define R16W_MAX_IV 127u
 #define R16W_MAX_CARD 4096u

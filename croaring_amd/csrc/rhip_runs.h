@@ -114,19 +114,28 @@ __device__ __forceinline__ void ivl_body(uint8_t* lds, uint32_t bid, uint32_t nb
         const uint32_t ib0 = d0 - ia0, steps = d1 - d0;
         // op as a truth table over (inA, inB): bit (inA + 2 inB)
         const uint32_t tt = op == OP_AND ? 0x8u : op == OP_OR ? 0xEu : op == OP_XOR ? 0x6u : 0x2u;
-        // Walk the chunk, branch-free: fn(p, eff, g) for every event at position p; eff = it is the LAST event at that
-        // position (the only kind that counts), g = op state after it.
+        // ONE branch-free walk over the chunk's events.  An event at position p is EFFECTIVE when it is the last one at
+        // that position (the only kind that counts); g = op state after it.  The lane's transitions (start / end values,
+        // alternating) go to a lane-private slice of the run table as if the state before the chunk were 0; the true
+        // state (a ballot pair and a count-leading-zeros) only changes the FIRST effective event: its start is dropped
+        // (the run began in an earlier chunk) or an end is put in front of it.  The slices are then compacted to their
+        // scanned positions -- independent LDS copies, into the staging area of the two lists, which is dead by now.
+        // (A second walk to write them cost as much as the first: a chain of dependent LDS reads.)
         // The next boundary of each list is read ONE EVENT AHEAD (pa1 / pb1): the step that consumes a boundary only
         // selects registers, and the LDS read it issues is for the event after next -- off the dependent chain unless
-        // the same list advances twice in a row.
-        auto walk = [&](auto&& fn) {
-            uint32_t ia = ia0, ib = ib0, inA = ia0 & 1u, inB = ib0 & 1u;
+        // the same list advances twice in a row.  All state is 0 / 1 integers in vector registers: as bools the compiler
+        // kept it in scalar lane masks, three scalar instructions per update (the loop was 68 instructions a step).
+        uint32_t heff = 0, g_first = 0, gp = 0, p_first = 0, nrec = 0;
+        uint16_t* TMP = RSE + gl * per;
+        {
+            uint32_t ia = ia0, ib = ib0;
+            uint32_t x = (ia0 & 1u) | ((ib0 & 1u) << 1);  // inA + 2 inB
             uint32_t pa = ia < nA ? bnd(0, ia) : SENT, pb = ib < nB2 ? bnd(HALF, ib) : SENT;
             uint32_t pa1 = ia + 1u < nA ? bnd(0, ia + 1u) : SENT, pb1 = ib + 1u < nB2 ? bnd(HALF, ib + 1u) : SENT;
             for (uint32_t sidx = 0; sidx < steps; ++sidx) {
                 const bool tA = pa <= pb;
                 const uint32_t pcur = tA ? pa : pb;
-                inA ^= tA ? 1u : 0u; inB ^= tA ? 0u : 1u;
+                x ^= tA ? 1u : 2u;
                 ia += tA ? 1u : 0u; ib += tA ? 0u : 1u;
                 const uint32_t idx = (tA ? ia : ib) + 1u, lim = tA ? nA : nB2;
                 const uint32_t raw = bnd(tA ? 0u : HALF, idx);  // (two slots past the list are inside the staging area)
@@ -134,38 +143,26 @@ __device__ __forceinline__ void ivl_body(uint8_t* lds, uint32_t bid, uint32_t nb
                 pa = tA ? pa1 : pa; pb = tA ? pb : pb1;
                 pa1 = tA ? val : pa1; pb1 = tA ? pb1 : val;
                 const uint32_t pnext = pa < pb ? pa : pb;
-                fn(pcur, pnext != pcur, ((tt >> (inA + 2u * inB)) & 1u) != 0u);
-            }
-        };
-        // ONE walk: the lane's transitions (start / end values, alternating) go to a lane-private slice of the run table
-        // as if the state before the chunk were 0; the true state (a ballot pair and a count-leading-zeros) only changes
-        // the FIRST effective event: its start is dropped (the run began in an earlier chunk) or an end is put in front
-        // of it.  The slices are then compacted to their scanned positions -- independent LDS copies, into the staging
-        // area of the two lists, which is dead by now.  (A second walk to write them cost as much as the first: a chain
-        // of dependent LDS reads.)
-        bool has_eff = false, g_first = false, g_last = false;
-        uint32_t ns = 0, ne = 0, p_first = 0;
-        uint16_t* TMP = RSE + gl * per;
-        {
-            bool gp = false;
-            uint32_t k = 0;
-            walk([&](uint32_t pcur, bool eff, bool g) {
-                g_first = (eff && !has_eff) ? g : g_first;
-                p_first = (eff && !has_eff) ? pcur : p_first;
-                has_eff = has_eff || eff;
-                g_last = eff ? g : g_last;
-                if (eff && g != gp) TMP[k++] = (uint16_t)(g ? pcur : pcur - 1u);
-                ns += (eff && g && !gp) ? 1u : 0u; ne += (eff && !g && gp) ? 1u : 0u;
+                const uint32_t eff = pnext != pcur ? 1u : 0u;
+                const uint32_t g = (tt >> x) & 1u;
+                const uint32_t first = eff & ~heff;
+                g_first = first ? g : g_first;
+                p_first = first ? pcur : p_first;
+                heff |= eff;
+                TMP[nrec] = (uint16_t)(pcur + g - 1u);  // start: p, end: p - 1 (kept only when this is a transition)
+                nrec += eff & (g ^ gp);
                 gp = eff ? g : gp;
-            });
+            }
         }
+        const bool has_eff = heff != 0u, g_last = gp != 0u;
+        // starts and ends alternate, beginning with a start
+        uint32_t ns = (nrec + 1u) >> 1, ne = nrec >> 1;
         bool gprev = false;  // state after the last effective event BEFORE this chunk
         {
             const u64 mh = gr.ballot(has_eff), mg = gr.ballot(g_last);
             const u64 below = mh & ((1ull << gl) - 1ull);
             if (below) gprev = (mg >> (63 - __clzll((long long)below))) & 1ull;
         }
-        const uint32_t nrec = ns + ne;
         const bool drop_first = gprev && has_eff && g_first;   // no start: the state was 1 already
         const bool add_end = gprev && has_eff && !g_first;     // the first event ends a run begun in an earlier chunk
         ns -= drop_first ? 1u : 0u;
@@ -254,13 +251,13 @@ struct IvlQueues {
 __global__ __launch_bounds__(256) void k_ivl_all(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                                  OutView O, IvlQueues Q, uint32_t g1, uint32_t g2, int op, int cardmode,
                                                  u64* pair_acc, GenItem* retry_q, uint32_t* retry_count) {
-    constexpr uint32_t LDS_A = IvlShape<16, R16_MAX_IV>::LDS_BYTES, LDS_B = IvlShape<16, R16W_MAX_IV>::LDS_BYTES,
+    constexpr uint32_t LDS_A = IvlShape<R16_G, R16_MAX_IV>::LDS_BYTES, LDS_B = IvlShape<16, R16W_MAX_IV>::LDS_BYTES,
                        LDS_C = IvlShape<64, RUNS_MAX_INTERVALS>::LDS_BYTES;
     constexpr uint32_t LDS_MAX = LDS_A > LDS_B ? (LDS_A > LDS_C ? LDS_A : LDS_C) : (LDS_B > LDS_C ? LDS_B : LDS_C);
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_MAX];
     const uint32_t b = blockIdx.x;
     if (b < g1)
-        ivl_body<16, R16_MAX_IV>(lds, b, g1, arenaA, arenaB, O, Q.q[0], Q.range[0], op, cardmode, pair_acc, retry_q, retry_count);
+        ivl_body<R16_G, R16_MAX_IV>(lds, b, g1, arenaA, arenaB, O, Q.q[0], Q.range[0], op, cardmode, pair_acc, retry_q, retry_count);
     else if (b < g1 + g2)
         ivl_body<16, R16W_MAX_IV>(lds, b - g1, g2, arenaA, arenaB, O, Q.q[1], Q.range[1], op, cardmode, pair_acc, retry_q,
                                   retry_count);
