@@ -13,18 +13,19 @@
 // (arrays: e = s).  Membership is a parity: x is in the operand iff an odd number of its boundaries are <= x.  The
 // two lists (staged in LDS) are merged by MERGE PATH: lane l owns merged positions [l * per, (l+1) * per) and finds
 // its split (ia, ib) with one binary search along its diagonal; the state before its chunk is just (ia & 1, ib & 1).
-// It then walks its <= 16 events sequentially (one LDS read per event, no branch), toggling inA / inB.  Only the LAST event at
-// a position is "effective" (an array's v+1 / next-v pair, or a boundary shared by both lists, toggles twice at
-// one position); a result run starts at an effective event where op(inA, inB) turns 1 and ends before one where it
-// turns 0, "turns" being relative to the previous effective event -- across lanes that is one ballot pair and a
-// count-leading-zeros.  Two walks: (1) first / last effective state per lane and its starts / ends, (2) write them
-// at scanned positions.  The run list is then typed by the reference's rules (convert_run_to_efficient_container
-// etc.) and written as runs or expanded into an array; the rare bitset result is re-queued for k_genw.
-// (Round 1 evaluated every boundary with a binary search into the other list, twice: 7 ns per pair of 100-run
-// containers; the merge walk does the same in a fraction of the LDS round trips.)
+// It then walks its <= 16 events sequentially (one LDS read per event -- issued one event ahead -- and no branch), toggling
+// inA / inB.  Only the LAST event at a position is "effective" (an array's v+1 / next-v pair, or a boundary shared by
+// both lists, toggles twice at one position); a result run starts at an effective event where op(inA, inB) turns 1 and
+// ends before one where it turns 0, "turns" being relative to the previous effective event -- across lanes that is one
+// ballot pair and a count-leading-zeros.  ONE walk: a lane's transitions go to a private slice of the run table and are
+// compacted to their scanned positions afterwards.  The run list is then typed by the reference's rules
+// (convert_run_to_efficient_container etc.) and written as runs or expanded into an array; the rare bitset result is
+// re-queued for k_genw.  The kernel is bound by VALU issue, not by memory: ~43 instructions per event (round 1
+// evaluated every boundary with a binary search into the other list, twice: 7 ns per pair of 100-run containers;
+// round 2 walked twice with boolean state the compiler kept in scalar masks: 68 instructions per event and walk).
 // G lanes per pair (64 / G pairs per wave), at most MAXIV intervals per operand.  The walk of a lane's chunk is a chain
 // of dependent LDS reads, so a wave is latency-bound whatever its width: sparse run-compressed data (wikileaks-noquotes:
-// nine tenths of the matched pairs have <= 127 intervals a side) runs FOUR pairs per wave on 16-lane groups -- group-wide
+// nine tenths of the matched pairs have <= 127 intervals a side) runs EIGHT (<= 31 intervals) or FOUR pairs per wave on 8- / 16-lane groups -- group-wide
 // scans and sums by shuffles that never leave the group, group-private LDS -- and only long lists take the whole wave.
 // Control flow around the collectives stays wave-uniform: the groups of a wave walk their items in lockstep.
 template <uint32_t G, uint32_t MAXIV>
@@ -36,35 +37,26 @@ struct IvlShape {
     static constexpr uint32_t RSE_BYTES = 4 * NG * 2 * NB * 2;
     static constexpr uint32_t LDS_BYTES = LIST_BYTES + RSE_BYTES;
 };
-// bid / nblk: this block's index and the number of blocks of ITS size class (k_ivl_all runs the three classes in one
-// launch); lds: the block's LDS, IvlShape<G, MAXIV>::LDS_BYTES of it
-template <uint32_t G, uint32_t MAXIV>
-__device__ __forceinline__ void ivl_body(uint8_t* lds, uint32_t bid, uint32_t nblk, const uint8_t* __restrict__ arenaA,
-                                         const uint8_t* __restrict__ arenaB, const OutView& O,
-                                         const GenItem* __restrict__ q, const u64* __restrict__ qrange, int kop,
-                                         int cardmode, u64* pair_acc, GenItem* retry_q, uint32_t* retry_count) {
-    using SH = IvlShape<G, MAXIV>;
-    constexpr uint32_t NG = SH::NG, NB = SH::NB, LBYTES = SH::LBYTES;
-    const Grp<G> gr;
+// One item of a group: both lists staged at lsA (list A, then list B HALF u16 slots later), run table at RSE.
+// HALF_FIXED != 0: the fixed two-slot layout of the queue kernels.  HALF_FIXED == 0 (PACKED, one pair per wave): list B
+// follows list A directly, so the LDS need is set by the SUM of the two lengths -- a 100-run container against a
+// 1 800-value array fits where two fixed 2 047-interval slots would not (k_genw's long-list path).
+// Returns true when the result must be a bitset and retry_q is null (the caller's image path redoes the pair); with a
+// retry queue the item is re-queued there.
+template <uint32_t G, uint32_t HALF_FIXED>
+__device__ __forceinline__ bool ivl_item(const Grp<G>& gr, uint8_t* lsA, uint16_t* RSE, bool have, const GenItem& t,
+                                         const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+                                         const OutView& O, int kop, int cardmode, u64* pair_acc, GenItem* retry_q,
+                                         uint32_t* retry_count) {
     const uint32_t lane = gr.lane, gl = gr.gl;
-    const uint32_t gslot = threadIdx.x / G;
-    uint8_t* lsA = lds + (size_t)gslot * 2 * LBYTES;   // this group's two lists, then (after all lists) its run table
-    uint8_t* lsB = lsA + LBYTES;
-    uint16_t* RSE = (uint16_t*)(lds + SH::LIST_BYTES) + (size_t)gslot * 2 * NB;
-    const uint32_t nwaves = (nblk * blockDim.x) >> 6;
-    const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    uint32_t wi = (bid * blockDim.x + threadIdx.x) >> 6;
-    GenItem tnext = {};
-    if (NG * wi + gr.grp < n) tnext = q[NG * wi + gr.grp];
-    for (; NG * wi < n; wi += nwaves) {
-        const bool have = NG * wi + gr.grp < n;
-        const GenItem t = tnext;
-        if (NG * (wi + nwaves) + gr.grp < n) tnext = q[NG * (wi + nwaves) + gr.grp];  // next item in flight meanwhile
+    {
         const uint32_t ta = t.types & 0xFFu, tb = (t.types >> 8) & 0xFFu;
         const int op = item_op(kop, t.types);  // (multi-op batches: the groups of a wave may hold different ops)
         // boundary counts (2 x intervals); an absent item is a pair of empty lists
         const uint32_t nA = have ? 2u * (ta == T_RUN ? t.nra : t.ca) : 0u;
         const uint32_t nB2 = have ? 2u * (tb == T_RUN ? t.nrb : t.cb) : 0u;
+        // list B's first slot (u16 units; staging writes whole 16-slot granules)
+        const uint32_t HALF = HALF_FIXED ? HALF_FIXED : ((nA + 15u) & ~15u);
         {   // stage both payloads in BOUNDARY form, u16 x[j] with boundary j = x[j] + (j & 1): a run (s, len) becomes
             // (s, s + len), an array value v becomes (v, v) -- reading a boundary is then one LDS load and one add
             // whatever the container type, and the walk below has no branch on it.  16 payload bytes per lane and round.
@@ -88,11 +80,10 @@ __device__ __forceinline__ void ivl_body(uint8_t* lds, uint32_t bid, uint32_t nb
                 }
             };
             stage(lsA, arenaA + t.offa, ta == T_RUN, nA);
-            stage(lsB, arenaB + t.offb, tb == T_RUN, nB2);
+            stage(lsA + 2 * HALF, arenaB + t.offb, tb == T_RUN, nB2);
             __builtin_amdgcn_wave_barrier();
         }
         const uint16_t* __restrict__ LL = (const uint16_t*)lsA;  // A's boundaries at [0, HALF), B's at [HALF, 2 HALF)
-        constexpr uint32_t HALF = LBYTES / 2;
         auto bnd = [&](uint32_t base, uint32_t j) -> uint32_t { return (uint32_t)LL[base + j] + (j & 1u); };
         // ---- merge path: this lane's chunk of the merged boundary sequence
         constexpr uint32_t SENT = 0x20000u;  // past every boundary (the largest is 65536)
@@ -189,14 +180,14 @@ __device__ __forceinline__ void ivl_body(uint8_t* lds, uint32_t bid, uint32_t nb
         if (cardmode) {  // (wave-uniform)
             if (have && gl == 0 && rc) atomicAdd(&pair_acc[t.out], (u64)rc);
             __builtin_amdgcn_wave_barrier();
-            continue;
+            return false;
         }
         const bool fulla = ta == T_RUN && t.ca == 65536u, fullb = tb == T_RUN && t.cb == 65536u;
         int ty = T_ARRAY;
         if (rc) ty = decide_type(op, (int)ta, (int)tb, t.ca, t.cb, fulla, fullb, rc, rn);
         // a bitset result (rare for this class): let the image kernel redo the pair
         const bool redo = have && rc && ty == T_BITSET;
-        if (redo && gl == 0) retry_q[atomicAdd(retry_count, 1u)] = t;
+        if (redo && gl == 0 && retry_q) retry_q[atomicAdd(retry_count, 1u)] = t;
         const bool wr = have && rc && !redo;
         uint8_t* outp = O.arena + t.offo;
         if (wr && ty == T_RUN) {
@@ -238,6 +229,33 @@ __device__ __forceinline__ void ivl_body(uint8_t* lds, uint32_t bid, uint32_t nb
         }
         if (have && !redo && gl == 0) O.meta[t.out] = pack_meta(ty, rc, (ty == T_RUN) ? rn : 0u);
         __builtin_amdgcn_wave_barrier();
+        return redo && !retry_q;
+    }
+}
+
+// bid / nblk: this block's index and the number of blocks of ITS size class (k_ivl_all runs the three classes in one
+// launch); lds: the block's LDS, IvlShape<G, MAXIV>::LDS_BYTES of it
+template <uint32_t G, uint32_t MAXIV>
+__device__ __forceinline__ void ivl_body(uint8_t* lds, uint32_t bid, uint32_t nblk, const uint8_t* __restrict__ arenaA,
+                                         const uint8_t* __restrict__ arenaB, const OutView& O,
+                                         const GenItem* __restrict__ q, const u64* __restrict__ qrange, int kop,
+                                         int cardmode, u64* pair_acc, GenItem* retry_q, uint32_t* retry_count) {
+    using SH = IvlShape<G, MAXIV>;
+    constexpr uint32_t NG = SH::NG, NB = SH::NB, LBYTES = SH::LBYTES;
+    const Grp<G> gr;
+    const uint32_t gslot = threadIdx.x / G;
+    uint8_t* lsA = lds + (size_t)gslot * 2 * LBYTES;   // this group's two lists, then (after all lists) its run table
+    uint16_t* RSE = (uint16_t*)(lds + SH::LIST_BYTES) + (size_t)gslot * 2 * NB;
+    const uint32_t nwaves = (nblk * blockDim.x) >> 6;
+    const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
+    uint32_t wi = (bid * blockDim.x + threadIdx.x) >> 6;
+    GenItem tnext = {};
+    if (NG * wi + gr.grp < n) tnext = q[NG * wi + gr.grp];
+    for (; NG * wi < n; wi += nwaves) {
+        const bool have = NG * wi + gr.grp < n;
+        const GenItem t = tnext;
+        if (NG * (wi + nwaves) + gr.grp < n) tnext = q[NG * (wi + nwaves) + gr.grp];  // next item in flight meanwhile
+        ivl_item<G, LBYTES / 2>(gr, lsA, RSE, have, t, arenaA, arenaB, O, kop, cardmode, pair_acc, retry_q, retry_count);
     }
 }
 
@@ -346,15 +364,18 @@ __device__ void wimg_build(uint32_t* img, const uint8_t* __restrict__ p, uint32_
 // four-wave workgroup needs that on all four SIMDs of one CU at once -- next to a machine-filling k_filter / k_wave
 // (whose freed slots go to whoever fits first) such a workgroup waited for the big kernel's grid to drain: 216 us for
 // the 1 173 run pairs of a weather_sept_85 batch that take 47 us alone.  A single wave fits wherever two slots free up.
-__global__ __launch_bounds__(64) void k_genw(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+__global__ __launch_bounds__(64, 2) void k_genw(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                              OutView O, const GenItem* __restrict__ q,
                                              const u64* __restrict__ qrange, const uint32_t* __restrict__ qcount,
                                              int kop, int cardmode, u64* pair_acc,
                                              const GenItem* __restrict__ q2, const uint32_t* __restrict__ q2count) {
     // ONE 8 KiB image per wave: operand A is rasterised, pulled into registers, then the same image is
-    // reused for operand B and finally as the output staging buffer
-    __shared__ __attribute__((aligned(16))) uint32_t img_all[1][2048];
+    // reused for operand B and finally as the output staging buffer.  The long-list interval path uses the same LDS as
+    // two boundary lists (RUNSL_MAX_SUM intervals together) and a run table.
+    constexpr uint32_t IVL_LIST_BYTES = 4u * RUNSL_MAX_SUM + 64u, IVL_BYTES = IVL_LIST_BYTES + 4u * RUNSL_MAX_SUM;
+    __shared__ __attribute__((aligned(16))) uint32_t img_all[1][(IVL_BYTES > 8192u ? IVL_BYTES : 8192u) / 4];
     const uint32_t lane = lane_id();
+    const Grp<64> gr;
     uint32_t* ia = img_all[0];
     uint32_t* ib = ia;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -366,6 +387,25 @@ __global__ __launch_bounds__(64) void k_genw(const uint8_t* __restrict__ arenaA,
         const GenItem t = wi < n1 ? q[wi] : q2[wi - n1];
         const uint32_t ta = t.types & 0xFFu, tb = (t.types >> 8) & 0xFFu;
         const int op = item_op(kop, t.types);
+        // A run container against a run / an array, too long for the interval classes but RUNSL_MAX_SUM intervals or
+        // fewer together: interval algebra on the whole wave, O(intervals) instead of two 65 536-bit images (a 100-run
+        // container x an 874-value array: 7.5 -> ~3 ns per pair).  Not for re-queued items (their result is a bitset),
+        // and a pair whose result turns out to be a bitset falls through to the image path.
+        bool ivl = qrange && wi < n1 && (ta == T_RUN || tb == T_RUN) && ta != T_BITSET && tb != T_BITSET &&
+                   (ta == T_RUN ? t.nra : t.ca) + (tb == T_RUN ? t.nrb : t.cb) <= RUNSL_MAX_SUM;
+        if (ivl && !cardmode) {
+            // ... unless the reference's typing rule makes the result a bitset whatever its run count (a 30 000-value run
+            // container minus / xor an array: mixed_andnot.c:277-412, mixed_xor.c:104-138): with rn = 1 every rule that
+            // looks at the run count answers "run", so T_BITSET here means certain -- the true cardinality is >= the bound
+            const uint32_t lb = op == OP_AND ? 0u : op == OP_OR ? (t.ca > t.cb ? t.ca : t.cb)
+                              : op == OP_XOR ? (t.ca > t.cb ? t.ca - t.cb : t.cb - t.ca) : (t.ca > t.cb ? t.ca - t.cb : 0u);
+            ivl = decide_type(op, (int)ta, (int)tb, t.ca, t.cb, ta == T_RUN && t.ca == 65536u, tb == T_RUN && t.cb == 65536u, lb, 1u) != T_BITSET;
+        }
+        if (ivl) {
+            if (!ivl_item<64, 0>(gr, (uint8_t*)ia, (uint16_t*)((uint8_t*)ia + IVL_LIST_BYTES), true, t, arenaA, arenaB, O, kop,
+                                 cardmode, pair_acc, nullptr, nullptr))
+                continue;
+        }
         wimg_build(ia, arenaA + t.offa, ta, t.ca, t.nra);
         __builtin_amdgcn_wave_barrier();
         uint32_t r[32];

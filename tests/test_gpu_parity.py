@@ -666,6 +666,56 @@ def test_tiny_interval_pairs(engine, oracle):
         oracle.free(h)
 
 
+def test_long_interval_lists(engine, oracle):
+    """k_genw's long-list interval path (a run operand, lists too long for the k_ivl classes, at most 2 032 intervals
+    together) and its neighbours: run containers of 100 .. 1 500 runs against arrays of 300 .. 3 000 values and against
+    each other, sums around the 2 032 limit (2 031 / 2 032 / 2 033: the last one takes the image path), dense operands
+    whose or / xor must come out as a bitset (the interval path hands those over to the image path), full and
+    near-full runs, both ends of the u16 range; four ops + cardinalities, both operand orders."""
+    rng = np.random.default_rng(2718)
+
+    def runs(k, maxlen):
+        cuts = np.sort(rng.choice(65536, 2 * k, replace=False))
+        parts = [np.arange(cuts[2 * i], min(cuts[2 * i + 1], cuts[2 * i] + maxlen) + 1) for i in range(k)]
+        return np.unique(np.concatenate(parts))
+
+    def exact_runs(k):  # exactly k runs of two values, gaps of at least one
+        starts = np.sort(rng.choice(65536 // 4, k, replace=False)).astype(np.int64) * 4
+        return np.concatenate([starts, starts + 1])
+
+    shapes = [("run", runs(100, 30)), ("run", runs(100, 400)), ("run", runs(300, 8)), ("run", runs(600, 4)),
+              ("run", runs(1000, 2)), ("run", runs(1500, 2)),
+              ("arr", np.sort(rng.choice(65536, 300, replace=False))), ("arr", np.sort(rng.choice(65536, 874, replace=False))),
+              ("arr", np.sort(rng.choice(65536, 1500, replace=False))), ("arr", np.sort(rng.choice(65536, 3000, replace=False))),
+              ("arr", np.sort(rng.choice(3000, 1900, replace=False)) + 20000),
+              ("arr", np.concatenate([[0, 1, 2], np.sort(rng.choice(60000, 1000, replace=False)) + 100, [65534, 65535]])),
+              ("run", np.sort(exact_runs(1016))), ("arr", np.sort(rng.choice(65536, 1015, replace=False))),
+              ("arr", np.sort(rng.choice(65536, 1016, replace=False))), ("arr", np.sort(rng.choice(65536, 1017, replace=False))),
+              ("run", np.concatenate([np.arange(0, 30000), np.arange(30002, 65536)])), ("run", np.arange(65536)),
+              ("run", np.concatenate([np.arange(40 * i, 40 * i + 25) for i in range(1600)])[:40000]),
+              ("run", runs(400, 60))]
+    hs = [oracle.from_sorted(np.asarray(np.sort(v), np.uint32) + (5 << 16), run_optimize=(kind == "run")) for kind, v in shapes]
+    bufs = [oracle.serialize(h) for h in hs]
+    pool = engine.pool_from_serialized(bufs)
+    n = len(hs)
+    lhs, rhs = np.meshgrid(np.arange(n, dtype=np.uint32), np.arange(n, dtype=np.uint32))
+    lhs, rhs = lhs.ravel().copy(), rhs.ravel().copy()
+    for op in OPS:
+        res = engine.pairwise(op, pool, lhs, pool, rhs)
+        cards = engine.pairwise_cardinality(op, pool, lhs, pool, rhs)
+        blob, offs = res.serialize_many()
+        raw = blob.tobytes()
+        bad = []
+        for k in range(lhs.size):
+            oo = oracle.op(op, hs[lhs[k]], hs[rhs[k]])
+            if raw[int(offs[k]):int(offs[k + 1])] != oracle.serialize(oo) or cards[k] != oracle.cardinality(oo):
+                bad.append((int(lhs[k]), int(rhs[k])))
+            oracle.free(oo)
+        assert not bad, f"{op}: {len(bad)} mismatching pairs, first {bad[:6]}"
+    for h in hs:
+        oracle.free(h)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["1", "2", "fork", "nomerge"])
 def test_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
