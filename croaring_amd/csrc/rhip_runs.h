@@ -158,18 +158,24 @@ __device__ __forceinline__ bool ivl_item(const Grp<G>& gr, uint8_t* lsA, uint16_
         const bool add_end = gprev && has_eff && !g_first;     // the first event ends a run begun in an earlier chunk
         ns -= drop_first ? 1u : 0u;
         ne += add_end ? 1u : 0u;
-        const uint32_t incs = gr.incl_scan(ns), ince = gr.incl_scan(ne);
-        const uint32_t rn = __shfl(incs, gr.glast);  // == total ends: every run that starts also ends (both states end at 0)
+        // (one scan for both: a lane has at most 2 x 64 transitions, the group at most 2 x 4096 of each kind)
+        const uint32_t inc2 = gr.incl_scan(ns | (ne << 16));
+        const uint32_t rn = __shfl(inc2, gr.glast) & 0xFFFFu;  // == total ends: every run that starts also ends (both states end at 0)
         uint16_t* OUT = (uint16_t*)lsA;
         __builtin_amdgcn_wave_barrier();  // every lane is done reading the lists
         {
-            uint32_t kt = (incs - ns) + (ince - ne);
+            uint32_t kt = ((inc2 & 0xFFFFu) - ns) + ((inc2 >> 16) - ne);
             if (add_end) OUT[kt++] = (uint16_t)(p_first - 1u);
             const uint32_t skip = drop_first ? 1u : 0u;
             for (uint32_t j = skip; j < nrec; ++j) OUT[kt + j - skip] = TMP[j];
         }
         const uint32_t* RUN = (const uint32_t*)OUT;  // run k = RUN[k]: start | end << 16
         __builtin_amdgcn_wave_barrier();
+        if (__ballot(rn != 0u) == 0ull) {  // every pair of the wave came out empty (most of a sparse `and` batch)
+            if (have && gl == 0 && !cardmode) O.meta[t.out] = pack_meta(T_ARRAY, 0u, 0u);
+            __builtin_amdgcn_wave_barrier();
+            return false;
+        }
         // ---- cardinality, typing
         uint32_t cnt = 0;
         for (uint32_t k = gl; k < rn; k += G) {
