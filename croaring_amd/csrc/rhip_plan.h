@@ -314,6 +314,9 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
     const bool keep_unmatched = bside || !(cardmode || op == OP_AND);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
+        // (a bitmap with fewer than G t containers leaves the later rounds empty: skipped when that holds for every
+        // unit of the wave -- the planning kernels are bound by instruction issue, not by memory)
+        if (__ballot(act[t]) == 0ull) continue;
         const bool found = act[t] && j[t] < l1 && LV.key[j[t]] == k[t];
         if (act[t]) match[(size_t)u * (4 * G) + G * t + lane] = (uint32_t)(j[t] - l0) | (found ? MATCH_FOUND : 0u);
         int cls = -1;
@@ -441,6 +444,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
         for (int t = 0; t < 4; ++t) {
             const u64 ai = s0 + G * t + lane;
             const bool act = ai < a1;
+            if (__ballot(act) == 0ull) break;  // (rounds past the end of every unit of the wave)
             const uint32_t mt = act ? match[(size_t)u * (4 * G) + G * t + lane] : 0u;
             const bool found = (mt & MATCH_FOUND) != 0;
             const uint32_t lbcount = mt & ~MATCH_FOUND;
@@ -540,6 +544,7 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
         for (int t = 0; t < 4; ++t) {
             const u64 bi = s0 + G * t + lane;
             const bool act = bi < b1;
+            if (__ballot(act) == 0ull) break;
             const uint32_t mt = act ? match[(size_t)u * (4 * G) + G * t + lane] : 0u;
             const bool found = (mt & MATCH_FOUND) != 0;
             const u64 fm = gr.ballot(found);
