@@ -389,6 +389,7 @@ __global__ __launch_bounds__(64, 2) void k_genw(const uint8_t* __restrict__ aren
     // results in q2 (single-stream batches run both in one launch, after every kernel that re-queues)
     const uint32_t n1 = qrange ? (uint32_t)(qrange[1] - qrange[0]) : *qcount;
     const uint32_t n = n1 + (q2 ? *q2count : 0u);
+    PH_BEGIN();
     for (uint32_t wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wi < n; wi += nwaves) {
         const GenItem t = wi < n1 ? q[wi] : q2[wi - n1];
         const uint32_t ta = t.types & 0xFFu, tb = (t.types >> 8) & 0xFFu;
@@ -408,18 +409,23 @@ __global__ __launch_bounds__(64, 2) void k_genw(const uint8_t* __restrict__ aren
             ivl = decide_type(op, (int)ta, (int)tb, t.ca, t.cb, ta == T_RUN && t.ca == 65536u, tb == T_RUN && t.cb == 65536u, lb, 1u) != T_BITSET;
         }
         if (ivl) {
-            if (!ivl_item<64, 0>(gr, (uint8_t*)ia, (uint16_t*)((uint8_t*)ia + IVL_LIST_BYTES), true, t, arenaA, arenaB, O, kop,
-                                 cardmode, pair_acc, nullptr, nullptr))
-                continue;
+            PH(0);
+            const bool redo = ivl_item<64, 0>(gr, (uint8_t*)ia, (uint16_t*)((uint8_t*)ia + IVL_LIST_BYTES), true, t, arenaA, arenaB, O, kop,
+                                              cardmode, pair_acc, nullptr, nullptr);
+            PH(1);
+            if (!redo) continue;
         }
+        PH(0);
         wimg_build(ia, arenaA + t.offa, ta, t.ca, t.nra);
         __builtin_amdgcn_wave_barrier();
+        PH(2);
         uint32_t r[32];
 #pragma unroll
         for (int k = 0; k < 32; ++k) r[k] = ia[wown(lane, k)];
         __builtin_amdgcn_wave_barrier();
         wimg_build(ib, arenaB + t.offb, tb, t.cb, t.nrb);
         __builtin_amdgcn_wave_barrier();
+        PH(3);
         uint32_t cnt = 0;
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
@@ -453,8 +459,11 @@ __global__ __launch_bounds__(64, 2) void k_genw(const uint8_t* __restrict__ aren
         if (rc) ty = decide_type(op, (int)ta, (int)tb, t.ca, t.cb, fulla, fullb, rc, rn);
         uint8_t* outp = O.arena + t.offo;
         uint32_t* img = ia;
+        PH(4);
 #include "rhip_wemit.inc"
         if (lane == 0) O.meta[t.out] = pack_meta(ty, rc, (ty == T_RUN) ? rn : 0u);
         __builtin_amdgcn_wave_barrier();
+        PH(5);
     }
+    PH_FLUSH(24);
 }

@@ -12,14 +12,15 @@ eng.lib.rhip_debug_phases.restype = C.c_int
 eng.lib.rhip_debug_phases.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 NAMES = {"k_filter": (0, ["item", "stage X", "test+emit", "meta"]),
          "k_wave": (8, ["item", "build X", "apply Y", "reduce+type", "table", "emit", "meta"]),
-         "k_usmall": (16, ["item+zero", "probe ranks", "stream X", "new values+meta"])}
+         "k_usmall": (16, ["item+zero", "probe ranks", "stream X", "new values+meta"]),
+         "k_genw": (24, ["item", "interval path", "image A", "image B", "combine+count+type", "emit"])}
 def phases():
     buf = (C.c_ulonglong * 32)()
     assert eng.lib.rhip_debug_phases(eng.h, buf, 1) == 0
     return np.array(list(buf), dtype=np.float64)
 pool = eng.pool_from_serialized(load_bundle(sys.argv[1] if len(sys.argv) > 1 else "weather_sept_85"))
 lhs, rhs = all_pairs(len(pool))
-for op in ("and", "or", "andnot"):
+for op in ("and", "or", "andnot") if len(sys.argv) < 3 else sys.argv[2:]:
     eng.pairwise(op, pool, lhs, pool, rhs)
     phases()
     for _ in range(4):
