@@ -1305,15 +1305,15 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
         if (has_runs || has_retry) {  // the general image class and / or the re-queued results, after their producers
             const bool gen = has_runs, ret = has_retry;
             if (gen && ret)
-                hipLaunchKernelGGL(k_genw, dim3(4 * ::bounded_grid(nm, 512)), dim3(64), 0, s, VA.arena, VB.arena, O,
+                hipLaunchKernelGGL(k_genw<true>, dim3(4 * ::bounded_grid(nm, 512)), dim3(64), 0, s, VA.arena, VB.arena, O,
                                    SS.q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, cardmode,
                                    c->pair_acc.as<u64>(), (const GenItem*)SS.q[CLS_RETRY].as<GenItem>(), (const uint32_t*)retry_count);
             else if (gen)
-                hipLaunchKernelGGL(k_genw, dim3(4 * ::bounded_grid(nm, 512)), dim3(64), 0, s, VA.arena, VB.arena, O,
+                hipLaunchKernelGGL(k_genw<true>, dim3(4 * ::bounded_grid(nm, 512)), dim3(64), 0, s, VA.arena, VB.arena, O,
                                    SS.q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, cardmode,
                                    c->pair_acc.as<u64>(), (const GenItem*)nullptr, (const uint32_t*)nullptr);
             else
-                hipLaunchKernelGGL(k_genw, dim3(4 * ::bounded_grid(nm, 512)), dim3(64), 0, s, VA.arena, VB.arena, O,
+                hipLaunchKernelGGL(k_genw<false>, dim3(4 * ::bounded_grid(nm, 512)), dim3(64), 0, s, VA.arena, VB.arena, O,
                                    SS.q[CLS_RETRY].as<GenItem>(), (const u64*)nullptr, retry_count, op, 0,
                                    c->pair_acc.as<u64>(), (const GenItem*)nullptr, (const uint32_t*)nullptr);
         }
@@ -1345,7 +1345,7 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
     // stream it shares a launch with the retry pass further down
     const bool genw_merged = !fork && has_runs && has_retry;
     auto launch_genw_general = [&](hipStream_t sg) {
-        hipLaunchKernelGGL(k_genw, dim3(4 * bounded_grid(nm, 512)), dim3(64), 0, sg, VA.arena, VB.arena, O,
+        hipLaunchKernelGGL(k_genw<true>, dim3(4 * bounded_grid(nm, 512)), dim3(64), 0, sg, VA.arena, VB.arena, O,
                            c->ss[P.slot].q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op,
                            cardmode, c->pair_acc.as<u64>(), (const GenItem*)nullptr, (const uint32_t*)nullptr);
     };
@@ -1390,11 +1390,11 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
         if (fork && has_ba && op != OP_OR) HIPCHK(hipStreamWaitEvent(sr, c->ev_ba, 0));  // k_ba re-queues its rare array results
         rhip_ctx_s::SlotScratch& SS = c->ss[P.slot];
         if (genw_merged)  // one stream: the general class and the re-queued results in one launch, after their producers
-            hipLaunchKernelGGL(k_genw, dim3(4 * bounded_grid(nm, 512)), dim3(64), 0, sr, VA.arena, VB.arena, O,
+            hipLaunchKernelGGL(k_genw<true>, dim3(4 * bounded_grid(nm, 512)), dim3(64), 0, sr, VA.arena, VB.arena, O,
                                SS.q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, 0,
                                c->pair_acc.as<u64>(), (const GenItem*)SS.q[CLS_RETRY].as<GenItem>(), (const uint32_t*)retry_count);
         else
-            hipLaunchKernelGGL(k_genw, dim3(4 * bounded_grid(nm, 512)), dim3(64), 0, sr, VA.arena, VB.arena, O,
+            hipLaunchKernelGGL(k_genw<false>, dim3(4 * bounded_grid(nm, 512)), dim3(64), 0, sr, VA.arena, VB.arena, O,
                                SS.q[CLS_RETRY].as<GenItem>(), (const u64*)nullptr, retry_count, op, 0,
                                c->pair_acc.as<u64>(), (const GenItem*)nullptr, (const uint32_t*)nullptr);
     }

@@ -265,6 +265,26 @@ __device__ __forceinline__ void ivl_body(uint8_t* lds, uint32_t bid, uint32_t nb
     }
 }
 
+// ------------------------------------------------------------------ long interval lists (items of the GENERAL queue)
+// A run container against a run / an array, too long for the three size classes above but RUNSL_MAX_SUM intervals or fewer
+// together: interval algebra on a whole wave with the two lists packed back to back, O(intervals) instead of k_genw's two
+// 65 536-bit images (census-income, wikileaks-noquotes: most of the general queue).  The items stay in the general
+// queue; k_genw<true> takes this path for them.
+__device__ __forceinline__ bool gen_item_is_interval(const GenItem& t, int op, int cardmode) {
+    const uint32_t ta = t.types & 0xFFu, tb = (t.types >> 8) & 0xFFu;
+    if (!((ta == T_RUN || tb == T_RUN) && ta != T_BITSET && tb != T_BITSET &&
+          (ta == T_RUN ? t.nra : t.ca) + (tb == T_RUN ? t.nrb : t.cb) <= RUNSL_MAX_SUM))
+        return false;
+    if (cardmode) return true;
+    // ... unless the reference's typing rule makes the result a bitset whatever its run count (a 30 000-value run
+    // container minus / xor an array: mixed_andnot.c:277-412, mixed_xor.c:104-138): with rn = 1 every rule that looks at
+    // the run count answers "run", so T_BITSET here means certain -- the true cardinality is >= the bound
+    const uint32_t lb = op == OP_AND ? 0u : op == OP_OR ? (t.ca > t.cb ? t.ca : t.cb)
+                      : op == OP_XOR ? (t.ca > t.cb ? t.ca - t.cb : t.cb - t.ca) : (t.ca > t.cb ? t.ca - t.cb : 0u);
+    return decide_type(op, (int)ta, (int)tb, t.ca, t.cb, ta == T_RUN && t.ca == 65536u, tb == T_RUN && t.cb == 65536u, lb, 1u) != T_BITSET;
+}
+constexpr uint32_t IVLL_LIST_BYTES = 4u * RUNSL_MAX_SUM + 64u;         // both lists + over-read slack
+constexpr uint32_t IVLL_BYTES = IVLL_LIST_BYTES + 4u * RUNSL_MAX_SUM;  // + run table: 16 320 bytes a wave
 // The three size classes in ONE launch (a small batch is a chain of dependent launches: each one less is ~7 us):
 // blocks [0, g1) take the short lists, [g1, g1 + g2) the wide ones, the rest one pair per wave.  The block's LDS is
 // the largest of the three shapes (32 KiB); at ~100 VGPRs four blocks per CU fit either way.
@@ -370,18 +390,23 @@ __device__ void wimg_build(uint32_t* img, const uint8_t* __restrict__ p, uint32_
 // four-wave workgroup needs that on all four SIMDs of one CU at once -- next to a machine-filling k_filter / k_wave
 // (whose freed slots go to whoever fits first) such a workgroup waited for the big kernel's grid to drain: 216 us for
 // the 1 173 run pairs of a weather_sept_85 batch that take 47 us alone.  A single wave fits wherever two slots free up.
+// INLINE_IVL (the instantiation that serves the general queue): its long interval lists (gen_item_is_interval) take the
+// interval path, here, next to the image items.  Every such item is a 10-20 us chain of dependent steps whatever the
+// machine does around it, so what counts is that the chains run beside other work: a kernel of their own for them
+// (one-wave blocks, 71 VGPRs) was measured and dropped -- behind k_ivl_all on its stream it made census1881 or / andnot
+// 10-15 % slower, as a block range of k_ivl_all / k_classes its two working waves sat on two of the four SIMDs.  The
+// price here -- 256 VGPRs and a few spilled registers where the image path alone needs 246 -- is not paid by the
+// retry pass (k_genw<false>).
+template <bool INLINE_IVL>
 __global__ __launch_bounds__(64, 2) void k_genw(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                              OutView O, const GenItem* __restrict__ q,
                                              const u64* __restrict__ qrange, const uint32_t* __restrict__ qcount,
                                              int kop, int cardmode, u64* pair_acc,
                                              const GenItem* __restrict__ q2, const uint32_t* __restrict__ q2count) {
     // ONE 8 KiB image per wave: operand A is rasterised, pulled into registers, then the same image is
-    // reused for operand B and finally as the output staging buffer.  The long-list interval path uses the same LDS as
-    // two boundary lists (RUNSL_MAX_SUM intervals together) and a run table.
-    constexpr uint32_t IVL_LIST_BYTES = 4u * RUNSL_MAX_SUM + 64u, IVL_BYTES = IVL_LIST_BYTES + 4u * RUNSL_MAX_SUM;
-    __shared__ __attribute__((aligned(16))) uint32_t img_all[1][(IVL_BYTES > 8192u ? IVL_BYTES : 8192u) / 4];
+    // reused for operand B and finally as the output staging buffer
+    __shared__ __attribute__((aligned(16))) uint32_t img_all[1][(INLINE_IVL ? 16384 : 8192) / 4];
     const uint32_t lane = lane_id();
-    const Grp<64> gr;
     uint32_t* ia = img_all[0];
     uint32_t* ib = ia;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -394,26 +419,14 @@ __global__ __launch_bounds__(64, 2) void k_genw(const uint8_t* __restrict__ aren
         const GenItem t = wi < n1 ? q[wi] : q2[wi - n1];
         const uint32_t ta = t.types & 0xFFu, tb = (t.types >> 8) & 0xFFu;
         const int op = item_op(kop, t.types);
-        // A run container against a run / an array, too long for the interval classes but RUNSL_MAX_SUM intervals or
-        // fewer together: interval algebra on the whole wave, O(intervals) instead of two 65 536-bit images (a 100-run
-        // container x an 874-value array: 7.5 -> ~3 ns per pair).  Not for re-queued items (their result is a bitset),
-        // and a pair whose result turns out to be a bitset falls through to the image path.
-        bool ivl = qrange && wi < n1 && (ta == T_RUN || tb == T_RUN) && ta != T_BITSET && tb != T_BITSET &&
-                   (ta == T_RUN ? t.nra : t.ca) + (tb == T_RUN ? t.nrb : t.cb) <= RUNSL_MAX_SUM;
-        if (ivl && !cardmode) {
-            // ... unless the reference's typing rule makes the result a bitset whatever its run count (a 30 000-value run
-            // container minus / xor an array: mixed_andnot.c:277-412, mixed_xor.c:104-138): with rn = 1 every rule that
-            // looks at the run count answers "run", so T_BITSET here means certain -- the true cardinality is >= the bound
-            const uint32_t lb = op == OP_AND ? 0u : op == OP_OR ? (t.ca > t.cb ? t.ca : t.cb)
-                              : op == OP_XOR ? (t.ca > t.cb ? t.ca - t.cb : t.cb - t.ca) : (t.ca > t.cb ? t.ca - t.cb : 0u);
-            ivl = decide_type(op, (int)ta, (int)tb, t.ca, t.cb, ta == T_RUN && t.ca == 65536u, tb == T_RUN && t.cb == 65536u, lb, 1u) != T_BITSET;
-        }
-        if (ivl) {
-            PH(0);
-            const bool redo = ivl_item<64, 0>(gr, (uint8_t*)ia, (uint16_t*)((uint8_t*)ia + IVL_LIST_BYTES), true, t, arenaA, arenaB, O, kop,
-                                              cardmode, pair_acc, nullptr, nullptr);
-            PH(1);
-            if (!redo) continue;
+        // the long interval lists of the general queue: the interval path (here or in k_ivl_long); a result that has to be
+        // a bitset comes back through the image path (here: right away; there: re-queued)
+        if (qrange && wi < n1 && gen_item_is_interval(t, op, cardmode)) {
+            if (!INLINE_IVL) continue;  // (not reached: the retry pass has no section range)
+            const Grp<64> gr;
+            if (!ivl_item<64, 0>(gr, (uint8_t*)ia, (uint16_t*)((uint8_t*)ia + IVLL_LIST_BYTES), true, t, arenaA, arenaB, O, kop, cardmode,
+                                 pair_acc, nullptr, nullptr))
+                continue;
         }
         PH(0);
         wimg_build(ia, arenaA + t.offa, ta, t.ca, t.nra);
