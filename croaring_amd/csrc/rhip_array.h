@@ -345,12 +345,18 @@ __global__ __launch_bounds__(256) void k_usmall(const uint8_t* __restrict__ aren
 // (array_util.c:385-459) and array_bitset_container_intersection / _andnot (mixed_intersection.c:19-46,
 // mixed_andnot.c:24-39); short streamed arrays take k_probe instead.  The result is always an array
 // (containers.h:741-746, 1799-1803).
+constexpr uint32_t FILTER_ST_WORDS = 264;                              // 528 u16 >= 7 + 512, a multiple of 16 bytes
+constexpr uint32_t FILTER_LDS_WORDS = 4 * 2048 + 4 * FILTER_ST_WORDS;   // four waves: image + output window
+// STAGED: with the output window (andnot and multi-op batches).  An `and` batch runs the instantiation without it: its
+// 32 KiB blocks leave room for k_genw's 16 KiB waves on the same CU, and few of its values survive anyway.
+template <bool STAGED>
 __device__ __forceinline__ void filter_body(uint32_t* __restrict__ lds, uint32_t bid, uint32_t nblk, const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                                 OutView O, const FatItem* __restrict__ q,
                                                 const u64* __restrict__ qrange, int kop, int cardmode,
                                                 u64* pair_acc) {
     const uint32_t lane = lane_id();
     uint32_t* img = lds + (threadIdx.x >> 6) * 2048u;
+    uint16_t* ST = STAGED ? (uint16_t*)(lds + 4u * 2048u + (threadIdx.x >> 6) * FILTER_ST_WORDS) : nullptr;  // output window: 7 + 512 values
     const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
     uint32_t w = (bid * blockDim.x + threadIdx.x) >> 6;
@@ -391,8 +397,11 @@ __device__ __forceinline__ void filter_body(uint32_t* __restrict__ lds, uint32_t
         }
         __builtin_amdgcn_wave_barrier();
         PH(1);
-        uint16_t* __restrict__ out = cardmode ? nullptr : (uint16_t*)(O.arena + t.offo);
-        uint32_t run = 0;
+        // The kept values of a step are compacted into the LDS window ST (behind the <= 7 values the previous step left
+        // over) and leave as whole 16-byte groups: written straight to global they were eight conditional 2-byte stores
+        // per lane and step, the larger part of an andnot batch (most values survive).
+        uint4* __restrict__ po4 = cardmode ? nullptr : (uint4*)(O.arena + t.offo);
+        uint32_t run = 0, carry = 0;  // run: values already in global memory (a multiple of 8) -- cardinality mode: all
         for (uint32_t base = 0; base < ny; base += 512) {
             const uint32_t i0 = base + 8 * lane;
             uint4 q4 = yfirst;
@@ -411,13 +420,38 @@ __device__ __forceinline__ void filter_body(uint32_t* __restrict__ lds, uint32_t
             keepmask &= (1u << nval) - 1u;
             const uint32_t cnt = __popc(keepmask);
             const uint32_t inc = wave_incl_scan(cnt);
-            if (!cardmode) {
+            const uint32_t tot = __shfl(inc, 63);
+            if (cardmode) {
+                run += tot;
+                continue;
+            }
+            if (!STAGED || keep_present) {  // and: few values survive as a rule -- the window's bookkeeping costs more than their stores
+                uint16_t* __restrict__ out = (uint16_t*)po4;
                 uint32_t pos = run + inc - cnt;
 #pragma unroll
                 for (int h = 0; h < 8; ++h)
                     if ((keepmask >> h) & 1u) out[pos++] = (uint16_t)vals[h];
+                run += tot;
+                continue;
             }
-            run += __shfl(inc, 63);
+            uint32_t pos = carry + inc - cnt;
+#pragma unroll
+            for (int h = 0; h < 8; ++h)
+                if ((keepmask >> h) & 1u) ST[pos++] = (uint16_t)vals[h];
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t filled = carry + tot, nfull = filled >> 3;
+            for (uint32_t j = lane; j < nfull; j += 64) po4[(run >> 3) + j] = ((const uint4*)ST)[j];
+            carry = filled & 7u;
+            uint16_t keep = 0;
+            if (lane < carry) keep = ST[8u * nfull + lane];
+            __builtin_amdgcn_wave_barrier();  // the window has been read
+            if (lane < carry) ST[lane] = keep;
+            run += 8u * nfull;
+        }
+        if (!cardmode) {
+            __builtin_amdgcn_wave_barrier();
+            if (carry && lane == 0) po4[run >> 3] = ((const uint4*)ST)[0];  // (the slot is padded to 16 bytes)
+            run += carry;
         }
         PH(2);
         if (cardmode) {
@@ -430,12 +464,13 @@ __device__ __forceinline__ void filter_body(uint32_t* __restrict__ lds, uint32_t
     }
     PH_FLUSH(0);
 }
+template <bool STAGED>
 __global__ __launch_bounds__(256) void k_filter(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                                 OutView O, const FatItem* __restrict__ q,
                                                 const u64* __restrict__ qrange, int kop, int cardmode,
                                                 u64* pair_acc) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[8192];
-    filter_body(lds, blockIdx.x, gridDim.x, arenaA, arenaB, O, q, qrange, kop, cardmode, pair_acc);
+    __shared__ __attribute__((aligned(16))) uint32_t lds[STAGED ? FILTER_LDS_WORDS : 8192];
+    filter_body<STAGED>(lds, blockIdx.x, gridDim.x, arenaA, arenaB, O, q, qrange, kop, cardmode, pair_acc);
 }
 
 

@@ -30,10 +30,11 @@ struct ClassLaunch {
     int kop, cardmode;
     uint32_t nb[N_CSEG];      // blocks of each segment (0: the class cannot occur)
 };
-static_assert(USMALL_LDS_WORDS <= 8192, "k_classes: LDS of the largest body");
+constexpr uint32_t CLASSES_LDS_WORDS = FILTER_LDS_WORDS > 8192 ? FILTER_LDS_WORDS : 8192;
+static_assert(USMALL_LDS_WORDS <= CLASSES_LDS_WORDS, "k_classes: LDS of the largest body");
 
 __global__ __launch_bounds__(256) void k_classes(ClassLaunch L) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[8192];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[CLASSES_LDS_WORDS];
     uint32_t b = blockIdx.x, seg = 0;
     while (seg < N_CSEG && b >= L.nb[seg]) { b -= L.nb[seg]; ++seg; }
     const uint32_t nblk = seg < N_CSEG ? L.nb[seg] : 0u;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void k_classes(ClassLaunch L) {
                                              L.cardmode, L.pair_acc, L.retry_q, L.retry_count);
             break;
         case CSEG_FILT:
-            filter_body(lds, b, nblk, L.arenaA, L.arenaB, L.O, L.q_filt, R + 2 * SEC_FILT, L.kop, L.cardmode, L.pair_acc);
+            filter_body<true>(lds, b, nblk, L.arenaA, L.arenaB, L.O, L.q_filt, R + 2 * SEC_FILT, L.kop, L.cardmode, L.pair_acc);
             break;
         case CSEG_PROBE:
             probe_body(lds, b, nblk, L.arenaA, L.arenaB, L.O, L.q_probe, R + 2 * SEC_PROBE, L.kop, L.cardmode, L.pair_acc);

@@ -1351,7 +1351,7 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
     };
     if (multi && has_runs && !genw_merged) launch_genw_general(on(1));
     if (has_filt)
-        hipLaunchKernelGGL(k_filter, dim3(bounded_grid(nm)), dim3(256), 0, on(1), VA.arena, VB.arena, O,
+        hipLaunchKernelGGL((op == OP_AND || cardmode) ? k_filter<false> : k_filter<true>, dim3(bounded_grid(nm)), dim3(256), 0, on(1), VA.arena, VB.arena, O,
                            c->ss[P.slot].q[CLS_FILT].as<FatItem>(), ranges + 2 * SEC_FILT, op, cardmode, c->pair_acc.as<u64>());
     if (has_wave)
         hipLaunchKernelGGL(k_wave, dim3(bounded_grid(nm)), dim3(256), 0, on(2), VA.arena, VB.arena, O,
