@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_classes(ClassLaunch L) {
                                       L.pair_acc, L.retry_q, L.retry_count);
             break;
         case CSEG_IVL64:
-            ivl_body<64, RUNS_MAX_INTERVALS>((uint8_t*)lds, b, nblk, L.arenaA, L.arenaB, L.O, L.q_r64, R + 2 * SEC_RUNS, L.kop,
+            ivl_body<RUNS_G, RUNS_MAX_INTERVALS>((uint8_t*)lds, b, nblk, L.arenaA, L.arenaB, L.O, L.q_r64, R + 2 * SEC_RUNS, L.kop,
                                              L.cardmode, L.pair_acc, L.retry_q, L.retry_count);
             break;
         case CSEG_FILT:

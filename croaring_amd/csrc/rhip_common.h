@@ -22,6 +22,7 @@ enum { CLS_BB = 0, CLS_GEN = 1, CLS_COPY = 2, CLS_RETRY = 3, CLS_FILT = 4, CLS_W
 #define R16W_MAX_CARD 4096u
 #define USMALL_MAX 255u  // smaller array of a k_usmall item (or / xor of two arrays): at most four values per lane
 #define PROBE_MAX 256u  // streamed array of a k_probe item: at most four values per lane
+#define RUNS_G 32u  // lanes per pair of the long class
 #define RUNS_MAX_INTERVALS 255u  // per operand, for the interval kernel (k_runs); 255 keeps its LDS at 4 x 8 KiB - 64 B
 // k_genw's long-list interval path: intervals of both operands together (LDS: 8 bytes per interval and list, as much again
 // for the run table: 2 x 8 KiB)

@@ -354,8 +354,8 @@ extern "C" int rhip_ctx_synchronize(rhip_ctx_t* c) {
 }
 extern "C" void rhip_ctx_set_timing(rhip_ctx_t* c, int enabled) { c->timing = enabled != 0; }
 extern "C" void rhip_ctx_set_class_stats(rhip_ctx_t* c, int enabled) { c->class_stats = enabled != 0; }
-static const char* const k_class_names[N_CLS] = {"k_bb", "k_genw", "k_copy", "(retry)", "k_filter", "k_wave", "k_ivl<64,255>", "k_probe",
-                                                 "k_bba", "k_usmall", "k_ivl<16,31>", "k_ivl<16,127>", "k_ba"};
+static const char* const k_class_names[N_CLS] = {"k_bb", "k_genw", "k_copy", "(retry)", "k_filter", "k_wave", "k_ivl<32,255>", "k_probe",
+                                                 "k_bba", "k_usmall", "k_ivl<8,31>", "k_ivl<16,127>", "k_ba"};
 extern "C" int rhip_last_class_stats(rhip_ctx_t* c, rhip_class_stats_t* out, int capacity) {
     if (!c || (!out && capacity > 0)) return RHIP_ERR_ARG;
     int n = 0;

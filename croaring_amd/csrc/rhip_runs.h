@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void k_ivl_all(const uint8_t* __restrict__ are
                                                  OutView O, IvlQueues Q, uint32_t g1, uint32_t g2, int op, int cardmode,
                                                  u64* pair_acc, GenItem* retry_q, uint32_t* retry_count) {
     constexpr uint32_t LDS_A = IvlShape<R16_G, R16_MAX_IV>::LDS_BYTES, LDS_B = IvlShape<16, R16W_MAX_IV>::LDS_BYTES,
-                       LDS_C = IvlShape<64, RUNS_MAX_INTERVALS>::LDS_BYTES;
+                       LDS_C = IvlShape<RUNS_G, RUNS_MAX_INTERVALS>::LDS_BYTES;
     constexpr uint32_t LDS_MAX = LDS_A > LDS_B ? (LDS_A > LDS_C ? LDS_A : LDS_C) : (LDS_B > LDS_C ? LDS_B : LDS_C);
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_MAX];
     const uint32_t b = blockIdx.x;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void k_ivl_all(const uint8_t* __restrict__ are
         ivl_body<16, R16W_MAX_IV>(lds, b - g1, g2, arenaA, arenaB, O, Q.q[1], Q.range[1], op, cardmode, pair_acc, retry_q,
                                   retry_count);
     else
-        ivl_body<64, RUNS_MAX_INTERVALS>(lds, b - g1 - g2, gridDim.x - g1 - g2, arenaA, arenaB, O, Q.q[2], Q.range[2], op,
+        ivl_body<RUNS_G, RUNS_MAX_INTERVALS>(lds, b - g1 - g2, gridDim.x - g1 - g2, arenaA, arenaB, O, Q.q[2], Q.range[2], op,
                                          cardmode, pair_acc, retry_q, retry_count);
 }
 
