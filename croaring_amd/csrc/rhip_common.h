@@ -13,9 +13,10 @@ enum { OP_AND = 0, OP_OR = 1, OP_XOR = 2, OP_ANDNOT = 3,
 #define ITEM_OP_SHIFT 16
 __device__ __forceinline__ int item_op(int kop, uint32_t field) { return kop < OP_ITEM ? kop : (int)((field >> ITEM_OP_SHIFT) & 3u); }
 enum { CLS_BB = 0, CLS_GEN = 1, CLS_COPY = 2, CLS_RETRY = 3, CLS_FILT = 4, CLS_WAVE = 5, CLS_RUNS = 6, CLS_PROBE = 7, CLS_BBA = 8, CLS_USMALL = 9, CLS_RUNS16 = 10, CLS_RUNS16W = 11, CLS_BA = 12, N_CLS = 13 };
-// interval pairs that run four to a wave (k_ivl<16, .>): at most that many intervals per operand and values in both
-// operands together; two size classes, because the four pairs of a wave advance in lockstep
-#define R16_MAX_IV 31u
+// interval pairs that run eight / four to a wave (k_ivl<8, .>, k_ivl<16, .>): at most that many intervals per operand and
+// values in both operands together; two size classes, because the pairs of a wave advance in lockstep.  (63 / 8 lanes:
+// round 3 -- the walk costs the same wave instructions per pair whatever the group width, the per-wave overhead is shared)
+#define R16_MAX_IV 63u
 #define R16_G 8u  // lanes per pair of that class (eight pairs per wave)
 #define R16_MAX_CARD 1024u
 #define R16W_MAX_IV 127u

@@ -355,7 +355,7 @@ extern "C" int rhip_ctx_synchronize(rhip_ctx_t* c) {
 extern "C" void rhip_ctx_set_timing(rhip_ctx_t* c, int enabled) { c->timing = enabled != 0; }
 extern "C" void rhip_ctx_set_class_stats(rhip_ctx_t* c, int enabled) { c->class_stats = enabled != 0; }
 static const char* const k_class_names[N_CLS] = {"k_bb", "k_genw", "k_copy", "(retry)", "k_filter", "k_wave", "k_ivl<32,255>", "k_probe",
-                                                 "k_bba", "k_usmall", "k_ivl<8,31>", "k_ivl<16,127>", "k_ba"};
+                                                 "k_bba", "k_usmall", "k_ivl<8,63>", "k_ivl<16,127>", "k_ba"};
 extern "C" int rhip_last_class_stats(rhip_ctx_t* c, rhip_class_stats_t* out, int capacity) {
     if (!c || (!out && capacity > 0)) return RHIP_ERR_ARG;
     int n = 0;
@@ -1242,7 +1242,7 @@ Plan plan(rhip_ctx_t* c, const OpSet& ops, rhip_pool_t* A, rhip_pool_t* B, size_
 // planning and joined before the tail -- four streams in all, one per hardware queue of the device (a fifth
 // stream shares a queue with another and serialises behind it):
 //     main : k_bb -> [ev_bb] -> k_usmall | k_probe -> k_bba -> k_copy -> [join] -> k_tail      streaming / light classes
-//     aux0 : k_ivl_all (<16,31> | <16,127> | <64,255> in one launch) -> [wait ev_bb] -> k_genw(retry)     interval algebra
+//     aux0 : k_ivl_all (<8,63> | <16,127> | <32,255> in one launch) -> [wait ev_bb] -> k_genw(retry)     interval algebra
 //     aux1 : k_filter                                                                and / andnot / cardinality
 //     aux2 : k_wave                                                                  or / xor / bitset \ array
 //     k_genw(general): on aux1 for or / xor, aux2 for and / cardinality (the stream the op leaves idle), else after k_filter

@@ -10,7 +10,7 @@ for r in rows:
     if "k_class_stats" in r["Kernel_Name"]:
         segs.append(cur); cur = []
 NAMES = {"k_bb": "k_bb<", "k_bba": "k_bba<", "k_ba": "k_ba<", "k_genw": "k_genw", "k_copy": "k_copy", "k_filter": "k_filter",
-         "k_wave": "k_wave", "k_probe": "k_probe", "k_usmall": "k_usmall", "k_ivl<32,255>": "k_ivl_all", "k_ivl<8,31>": "k_ivl_all",
+         "k_wave": "k_wave", "k_probe": "k_probe", "k_usmall": "k_usmall", "k_ivl<32,255>": "k_ivl_all", "k_ivl<8,63>": "k_ivl_all",
          "k_ivl<16,127>": "k_ivl_all"}
 for st, seg in zip(stats, segs):
     dur = {}
