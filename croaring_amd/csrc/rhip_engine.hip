@@ -55,23 +55,28 @@ static int& last_status() {
 struct DBuf {
     void* p = nullptr;
     size_t cap = 0;
+    void* base = nullptr;  // the allocation; p = base + skew
+    size_t skew = 0;       // set before the first ensure(): see rhip_ctx_s::arena_skew
+    size_t round_to = 0;   // allocations at least this large are rounded up to a multiple of it
     void ensure(size_t n) {
         if (n <= cap) return;
-        if (p) (void)hipFree(p);
-        p = nullptr;
+        if (base) (void)hipFree(base);
+        p = base = nullptr;
         cap = 0;
         size_t want = n + n / 8 + 256;
-        hipError_t e = hipMalloc(&p, want);
+        if (round_to && want + skew >= round_to) want = (want + skew + round_to - 1) / round_to * round_to - skew;
+        hipError_t e = hipMalloc(&base, want + skew);
         if (e != hipSuccess) {
-            p = nullptr;
-            set_err("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            base = nullptr;
+            set_err("hipMalloc(%zu) failed: %s", want + skew, hipGetErrorString(e));
             throw (int)RHIP_ERR_ALLOC;
         }
+        p = (char*)base + skew;
         cap = want;
     }
     void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
+        if (base) (void)hipFree(base);
+        p = base = nullptr;
         cap = 0;
     }
     template <class T>
@@ -147,6 +152,8 @@ struct rhip_ctx_s {
     hipEvent_t ev_many_stage = nullptr;
     bool many_stage_pending = false;
     std::vector<rhip_pool_t*> many_free;  // retired results of rhip_or_many / rhip_xor_many: their buffers are recycled
+    size_t arena_skew = 0;  // result arenas start this many bytes into their allocation (RHIP_ARENA_SKEW)
+    size_t arena_round = 0; // RHIP_ARENA_ROUND_MB
     bool merge_classes = true;  // RHIP_MERGE_CLASSES=0: a small batch launches its class kernels one by one
     uint64_t merge_max_items = 256u << 10;  // ... "small" = at most that many matched container pairs (upper bound)
     int many_pf = 4;  // RHIP_MANY_PF: payload groups per lane k_many_l1 loads ahead (2 / 4 / 8)
@@ -299,6 +306,8 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_PLAN_OVERLAP")) c->plan_overlap = !(e[0] == '0');
         if (const char* e = getenv("RHIP_MANY_PF")) c->many_pf = atoi(e);
         if (const char* e = getenv("RHIP_MERGE_CLASSES")) c->merge_classes = !(e[0] == '0');
+        if (const char* e = getenv("RHIP_ARENA_ROUND_MB")) c->arena_round = (size_t)strtoull(e, nullptr, 0) << 20;
+        if (const char* e = getenv("RHIP_ARENA_SKEW")) c->arena_skew = (size_t)strtoull(e, nullptr, 0) & ~(size_t)255;
         if (const char* e = getenv("RHIP_MANY_CH")) c->many_ch = std::max(1, std::min(1024, atoi(e)));
         memset(c->h_pinned, 0, 4096);
         {
@@ -1550,6 +1559,8 @@ static rhip_batch_t* pairwise_begin_ops(rhip_ctx_t* c, size_t n_ops, const rhip_
         R->host_w = false;
         R->h_cards.clear();
         ensure_dir(R, (uint32_t)(npairs * n_ops), P.ub_cand);
+        R->arena.skew = c->arena_skew;
+        R->arena.round_to = c->arena_round;
         R->arena.ensure(P.arena_bound + 64);
         OutView O{};
         O.key = CO.key; O.meta = c->ss[slot].o_meta.as<u64>(); O.off = CO.off; O.slot = nullptr;
@@ -1698,6 +1709,10 @@ extern "C" int rhip_pairwise_cardinality(rhip_ctx_t* c, rhip_op op_, rhip_pool_t
 // host-side phase clock of rhip_pairwise, microseconds accumulated since the last reset: [0] pair-list passes,
 // [1] scratch sizing + host-to-device copy of the batch description, [2] planning launches, [3] class + tail launches,
 // [4] wait for completion, [5] result bookkeeping
+// (diagnostics for scripts/arena_skew_sweep.py, not part of the boundary)
+extern "C" void rhip_debug_set_arena_skew(rhip_ctx_t* c, unsigned long long bytes) { c->arena_skew = (size_t)bytes & ~(size_t)255; }
+extern "C" void rhip_debug_set_arena_round(rhip_ctx_t* c, unsigned long long bytes) { c->arena_round = (size_t)bytes; }
+extern "C" unsigned long long rhip_debug_pool_arena(rhip_pool_t* P) { return (unsigned long long)(uintptr_t)P->arena.p; }
 extern "C" int rhip_debug_host_clock(rhip_ctx_t* c, double out[8], int reset) {
     if (!c || !out) return RHIP_ERR_ARG;
     for (int i = 0; i < 8; ++i) out[i] = c->hclk[i];

@@ -38,7 +38,15 @@ t.append("""
 (`k_bb<and>` against `k_bb<or>`: within 0.5 % in all three runs.  The "bimodality" of rounds 1-2 is WHERE THE RESULT ARENA
 LANDS: with a freshly allocated result pool per op `k_bb<xor>` takes 4.63 ms and `k_bb<or>` 4.40 ms, recycling the other
 op's arena swaps them (`scripts/c2_or_clock.py`) -- the three streams of the kernel advance in lockstep, so their relative
-placement holds for the whole launch.  Cardinality mode: the events of the call's own slot are read now; round 2's
+placement holds for the whole launch.  Run down in the second half of round 3 (`scripts/arena_skew_sweep.py`): ONE
+pool, ONE process, the result arena freed and re-allocated for every row -- the same virtual address gives 4.37-4.45 ms
+or 4.64-4.71 ms at random, whatever the arena's offset into its allocation (256 B ... 1 GiB) and whatever its size is
+rounded to (1 ... 16 GiB).  It is the PHYSICAL pages the driver hands out, nothing the address shows, and consecutive
+allocations come in streaks of one mode.  So the only handle is to look: `Engine.pairwise_placed` runs a batch into
+`tries` freshly allocated result pools and keeps the fastest; `bench.py` does that once per recycled result pool at
+start-up, untimed (`config.result_arena_startup` lists the `k_bb` time of every try; `--arena-tries 0` takes the first
+allocation).  With 8 tries three consecutive bench runs gave 0.712 / 0.714 / 0.715 of peak; with 4, two of three stayed
+in the slow mode for `and` (0.687).  Cardinality mode: the events of the call's own slot are read now; round 2's
 table repeated a stale pair.)
 
 **Realdata, ALL unordered pairs in one batched call per op** (`bench.py` secondary block: wall time of the whole call

@@ -250,6 +250,10 @@ def test_emu_long_interval_lists(emu, oracle):
     G.test_long_interval_lists(emu, oracle)
 
 
+def test_emu_pairwise_placed(emu, oracle, synth):
+    G.test_pairwise_placed(emu, oracle, synth)
+
+
 @pytest.mark.parametrize("mode", ["1", "2", "fork", "nomerge"])
 def test_emu_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
     """Batches whose bitmaps all have <= 256 containers plan on implicit units (unit = pair / 2 pair + side), four

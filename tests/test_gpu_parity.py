@@ -666,6 +666,26 @@ def test_tiny_interval_pairs(engine, oracle):
         oracle.free(h)
 
 
+def test_pairwise_placed(engine, oracle, synth):
+    """Engine.pairwise_placed: the result pool kept after the start-up tries holds the batch's results and can be
+    recycled; the other tries are gone."""
+    bufs = synth[0]
+    hs = [oracle.deserialize(b) for b in bufs]
+    pool = engine.pool_from_serialized(bufs)
+    n = len(hs)
+    lhs = np.arange(n, dtype=np.uint32)
+    rhs = np.roll(lhs, 3)
+    res, ms = engine.pairwise_placed("or", pool, lhs, pool, rhs, tries=3)
+    assert len(ms) == 3 and all(m >= 0 for m in ms)
+    res = engine.pairwise("xor", pool, lhs, pool, rhs, reuse=res)
+    for k in range(n):
+        oo = oracle.op("xor", hs[lhs[k]], hs[rhs[k]])
+        assert res.serialize(k) == oracle.serialize(oo), k
+        oracle.free(oo)
+    for h in hs:
+        oracle.free(h)
+
+
 def test_long_interval_lists(engine, oracle):
     """k_genw's long-list interval path (a run operand, lists too long for the k_ivl classes, at most 2 032 intervals
     together) and its neighbours: run containers of 100 .. 1 500 runs against arrays of 300 .. 3 000 values and against
