@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void k_ivl_all(const uint8_t* __restrict__ are
 // ------------------------------------------------------------------ wave-level general pair kernel (K5, K7, K13-K16)
 // Every type pair the specialised kernels do not take (all pairs with a run container, plus
 // bitset x bitset results that must become arrays): ONE WAVE per container pair, two wave-private
-// 8 KiB LDS images, no workgroup barrier.  Lane l owns the 32 consecutive logical words
+// 8 KiB LDS images (operand A, operand B; A's doubles as output staging), no workgroup barrier.  Lane l owns the 32 consecutive logical words
 // [32 l, 32 l + 32) -- the ownership that prefix-XOR run rasterisation and run counting need -- and a
 // skewed transposed physical layout keeps both the per-lane accesses (k-th word of every lane) and
 // the coalesced global<->LDS copies conflict-free:
@@ -341,29 +341,46 @@ __device__ void wimg_build(uint32_t* img, const uint8_t* __restrict__ p, uint32_
     for (int i = 0; i < 8; ++i) ((uint4*)img)[i * 64 + lane] = z;
     __builtin_amdgcn_wave_barrier();  // the whole image is zero before any lane scatters into another lane's words
     const uint4* __restrict__ q4p = (const uint4*)p;
+    // (four 16-byte loads of a lane in flight per round: a 3 000-value array is two global round trips, not six)
     if (type == T_ARRAY) {
-        for (uint32_t i = lane; 8 * i < card; i += 64) {
-            const uint4 q4 = q4p[i];
-            const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
+        const uint32_t n16 = (card + 7u) >> 3;
+        for (uint32_t i0 = 0; i0 < n16; i0 += 256) {
+            uint4 q4[4];
 #pragma unroll
-            for (int h = 0; h < 8; ++h) {
-                if (8 * i + h < card) {
-                    const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
-                    atomicOr(&img[wphys(v >> 5)], 1u << (v & 31));
+            for (int u = 0; u < 4; ++u) q4[u] = i0 + 64u * u + lane < n16 ? q4p[i0 + 64u * u + lane] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + 64u * u + lane;
+                const uint32_t d[4] = {q4[u].x, q4[u].y, q4[u].z, q4[u].w};
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    if (8 * i + h < card) {
+                        const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                        atomicOr(&img[wphys(v >> 5)], 1u << (v & 31));
+                    }
                 }
             }
         }
         return;
     }
-    for (uint32_t i = lane; 4 * i < nruns; i += 64) {  // 4 runs {u16 value, u16 length} per 16-byte load
-        const uint4 q4 = q4p[i];
-        const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
+    {
+        const uint32_t n16 = (nruns + 3u) >> 2;  // 4 runs {u16 value, u16 length} per 16-byte load
+        for (uint32_t i0 = 0; i0 < n16; i0 += 256) {
+            uint4 q4[4];
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            if (4 * i + h < nruns) {
-                const uint32_t s0 = d[h] & 0xFFFFu, e1 = s0 + (d[h] >> 16) + 1u;
-                atomicXor(&img[wphys(s0 >> 5)], 1u << (s0 & 31));
-                if (e1 < 65536u) atomicXor(&img[wphys(e1 >> 5)], 1u << (e1 & 31));
+            for (int u = 0; u < 4; ++u) q4[u] = i0 + 64u * u + lane < n16 ? q4p[i0 + 64u * u + lane] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + 64u * u + lane;
+                const uint32_t d[4] = {q4[u].x, q4[u].y, q4[u].z, q4[u].w};
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    if (4 * i + h < nruns) {
+                        const uint32_t s0 = d[h] & 0xFFFFu, e1 = s0 + (d[h] >> 16) + 1u;
+                        atomicXor(&img[wphys(s0 >> 5)], 1u << (s0 & 31));
+                        if (e1 < 65536u) atomicXor(&img[wphys(e1 >> 5)], 1u << (e1 & 31));
+                    }
+                }
             }
         }
     }
@@ -403,12 +420,13 @@ __global__ __launch_bounds__(64, 2) void k_genw(const uint8_t* __restrict__ aren
                                              const u64* __restrict__ qrange, const uint32_t* __restrict__ qcount,
                                              int kop, int cardmode, u64* pair_acc,
                                              const GenItem* __restrict__ q2, const uint32_t* __restrict__ q2count) {
-    // ONE 8 KiB image per wave: operand A is rasterised, pulled into registers, then the same image is
-    // reused for operand B and finally as the output staging buffer
-    __shared__ __attribute__((aligned(16))) uint32_t img_all[1][(INLINE_IVL ? 16384 : 8192) / 4];
+    // TWO 8 KiB images per wave (round 3; one image, operand A parked in 32 registers while B was built, until then):
+    // both payloads are fetched together, A and B are rasterised side by side, the result is formed in registers and
+    // image A becomes the output staging buffer.  The long-list interval path uses the same 16 KiB.
+    __shared__ __attribute__((aligned(16))) uint32_t img_all[1][16384 / 4];
     const uint32_t lane = lane_id();
     uint32_t* ia = img_all[0];
-    uint32_t* ib = ia;
+    uint32_t* ib = ia + 2048;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     // items: queue q (its length from the section range, or from a counter), then -- when given -- the re-queued
     // results in q2 (single-stream batches run both in one launch, after every kernel that re-queues)
@@ -430,19 +448,15 @@ __global__ __launch_bounds__(64, 2) void k_genw(const uint8_t* __restrict__ aren
         }
         PH(0);
         wimg_build(ia, arenaA + t.offa, ta, t.ca, t.nra);
-        __builtin_amdgcn_wave_barrier();
         PH(2);
-        uint32_t r[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) r[k] = ia[wown(lane, k)];
-        __builtin_amdgcn_wave_barrier();
         wimg_build(ib, arenaB + t.offb, tb, t.cb, t.nrb);
         __builtin_amdgcn_wave_barrier();
         PH(3);
+        uint32_t r[32];
         uint32_t cnt = 0;
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
-            const uint32_t a = r[k], b = ib[wown(lane, k)];
+            const uint32_t a = ia[wown(lane, k)], b = ib[wown(lane, k)];
             r[k] = op == OP_AND ? (a & b) : op == OP_OR ? (a | b) : op == OP_XOR ? (a ^ b) : (a & ~b);
             cnt += __popc(r[k]);
         }
