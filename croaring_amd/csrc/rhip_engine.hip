@@ -154,6 +154,7 @@ struct rhip_ctx_s {
     std::vector<rhip_pool_t*> many_free;  // retired results of rhip_or_many / rhip_xor_many: their buffers are recycled
     size_t arena_skew = 0;  // result arenas start this many bytes into their allocation (RHIP_ARENA_SKEW)
     size_t arena_round = 0; // RHIP_ARENA_ROUND_MB
+    bool debug_plan = false;  // RHIP_DEBUG_PLAN=1: one line per batch on stderr (bounds, fork / merge decision)
     bool merge_classes = true;  // RHIP_MERGE_CLASSES=0: a small batch launches its class kernels one by one
     uint64_t merge_max_items = 256u << 10;  // ... "small" = at most that many matched container pairs (upper bound)
     int many_pf = 4;  // RHIP_MANY_PF: payload groups per lane k_many_l1 loads ahead (2 / 4 / 8)
@@ -186,6 +187,9 @@ struct rhip_ctx_s {
     // pay for the fork / join (two cross-queue dependencies, 40-50 us, and no overlap between consecutive batches):
     // measured break-even on the realdata sets ~150 MB of result-slot bound (RHIP_FORK_MIN_MB overrides; 0 = always)
     uint64_t fork_min_bytes = 144ull << 20;
+    // ... unless the batch is LIGHT: at most 128 k matched container pairs and a slot bound below this (RHIP_FORK_MIN_MB
+    // sets both: 0 = always fork)
+    uint64_t fork_light_bytes = 320ull << 20;
 };
 
 void rhip_ctx_s::ensure_stage(int slot, size_t n) {
@@ -302,10 +306,12 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_SPIN_WAIT")) c->spin_wait = !(e[0] == '0');
         if (const char* e = getenv("RHIP_EXPLICIT_UNITS")) c->explicit_units = atoi(e);
         if (const char* e = getenv("RHIP_STAGE_KERNEL")) c->stage_kernel = !(e[0] == '0');
-        if (const char* e = getenv("RHIP_FORK_MIN_MB")) c->fork_min_bytes = (uint64_t)atoll(e) << 20;
+        if (const char* e = getenv("RHIP_FORK_MIN_MB")) c->fork_min_bytes = c->fork_light_bytes = (uint64_t)atoll(e) << 20;
         if (const char* e = getenv("RHIP_PLAN_OVERLAP")) c->plan_overlap = !(e[0] == '0');
         if (const char* e = getenv("RHIP_MANY_PF")) c->many_pf = atoi(e);
         if (const char* e = getenv("RHIP_MERGE_CLASSES")) c->merge_classes = !(e[0] == '0');
+        if (const char* e = getenv("RHIP_DEBUG_PLAN")) c->debug_plan = e[0] == '1';
+        if (const char* e = getenv("RHIP_MERGE_MAX_K")) c->merge_max_items = strtoull(e, nullptr, 0) << 10;
         if (const char* e = getenv("RHIP_ARENA_ROUND_MB")) c->arena_round = (size_t)strtoull(e, nullptr, 0) << 20;
         if (const char* e = getenv("RHIP_ARENA_SKEW")) c->arena_skew = (size_t)strtoull(e, nullptr, 0) & ~(size_t)255;
         if (const char* e = getenv("RHIP_MANY_CH")) c->many_ch = std::max(1, std::min(1024, atoi(e)));
@@ -1284,13 +1290,19 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
     const bool has_bba = has_bb && !cardmode && any_and_like;
     const bool has_retry = !cardmode && ((has_bb && any_not_or) || has_runs || (P.may_ba && nm && any_not_or));
     const bool has_ba = P.may_ba && nm && !cardmode;
-    const bool fork = c->overlap && (has_runs || has_filt || has_wave || has_ba) && P.work_bound >= c->fork_min_bytes;
+    // (few items AND a moderate slot bound: the class kernels are short whatever the bytes say -- one merged launch beats
+    // the fork / join: census-income andnot, 73 k container pairs / 223 MB: 0.30 -> 0.27 ms)
+    const bool light = nm <= (128u << 10) && P.work_bound < c->fork_light_bytes;
+    const bool fork = c->overlap && (has_runs || has_filt || has_wave || has_ba) && P.work_bound >= c->fork_min_bytes && !light;
+    if (c->debug_plan)
+        fprintf(stderr, "[rhip plan] ops %d nm %llu work_bound %.1f MB fork %d merge_eligible %d\n", ops.n, (unsigned long long)nm,
+                P.work_bound / 1048576.0, (int)fork, (int)(nm <= c->merge_max_items));
     // A small batch (below the fork threshold) runs its class kernels as ONE launch, block ranges per class
     // (rhip_classes.h): their latency chains side by side instead of one after the other.  k_genw follows on its own.
     // (Only batches with few items: the combined kernel has the registers and LDS of its largest body -- 3 waves per SIMD
     // -- which cost the 847 000 interval pairs of a C5 `and` batch 0.35 -> 0.41 ms, while census1881 `and` went 0.152 ->
     // 0.144 ms.)
-    if (c->merge_classes && c->overlap && !fork && P.work_bound < c->fork_min_bytes && nm <= c->merge_max_items) {
+    if (c->merge_classes && c->overlap && !fork && (P.work_bound < c->fork_min_bytes || light) && nm <= c->merge_max_items) {
         rhip_ctx_s::SlotScratch& SS = c->ss[P.slot];
         ClassLaunch L{};
         L.arenaA = VA.arena; L.arenaB = VB.arena; L.O = O; L.ranges = ranges;
