@@ -46,7 +46,7 @@ __device__ __forceinline__ void probe_body(uint32_t* __restrict__ lds, uint32_t 
     const uint32_t lane = lane_id();
     const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    uint32_t w = (bid * blockDim.x + threadIdx.x) >> 6;
+    uint32_t w = wave_uniform((bid * blockDim.x + threadIdx.x) >> 6);
     FatItem tnext;
     if (w < n) tnext = q[w];
     for (; w < n; w += nwaves) {
@@ -201,7 +201,7 @@ __device__ __forceinline__ void usmall_body(uint32_t* __restrict__ lds, uint32_t
     uint16_t* ST = (uint16_t*)(DEL + DEL_WORDS + GP_WORDS);
     const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    uint32_t w = (bid * blockDim.x + threadIdx.x) >> 6;
+    uint32_t w = wave_uniform((bid * blockDim.x + threadIdx.x) >> 6);
     FatItem tnext;
     if (w < n) tnext = q[w];
     PH_BEGIN();
@@ -359,7 +359,7 @@ __device__ __forceinline__ void filter_body(uint32_t* __restrict__ lds, uint32_t
     uint16_t* ST = STAGED ? (uint16_t*)(lds + 4u * 2048u + (threadIdx.x >> 6) * FILTER_ST_WORDS) : nullptr;  // output window: 7 + 512 values
     const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    uint32_t w = (bid * blockDim.x + threadIdx.x) >> 6;
+    uint32_t w = wave_uniform((bid * blockDim.x + threadIdx.x) >> 6);
     FatItem tnext;
     if (w < n) tnext = q[w];
     PH_BEGIN();
@@ -402,11 +402,13 @@ __device__ __forceinline__ void filter_body(uint32_t* __restrict__ lds, uint32_t
         // per lane and step, the larger part of an andnot batch (most values survive).
         uint4* __restrict__ po4 = cardmode ? nullptr : (uint4*)(O.arena + t.offo);
         uint32_t run = 0, carry = 0;  // run: values already in global memory (a multiple of 8) -- cardinality mode: all
+        uint4 q4 = yfirst;
         for (uint32_t base = 0; base < ny; base += 512) {
             const uint32_t i0 = base + 8 * lane;
-            uint4 q4 = yfirst;
-            if (base) q4 = (i0 < ny) ? y4[(base >> 3) + lane] : make_uint4(0, 0, 0, 0);
+            uint4 nxt = make_uint4(0, 0, 0, 0);  // the next step's 16 bytes: in flight while this step is tested
+            if (i0 + 512 < ny) nxt = y4[(base >> 3) + 64 + lane];
             const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
+            q4 = nxt;
             const uint32_t nval = i0 < ny ? (ny - i0 < 8u ? ny - i0 : 8u) : 0u;  // values this lane holds
             uint32_t vals[8];
             uint32_t keepmask = 0;
@@ -493,7 +495,7 @@ __device__ __forceinline__ void ba_body(uint32_t* __restrict__ lds, uint32_t bid
     uint32_t* img = lds + (threadIdx.x >> 6) * 2048u;
     const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    uint32_t w = (bid * blockDim.x + threadIdx.x) >> 6;
+    uint32_t w = wave_uniform((bid * blockDim.x + threadIdx.x) >> 6);
     FatItem tnext;
     if (w < n) tnext = q[w];
     for (; w < n; w += nwaves) {
@@ -586,7 +588,7 @@ __device__ __forceinline__ void wave_body(uint32_t* __restrict__ lds, uint32_t b
     uint32_t* img = lds + (threadIdx.x >> 6) * 2048u;
     const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    uint32_t w = (bid * blockDim.x + threadIdx.x) >> 6;
+    uint32_t w = wave_uniform((bid * blockDim.x + threadIdx.x) >> 6);
     FatItem tnext;
     if (w < n) tnext = q[w];
     PH_BEGIN();
@@ -623,30 +625,40 @@ __device__ __forceinline__ void wave_body(uint32_t* __restrict__ lds, uint32_t b
         }
         __builtin_amdgcn_wave_barrier();  // X is complete in the image before Y is applied (xor / clear are order-sensitive)
         PH(1);
+        // (one copy of the loop per op, the next 16 bytes of Y loaded while the current ones are applied: written as
+        // `i == lane ? yfirst : y4[i]` with the op tested per value the compiler produced four branch-guarded dword
+        // loads with a full wait each, and three-way branches around every atomic)
         int delta = 0;
-        for (uint32_t i = lane; 8 * i < cy; i += 64) {
-            const uint4 q4 = i == lane ? yfirst : y4[i];
-            const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
-            const uint32_t nval = cy - 8 * i < 8u ? cy - 8 * i : 8u;
-            uint32_t old[8], bit[8];
+        auto apply = [&](auto opc) {
+            constexpr int OPK = decltype(opc)::value;
+            uint4 q4 = yfirst;
+            for (uint32_t i = lane; 8 * i < cy; i += 64) {
+                uint4 nxt = make_uint4(0, 0, 0, 0);
+                if (8 * (i + 64) < cy) nxt = y4[i + 64];
+                const uint32_t d[4] = {q4.x, q4.y, q4.z, q4.w};
+                const uint32_t nval = cy - 8 * i < 8u ? cy - 8 * i : 8u;
+                uint32_t old[8], bit[8];
 #pragma unroll
-            for (int h = 0; h < 8; ++h) {
-                const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
-                bit[h] = ((uint32_t)h < nval) ? (1u << (v & 31)) : 0u;
-                if (op == OP_OR) old[h] = atomicOr(&img[v >> 5], bit[h]);
-                else if (op == OP_XOR) old[h] = atomicXor(&img[v >> 5], bit[h]);
-                else old[h] = atomicAnd(&img[v >> 5], ~bit[h]);
-            }
-#pragma unroll
-            for (int h = 0; h < 8; ++h) {
-                if (bit[h]) {
-                    const bool was = (old[h] & bit[h]) != 0;
-                    if (op == OP_OR) delta += was ? 0 : 1;
-                    else if (op == OP_XOR) delta += was ? -1 : 1;
-                    else delta -= was ? 1 : 0;
+                for (int h = 0; h < 8; ++h) {
+                    const uint32_t v = (d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+                    bit[h] = ((uint32_t)h < nval) ? (1u << (v & 31)) : 0u;
+                    if (OPK == OP_OR) old[h] = atomicOr(&img[v >> 5], bit[h]);
+                    else if (OPK == OP_XOR) old[h] = atomicXor(&img[v >> 5], bit[h]);
+                    else old[h] = atomicAnd(&img[v >> 5], ~bit[h]);
                 }
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    const int was = (old[h] & bit[h]) != 0 ? 1 : 0, has = bit[h] != 0 ? 1 : 0;
+                    if (OPK == OP_OR) delta += has - was;           // (was implies has)
+                    else if (OPK == OP_XOR) delta += has - 2 * was;
+                    else delta -= was;
+                }
+                q4 = nxt;
             }
-        }
+        };
+        if (op == OP_OR) apply(std::integral_constant<int, OP_OR>{});
+        else if (op == OP_XOR) apply(std::integral_constant<int, OP_XOR>{});
+        else apply(std::integral_constant<int, OP_ANDNOT>{});
         PH(2);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) delta += __shfl_xor(delta, o);

@@ -43,7 +43,7 @@ __device__ __forceinline__ void bb_body(uint32_t* __restrict__ lds, uint32_t bid
     const uint32_t lane = lane_id();
     const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    for (uint32_t w = (bid * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
+    for (uint32_t w = wave_uniform((bid * blockDim.x + threadIdx.x) >> 6); w < n; w += nwaves) {
         const BBItem t = q[w];
         const int op = item_op(OP, t.slot);            // (OP_ITEM: the item's own op, wave-uniform)
         const uint32_t slot = t.slot & 0xFFFFu;
@@ -118,7 +118,7 @@ __device__ __forceinline__ void bba_body(uint32_t* __restrict__ lds, uint32_t bi
     uint16_t* st16 = (uint16_t*)(lds + (threadIdx.x >> 6) * 2048u);
     const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    for (uint32_t w = (bid * blockDim.x + threadIdx.x) >> 6; w < n; w += nwaves) {
+    for (uint32_t w = wave_uniform((bid * blockDim.x + threadIdx.x) >> 6); w < n; w += nwaves) {
         const BBItem t = q[w];
         const int op = item_op(OP, t.slot);
         const u32x4* __restrict__ pa = (const u32x4*)(arenaA + t.offa);
@@ -189,7 +189,7 @@ __device__ __forceinline__ void copy_body(uint32_t* __restrict__ lds, uint32_t b
     const uint32_t lane = lane_id(), grp = lane >> 4, gl = lane & 15u;
     const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
-    uint32_t w = (bid * blockDim.x + threadIdx.x) >> 6;
+    uint32_t w = wave_uniform((bid * blockDim.x + threadIdx.x) >> 6);
     CopyItem tn;
     if (4 * w + grp < n) tn = q[4 * w + grp];
     for (; 4 * w < n; w += nwaves) {

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef unsigned long long u64;
 
@@ -217,6 +218,18 @@ __device__ int decide_type(int op, int ta, int tb, uint32_t ca, uint32_t cb, boo
             if (ca <= 32u) return type_eff(rc, rn);                // mixed_andnot.c:277-361
             return ca <= 4096u ? T_ARRAY : type_ba(rc);
     }
+}
+
+// A value every lane of the wave holds alike, TOLD to the compiler (v_readfirstlane): the index of the wave in its launch,
+// above all.  The item a wave works on is then fetched by scalar loads, lives in scalar registers, and every branch on its
+// op / types / sizes is a scalar branch -- without it the compiler treated them as divergent (exec-mask bookkeeping
+// around each one: k_wave was 982 vector + 1229 scalar instructions).
+__device__ __forceinline__ uint32_t wave_uniform(uint32_t v) {
+#ifdef RHIP_EMU
+    return v;
+#else
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#endif
 }
 
 // ------------------------------------------------------------------ sub-wave groups

@@ -433,7 +433,7 @@ __global__ __launch_bounds__(64, 2) void k_genw(const uint8_t* __restrict__ aren
     const uint32_t n1 = qrange ? (uint32_t)(qrange[1] - qrange[0]) : *qcount;
     const uint32_t n = n1 + (q2 ? *q2count : 0u);
     PH_BEGIN();
-    for (uint32_t wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; wi < n; wi += nwaves) {
+    for (uint32_t wi = wave_uniform((blockIdx.x * blockDim.x + threadIdx.x) >> 6); wi < n; wi += nwaves) {
         const GenItem t = wi < n1 ? q[wi] : q2[wi - n1];
         const uint32_t ta = t.types & 0xFFu, tb = (t.types >> 8) & 0xFFu;
         const int op = item_op(kop, t.types);
