@@ -284,7 +284,8 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
         for (u64 i = gid; i < U.n_pairs; i += nthreads) Z.pair_acc[i] = 0;
     if (gid < N_SEC) counts[gid * S + U.n_units] = 0;  // section sentinels
     const Grp<G> gr;
-    const uint32_t u = unit_of_group<G>(U, (uint32_t)(gid >> 6), gr.grp);
+    // (one unit per wave: its index, pair, ranges and op are wave-uniform -- scalar loads, scalar branches)
+    const uint32_t u = G == 64 ? wave_uniform(unit_of_group<G>(U, (uint32_t)(gid >> 6), gr.grp)) : unit_of_group<G>(U, (uint32_t)(gid >> 6), gr.grp);
     if (u >= U.n_units) return;
     const uint32_t lane = gr.gl;
     const UnitId uid = unit_id(U, u);
@@ -408,7 +409,8 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                                               const u64* __restrict__ starts, const uint32_t* __restrict__ match,
                                               CandOut O, EmitQueues Q) {
     const Grp<G> gr;
-    const uint32_t u = unit_of_group<G>(U, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, gr.grp);
+    const uint32_t u = G == 64 ? wave_uniform(unit_of_group<G>(U, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, gr.grp))
+                               : unit_of_group<G>(U, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, gr.grp);
     if (u >= U.n_units) return;
     const uint32_t lane = gr.gl;
     const size_t S = (size_t)U.n_units + 1;
