@@ -193,22 +193,23 @@ class Engine:
             raise RoaringHipError(f"pairwise {op} failed: " + err)
         return Pool(self, h)
 
-    def pairwise_placed(self, op: str, A: "Pool", lhs, B: Optional["Pool"] = None, rhs=None, tries: int = 8,
-                        timing_after: bool = False):
-        """Warm-up helper for a service that recycles ONE large result pool (`reuse=`): run the batch `tries` times,
-        each into a freshly allocated result pool while the earlier ones are still alive, and keep the pool whose
-        kernels ran fastest.  Returns (result pool, [device ms of every try]).
+    def pairwise_placed(self, op: str, A: "Pool", lhs, B: Optional["Pool"] = None, rhs=None, tries: int = 12,
+                        keep: int = 1, timing_after: bool = False):
+        """Warm-up helper for a service that recycles large result pools (`reuse=`): run the batch `tries` times, each
+        into a freshly allocated result pool while the earlier ones are still alive, and keep the `keep` pools whose
+        kernels ran fastest (a result pool serves any op).  Returns (list of `keep` result pools, fastest first,
+        [device ms of every try]).
 
         Why: the time of a streaming kernel over multi-GiB operands depends on which PHYSICAL pages the driver hands
         the result arena -- the same virtual address re-allocated gives the bitset kernel of BASELINE config C2
         4.37-4.45 ms or 4.64-4.71 ms per 250-pair batch, at random and for the life of the allocation, whatever the
         arena's offset, alignment or size rounding (scripts/arena_skew_sweep.py).  Nothing in the address
-        predicts the mode, and consecutive allocations come in streaks of one mode (three or four in a row), so the only
-        handle is to look: eight allocations at start-up, one kept.
+        predicts the mode, and consecutive allocations come in streaks of one mode (eight in a row have been seen), so
+        the only handle is to look: a dozen allocations at start-up, the best kept.
         (Uses the HIP-event timing of the context; leaves it `timing_after`.)"""
         self.set_timing(True)
         cands = []
-        for _ in range(max(1, tries)):
+        for _ in range(max(keep, tries)):
             res = self.pairwise(op, A, lhs, B, rhs)  # (first touch of a fresh arena)
             ms = []
             for _ in range(2):
@@ -216,12 +217,11 @@ class Engine:
                 st = self.last_stats()
                 ms.append(st["ms_bitset_kernel"] if st["ms_bitset_kernel"] > 0 else st["ms_total"])
             cands.append((min(ms), res))
-        best = min(range(len(cands)), key=lambda k: cands[k][0])
-        for k, (_, r) in enumerate(cands):
-            if k != best:
-                r.free()
+        order = sorted(range(len(cands)), key=lambda k: cands[k][0])
+        for k in order[keep:]:
+            cands[k][1].free()
         self.set_timing(timing_after)
-        return cands[best][1], [round(c[0], 4) for c in cands]
+        return [cands[k][1] for k in order[:keep]], [round(c[0], 4) for c in cands]
 
     def pairwise_multi(self, ops: Sequence[str], A: "Pool", lhs, B: Optional["Pool"] = None, rhs=None,
                        reuse: Optional["Pool"] = None) -> "Pool":

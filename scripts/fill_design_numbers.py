@@ -42,11 +42,13 @@ placement holds for the whole launch.  Run down in the second half of round 3 (`
 pool, ONE process, the result arena freed and re-allocated for every row -- the same virtual address gives 4.37-4.45 ms
 or 4.64-4.71 ms at random, whatever the arena's offset into its allocation (256 B ... 1 GiB) and whatever its size is
 rounded to (1 ... 16 GiB).  It is the PHYSICAL pages the driver hands out, nothing the address shows, and consecutive
-allocations come in streaks of one mode.  So the only handle is to look: `Engine.pairwise_placed` runs a batch into
-`tries` freshly allocated result pools and keeps the fastest; `bench.py` does that once per recycled result pool at
-start-up, untimed (`config.result_arena_startup` lists the `k_bb` time of every try; `--arena-tries 0` takes the first
-allocation).  With 8 tries three consecutive bench runs gave 0.712 / 0.714 / 0.715 of peak; with 4, two of three stayed
-in the slow mode for `and` (0.687).  Cardinality mode: the events of the call's own slot are read now; round 2's
+allocations come in streaks of one mode (eight slow ones in a row have been seen).  So the only handle is to look:
+`Engine.pairwise_placed` runs a batch into `tries` freshly allocated result pools, all kept alive until the end, and
+keeps the fastest `keep` of them (a result pool serves any op); `bench.py` does that once at start-up, untimed, for the
+two result pools its steps recycle (`config.result_arena_startup` lists the `k_bb` time of every try; `--arena-tries 0`
+takes the first allocations).  Twelve candidates, the best two kept: four consecutive bench runs gave 0.713 / 0.717 /
+0.718 / 0.722 of peak; with eight tries per op, separately, one run of four still had eight slow `and` arenas in a row
+(0.692).  Cardinality mode: the events of the call's own slot are read now; round 2's
 table repeated a stale pair.)
 
 **Realdata, ALL unordered pairs in one batched call per op** (`bench.py` secondary block: wall time of the whole call

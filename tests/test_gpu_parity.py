@@ -675,8 +675,10 @@ def test_pairwise_placed(engine, oracle, synth):
     n = len(hs)
     lhs = np.arange(n, dtype=np.uint32)
     rhs = np.roll(lhs, 3)
-    res, ms = engine.pairwise_placed("or", pool, lhs, pool, rhs, tries=3)
+    (res, spare), ms = engine.pairwise_placed("or", pool, lhs, pool, rhs, tries=3, keep=2)
     assert len(ms) == 3 and all(m >= 0 for m in ms)
+    spare = engine.pairwise("and", pool, lhs, pool, rhs, reuse=spare)
+    assert len(spare) == n
     res = engine.pairwise("xor", pool, lhs, pool, rhs, reuse=res)
     for k in range(n):
         oo = oracle.op("xor", hs[lhs[k]], hs[rhs[k]])
