@@ -128,6 +128,7 @@ struct rhip_ctx_s {
     bool stage_kernel = true;  // small descriptions are pulled by k_stage_in (RHIP_STAGE_KERNEL=0: always a copy command)
     size_t h_stage_cap[N_SLOTS + 1] = {};
     bool slot_busy[N_SLOTS] = {};
+    bool bb_timed[N_SLOTS + 1] = {};  // the slot's k_bb events were recorded by its current call (not in a merged launch)
     // device scratch of a pairwise batch (planning arrays, candidate directory, class queues, scan / tail words): one
     // set per slot, so that the planning kernels of a batch can run while the class kernels of the previous one do
     struct SlotScratch {
@@ -1392,7 +1393,7 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
     }
     if (has_bb) {
         unsigned grid = persistent_grid(nm, 4, 256 * 32);
-        if (c->timing) HIPCHK(hipEventRecord(c->evs[P.slot][2], s));
+        if (c->timing) { HIPCHK(hipEventRecord(c->evs[P.slot][2], s)); c->bb_timed[P.slot] = true; }
         switch (op) {
             case OP_ITEM: launch_bb<OP_ITEM>(c, grid, VA, VB, O, P, cardmode); break;
             case OP_AND: launch_bb<OP_AND>(c, grid, VA, VB, O, P, cardmode); break;
@@ -1504,7 +1505,11 @@ void finish_stats(rhip_ctx_t* c, const Stats* dstats, Stats* out, bool had_bb, u
     if (c->timing) {
         if (wait_seq) HIPCHK(hipEventSynchronize(ev[1]));  // the completion word can be seen before the event signals
         (void)hipEventElapsedTime(&c->stats.ms_total, ev[0], ev[1]);
-        if (had_bb && st.n_bb) (void)hipEventElapsedTime(&c->stats.ms_bitset_kernel, ev[2], ev[3]);
+        // (k_bb inside a merged k_classes launch has no events of its own: elapsed time of events never recorded is an
+        // error that would surface at the next call's hipGetLastError)
+        const int tslot = wait_seq ? slot : rhip_ctx_s::SYNC_SLOT;
+        if (had_bb && st.n_bb && c->bb_timed[tslot]) (void)hipEventElapsedTime(&c->stats.ms_bitset_kernel, ev[2], ev[3]);
+        c->bb_timed[tslot] = false;
     }
 }
 }  // namespace
