@@ -437,8 +437,8 @@ __global__ __launch_bounds__(64, 2) void k_genw(const uint8_t* __restrict__ aren
         const GenItem t = wi < n1 ? q[wi] : q2[wi - n1];
         const uint32_t ta = t.types & 0xFFu, tb = (t.types >> 8) & 0xFFu;
         const int op = item_op(kop, t.types);
-        // the long interval lists of the general queue: the interval path (here or in k_ivl_long); a result that has to be
-        // a bitset comes back through the image path (here: right away; there: re-queued)
+        // the long interval lists of the general queue: the interval path; a result that has to be a bitset comes back
+        // through the image path right away
         if (qrange && wi < n1 && gen_item_is_interval(t, op, cardmode)) {
             if (!INLINE_IVL) continue;  // (not reached: the retry pass has no section range)
             const Grp<64> gr;
