@@ -224,13 +224,7 @@ __device__ int decide_type(int op, int ta, int tb, uint32_t ca, uint32_t cb, boo
 // above all.  The item a wave works on is then fetched by scalar loads, lives in scalar registers, and every branch on its
 // op / types / sizes is a scalar branch -- without it the compiler treated them as divergent (exec-mask bookkeeping
 // around each one: k_wave was 982 vector + 1229 scalar instructions).
-__device__ __forceinline__ uint32_t wave_uniform(uint32_t v) {
-#ifdef RHIP_EMU
-    return v;
-#else
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-#endif
-}
+__device__ __forceinline__ uint32_t wave_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // ------------------------------------------------------------------ sub-wave groups
 // G consecutive lanes (G = 16, 32 or 64) that work on one item: the group's view of the wave collectives.  The wave

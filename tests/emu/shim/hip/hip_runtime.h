@@ -208,6 +208,8 @@ static inline unsigned mbcnt(unsigned mask, unsigned add, int hi) {
 #define __builtin_amdgcn_wave_barrier() ((void)hipemu::wave_sync(-1, 0))
 #define __builtin_amdgcn_mbcnt_lo(m, a) hipemu::mbcnt((m), (a), 0)
 #define __builtin_amdgcn_mbcnt_hi(m, a) hipemu::mbcnt((m), (a), 1)
+// (only ever applied to values the whole wave shares: the emulated lanes each keep their own copy)
+#define __builtin_amdgcn_readfirstlane(x) (x)
 
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
