@@ -210,7 +210,12 @@ class Engine:
         self.set_timing(True)
         cands = []
         for _ in range(max(keep, tries)):
-            res = self.pairwise(op, A, lhs, B, rhs)  # (first touch of a fresh arena)
+            try:
+                res = self.pairwise(op, A, lhs, B, rhs)  # (first touch of a fresh arena)
+            except RoaringHipError:
+                if len(cands) >= keep:  # (out of device memory for another candidate: choose among those there are)
+                    break
+                raise
             ms = []
             for _ in range(2):
                 res = self.pairwise(op, A, lhs, B, rhs, reuse=res)
