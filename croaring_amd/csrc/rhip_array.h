@@ -284,7 +284,7 @@ __device__ __forceinline__ void usmall_body(uint32_t* __restrict__ lds, uint32_t
             const uint32_t excl = inc - packed;
             uint32_t newc = run_new + (excl & 0xFFFFu), delc = run_del + (excl >> 16);
             if (op == OP_XOR && act) GP[g] = (uint16_t)delc;
-            const uint32_t tot = __shfl(inc, 63);
+            const uint32_t tot = wave_lane<63>(inc);
             run_new += tot & 0xFFFFu;
             run_del += tot >> 16;
             const uint32_t nval = act ? (nx - 8u * g < 8u ? nx - 8u * g : 8u) : 0u;
@@ -422,7 +422,7 @@ __device__ __forceinline__ void filter_body(uint32_t* __restrict__ lds, uint32_t
             keepmask &= (1u << nval) - 1u;
             const uint32_t cnt = __popc(keepmask);
             const uint32_t inc = wave_incl_scan(cnt);
-            const uint32_t tot = __shfl(inc, 63);
+            const uint32_t tot = wave_lane<63>(inc);
             if (cardmode) {
                 run += tot;
                 continue;
@@ -571,6 +571,68 @@ __global__ __launch_bounds__(256) void k_ba(const uint8_t* __restrict__ arenaA, 
 }
 
 
+// Sorted array out of a wave-private 8 KiB image holding rc <= 4096 set bits (the image is destroyed: it becomes the staging
+// buffer), written to outp with coalesced 16-byte stores.  Shared by k_wave and the grouped union kernel (rhip_grouped.h).
+__device__ __forceinline__ void wave_extract_array(uint32_t* __restrict__ img, uint32_t lane, uint32_t rc, uint8_t* __restrict__ outp) {
+    // Balanced extraction.  Words are owned strided (lane l: words 64 r + l), so clustered values
+    // spread over all lanes; the output position of each word comes from a two-level prefix:
+    // per-word popcounts -> LDS, each lane prefix-sums 32 CONSECUTIVE counts, one wave scan of the
+    // lane totals, word bases back to LDS and from there into registers.  The image is dead once the
+    // words are in registers: first its lower half holds the u16 count/base table, then all of it is the
+    // staging buffer the sorted values are compacted into (rc <= 4096 values = 8 KiB).
+    uint32_t wv[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) wv[r] = img[64 * r + lane];
+    __builtin_amdgcn_wave_barrier();
+    uint16_t* tab = (uint16_t*)img;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) tab[64 * r + lane] = (uint16_t)__popc(wv[r]);
+    __builtin_amdgcn_wave_barrier();
+    {
+        uint4 c4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c4[i] = ((const uint4*)tab)[4 * lane + i];
+        const uint32_t cw[16] = {c4[0].x, c4[0].y, c4[0].z, c4[0].w, c4[1].x, c4[1].y, c4[1].z, c4[1].w,
+                                 c4[2].x, c4[2].y, c4[2].z, c4[2].w, c4[3].x, c4[3].y, c4[3].z, c4[3].w};
+        uint32_t tot = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot += (cw[i] & 0xFFFFu) + (cw[i] >> 16);
+        uint32_t base = wave_incl_scan(tot) - tot;
+        uint32_t ow[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t lo = base;
+            base += cw[i] & 0xFFFFu;
+            const uint32_t hi = base;
+            base += cw[i] >> 16;
+            ow[i] = lo | (hi << 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            ((uint4*)tab)[4 * lane + i] = make_uint4(ow[4 * i], ow[4 * i + 1], ow[4 * i + 2], ow[4 * i + 3]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint16_t pos16[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) pos16[r] = tab[64 * r + lane];
+    __builtin_amdgcn_wave_barrier();  // every base is in registers: the table may be overwritten
+    uint16_t* st16 = (uint16_t*)img;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        uint32_t x = wv[r];
+        uint32_t pos = pos16[r];
+        const uint32_t vbase = (64u * r + lane) * 32u;
+        while (x) {
+            st16[pos++] = (uint16_t)(vbase + (__ffs((int)x) - 1));
+            x &= x - 1;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t n16 = (2u * rc + 15u) >> 4;
+    uint4* __restrict__ po = (uint4*)outp;
+    for (uint32_t i = lane; i < n16; i += 64) po[i] = ((const uint4*)img)[i];
+}
+
 // ------------------------------------------------------------------ wave-private LDS image kernel (K6, K10, K11)
 // One WAVE per container pair for {array,bitset} x {array,bitset} pairs with at least one array under
 // or / xor, and bitset \ array.  The wave owns an 8 KiB LDS image: X is loaded into it (bitset: 8
@@ -676,64 +738,7 @@ __device__ __forceinline__ void wave_body(uint32_t* __restrict__ lds, uint32_t b
 #pragma unroll
             for (int i = 0; i < 8; ++i) po[i * 64 + lane] = xv[i];
         } else if (rc) {
-            // Balanced extraction.  Words are owned strided (lane l: words 64 r + l), so clustered values
-            // spread over all lanes; the output position of each word comes from a two-level prefix:
-            // per-word popcounts -> LDS, each lane prefix-sums 32 CONSECUTIVE counts, one wave scan of the
-            // lane totals, word bases back to LDS and from there into registers.  The image is dead once the
-            // words are in registers: first its lower half holds the u16 count/base table, then all of it is the
-            // staging buffer the sorted values are compacted into (rc <= 4096 values = 8 KiB).
-            uint32_t wv[32];
-#pragma unroll
-            for (int r = 0; r < 32; ++r) wv[r] = img[64 * r + lane];
-            __builtin_amdgcn_wave_barrier();
-            uint16_t* tab = (uint16_t*)img;
-#pragma unroll
-            for (int r = 0; r < 32; ++r) tab[64 * r + lane] = (uint16_t)__popc(wv[r]);
-            __builtin_amdgcn_wave_barrier();
-            {
-                uint4 c4[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) c4[i] = ((const uint4*)tab)[4 * lane + i];
-                const uint32_t cw[16] = {c4[0].x, c4[0].y, c4[0].z, c4[0].w, c4[1].x, c4[1].y, c4[1].z, c4[1].w,
-                                         c4[2].x, c4[2].y, c4[2].z, c4[2].w, c4[3].x, c4[3].y, c4[3].z, c4[3].w};
-                uint32_t tot = 0;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) tot += (cw[i] & 0xFFFFu) + (cw[i] >> 16);
-                uint32_t base = wave_incl_scan(tot) - tot;
-                uint32_t ow[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const uint32_t lo = base;
-                    base += cw[i] & 0xFFFFu;
-                    const uint32_t hi = base;
-                    base += cw[i] >> 16;
-                    ow[i] = lo | (hi << 16);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    ((uint4*)tab)[4 * lane + i] = make_uint4(ow[4 * i], ow[4 * i + 1], ow[4 * i + 2], ow[4 * i + 3]);
-            }
-            __builtin_amdgcn_wave_barrier();
-            PH(4);
-            uint16_t pos16[32];
-#pragma unroll
-            for (int r = 0; r < 32; ++r) pos16[r] = tab[64 * r + lane];
-            __builtin_amdgcn_wave_barrier();  // every base is in registers: the table may be overwritten
-            uint16_t* st16 = (uint16_t*)img;
-#pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                uint32_t x = wv[r];
-                uint32_t pos = pos16[r];
-                const uint32_t vbase = (64u * r + lane) * 32u;
-                while (x) {
-                    st16[pos++] = (uint16_t)(vbase + (__ffs((int)x) - 1));
-                    x &= x - 1;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t n16 = (2u * rc + 15u) >> 4;
-            uint4* __restrict__ po = (uint4*)outp;
-            for (uint32_t i = lane; i < n16; i += 64) po[i] = ((const uint4*)img)[i];
+            wave_extract_array(img, lane, rc, outp);
         }
         PH(5);
         if (lane == 0) O.meta[t.out] = pack_meta(ty, rc, 0);

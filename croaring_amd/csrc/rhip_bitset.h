@@ -150,7 +150,7 @@ __device__ __forceinline__ void bba_body(uint32_t* __restrict__ lds, uint32_t bi
             for (int i = 0; i < 8; ++i) {
                 const uint32_t inc = wave_incl_scan(cnt[i]);
                 uint32_t pos = run + inc - cnt[i];
-                run += __shfl(inc, 63);
+                run += wave_lane<63>(inc);
                 const uint32_t wd[4] = {va[i].x, va[i].y, va[i].z, va[i].w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {

@@ -112,22 +112,36 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t mbcnt(u64 m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+// Cross-lane moves by DPP (data-parallel primitives: the operand of a VALU instruction is read from another lane of the
+// same 16-lane row, or broadcast from the last lane of the previous row) instead of ds_bpermute: no LDS-crossbar round
+// trip (~100 cycles, an address computation and a full wait per step of a scan), one instruction per step.  Round 4:
+// every step loop of the array kernels ends in a wave prefix sum, and those kernels are bound by instruction issue and
+// by exactly such dependent chains.
+//   0x110 + n  row_shr:n    lane i of a row reads lane i - n of the same row (invalid below the row: 0 with bound_ctrl)
+//   0x142      row_bcast:15 lane 15 of a row to every lane of the next row   (row_mask 0xA: rows 1 and 3 take it)
+//   0x143      row_bcast:31 lane 31 to every lane of rows 2 and 3            (row_mask 0xC)
+// Lanes whose row is masked out, or whose source is invalid without bound_ctrl, get `old` = 0.
+template <int CTRL, int ROW_MASK, bool BOUND_CTRL>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, BOUND_CTRL);
 }
+// value of lane `l` (a constant) for the whole wave: one v_readlane, the result is wave-uniform (a scalar register)
+template <int L>
+__device__ __forceinline__ uint32_t wave_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, L); }
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v);
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return wave_lane<63>(wave_incl_scan(v)); }
 __device__ __forceinline__ u64 wave_sum64(u64 v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(v, o);
-        if (lane_id() >= (uint32_t)o) v += t;
-    }
+    v += dpp0<0x111, 0xF, true>(v);   // within rows of 16: Hillis-Steele, zeros shifted in
+    v += dpp0<0x112, 0xF, true>(v);
+    v += dpp0<0x114, 0xF, true>(v);
+    v += dpp0<0x118, 0xF, true>(v);
+    v += dpp0<0x142, 0xA, false>(v);  // rows 1, 3 += total of rows 0, 2
+    v += dpp0<0x143, 0xC, false>(v);  // rows 2, 3 += total of rows 0 + 1
     return v;
 }
 
@@ -220,6 +234,45 @@ __device__ int decide_type(int op, int ta, int tb, uint32_t ca, uint32_t cb, boo
     }
 }
 
+// ------------------------------------------------------------------ which operand is the MEMBERSHIP / image side
+// The image kernels treat their operands asymmetrically: X is rasterised (8 KiB image: LDS for the filter, registers for
+// the union kernels), Y is streamed against it.  One definition, used by the planning kernels (X-grouped queues, below)
+// and by every kernel that builds an image, so that they always agree.
+//   filter (and / cardinality): Y = the array, the SMALLER one of two arrays; andnot: Y = a (the array), X = b
+//   union  (or / xor): X = the bitset, else the larger array; bitset \ array: X = a
+__device__ __forceinline__ bool filt_y_is_a(int op, uint32_t ta, uint32_t tb, uint32_t ca, uint32_t cb) {
+    if (op != OP_AND) return true;
+    return (ta == T_ARRAY) && (tb != T_ARRAY || ca <= cb);
+}
+__device__ __forceinline__ bool union_x_is_a(int op, uint32_t ta, uint32_t tb, uint32_t ca, uint32_t cb) {
+    if (op == OP_ANDNOT) return true;
+    return (ta == T_BITSET) || (tb != T_BITSET && ca >= cb);
+}
+// X-grouped queues (round 4).  In a batch where a container meets MANY partners (all pairs of a pool: ~85 per container
+// on weather_sept_85) the image kernels used to rasterise the same X once per item -- 55-62 % of their time.  When the
+// host expects that much reuse, the items of the filter class and of the union classes (two-array image pairs, bitset
+// (op) array) are not queued in pair order but COUNTING-SORTED by their X container: k_count adds every such item to a
+// histogram over (group, X container), the batch's one prefix scan runs over the histogram as well, k_emit claims a
+// slot inside the item's bucket with an atomic decrement (which also returns the histogram to zero for the next
+// batch), and the grouped kernels (rhip_grouped.h) walk runs of items with the same X, building its image once.
+// Results do not depend on the order inside a bucket: every item carries its own result slot.
+struct XGroupView {
+    uint32_t* hist;       // [2 * nx + 1] item counts per (group, X container); zero outside k_count .. k_emit
+    const u64* hstart;    // exclusive scan of hist (same indexing)
+    uint32_t nx;          // X containers per group: n_cont(A) + n_cont(B), or n_cont(A) when both operands are ONE pool
+    uint32_t na;          // n_cont(A): index of B's first container inside a group (0 when both are one pool)
+    uint32_t on;
+};
+enum { XG_FILT = 0, XG_UNION = 1 };
+__device__ __forceinline__ uint32_t xg_index(const XGroupView& X, int grp, bool x_in_a, u64 ia, u64 ib) {
+    return (uint32_t)grp * X.nx + (x_in_a ? (uint32_t)ia : X.na + (uint32_t)ib);
+}
+// items of a grouped queue one wave walks in a row (the reuse it can see), given the queue length and the launch
+__device__ __forceinline__ uint32_t xg_chunk(uint32_t n, uint32_t nwaves, uint32_t cmin) {
+    const uint32_t c = (n + nwaves - 1) / nwaves;
+    return c < cmin ? cmin : c;
+}
+
 // A value every lane of the wave holds alike, TOLD to the compiler (v_readfirstlane): the index of the wave in its launch,
 // above all.  The item a wave works on is then fetched by scalar loads, lives in scalar registers, and every branch on its
 // op / types / sizes is a scalar branch -- without it the compiler treated them as divergent (exec-mask bookkeeping
@@ -245,11 +298,13 @@ struct Grp {
     }
     __device__ __forceinline__ uint32_t incl_scan(uint32_t v) const {
         if (G == 64) return wave_incl_scan(v);
-#pragma unroll
-        for (uint32_t o = 1; o < G; o <<= 1) {
-            const uint32_t t = __shfl_up(v, o);
-            if (gl >= o) v += t;
-        }
+        // (DPP rows are 16 lanes: a 16-lane group is a row, a 32-lane group two rows + one broadcast; an 8-lane group
+        // shares its row with another group, so its steps are masked by the lane's position in the group)
+        { const uint32_t t = dpp0<0x111, 0xF, true>(v); v += (G >= 16 || gl >= 1u) ? t : 0u; }
+        { const uint32_t t = dpp0<0x112, 0xF, true>(v); v += (G >= 16 || gl >= 2u) ? t : 0u; }
+        { const uint32_t t = dpp0<0x114, 0xF, true>(v); v += (G >= 16 || gl >= 4u) ? t : 0u; }
+        if (G >= 16) v += dpp0<0x118, 0xF, true>(v);
+        if (G >= 32) v += dpp0<0x142, 0xA, false>(v);
         return v;
     }
     __device__ __forceinline__ uint32_t sum(uint32_t v) const {

@@ -58,8 +58,10 @@ struct DBuf {
     void* base = nullptr;  // the allocation; p = base + skew
     size_t skew = 0;       // set before the first ensure(): see rhip_ctx_s::arena_skew
     size_t round_to = 0;   // allocations at least this large are rounded up to a multiple of it
+    uint64_t gen = 0;      // bumped by every (re)allocation: "is this still the memory I initialised?"
     void ensure(size_t n) {
         if (n <= cap) return;
+        ++gen;
         if (base) (void)hipFree(base);
         p = base = nullptr;
         cap = 0;
@@ -133,6 +135,11 @@ struct rhip_ctx_s {
     // set per slot, so that the planning kernels of a batch can run while the class kernels of the previous one do
     struct SlotScratch {
         DBuf plan_in, match, cand, cand_start, o_key, o_meta, o_off, o_pair, q[N_CLS], misc;
+        // X-group histogram of the slot's last grouped batch (inside `cand`): zero between batches -- k_emit's decrements
+        // undo k_count's increments -- so it is only cleared when it moves or grows
+        void* hist_at = nullptr;
+        size_t hist_n = 0;
+        uint64_t hist_gen = 0;
         void release() {
             DBuf* all[] = {&plan_in, &match, &cand, &cand_start, &o_key, &o_meta, &o_off, &o_pair, &misc};
             for (auto* b : all) b->release();
@@ -158,6 +165,12 @@ struct rhip_ctx_s {
     bool debug_plan = false;  // RHIP_DEBUG_PLAN=1: one line per batch on stderr (bounds, fork / merge decision)
     bool merge_classes = true;  // RHIP_MERGE_CLASSES=0: a small batch launches its class kernels one by one
     uint64_t merge_max_items = 256u << 10;  // ... "small" = at most that many matched container pairs (upper bound)
+    // X-grouped image queues (rhip_common.h XGroupView): 0 never, 1 when the batch promises enough reuse (at least
+    // group_min_reuse matched container pairs -- upper bound -- per container of the operand pools), 2 always (tests)
+    int group_x = 1;             // RHIP_GROUP_X
+    uint64_t group_min_reuse = 4;
+    uint64_t group_min_items = 16u << 10;
+    uint32_t group_chunk = 8;    // RHIP_XG_CHUNK: items a wave of the grouped kernels walks in a row, at least
     int many_pf = 4;  // RHIP_MANY_PF: payload groups per lane k_many_l1 loads ahead (2 / 4 / 8)
     int many_ch = 0;  // RHIP_MANY_CH: members per unit (tests of the multi-chunk / multi-unit paths on small inputs); 0 = by size
     static constexpr size_t PINNED_MANY_FLAG_OFF = 2304, PINNED_MANY_TOT_OFF = 2560, PINNED_MANY_ERR_OFF = 2816;
@@ -315,6 +328,8 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_MERGE_MAX_K")) c->merge_max_items = strtoull(e, nullptr, 0) << 10;
         if (const char* e = getenv("RHIP_ARENA_ROUND_MB")) c->arena_round = (size_t)strtoull(e, nullptr, 0) << 20;
         if (const char* e = getenv("RHIP_ARENA_SKEW")) c->arena_skew = (size_t)strtoull(e, nullptr, 0) & ~(size_t)255;
+        if (const char* e = getenv("RHIP_GROUP_X")) c->group_x = atoi(e);
+        if (const char* e = getenv("RHIP_XG_CHUNK")) c->group_chunk = (uint32_t)std::max(1, atoi(e));
         if (const char* e = getenv("RHIP_MANY_CH")) c->many_ch = std::max(1, std::min(1024, atoi(e)));
         memset(c->h_pinned, 0, 4096);
         {
@@ -993,7 +1008,7 @@ struct PlanScratch {
         w = (w + 15) & ~(size_t)15;
         w_tickets = w; w += 2 * 16;
         w_retry = w; w += 16;
-        w_ranges = w; w += (2 * N_SEC + 15) & ~15;
+        w_ranges = w; w += (2 * N_SEC + 3 + 15) & ~15;  // (+ 3: the group boundaries of a grouped batch)
         n_words = w;
     }
 };
@@ -1006,6 +1021,8 @@ struct Plan {
     int slot = 0;
     hipStream_t plan_stream = nullptr;
     bool may_bb = true, may_filt = true, may_wave = true, may_runs = true, may_copy = true, may_ba = true;
+    bool grouped = false;  // the filter / union items are queued by X container (k_filter_g / k_union_g)
+    const u64* xranges() const { return words + sc.w_ranges + 2 * N_SEC; }
     // device pointers
     uint32_t *d_lhs = nullptr, *d_rhs = nullptr, *d_upair = nullptr, *d_utile = nullptr;
     u64* d_pair0 = nullptr;
@@ -1177,12 +1194,29 @@ Plan plan(rhip_ctx_t* c, const OpSet& ops, rhip_pool_t* A, rhip_pool_t* B, size_
             P.may_copy = true;
         }
     }
+    // ---- X-grouped queues: when a container is expected to meet many partners (an all-pairs batch) and the batch has
+    // image-class work at all.  ub_match is an upper bound, so the estimate errs towards grouping; a batch that groups
+    // without reuse pays one atomic per item in k_count / k_emit and nothing else.
+    const bool same_pool = A == B;
+    const uint64_t nxc = same_pool ? A->n_cont : A->n_cont + B->n_cont;
+    P.grouped = c->group_x == 2 ? (P.may_filt || P.may_wave || P.may_ba) && nxc > 0 && nxc < 0x3FFFFFF0ull
+                                : c->group_x == 1 && (P.may_filt || P.may_wave || P.may_ba) && nxc > 0 && nxc < 0x3FFFFFF0ull &&
+                                      ub_match >= c->group_min_items && ub_match >= c->group_min_reuse * nxc;
+    const size_t n_hist = P.grouped ? 2 * (size_t)nxc + 1 : 0;
     // ---- device scratch
     const size_t S = P.S;
-    P.sc.layout(N_SEC * S, P.ub_cand);
+    P.sc.layout(N_SEC * S + n_hist, P.ub_cand);
     SS.plan_in.ensure(stage_bytes + 16);
-    SS.cand.ensure(4 * (N_SEC * S + 8));
-    SS.cand_start.ensure(8 * (N_SEC * S + 8));
+    SS.cand.ensure(4 * (N_SEC * S + n_hist + 8));
+    SS.cand_start.ensure(8 * (N_SEC * S + n_hist + 8));
+    XGroupView XG{nullptr, nullptr, 0, 0, 0};
+    if (P.grouped) {
+        uint32_t* hist = SS.cand.as<uint32_t>() + N_SEC * S;
+        XG = XGroupView{hist, SS.cand_start.as<u64>() + N_SEC * S, (uint32_t)nxc, same_pool ? 0u : (uint32_t)A->n_cont, 1u};
+        if (SS.hist_at != (void*)hist || SS.hist_n != n_hist || SS.hist_gen != SS.cand.gen)  // (else: still zero)
+            HIPCHK(hipMemsetAsync(hist, 0, 4 * n_hist, s));
+    }
+    SS.hist_at = nullptr;  // until this batch's k_emit is enqueued the area is not known to come back to zero
     SS.misc.ensure(8 * P.sc.n_words + 64);
     P.words = SS.misc.as<u64>();
     SS.q[CLS_BB].ensure(sizeof(BBItem) * (ub_match + 1));
@@ -1233,7 +1267,7 @@ Plan plan(rhip_ctx_t* c, const OpSet& ops, rhip_pool_t* A, rhip_pool_t* B, size_
     SS.match.ensure(4 * (size_t)(4 * G) * (NU + 1));  // one word per directory entry of a unit (<= 4 G of them)
     const size_t plan_waves = G == 64 ? NU : (NU + 64 / G - 1) / (64 / G) + 1;
     unsigned gp = (unsigned)std::max<size_t>(1, (std::max<size_t>(plan_waves * 64, std::min<size_t>(zero_threads, 1 << 16)) + 255) / 256);
-    const u64 n_scan = (u64)N_SEC * S;
+    const u64 n_scan = (u64)N_SEC * S + n_hist;
     EmitQueues Q{SS.q[CLS_BB].as<BBItem>(), SS.q[CLS_GEN].as<GenItem>(), SS.q[CLS_COPY].as<CopyItem>(),
                  SS.q[CLS_FILT].as<FatItem>(), SS.q[CLS_WAVE].as<FatItem>(), SS.q[CLS_RUNS].as<GenItem>(),
                  SS.q[CLS_PROBE].as<FatItem>(), SS.q[CLS_BBA].as<BBItem>(), SS.q[CLS_USMALL].as<FatItem>(),
@@ -1242,12 +1276,14 @@ Plan plan(rhip_ctx_t* c, const OpSet& ops, rhip_pool_t* A, rhip_pool_t* B, size_
     auto count = G == 16 ? k_count<16> : G == 32 ? k_count<32> : k_count<64>;
     auto emit = G == 16 ? k_emit<16> : G == 32 ? k_emit<32> : k_emit<64>;
     hipLaunchKernelGGL(count, dim3(gp), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, cardmode,
-                       SS.cand.as<uint32_t>(), SS.match.as<uint32_t>(), Z);
+                       SS.cand.as<uint32_t>(), SS.match.as<uint32_t>(), Z, XG);
     hipLaunchKernelGGL(k_scan, dim3((unsigned)((n_scan + SCAN_TILE - 1) / SCAN_TILE)), dim3(256), 0, s,
-                       SS.cand.as<uint32_t>(), SS.cand_start.as<u64>(), n_scan, P.scan_lb(), P.ranges(), (u64)S);
+                       SS.cand.as<uint32_t>(), SS.cand_start.as<u64>(), n_scan, P.scan_lb(), P.ranges(), (u64)S, (u64)N_SEC,
+                       (u64)XG.nx);
     if (NU)
         hipLaunchKernelGGL(emit, dim3(ge), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, cardmode,
-                           SS.cand_start.as<u64>(), SS.match.as<uint32_t>(), P.CO, Q);
+                           SS.cand_start.as<u64>(), SS.match.as<uint32_t>(), P.CO, Q, XG);
+    if (P.grouped) { SS.hist_at = XG.hist; SS.hist_n = n_hist; SS.hist_gen = SS.cand.gen; }
     if (clk) clk->lap(2);
     return P;
 }
@@ -1289,21 +1325,22 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
     const bool has_bb = P.may_bb && nm, has_runs = P.may_runs && nm, has_filt = P.may_filt && nm;
     const bool has_wave = P.may_wave && nm && !cardmode, has_copy = P.may_copy && P.ub_cand && !cardmode;
     const bool has_bba = has_bb && !cardmode && any_and_like;
-    const bool has_retry = !cardmode && ((has_bb && any_not_or) || has_runs || (P.may_ba && nm && any_not_or));
+    // (a grouped batch types its bitset (op) array results itself: k_union_g re-queues nothing)
+    const bool has_retry = !cardmode && ((has_bb && any_not_or) || has_runs || (P.may_ba && nm && any_not_or && !P.grouped));
     const bool has_ba = P.may_ba && nm && !cardmode;
     // (few items AND a moderate slot bound: the class kernels are short whatever the bytes say -- one merged launch beats
     // the fork / join: census-income andnot, 73 k container pairs / 223 MB: 0.30 -> 0.27 ms)
     const bool light = nm <= (128u << 10) && P.work_bound < c->fork_light_bytes;
     const bool fork = c->overlap && (has_runs || has_filt || has_wave || has_ba) && P.work_bound >= c->fork_min_bytes && !light;
     if (c->debug_plan)
-        fprintf(stderr, "[rhip plan] ops %d nm %llu work_bound %.1f MB fork %d merge_eligible %d\n", ops.n, (unsigned long long)nm,
-                P.work_bound / 1048576.0, (int)fork, (int)(nm <= c->merge_max_items));
+        fprintf(stderr, "[rhip plan] ops %d nm %llu work_bound %.1f MB fork %d merge_eligible %d grouped %d\n", ops.n, (unsigned long long)nm,
+                P.work_bound / 1048576.0, (int)fork, (int)(nm <= c->merge_max_items), (int)P.grouped);
     // A small batch (below the fork threshold) runs its class kernels as ONE launch, block ranges per class
     // (rhip_classes.h): their latency chains side by side instead of one after the other.  k_genw follows on its own.
     // (Only batches with few items: the combined kernel has the registers and LDS of its largest body -- 3 waves per SIMD
     // -- which cost the 847 000 interval pairs of a C5 `and` batch 0.35 -> 0.41 ms, while census1881 `and` went 0.152 ->
     // 0.144 ms.)
-    if (c->merge_classes && c->overlap && !fork && (P.work_bound < c->fork_min_bytes || light) && nm <= c->merge_max_items) {
+    if (c->merge_classes && c->overlap && !fork && !P.grouped && (P.work_bound < c->fork_min_bytes || light) && nm <= c->merge_max_items) {
         rhip_ctx_s::SlotScratch& SS = c->ss[P.slot];
         ClassLaunch L{};
         L.arenaA = VA.arena; L.arenaB = VB.arena; L.O = O; L.ranges = ranges;
@@ -1372,14 +1409,28 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
                            cardmode, c->pair_acc.as<u64>(), (const GenItem*)nullptr, (const uint32_t*)nullptr);
     };
     if (multi && has_runs && !genw_merged) launch_genw_general(on(1));
-    if (has_filt)
+    // grouped batch: the filter and the union items sit in ONE queue (the filter class's buffer), sorted by X container;
+    // a wave walks >= 8 items in a row, so the grids are an eighth of the wave-per-item ones (and at most two rounds of
+    // the machine's 5 120 resident image waves)
+    const FatItem* xq = c->ss[P.slot].q[CLS_FILT].as<FatItem>();
+    const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>((nm + 4 * c->group_chunk - 1) / (4 * c->group_chunk), 1), 2560u * 8u / c->group_chunk);
+    if (has_filt && P.grouped)
+        hipLaunchKernelGGL((op == OP_AND || cardmode) ? k_filter_g<false> : k_filter_g<true>, dim3(gx), dim3(256), 0, on(1), VA.arena,
+                           VB.arena, O, xq, P.xranges(), op, cardmode, c->pair_acc.as<u64>(), c->group_chunk);
+    else if (has_filt)
         hipLaunchKernelGGL((op == OP_AND || cardmode) ? k_filter<false> : k_filter<true>, dim3(bounded_grid(nm)), dim3(256), 0, on(1), VA.arena, VB.arena, O,
                            c->ss[P.slot].q[CLS_FILT].as<FatItem>(), ranges + 2 * SEC_FILT, op, cardmode, c->pair_acc.as<u64>());
-    if (has_wave)
+    if ((has_wave || has_ba) && P.grouped) {
+        hipStream_t su = on(2);
+        if (multi) hipLaunchKernelGGL(k_union_g<OP_ITEM>, dim3(gx), dim3(256), 0, su, VA.arena, VB.arena, O, xq, P.xranges(), c->group_chunk);
+        else if (op == OP_OR) hipLaunchKernelGGL(k_union_g<OP_OR>, dim3(gx), dim3(256), 0, su, VA.arena, VB.arena, O, xq, P.xranges(), c->group_chunk);
+        else if (op == OP_XOR) hipLaunchKernelGGL(k_union_g<OP_XOR>, dim3(gx), dim3(256), 0, su, VA.arena, VB.arena, O, xq, P.xranges(), c->group_chunk);
+        else hipLaunchKernelGGL(k_union_g<OP_ANDNOT>, dim3(gx), dim3(256), 0, su, VA.arena, VB.arena, O, xq, P.xranges(), c->group_chunk);
+    } else if (has_wave)
         hipLaunchKernelGGL(k_wave, dim3(bounded_grid(nm)), dim3(256), 0, on(2), VA.arena, VB.arena, O,
                            c->ss[P.slot].q[CLS_WAVE].as<FatItem>(), ranges + 2 * SEC_WAVE, op);
     if (!multi && has_runs && !genw_merged) launch_genw_general(on(!has_filt ? 1 : !has_wave ? 2 : 1));
-    if (has_ba) {  // bitset (op) array, behind the few general items of its stream: andnot has no k_wave items, so that
+    if (has_ba && !P.grouped) {  // bitset (op) array, behind the few general items of its stream: andnot has no k_wave items, so that
                    // stream is free; or / xor: the filter's stream
         hipStream_t sb = on(multi ? 0 : (op == OP_ANDNOT ? 2 : 1));  // (multi-op: behind the interval kernel)
         const FatItem* qb = c->ss[P.slot].q[CLS_BA].as<FatItem>();
@@ -1409,7 +1460,7 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
         // arrays (card <= 4096), interval results that must become bitsets
         hipStream_t sr = has_runs ? on(0) : s;
         if (fork && has_runs && has_bb) HIPCHK(hipStreamWaitEvent(sr, c->ev_runs, 0));
-        if (fork && has_ba && op != OP_OR) HIPCHK(hipStreamWaitEvent(sr, c->ev_ba, 0));  // k_ba re-queues its rare array results
+        if (fork && has_ba && !P.grouped && op != OP_OR) HIPCHK(hipStreamWaitEvent(sr, c->ev_ba, 0));  // k_ba re-queues its rare array results
         rhip_ctx_s::SlotScratch& SS = c->ss[P.slot];
         if (genw_merged)  // one stream: the general class and the re-queued results in one launch, after their producers
             hipLaunchKernelGGL(k_genw<true>, dim3(4 * bounded_grid(nm, 512)), dim3(64), 0, sr, VA.arena, VB.arena, O,
@@ -1522,6 +1573,7 @@ struct rhip_batch_s {
     int slot;
     bool may_bb;
     const u64* ranges;  // the batch's section ranges (device)
+    bool grouped;       // its filter / union items are in the X-grouped queue
 };
 
 // Everything of a pairwise call up to and including the launch of k_tail: nothing here waits for the device.
@@ -1594,7 +1646,7 @@ static rhip_batch_t* pairwise_begin_ops(rhip_ctx_t* c, size_t n_ops, const rhip_
         if (c->timing) HIPCHK(hipEventRecord(c->evs[slot][1], s));
         HIPCHK(hipGetLastError());  // a refused launch anywhere above must not pass silently
         clk.lap(3);
-        rhip_batch_t* b = new rhip_batch_s{c, R, A, B, seq, slot, P.may_bb, P.ranges()};
+        rhip_batch_t* b = new rhip_batch_s{c, R, A, B, seq, slot, P.may_bb, P.ranges(), P.grouped};
         c->slot_busy[slot] = true;
         R->pending = true;
         ++A->in_use;
@@ -1649,7 +1701,7 @@ extern "C" rhip_pool_t* rhip_pairwise_end(rhip_batch_t* b) {
                            SS.q[CLS_COPY].as<CopyItem>()};
             c->misc.ensure(8 * 3 * N_CLS + 64);
             hipLaunchKernelGGL(k_class_stats, dim3(N_CLS), dim3(256), 0, c->stream, (const u64*)b->ranges, CQ,
-                               (const u64*)SS.o_meta.as<u64>(), c->misc.as<u64>());
+                               (const u64*)SS.o_meta.as<u64>(), c->misc.as<u64>(), b->grouped ? 1 : 0);
             HIPCHK(hipMemcpyAsync(c->cls_stats, c->misc.p, 8 * 3 * N_CLS, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
         }

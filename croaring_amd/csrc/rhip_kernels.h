@@ -20,6 +20,8 @@
 //   k_usmall           K10/K11 for a short operand (<= 255 values): rank merge into the long array
 //   k_wave             K6/K10/K11: or / xor / bitset \ array with an array operand, wave-private LDS image +
 //                      returning LDS atomics, wave per pair
+//   k_filter_g / k_union_g   the same algebra for an X-GROUPED batch (rhip_grouped.h): the queue is counting-sorted by the
+//                      image-side container, a wave rebuilds its image only when that container changes
 //   k_ivl<G, MAXIV>    K13/K14/K16: interval algebra by merge path on boundary lists; four pairs per wave (G = 16) up
 //                      to 31 / 127 intervals a side, one pair per wave (G = 64) up to 255
 //   k_genw             K5/K7/K15 + the rest: run x bitset, long run/array pairs, bitset x bitset results that become
@@ -33,6 +35,7 @@
 #include "rhip_plan.h"
 #include "rhip_bitset.h"
 #include "rhip_array.h"
+#include "rhip_grouped.h"
 #include "rhip_runs.h"
 #include "rhip_classes.h"
 #include "rhip_block.h"

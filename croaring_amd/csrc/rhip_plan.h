@@ -87,8 +87,10 @@ constexpr uint32_t SCAN_TILE = 2048;  // elements per block: 256 threads x 8
 // out[i] = sum_{j<i} in[j], i in [0, n).  `ranges` (may be null): for every section k of `sec_len` elements,
 // ranges[2k] = out[k * sec_len] and ranges[2k+1] = out[k * sec_len + sec_len - 1] (begin / end of the section when its
 // last element is a zero sentinel).
+// Elements behind the n_sec sections (the X-group histogram of a grouped batch, rhip_common.h): every xlen-th of them
+// marks a group boundary, ranges[2 n_sec + k] = out[n_sec * sec_len + k * xlen].
 __global__ __launch_bounds__(256) void k_scan(const uint32_t* __restrict__ in, u64* __restrict__ out, u64 n, LbState lb,
-                                              u64* __restrict__ ranges, u64 sec_len) {
+                                              u64* __restrict__ ranges, u64 sec_len, u64 n_sec, u64 xlen) {
     __shared__ u64 sm[4];
     __shared__ uint32_t s_tile;
     __shared__ u64 s_prefix;
@@ -117,8 +119,13 @@ __global__ __launch_bounds__(256) void k_scan(const uint32_t* __restrict__ in, u
             out[i] = ex;
             if (ranges) {
                 const u64 sec = i / sec_len, r = i - sec * sec_len;
-                if (r == 0) ranges[2 * sec] = ex;
-                if (r == sec_len - 1) ranges[2 * sec + 1] = ex;
+                if (sec < n_sec) {
+                    if (r == 0) ranges[2 * sec] = ex;
+                    if (r == sec_len - 1) ranges[2 * sec + 1] = ex;
+                } else if (xlen) {
+                    const u64 x = i - n_sec * sec_len;
+                    if (x % xlen == 0) ranges[2 * n_sec + x / xlen] = ex;
+                }
             }
         }
         ex += v[k];
@@ -275,7 +282,8 @@ __device__ __forceinline__ uint32_t unit_of_group(const UnitView& U, uint32_t w,
 template <uint32_t G>
 __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uint32_t* __restrict__ lhs,
                                                const uint32_t* __restrict__ rhs, UnitView U, int cardmode,
-                                               uint32_t* __restrict__ counts, uint32_t* __restrict__ match, PlanZero Z) {
+                                               uint32_t* __restrict__ counts, uint32_t* __restrict__ match, PlanZero Z,
+                                               XGroupView X) {
     const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 nthreads = (u64)gridDim.x * blockDim.x;
     const size_t S = (size_t)U.n_units + 1;
@@ -333,6 +341,10 @@ __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uin
                 bytes += payload_bytes(tl, cl, nl);
                 cls = classify(op, cardmode, ts, tl, ts == T_RUN ? ns : cs, tl == T_RUN ? nl : cl, cs, cl);
                 if (!cardmode) slot16 += matched_slot(op, cs, cl) >> 4;
+                if (X.on && (cls == CLS_FILT || cls == CLS_WAVE || cls == CLS_BA)) {  // grouped queues: one more item for its X
+                    const bool x_in_a = cls == CLS_FILT ? !filt_y_is_a(op, ts, tl, cs, cl) : union_x_is_a(op, ts, tl, cs, cl);
+                    atomicAdd(&X.hist[xg_index(X, cls == CLS_FILT ? XG_FILT : XG_UNION, x_in_a, si, j[t])], 1u);
+                }
             } else if (!cardmode) {
                 const uint32_t sl = align16(ps) >> 4;
                 slot16 += sl ? sl : 1u;
@@ -407,7 +419,7 @@ template <uint32_t G>
 __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint32_t* __restrict__ lhs,
                                               const uint32_t* __restrict__ rhs, UnitView U, int cardmode,
                                               const u64* __restrict__ starts, const uint32_t* __restrict__ match,
-                                              CandOut O, EmitQueues Q) {
+                                              CandOut O, EmitQueues Q, XGroupView X) {
     const Grp<G> gr;
     const uint32_t u = G == 64 ? wave_uniform(unit_of_group<G>(U, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, gr.grp))
                                : unit_of_group<G>(U, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, gr.grp);
@@ -524,7 +536,14 @@ __global__ __launch_bounds__(256) void k_emit(PoolView A, PoolView B, const uint
                 it.offa = A.off[ai]; it.offb = B.off[bj]; it.offo = offo;
                 it.out = outidx; it.ca = ca; it.cb = cb; it.types = (uint32_t)ta | ((uint32_t)tb << 8) | opbits;
                 it.pad0 = 0; it.pad1 = 0;
-                if (isfilt) Q.filt[qfilt + gr.rank(mfl)] = it;
+                if (X.on && (isfilt || iswave || isba)) {
+                    // grouped queue (Q.filt's buffer): a slot inside the bucket of the item's X container; the decrement
+                    // hands out count-1 .. 0 and leaves the histogram zero for the next batch
+                    const bool x_in_a = isfilt ? !filt_y_is_a(op, ta, tb, ca, cb) : union_x_is_a(op, ta, tb, ca, cb);
+                    const uint32_t xi = xg_index(X, isfilt ? XG_FILT : XG_UNION, x_in_a, ai, bj);
+                    const uint32_t k = atomicSub(&X.hist[xi], 1u) - 1u;
+                    Q.filt[X.hstart[xi] - X.hstart[0] + k] = it;
+                } else if (isfilt) Q.filt[qfilt + gr.rank(mfl)] = it;
                 else if (iswave) Q.wave[qwave + gr.rank(mwv)] = it;
                 else if (isprobe) Q.probe[qprobe + gr.rank(mpr)] = it;
                 else if (isba) Q.ba[qba + gr.rank(mbar)] = it;
@@ -769,15 +788,30 @@ struct ClassQueues {
 __device__ __forceinline__ uint32_t meta_payload(u64 m) {
     return meta_card(m) ? payload_bytes((uint8_t)meta_type(m), meta_card(m), meta_nruns(m)) : 0u;
 }
+// grouped != 0: the filter class's buffer holds the X-grouped queue -- the filter items first, then the union items
+// (two-array image pairs = k_wave's class, bitset (op) array = k_ba's), told apart by their types.
 __global__ __launch_bounds__(256) void k_class_stats(const u64* __restrict__ ranges, ClassQueues Q,
-                                                     const u64* __restrict__ meta, u64* __restrict__ out) {
-    __shared__ u64 sb[4][2];
+                                                     const u64* __restrict__ meta, u64* __restrict__ out, int grouped) {
+    __shared__ u64 sb[4][3];
     const int secs[N_CLS] = {SEC_BB, SEC_GEN, SEC_COPY, -1, SEC_FILT, SEC_WAVE, SEC_RUNS, SEC_PROBE, SEC_BBA, SEC_USMALL,
                              SEC_RUNS16, SEC_RUNS16W, SEC_BA};
     const int cls = blockIdx.x;
     const int sec = secs[cls];
-    u64 n = 0, bin = 0, bout = 0;
-    if (sec >= 0) {
+    u64 n = 0, bin = 0, bout = 0, nx = 0;
+    const bool xcls = grouped && (cls == CLS_FILT || cls == CLS_WAVE || cls == CLS_BA);
+    if (xcls) {
+        const u64* xr = ranges + 2 * N_SEC;
+        const u64 lo = cls == CLS_FILT ? 0 : xr[1] - xr[0], hi = (cls == CLS_FILT ? xr[1] : xr[2]) - xr[0];
+        for (u64 i = lo + threadIdx.x; i < hi; i += 256) {
+            const FatItem& t = Q.fat[0][i];
+            const bool a_bitset = (t.types & 0xFF) == T_BITSET || ((t.types >> 8) & 0xFF) == T_BITSET;
+            if (cls == CLS_WAVE && a_bitset) continue;
+            if (cls == CLS_BA && !a_bitset) continue;
+            ++nx;
+            bin += payload_bytes((uint8_t)(t.types & 0xFF), t.ca, 0) + payload_bytes((uint8_t)(t.types >> 8), t.cb, 0);
+            bout += meta_payload(meta[t.out]);
+        }
+    } else if (sec >= 0) {
         n = ranges[2 * sec + 1] - ranges[2 * sec];
         for (u64 i = threadIdx.x; i < n; i += 256) {
             uint32_t o = 0;
@@ -799,10 +833,11 @@ __global__ __launch_bounds__(256) void k_class_stats(const u64* __restrict__ ran
             bout += meta_payload(meta[o]);
         }
     }
-    bin = wave_sum64(bin); bout = wave_sum64(bout);
-    if (lane_id() == 0) { sb[threadIdx.x >> 6][0] = bin; sb[threadIdx.x >> 6][1] = bout; }
+    bin = wave_sum64(bin); bout = wave_sum64(bout); nx = wave_sum64(nx);
+    if (lane_id() == 0) { sb[threadIdx.x >> 6][0] = bin; sb[threadIdx.x >> 6][1] = bout; sb[threadIdx.x >> 6][2] = nx; }
     __syncthreads();
     if (threadIdx.x == 0) {
+        if (xcls) n = sb[0][2] + sb[1][2] + sb[2][2] + sb[3][2];
         out[3 * cls] = n;
         out[3 * cls + 1] = sb[0][0] + sb[1][0] + sb[2][0] + sb[3][0];
         out[3 * cls + 2] = sb[0][1] + sb[1][1] + sb[2][1] + sb[3][1];

@@ -16,6 +16,7 @@ Outputs (committed; the GPU box cannot see /root/reference):
                                     tests/testdata/* (format_portability_unit.c:51-90).
   tests/golden/c5_wikileaks64_pairs.npz  BASELINE config C5: roaring64, wikileaks-noquotes x 10 high-32 buckets -- all pairs x
                                     4 ops (cardinality, portable size, crc32) + the 200-way union (serialized).
+  tests/golden/c4x10_or_many.npz    the C4 generator at 10^6 bitmaps (opt-in: `gen_golden.py c4x10`): cardinality / size / crc32
   tests/golden/c4_or_many.npz       BASELINE config C4: roaring_bitmap_or_many over the 100 000 seeded sparse bitmaps
                                     (cardinality, size, crc32 of the reference's result; crc32 of the inputs).
   tests/golden/synth_mixed.npz      crc32/size/cardinality of the reference's results on seeded synthetic
@@ -212,6 +213,38 @@ def c4_golden(R, n_bitmaps=100000):
         R.free(h)
 
 
+def c4x10_golden(R, n_bitmaps=1000000, chunk=50000):
+    """The C4 generator at 10 x the size (10^6 bitmaps, 16.6 GB of portable images): the row of the bench where the
+    many-way reduction is large enough for N GPUs to split it.  The reference's answer, chunk by chunk:
+    roaring_bitmap_or_many over `chunk` bitmaps at a time, the partial unions folded with roaring_bitmap_or (set-equal
+    to one or_many over all of them).  Stored: cardinality, container count and crc32 of the serialized result."""
+    import croaring_amd
+    acc = None
+    for first in range(0, n_bitmaps, chunk):
+        cnt = min(chunk, n_bitmaps - first)
+        blob, offs = croaring_amd.synth_sparse_portable(first, 1, cnt)
+        mv = memoryview(blob)
+        hs = [R.deserialize(bytes(mv[int(offs[b]):int(offs[b + 1])])) for b in range(cnt)]
+        part = R.or_many(hs)
+        for h in hs:
+            R.free(h)
+        if acc is None:
+            acc = part
+        else:
+            nxt = R.op("or", acc, part)
+            R.free(acc)
+            R.free(part)
+            acc = nxt
+        print(f"  c4x10: {first + cnt} bitmaps, card {R.cardinality(acc)}", flush=True)
+    R.run_optimize(acc)
+    s = R.serialize(acc)
+    out = {"n_bitmaps": np.array([n_bitmaps], np.uint64),
+           "or_many": np.array([R.cardinality(acc), len(s), zlib.crc32(s)], np.uint64)}
+    np.savez_compressed(os.path.join(GOLD, "c4x10_or_many.npz"), **out)
+    print("  c4x10 or_many:", out["or_many"])
+    R.free(acc)
+
+
 def main():
     R = Ref()
     os.makedirs(GOLD, exist_ok=True)
@@ -226,7 +259,9 @@ def main():
         c5_golden(R)
     if "c4" in names:
         c4_golden(R)
-    for name in [n for n in names if n not in ("synth", "c4", "c5")]:
+    if "c4x10" in names:  # (not in the default list: 10^6 bitmaps, a few minutes)
+        c4x10_golden(R)
+    for name in [n for n in names if n not in ("synth", "c4", "c5", "c4x10")]:
         print(name)
         hs = load_text_dataset(R, name)
         write_bundle(os.path.join(GOLD, f"{name}.rbnd.xz"), [R.serialize(h) for h in hs])

@@ -172,6 +172,29 @@ static inline T shfl_xor(int site, T v, unsigned m) {
     const unsigned s = (lane ^ m) & 63;
     return ((b.present >> s) & 1) ? unpack<T>(b.vals[s]) : v;
 }
+// v_mov_b32 with a DPP control (__builtin_amdgcn_update_dpp): the controls the kernels use -- row_shr:n (0x110 + n),
+// row_bcast:15 (0x142), row_bcast:31 (0x143) -- with row_mask, bound_ctrl and `old` as the ISA defines them (a lane whose
+// row is masked out, or whose source lane is invalid or absent without bound_ctrl, keeps `old`; with bound_ctrl it reads 0)
+static inline int update_dpp(int site, int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    const unsigned lane = cur->lane;
+    const WaveBuf& b = wave_sync(site, pack(src));
+    const unsigned row = lane >> 4, rl = lane & 15u;
+    if (!((row_mask >> row) & 1) || !((bank_mask >> (rl >> 2)) & 1)) return old;
+    int from = -1;
+    if (ctrl >= 0x111 && ctrl <= 0x11F) {
+        const unsigned n = (unsigned)ctrl - 0x110u;
+        if (rl >= n) from = (int)(lane - n);
+    } else if (ctrl == 0x142) {
+        if (row >= 1) from = (int)(16u * row - 1u);
+    } else if (ctrl == 0x143) {
+        if (row >= 2) from = 31;
+    } else {
+        fprintf(stderr, "hipemu: DPP control 0x%x not modelled (site %d)\n", ctrl, site);
+        abort();
+    }
+    if (from < 0 || !((b.present >> from) & 1)) return bound_ctrl ? 0 : old;
+    return unpack<int>(b.vals[from]);
+}
 static inline uint64_t ballot(int site, int pred) {
     const WaveBuf& b = wave_sync(site, pred ? 1 : 0);
     uint64_t m = 0;
@@ -205,6 +228,8 @@ static inline unsigned mbcnt(unsigned mask, unsigned add, int hi) {
 #define __shfl_down(v, d, ...) hipemu::shfl_down(HIPEMU_SITE, (v), (d))
 #define __shfl_xor(v, m, ...) hipemu::shfl_xor(HIPEMU_SITE, (v), (m))
 #define __ballot(p) hipemu::ballot(HIPEMU_SITE, (p))
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu::update_dpp(HIPEMU_SITE + (ctrl), (old), (src), (ctrl), (rm), (bm), (bc))
+#define __builtin_amdgcn_readlane(v, l) hipemu::shfl(HIPEMU_SITE, (v), (l))
 #define __builtin_amdgcn_wave_barrier() ((void)hipemu::wave_sync(-1, 0))
 #define __builtin_amdgcn_mbcnt_lo(m, a) hipemu::mbcnt((m), (a), 0)
 #define __builtin_amdgcn_mbcnt_hi(m, a) hipemu::mbcnt((m), (a), 1)
@@ -221,6 +246,8 @@ static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned lo
 // one OS thread executes everything, so the "atomics" are plain read-modify-writes
 template <class T, class U>
 static inline T atomicAdd(T* p, U v) { T o = *p; *p = (T)(o + (T)v); return o; }
+template <class T, class U>
+static inline T atomicSub(T* p, U v) { T o = *p; *p = (T)(o - (T)v); return o; }
 template <class T, class U>
 static inline T atomicOr(T* p, U v) { T o = *p; *p = (T)(o | (T)v); return o; }
 template <class T, class U>

@@ -6,6 +6,9 @@
   one fixed-shape all_to_all_single), or and xor, checked against the oracle's or_many / xor_many over ALL bitmaps.
 * test_sharded_or_many_exchange_gloo: the exchange alone with the oracle standing in for both stages (kept: it
   isolates a routing bug from a kernel bug).
+* test_sharded_many64_gloo: the same end-to-end path on ROARING64 pools (48-bit container keys, owner = key mod
+  world, sparse exchange): seeded random 64-bit bitmaps and a slice of BASELINE config C5 (wikileaks-noquotes x 10
+  high-32 buckets), checked against the oracle's roaring64 or / xor folds.
 The same composed path runs on a real MI355X in tests/test_gpu_distributed.py."""
 import os
 import socket
@@ -198,4 +201,85 @@ def test_exchange_dense_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+
+
+def _rand64(rng, random_bitmap):
+    highs = rng.choice(6, int(rng.integers(0, 4)), replace=False)
+    parts = [(np.uint64(int(h) * 7 + 1) << np.uint64(32)) | random_bitmap(rng, max_keys=4, key_space=6).astype(np.uint64)
+             for h in highs]
+    return np.sort(np.concatenate(parts)) if parts else np.zeros(0, np.uint64)
+
+
+def _many64_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from croaring_amd.distributed import gather_serialized, many_sharded, shard_ids
+        from emu import emu_engine
+        from gen_inputs import random_bitmap
+        from oracle.pyoracle import Oracle
+        from util import c5_inputs, load_bundle
+        oracle = Oracle()
+        eng = emu_engine()
+        rng = np.random.default_rng(6464)  # same stream on every rank: identical global input set
+        sets = {"rand64": [oracle.serialize64(oracle.from_sorted64(_rand64(rng, random_bitmap))) for _ in range(19)],
+                "c5_slice": c5_inputs(load_bundle("wikileaks-noquotes")[:24])}
+        ok = []
+        for name, bufs in sets.items():
+            hs_all = [oracle.deserialize64(b) for b in bufs]
+            mine = [int(i) for i in shard_ids(len(bufs), rank, world)]
+            pool = eng.pool_from_serialized64([bufs[i] for i in mine])
+            assert pool.is64
+            want_or = oracle.or_many64(hs_all)
+            want_xor = oracle.deserialize64(bufs[0])
+            for h in hs_all[1:]:
+                nx = oracle.op64("xor", want_xor, h)
+                oracle.free64(want_xor)
+                want_xor = nx
+            for op, want in (("or", want_or), ("xor", want_xor)):
+                owned = many_sharded(eng, pool, op)  # 48-bit keys: the sparse exchange
+                # every container key this rank ends up with is one it owns
+                vals, _ = owned.to_values()
+                ok.append(owned.is64 and bool(np.all(((vals >> np.uint64(16)) % np.uint64(world)) == np.uint64(rank))))
+                blob = gather_serialized(eng, owned)
+                if rank == 0:
+                    hg = oracle.deserialize64(blob)
+                    x = oracle.op64("xor", hg, want)
+                    ok.append(oracle.cardinality64(x) == 0 and oracle.cardinality64(hg) == oracle.cardinality64(want))
+                    oracle.free64(x)
+                    oracle.free64(hg)
+            try:
+                many_sharded(eng, pool, "or", key_space=4096)  # 48-bit keys do not fit a dense table: refused
+                ok.append(pool.max_key() < 4096)
+            except ValueError:
+                ok.append(True)
+        q.put((rank, all(ok), len(ok)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_many64_gloo():
+    """BASELINE configs[4] / SURVEY §8e "64-bit: identical, owner = key mod G": roaring64 pools sharded over two ranks,
+    the real stage-1 / stage-3 entry points through the kernel emulator."""
+    from emu import build_emu
+    if not os.path.exists(build_emu.CXX):
+        pytest.skip("hipemu needs the ROCm clang++")
+    build_emu.build()
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_many64_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] for r in res), res

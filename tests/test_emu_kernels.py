@@ -283,3 +283,22 @@ def test_emu_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
 
 def test_emu_batches_in_flight(emu, oracle, synth):
     G.test_batches_in_flight(emu, oracle, synth)
+
+
+@pytest.mark.parametrize("mode", ["group", "groupfork"])
+def test_emu_grouped_queues(oracle, synth, monkeypatch, mode):
+    """The X-grouped image queues (k_count histogram -> scan -> k_emit bucket slots -> k_filter_g / k_union_g), forced
+    on the small inputs with RHIP_GROUP_X=2; plus a sample of weather_sept_85 pairs against the reference fixture."""
+    from emu import build_emu, emu_engine
+    if not __import__("os").path.exists(build_emu.CXX):
+        pytest.skip("hipemu needs the ROCm clang++ to compile the kernels for the host")
+    monkeypatch.setenv("RHIP_GROUP_X", "2")
+    if mode == "groupfork":
+        monkeypatch.setenv("RHIP_FORK_MIN_MB", "0")
+    eng = emu_engine()
+    try:
+        G.grouped_body(eng, oracle, synth)
+        if mode == "group":
+            test_emu_realdata_pair_sample(eng, "weather_sept_85")
+    finally:
+        eng.close()

@@ -60,6 +60,46 @@ def test_c5_roaring64_union_200(engine, oracle, c5):
         oracle.free64(h)
 
 
+
+def test_c5_roaring64_union_sharded_8(engine, oracle, c5):
+    """BASELINE configs[4] "8 GPU aggregation" on 8 LOGICAL shards of one device ("64-bit: identical",
+    owner = key mod G on the 48-bit container keys): bitmaps b mod 8 -> partial chunks (rhip_many_partials on a
+    roaring64 pool) -> every chunk to the owner of its key -> rhip_many_finalize(is64).  The owners' results have
+    disjoint keys; their union is set-equal to the reference's 200-way fold (Roaring64Map::fastunion /
+    roaring64_bitmap_or_inplace, cpp/roaring/roaring64map.hh:1549-1670, src/roaring64.c:1541-1593), and the
+    cardinalities add up to the fixture's."""
+    import torch
+    from croaring_amd.distributed import _DevArray, shard_ids
+    pool, gold, _ = c5
+    G = 8
+    parts = [engine.many_partials("or", pool, shard_ids(len(pool), s, G)) for s in range(G)]
+    engine.synchronize()
+    K = torch.cat([torch.as_tensor(_DevArray(p.d_keys, (p.n_keys,)), device="cuda") for p in parts])
+    W = torch.cat([torch.as_tensor(_DevArray(p.d_words, (p.n_keys, 1024)), device="cuda") for p in parts])
+    assert int(K.max()) >= 1 << 16, "C5 keys must exercise the high-32 part of the 48-bit key"
+    card, owned = 0, []
+    for owner in range(G):
+        sel = (K % G) == owner
+        k, w = K[sel].contiguous(), W[sel].contiguous()
+        torch.cuda.synchronize()
+        res = engine.many_finalize("or", True, k.numel(), k.data_ptr(), w.data_ptr())
+        assert res.is64
+        vals, _ = res.to_values()
+        assert np.all(((vals >> np.uint64(16)) % np.uint64(G)) == np.uint64(owner)), "an owner holds a key it does not own"
+        card += int(res.cardinalities()[0])
+        owned.append(res.serialize(0))
+    assert card == int(gold["fold_or_card"][0])
+    whole = engine.or_many(engine.pool_from_serialized64(owned))  # disjoint keys: a pass-through union
+    hg = oracle.deserialize64(whole.serialize(0))
+    hw = oracle.deserialize64(bytes(gold["fold_or"]))
+    x = oracle.op64("xor", hg, hw)
+    assert oracle.cardinality64(x) == 0
+    for h in (hg, hw, x):
+        oracle.free64(h)
+    for p in parts:
+        p.free()
+
+
 # ------------------------------------------------------------------ C4
 @pytest.fixture(scope="module")
 def c4(engine):

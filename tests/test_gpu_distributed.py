@@ -79,6 +79,64 @@ def test_many_sharded_two_ranks_one_gpu():
     assert all(r[1] for r in res), res
 
 
+def _worker64(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import croaring_amd
+        from croaring_amd.distributed import gather_serialized, many_sharded, shard_ids
+        from oracle.pyoracle import Oracle
+        from util import GOLD, c5_inputs
+        oracle = Oracle()
+        eng = croaring_amd.Engine(0)
+        gold = np.load(os.path.join(GOLD, "c5_wikileaks64_pairs.npz"))
+        bufs = c5_inputs()
+        mine = [int(i) for i in shard_ids(len(bufs), rank, world)]
+        pool = eng.pool_from_serialized64([bufs[i] for i in mine])
+        owned = many_sharded(eng, pool, "or")  # 48-bit keys: sparse exchange
+        vals, _ = owned.to_values()
+        ok = [owned.is64, bool(np.all(((vals >> np.uint64(16)) % np.uint64(world)) == np.uint64(rank)))]
+        card = torch.tensor([int(owned.cardinalities()[0])], dtype=torch.int64)
+        dist.all_reduce(card)
+        ok.append(int(card.item()) == int(gold["fold_or_card"][0]))
+        blob = gather_serialized(eng, owned)
+        if rank == 0:
+            hg = oracle.deserialize64(blob)
+            hw = oracle.deserialize64(bytes(gold["fold_or"]))
+            x = oracle.op64("xor", hg, hw)
+            ok.append(oracle.cardinality64(x) == 0)
+        q.put((rank, all(ok), len(ok)))
+        dist.barrier()
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_many_sharded64_two_ranks_one_gpu():
+    """BASELINE configs[4]: the C5 200-way roaring64 union sharded b mod 2 over two ranks (two processes on the one
+    GPU, gloo, chunks staged through host), against the reference's fold fixture (tests/golden/c5_wikileaks64_pairs.npz)."""
+    import torch.multiprocessing as mp
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker64, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] for r in res), res
+
+
 def test_many_sharded_nccl_world1_dense(engine, oracle):
     """The dense (fixed-shape all_to_all_single) and sparse exchange on the RCCL backend with a 1-rank group,
     issued on the engine's stream with no host synchronisation between the stages."""

@@ -762,6 +762,52 @@ def test_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
         eng.close()
 
 
+def grouped_body(eng, oracle, synth):
+    """Everything with an image-class item, through the X-grouped queues (k_filter_g / k_union_g)."""
+    test_edge_cases(eng, oracle)
+    for op in OPS:
+        test_synth_every_type_pair(eng, oracle, synth, op)
+    test_pairwise_multi(eng, oracle, synth)
+    test_array_filter_probe_boundaries(eng, oracle)
+    test_array_array_union_boundaries(eng, oracle)
+    test_class_stats(eng, oracle, synth)
+    test_batches_in_flight(eng, oracle, synth)
+    # both operands from DIFFERENT pools (the X index space then has an A part and a B part)
+    bufs, _, _ = synth
+    n = len(bufs)
+    pa, pb = eng.pool_from_serialized(bufs[: n // 2 + 3]), eng.pool_from_serialized(bufs[n // 3:])
+    hs = [oracle.deserialize(b) for b in bufs]
+    rng = np.random.default_rng(77)
+    lhs = rng.integers(0, len(pa), 400).astype(np.uint32)
+    rhs = rng.integers(0, len(pb), 400).astype(np.uint32)
+    for op in OPS:
+        res = eng.pairwise(op, pa, lhs, pb, rhs)
+        cards = eng.pairwise_cardinality(op, pa, lhs, pb, rhs)
+        for k in range(len(lhs)):
+            want = oracle.op(op, hs[lhs[k]], hs[n // 3 + rhs[k]])
+            assert res.serialize(k) == oracle.serialize(want), (op, k)
+            assert cards[k] == oracle.cardinality(want), (op, k)
+            oracle.free(want)
+    for h in hs:
+        oracle.free(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["group", "groupfork"])
+def test_grouped_queues(oracle, synth, monkeypatch, mode):
+    """RHIP_GROUP_X=2 forces the X-grouped image queues (round 4; picked by themselves for all-pairs batches, where a
+    container meets many partners) on the small inputs, unforked and forked."""
+    import croaring_amd
+    monkeypatch.setenv("RHIP_GROUP_X", "2")
+    if mode == "groupfork":
+        monkeypatch.setenv("RHIP_FORK_MIN_MB", "0")
+    eng = croaring_amd.Engine()
+    try:
+        grouped_body(eng, oracle, synth)
+    finally:
+        eng.close()
+
+
 @pytest.mark.gpu
 def test_batches_in_flight(engine, oracle, synth):
     """rhip_pairwise_begin / _end: four batches of different ops and pair lists in flight at once, ended out of order,
