@@ -180,48 +180,71 @@ __global__ __launch_bounds__(256) void k_bba(const uint8_t* __restrict__ arenaA,
 
 
 // ------------------------------------------------------------------ pass-through copy
-// The item says where from, where to, how much -- no directory loads.  A wave takes FOUR items at a time: when all
-// of them are short (<= 256 bytes, the pass-through containers of sparse data) each quarter-wave copies one, 16 bytes
-// per lane; otherwise the whole wave copies them one after the other.
+// The item says where from, where to, how much -- no directory loads.  A wave takes `per_wave` items at a time: FOUR
+// (a quarter-wave each, 16 bytes per lane, while none of them exceeds 256 bytes; else the whole wave copies them one
+// after the other), or SIXTEEN when the host expects tiny containers (the operand pools average <= 96 payload bytes per
+// container: C5, wikileaks -- round 4: at four per wave k_copy was 226 us of a C5 `or` batch, three lanes in four
+// idle and one dependent load chain per four items): four lanes copy one item each when all sixteen are <= 64 bytes,
+// otherwise the sixteen go through the four-item form in four rounds.
 __device__ __forceinline__ void copy_body(uint32_t* __restrict__ lds, uint32_t bid, uint32_t nblk, const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                               OutView O, const CopyItem* __restrict__ q,
-                                              const u64* __restrict__ qrange) {
+                                              const u64* __restrict__ qrange, uint32_t per_wave) {
     const uint32_t lane = lane_id(), grp = lane >> 4, gl = lane & 15u;
     const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
     uint32_t w = wave_uniform((bid * blockDim.x + threadIdx.x) >> 6);
+    const bool wide = per_wave == 16u;                       // (wave-uniform: a kernel argument)
+    const uint32_t lsh = wide ? 2u : 4u;                     // lanes per item = 1 << lsh
+    const uint32_t mine = lane >> lsh, li = lane & ((1u << lsh) - 1u);
     CopyItem tn;
-    if (4 * w + grp < n) tn = q[4 * w + grp];
-    for (; 4 * w < n; w += nwaves) {
-        const bool have = 4 * w + grp < n;
+    tn.src = 0; tn.offo = 0; tn.meta = 0; tn.n16 = 0; tn.out = 0;
+    if (per_wave * w + mine < n) tn = q[per_wave * w + mine];
+    for (; per_wave * w < n; w += nwaves) {
+        const uint32_t i0 = per_wave * w;
+        const bool have = i0 + mine < n;
         const CopyItem t = tn;
-        if (4 * (w + nwaves) + grp < n) tn = q[4 * (w + nwaves) + grp];
-        if (__ballot(have && t.n16 > 16u) == 0) {
-            if (have) {
+        if (per_wave * (w + nwaves) + mine < n) tn = q[per_wave * (w + nwaves) + mine];  // the next items: in flight during the copy
+        if (__ballot(have && t.n16 > (1u << lsh)) == 0) {  // every item fits its lanes
+            if (have && li < t.n16) {
                 const uint8_t* base = (t.src & COPY_FROM_B) ? arenaB : arenaA;
-                if (gl < t.n16) ((uint4*)(O.arena + t.offo))[gl] = ((const uint4*)(base + (t.src & ~COPY_FROM_B)))[gl];
-                if (gl == 0) O.meta[t.out] = t.meta;
+                ((uint4*)(O.arena + t.offo))[li] = ((const uint4*)(base + (t.src & ~COPY_FROM_B)))[li];
             }
         } else {
-#pragma unroll
-            for (uint32_t g = 0; g < 4; ++g) {
-                if (4 * w + g >= n) break;
-                const u64 src = __shfl(t.src, 16 * g), offo = __shfl(t.offo, 16 * g);
-                const uint32_t n16 = __shfl(t.n16, 16 * g);
-                const uint8_t* base = (src & COPY_FROM_B) ? arenaB : arenaA;
-                const uint4* __restrict__ ps = (const uint4*)(base + (src & ~COPY_FROM_B));
-                uint4* __restrict__ po = (uint4*)(O.arena + offo);
-                for (uint32_t i = lane; i < n16; i += 64) po[i] = ps[i];
+            const u64 huge = __ballot(have && t.n16 > 16u);
+            const uint32_t rounds = per_wave >> 2;
+            for (uint32_t r = 0; r < rounds; ++r) {  // items 4 r .. 4 r + 3 (held by lanes 16 r .. 16 r + 15 in either form)
+                if (i0 + 4 * r >= n) break;
+                const u64 hr = wide ? ((huge >> (16 * r)) & 0xFFFFull) : huge;
+                if (hr == 0) {
+                    const uint32_t j = 4 * r + grp;  // this quarter-wave's item
+                    const u64 src = __shfl(t.src, (int)(j << lsh)), offo = __shfl(t.offo, (int)(j << lsh));
+                    const uint32_t n16 = __shfl(t.n16, (int)(j << lsh));
+                    if (i0 + j < n && gl < n16) {
+                        const uint8_t* base = (src & COPY_FROM_B) ? arenaB : arenaA;
+                        ((uint4*)(O.arena + offo))[gl] = ((const uint4*)(base + (src & ~COPY_FROM_B)))[gl];
+                    }
+                } else {
+                    for (uint32_t g = 0; g < 4; ++g) {
+                        const uint32_t j = 4 * r + g;
+                        if (i0 + j >= n) break;
+                        const u64 src = __shfl(t.src, (int)(j << lsh)), offo = __shfl(t.offo, (int)(j << lsh));
+                        const uint32_t n16 = __shfl(t.n16, (int)(j << lsh));
+                        const uint8_t* base = (src & COPY_FROM_B) ? arenaB : arenaA;
+                        const uint4* __restrict__ ps = (const uint4*)(base + (src & ~COPY_FROM_B));
+                        uint4* __restrict__ po = (uint4*)(O.arena + offo);
+                        for (uint32_t i = lane; i < n16; i += 64) po[i] = ps[i];
+                    }
+                }
             }
-            if (have && gl == 0) O.meta[t.out] = t.meta;
         }
+        if (have && li == 0) O.meta[t.out] = t.meta;
     }
 }
 __global__ __launch_bounds__(256) void k_copy(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                               OutView O, const CopyItem* __restrict__ q,
-                                              const u64* __restrict__ qrange) {
+                                              const u64* __restrict__ qrange, uint32_t per_wave) {
     uint32_t* lds = nullptr;
-    copy_body(lds, blockIdx.x, gridDim.x, arenaA, arenaB, O, q, qrange);
+    copy_body(lds, blockIdx.x, gridDim.x, arenaA, arenaB, O, q, qrange, per_wave);
 }
 
 

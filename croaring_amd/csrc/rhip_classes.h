@@ -28,6 +28,7 @@ struct ClassLaunch {
     uint32_t* retry_count;
     u64* pair_acc;
     int kop, cardmode;
+    uint32_t copy_per_wave;   // 4 or 16 (copy_body)
     uint32_t nb[N_CSEG];      // blocks of each segment (0: the class cannot occur)
 };
 constexpr uint32_t CLASSES_LDS_WORDS = FILTER_LDS_WORDS > 8192 ? FILTER_LDS_WORDS : 8192;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void k_classes(ClassLaunch L) {
                              L.retry_count);
             break;
         case CSEG_COPY:
-            copy_body(lds, b, nblk, L.arenaA, L.arenaB, L.O, L.q_copy, R + 2 * SEC_COPY);
+            copy_body(lds, b, nblk, L.arenaA, L.arenaB, L.O, L.q_copy, R + 2 * SEC_COPY, L.copy_per_wave);
             break;
         default: break;
     }

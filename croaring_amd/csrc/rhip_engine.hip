@@ -159,7 +159,9 @@ struct rhip_ctx_s {
     size_t h_many_cap = 0;
     hipEvent_t ev_many_stage = nullptr;
     bool many_stage_pending = false;
-    std::vector<rhip_pool_t*> many_free;  // retired results of rhip_or_many / rhip_xor_many: their buffers are recycled
+    std::vector<rhip_pool_t*> many_free;  // retired results of rhip_or_many / rhip_xor_many: their buffers are recycled (under g_ctx_mu)
+    uint64_t gen = 0;                     // generation number of this context (pools remember it: rhip_pool_s::ctx_gen)
+    uint64_t dense_pipe = 0, dense_pipe_seq = 0;  // open dense many-way pipeline (rhip_many_partials_dense .. _finalize_dense), 0 = none
     size_t arena_skew = 0;  // result arenas start this many bytes into their allocation (RHIP_ARENA_SKEW)
     size_t arena_round = 0; // RHIP_ARENA_ROUND_MB
     bool debug_plan = false;  // RHIP_DEBUG_PLAN=1: one line per batch on stderr (bounds, fork / merge decision)
@@ -168,9 +170,10 @@ struct rhip_ctx_s {
     // X-grouped image queues (rhip_common.h XGroupView): 0 never, 1 when the batch promises enough reuse (at least
     // group_min_reuse matched container pairs -- upper bound -- per container of the operand pools), 2 always (tests)
     int group_x = 1;             // RHIP_GROUP_X
-    uint64_t group_min_reuse = 4;
+    uint64_t group_min_reuse = 64;  // (C5: 47 partners per container by this bound, almost all interval pairs -- grouping costs it 4 %)
     uint64_t group_min_items = 16u << 10;
     uint32_t group_chunk = 8;    // RHIP_XG_CHUNK: items a wave of the grouped kernels walks in a row, at least
+    bool copy_wide = true;       // RHIP_COPY_WIDE=0: k_copy always takes four items per wave
     int many_pf = 4;  // RHIP_MANY_PF: payload groups per lane k_many_l1 loads ahead (2 / 4 / 8)
     int many_ch = 0;  // RHIP_MANY_CH: members per unit (tests of the multi-chunk / multi-unit paths on small inputs); 0 = by size
     static constexpr size_t PINNED_MANY_FLAG_OFF = 2304, PINNED_MANY_TOT_OFF = 2560, PINNED_MANY_ERR_OFF = 2816;
@@ -240,6 +243,7 @@ struct rhip_pool_s {
     int in_use = 0;             // batches in flight that read this pool as an operand: not recyclable yet
     bool free_deferred = false; // rhip_pool_free arrived while in_use: the last batch to end frees it
     bool from_many = false;     // result of the many-way path: rhip_pool_free hands its buffers back to the context
+    uint64_t ctx_gen = 0;       // ... the context it was made by, by GENERATION: an address can be reused by a later context
     uint64_t compact_mark = 0;  // arena_used right after the last compaction (0: never updated in place), see rhip_pairwise_inplace
     // host mirror of the directory (filled lazily for serialization); planning only needs bm_start
     bool host_dir = false;
@@ -287,10 +291,16 @@ static void ensure_dir(rhip_pool_t* P, uint32_t n_bitmaps, uint64_t n_cont) {
 // contexts that exist: a pool may outlive its context (rhip_pool_free then must not touch it)
 static std::mutex g_ctx_mu;
 static std::set<rhip_ctx_t*> g_live_ctx;
+static uint64_t g_ctx_gen = 0;  // (under g_ctx_mu) every context gets the next generation number
 static bool ctx_alive(rhip_ctx_t* c) {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     return g_live_ctx.count(c) != 0;
 }
+// The recycle list of many-way results (ctx->many_free) is only touched under g_ctx_mu: rhip_pool_free may come from
+// any thread (a finaliser), and the context a pool names may be gone -- or gone and its address taken by a NEW context
+// (another device, other buffers), which the generation number tells apart.
+static bool many_recycle_push(rhip_pool_t* P);
+static rhip_pool_t* many_recycle_pop(rhip_ctx_t* c);
 extern "C" const char* rhip_last_error(void) { return g_err.c_str(); }
 extern "C" const char* rhip_version(void) { return "roaring-hip 0.1 (gfx950)"; }
 
@@ -330,10 +340,12 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_ARENA_SKEW")) c->arena_skew = (size_t)strtoull(e, nullptr, 0) & ~(size_t)255;
         if (const char* e = getenv("RHIP_GROUP_X")) c->group_x = atoi(e);
         if (const char* e = getenv("RHIP_XG_CHUNK")) c->group_chunk = (uint32_t)std::max(1, atoi(e));
+        if (const char* e = getenv("RHIP_COPY_WIDE")) c->copy_wide = !(e[0] == '0');
         if (const char* e = getenv("RHIP_MANY_CH")) c->many_ch = std::max(1, std::min(1024, atoi(e)));
         memset(c->h_pinned, 0, 4096);
         {
             std::lock_guard<std::mutex> lk(g_ctx_mu);
+            c->gen = ++g_ctx_gen;
             g_live_ctx.insert(c);
         }
         return c;
@@ -380,6 +392,13 @@ extern "C" int rhip_ctx_synchronize(rhip_ctx_t* c) {
     if (e != hipSuccess) {
         set_err("hipStreamSynchronize: %s", hipGetErrorString(e));
         return RHIP_ERR_DEVICE;
+    }
+    if (c->dense_pipe) {  // an open dense many-way pipeline whose stage 1 has failed: say so here as well as in its finalize
+        const uint64_t ew = __atomic_load_n((uint64_t*)((char*)c->h_pinned + rhip_ctx_s::PINNED_MANY_ERR_OFF), __ATOMIC_ACQUIRE);
+        if ((ew >> 8) == c->dense_pipe && (ew & 0xFF)) {
+            set_err("dense many-way stage 1 met a container key >= key_space: use the sparse exchange");
+            return RHIP_ERR_ARG;
+        }
     }
     return RHIP_OK;
 }
@@ -653,12 +672,23 @@ extern "C" void rhip_pool_free(rhip_pool_t* P) {
     }
     // A many-way result goes back to its context, buffers and all: hipFree synchronises with the device and hipMalloc of
     // the next result costs as much again -- together more than the aggregation of a small bitmap set itself.
-    if (P->from_many && ctx_alive(P->ctx) && P->ctx->many_free.size() < 2) {
-        P->ctx->many_free.push_back(P);
-        return;
-    }
+    if (P->from_many && many_recycle_push(P)) return;
     P->release();  // hipFree synchronises with the device; the context may already be gone
     delete P;
+}
+static bool many_recycle_push(rhip_pool_t* P) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    rhip_ctx_t* c = P->ctx;
+    if (!g_live_ctx.count(c) || c->gen != P->ctx_gen || c->many_free.size() >= 2) return false;
+    c->many_free.push_back(P);
+    return true;
+}
+static rhip_pool_t* many_recycle_pop(rhip_ctx_t* c) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (c->many_free.empty()) return nullptr;
+    rhip_pool_t* R = c->many_free.back();
+    c->many_free.pop_back();
+    return R;
 }
 extern "C" uint32_t rhip_pool_size(const rhip_pool_t* P) { return P->n_bitmaps; }
 extern "C" uint64_t rhip_pool_containers(const rhip_pool_t* P) { return P->n_cont; }
@@ -1022,6 +1052,7 @@ struct Plan {
     hipStream_t plan_stream = nullptr;
     bool may_bb = true, may_filt = true, may_wave = true, may_runs = true, may_copy = true, may_ba = true;
     bool grouped = false;  // the filter / union items are queued by X container (k_filter_g / k_union_g)
+    uint32_t copy_per_wave = 4;  // pass-through items a wave of k_copy takes at a time: 16 when the pools hold tiny containers
     const u64* xranges() const { return words + sc.w_ranges + 2 * N_SEC; }
     // device pointers
     uint32_t *d_lhs = nullptr, *d_rhs = nullptr, *d_upair = nullptr, *d_utile = nullptr;
@@ -1174,6 +1205,11 @@ Plan plan(rhip_ctx_t* c, const OpSet& ops, rhip_pool_t* A, rhip_pool_t* B, size_
     P.ub_cand = cardmode ? 0 : ub;
     P.arena_bound = cardmode ? 0 : bound;
     P.work_bound = bound;
+    // tiny pass-through containers (pool average <= 96 payload bytes: C5, wikileaks): k_copy takes sixteen per wave
+    {
+        const uint64_t nc = A->n_cont + (A == B ? 0 : B->n_cont), by = A->arena_used + (A == B ? 0 : B->arena_used);
+        P.copy_per_wave = (nc && by / nc <= 96 && c->copy_wide) ? 16u : 4u;
+    }
     // which classes can occur at all (pool-level type census): a class that cannot is not launched
     auto has = [](const rhip_pool_t* X, int t) { return X->census[t] != 0; };
     const bool aB = has(A, 0), aA = has(A, 1), aR = has(A, 2), bB = has(B, 0), bA = has(B, 1), bR = has(B, 2);
@@ -1197,10 +1233,14 @@ Plan plan(rhip_ctx_t* c, const OpSet& ops, rhip_pool_t* A, rhip_pool_t* B, size_
     // ---- X-grouped queues: when a container is expected to meet many partners (an all-pairs batch) and the batch has
     // image-class work at all.  ub_match is an upper bound, so the estimate errs towards grouping; a batch that groups
     // without reuse pays one atomic per item in k_count / k_emit and nothing else.
+    // Only batches big enough to be forked (run_kernels: the same two bounds): a light batch runs its classes as the one
+    // merged launch, which beats grouping it (measured, round 4: census-income andnot 0.24 ms merged, 0.39 grouped;
+    // census1881 and 0.135 / 0.160; weather -- forked -- gains 3-5 %).
     const bool same_pool = A == B;
     const uint64_t nxc = same_pool ? A->n_cont : A->n_cont + B->n_cont;
+    const bool big = bound >= c->fork_min_bytes && !(ub_match <= (128u << 10) && bound < c->fork_light_bytes);
     P.grouped = c->group_x == 2 ? (P.may_filt || P.may_wave || P.may_ba) && nxc > 0 && nxc < 0x3FFFFFF0ull
-                                : c->group_x == 1 && (P.may_filt || P.may_wave || P.may_ba) && nxc > 0 && nxc < 0x3FFFFFF0ull &&
+                                : c->group_x == 1 && big && (P.may_filt || P.may_wave || P.may_ba) && nxc > 0 && nxc < 0x3FFFFFF0ull &&
                                       ub_match >= c->group_min_items && ub_match >= c->group_min_reuse * nxc;
     const size_t n_hist = P.grouped ? 2 * (size_t)nxc + 1 : 0;
     // ---- device scratch
@@ -1333,8 +1373,8 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
     const bool light = nm <= (128u << 10) && P.work_bound < c->fork_light_bytes;
     const bool fork = c->overlap && (has_runs || has_filt || has_wave || has_ba) && P.work_bound >= c->fork_min_bytes && !light;
     if (c->debug_plan)
-        fprintf(stderr, "[rhip plan] ops %d nm %llu work_bound %.1f MB fork %d merge_eligible %d grouped %d\n", ops.n, (unsigned long long)nm,
-                P.work_bound / 1048576.0, (int)fork, (int)(nm <= c->merge_max_items), (int)P.grouped);
+        fprintf(stderr, "[rhip plan] ops %d nm %llu work_bound %.1f MB fork %d merge_eligible %d grouped %d copy_per_wave %u\n", ops.n, (unsigned long long)nm,
+                P.work_bound / 1048576.0, (int)fork, (int)(nm <= c->merge_max_items), (int)P.grouped, P.copy_per_wave);
     // A small batch (below the fork threshold) runs its class kernels as ONE launch, block ranges per class
     // (rhip_classes.h): their latency chains side by side instead of one after the other.  k_genw follows on its own.
     // (Only batches with few items: the combined kernel has the registers and LDS of its largest body -- 3 waves per SIMD
@@ -1350,7 +1390,7 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
         L.q_copy = SS.q[CLS_COPY].as<CopyItem>();
         L.q_r16 = SS.q[CLS_RUNS16].as<GenItem>(); L.q_r16w = SS.q[CLS_RUNS16W].as<GenItem>(); L.q_r64 = SS.q[CLS_RUNS].as<GenItem>();
         L.retry_q = SS.q[CLS_RETRY].as<GenItem>(); L.retry_count = retry_count; L.pair_acc = c->pair_acc.as<u64>();
-        L.kop = op; L.cardmode = cardmode;
+        L.kop = op; L.cardmode = cardmode; L.copy_per_wave = P.copy_per_wave;
         const unsigned cap = 512;  // blocks per class: its waves loop over the queue (the real queues are short)
         auto seg = [&](bool present, uint64_t ub) { return present ? ::bounded_grid(ub, cap) : 0u; };
         L.nb[CSEG_IVL16] = seg(has_runs, nm); L.nb[CSEG_IVL16W] = seg(has_runs, nm); L.nb[CSEG_IVL64] = seg(has_runs, nm);
@@ -1489,8 +1529,8 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
                                c->ss[P.slot].q[CLS_BBA].as<BBItem>(), ranges + 2 * SEC_BBA);
     }
     if (has_copy)
-        hipLaunchKernelGGL(k_copy, dim3(bounded_grid(P.ub_cand)), dim3(256), 0, s, VA.arena, VB.arena, O,
-                           c->ss[P.slot].q[CLS_COPY].as<CopyItem>(), ranges + 2 * SEC_COPY);
+        hipLaunchKernelGGL(k_copy, dim3(bounded_grid(P.copy_per_wave == 16 ? (P.ub_cand + 3) / 4 : P.ub_cand)), dim3(256), 0, s, VA.arena, VB.arena, O,
+                           c->ss[P.slot].q[CLS_COPY].as<CopyItem>(), ranges + 2 * SEC_COPY, P.copy_per_wave);
     if (fork)
         for (int a = 0; a < rhip_ctx_s::N_AUX; ++a)
             if (used[a]) {

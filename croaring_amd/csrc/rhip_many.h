@@ -807,7 +807,7 @@ __global__ __launch_bounds__(256) void k_many_tail(const u64* __restrict__ key, 
                                                    const u64* __restrict__ off, u64 off_stride, DirOut R, u64 n_fixed,
                                                    int use_fixed, LbState lb, u64* __restrict__ part,
                                                    ManyTotals* __restrict__ tot, ManyTotals* __restrict__ host_tot,
-                                                   u64* host_flag, u64 seq, u64* host_err) {
+                                                   u64* host_flag, u64 seq, u64* host_err, u64 err_tag) {
     __shared__ uint32_t s_cnt[32];
     __shared__ uint32_t s_tile;
     __shared__ u64 s_prefix, s_total;
@@ -909,19 +909,22 @@ __global__ __launch_bounds__(256) void k_many_tail(const u64* __restrict__ key, 
         const u64* lv = (const u64*)&T;
         u64* hv = (u64*)host_tot;
         for (uint32_t k = 0; k < sizeof(ManyTotals) / 8; ++k) hv[k] = lv[k];
-        if (T.err) atomicOr(host_err, T.err);
+        if (T.err) __atomic_store_n(host_err, (err_tag << 8) | T.err, __ATOMIC_RELAXED);  // (see k_many_publish)
         __threadfence_system();
         __atomic_store_n(host_flag, seq, __ATOMIC_RELEASE);
     }
 }
 // partial modes have no tail: the totals (number of groups, largest key, error word) alone
+// The error word carries the TAG of the pipeline that raised it (err_tag << 8 | bits): the call that ends a pipeline
+// only believes a word with its own tag, so an abandoned pipeline (stage 1 ran, its finalize never did) cannot fail
+// the next one, and nothing ever has to clear the word.  Everything runs on the context's one stream, in order.
 __global__ void k_many_publish(const ManyTotals* __restrict__ tot, ManyTotals* __restrict__ host_tot, u64* host_flag, u64 seq,
-                               u64* host_err) {
+                               u64* host_err, u64 err_tag) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const u64* lv = (const u64*)tot;
         u64* hv = (u64*)host_tot;
         for (uint32_t k = 0; k < sizeof(ManyTotals) / 8; ++k) hv[k] = lv[k];
-        if (tot->err) atomicOr(host_err, tot->err);  // sticky: read (and cleared) by the call that ends the pipeline
+        if (tot->err) __atomic_store_n(host_err, (err_tag << 8) | tot->err, __ATOMIC_RELAXED);
         __threadfence_system();
         __atomic_store_n(host_flag, seq, __ATOMIC_RELEASE);
     }

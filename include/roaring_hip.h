@@ -21,6 +21,16 @@
  *    usable.
  *  - wire format = portable RoaringFormatSpec (src/roaring_array.c:469-813);
  *    64-bit pools use the portable 64-bit format (src/roaring64.c:2323-2393).
+ *  - threading: a CONTEXT IS SINGLE-THREADED.  Every call that takes a context
+ *    (or a pool / batch of it) shares its stream, its pinned staging areas and
+ *    its scratch buffers; callers serialise them (one context per thread is the
+ *    intended use -- contexts are independent of each other, also on one
+ *    device).  The exceptions, safe from any thread at any time: rhip_pool_free
+ *    (a finaliser may run anywhere; a pool that is an operand of batches in
+ *    flight is released by the last of them), rhip_last_error (thread-local)
+ *    and rhip_version.  The reference's functions are re-entrant on distinct
+ *    bitmaps (include/roaring/roaring.h:102-113); the CRoaring-named drop-ins of
+ *    roaring_hip_compat.h keep that property (they lock around the device).
  */
 #ifndef ROARING_HIP_H
 #define ROARING_HIP_H
@@ -153,9 +163,10 @@ rhip_pool_t *rhip_pairwise(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *A, rhip_poo
  * everything and returns without waiting for the device; `lhs` / `rhs` are copied and may be freed at once.
  * rhip_pairwise_end waits for that batch and returns its result pool (NULL on error; the handle is consumed either
  * way).  Up to RHIP_MAX_BATCHES_IN_FLIGHT batches of one context may be in flight, ended in any order; they execute in
- * begin order on the context's stream.  Until a batch has ended, its operand pools must not be freed or updated in
- * place (as `reuse` they are refused), its result cannot be an operand or the `reuse` of another batch (RHIP_ERR_ARG), and any other call on the
- * context simply waits for the batches in flight.  rhip_pairwise == begin followed by end. */
+ * begin order on the context's stream.  Until a batch has ended, its operand pools cannot be updated in place or
+ * recycled (as `reuse` they are refused, RHIP_ERR_ARG); rhip_pool_free of an operand is accepted and DEFERRED -- the last
+ * batch that reads the pool releases it when it ends; the batch's result cannot be an operand or the `reuse` of another
+ * batch (RHIP_ERR_ARG); and any other call on the context simply waits for the batches in flight.  rhip_pairwise == begin followed by end. */
 #define RHIP_MAX_BATCHES_IN_FLIGHT 4
 typedef struct rhip_batch_s rhip_batch_t;
 rhip_batch_t *rhip_pairwise_begin(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *A, rhip_pool_t *B, size_t npairs,

@@ -246,6 +246,10 @@ def test_emu_tiny_interval_pairs(emu, oracle):
     G.test_tiny_interval_pairs(emu, oracle)
 
 
+def test_emu_tiny_passthrough_containers(emu, oracle):
+    G.test_tiny_passthrough_containers(emu, oracle)
+
+
 def test_emu_long_interval_lists(emu, oracle):
     G.test_long_interval_lists(emu, oracle)
 
@@ -273,6 +277,8 @@ def test_emu_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
         G.test_edge_cases(eng, oracle)
         G.test_synth_every_type_pair(eng, oracle, synth, "xor")
         G.test_synth_every_type_pair(eng, oracle, synth, "andnot")
+        if mode == "nomerge":
+            G.test_tiny_passthrough_containers(eng, oracle)
         if mode in ("fork", "nomerge"):
             G.test_synth_every_type_pair(eng, oracle, synth, "and")
             G.test_synth_every_type_pair(eng, oracle, synth, "or")

@@ -76,6 +76,59 @@ def test_dropin_pairwise(hip, ref):
         ref.free(b)
 
 
+def test_dropin_reentrant(hip, ref):
+    """The reference's set operations may be called from any number of threads on distinct bitmaps
+    (roaring.h:102-113); so may the drop-ins: every call takes a lane -- a context of its own -- for its duration
+    (roaring_compat.inc).  Eight threads issue their own pairwise / in-place / cardinality / many-way calls side by side
+    (ctypes releases the GIL around each) and every result is checked against the reference."""
+    import threading
+    ref.L.roaring_bitmap_copy.restype = C.c_void_p
+    ref.L.roaring_bitmap_copy.argtypes = [C.c_void_p]
+    n_threads, iters = 8, 12
+    rngs = [np.random.default_rng(100 + t) for t in range(n_threads)]
+    inputs = [[(ref.from_sorted(random_bitmap(rngs[t])), ref.from_sorted(random_bitmap(rngs[t]))) for _ in range(iters)]
+              for t in range(n_threads)]
+    wants = [[{op: ref.op(op, a, b) for op in OPS} for a, b in inputs[t]] for t in range(n_threads)]
+    got = [[{} for _ in range(iters)] for _ in range(n_threads)]
+    start = threading.Barrier(n_threads)
+
+    def work(t):
+        start.wait()
+        for i, (a, b) in enumerate(inputs[t]):
+            for op in OPS:
+                r = getattr(hip, f"roaring_bitmap_{op}")(a, b)
+                card = getattr(hip, f"roaring_bitmap_{op}_cardinality")(a, b)
+                a2 = ref.L.roaring_bitmap_copy(a)
+                getattr(hip, f"roaring_bitmap_{op}_inplace")(a2, b)
+                arr = (C.c_void_p * 2)(a, b)
+                m = hip.roaring_bitmap_or_many(2, arr) if op == "or" else None
+                got[t][i][op] = (r, card, a2, m)
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    for t in range(n_threads):
+        for i in range(iters):
+            for op in OPS:
+                r, card, a2, m = got[t][i][op]
+                want = wants[t][i][op]
+                assert r, "drop-in returned NULL (no device?)"
+                ws = ref.serialize(want)
+                assert ref.validate(r) and ref.serialize(r) == ws, (t, i, op)
+                assert card == ref.cardinality(want), (t, i, op)
+                assert ref.validate(a2) and ref.serialize(a2) == ws, (t, i, op, "inplace")
+                if m is not None:
+                    assert ref.validate(m) and np.array_equal(ref.to_array(m), ref.to_array(want)), (t, i, "or_many")
+                    ref.free(m)
+                for h in (r, a2, want):
+                    ref.free(h)
+            a, b = inputs[t][i]
+            ref.free(a)
+            ref.free(b)
+
+
 def test_dropin_many(hip, ref):
     rng = np.random.default_rng(6)
     for it in range(10):

@@ -212,6 +212,20 @@ def sparse_many_body(eng, oracle, n=600, worlds=(1, 3)):
         eng.many_partials_dense("or", pool, None, 16, 1, t.data_ptr())
         with pytest.raises(Exception):
             eng.many_finalize_dense("or", False, 1, 0, 16, t.data_ptr())
+        # an ABANDONED pipeline (stage 1 failed on the device, its finalize never ran) is reported by synchronize and
+        # does not fail the next, healthy pipeline: the error word is tagged with the pipeline that raised it
+        eng.many_partials_dense("or", pool, None, 16, 1, t.data_ptr())
+        with pytest.raises(Exception):
+            eng.synchronize()
+        B = dense_block(4096, 1)
+        t2 = torch.empty((B, 1024), dtype=torch.int64, device=dev)
+        eng.many_partials_dense("or", pool, None, 4096, 1, t2.data_ptr())  # (joins the open pipeline: still failed)
+        with pytest.raises(Exception):
+            eng.many_finalize_dense("or", False, 1, 0, B, t2.data_ptr())
+        eng.many_partials_dense("or", pool, None, 4096, 1, t2.data_ptr())  # a fresh pipeline
+        res = eng.many_finalize_dense("or", False, 1, 0, B, t2.data_ptr())
+        assert res.serialize(0) == oracle.serialize(want_or)
+        eng.synchronize()
     for h in hs + [want_or, want_xor]:
         oracle.free(h)
 
@@ -666,6 +680,59 @@ def test_tiny_interval_pairs(engine, oracle):
         oracle.free(h)
 
 
+def test_tiny_passthrough_containers(engine, oracle):
+    """Pass-through containers of sparse bitmaps: the pool averages well under 96 payload bytes per container, so k_copy
+    takes SIXTEEN items per wave (four lanes each).  Bitmaps with disjoint key sets (everything passes through under or /
+    xor / andnot), 1 .. 32-value arrays and 1 .. 16-run containers mostly, with a few 60 .. 120-value arrays (the
+    quarter-wave rounds) and one bitset per ten bitmaps (the whole-wave round) among them; queue lengths around the
+    multiples of 16; chained once (the result pool is not tiny: four per wave)."""
+    rng = np.random.default_rng(2718)
+    vals = []
+    for b in range(30):
+        keys = np.sort(rng.choice(400, int(rng.integers(1, 50)), replace=False))
+        parts = []
+        for k in keys:
+            kind = rng.integers(0, 20)
+            if kind == 0 and b % 10 == 3:
+                v = np.sort(rng.choice(65536, 5000, replace=False))
+            elif kind <= 2:
+                v = np.sort(rng.choice(65536, int(rng.integers(60, 121)), replace=False))
+            elif kind <= 6:
+                st = np.sort(rng.choice(60000, int(rng.integers(1, 17)), replace=False))
+                v = np.unique(np.concatenate([np.arange(x, x + int(rng.integers(2, 40))) for x in st]))
+            else:
+                v = np.sort(rng.choice(65536, int(rng.integers(1, 33)), replace=False))
+            parts.append(v.astype(np.uint32) + (np.uint32(k) << 16))
+        vals.append(np.concatenate(parts))
+    hs = [oracle.from_sorted(v, run_optimize=True) for v in vals]
+    pool = engine.pool_from_serialized([oracle.serialize(h) for h in hs])
+    assert pool.payload_bytes() / max(1, sum(pool.type_counts())) <= 96
+    n = len(hs)
+    lhs, rhs = np.meshgrid(np.arange(n, dtype=np.uint32), np.arange(n, dtype=np.uint32))
+    lhs, rhs = lhs.ravel().copy(), rhs.ravel().copy()
+    for op in OPS:
+        for cut in (lhs.size, 17, 16, 1):
+            res = engine.pairwise(op, pool, lhs[:cut], pool, rhs[:cut])
+            blob, offs = res.serialize_many()
+            raw = blob.tobytes()
+            bad = []
+            for k in range(cut):
+                oo = oracle.op(op, hs[lhs[k]], hs[rhs[k]])
+                if raw[int(offs[k]):int(offs[k + 1])] != oracle.serialize(oo):
+                    bad.append((int(lhs[k]), int(rhs[k])))
+                oracle.free(oo)
+            assert not bad, f"{op} ({cut} pairs): {len(bad)} mismatching pairs, first {bad[:6]}"
+        idx = np.arange(min(len(res), 8), dtype=np.uint32)  # chained: (a op b) | a
+        res2 = engine.pairwise("or", res, idx, pool, lhs[idx])
+        for k in idx:
+            o1 = oracle.op(op, hs[lhs[k]], hs[rhs[k]])
+            o2 = oracle.op("or", o1, hs[lhs[k]])
+            assert res2.serialize(int(k)) == oracle.serialize(o2), (op, int(k))
+            oracle.free(o1); oracle.free(o2)
+    for h in hs:
+        oracle.free(h)
+
+
 def test_pairwise_placed(engine, oracle, synth):
     """Engine.pairwise_placed: the result pool kept after the start-up tries holds the batch's results and can be
     recycled; the other tries are gone."""
@@ -758,6 +825,8 @@ def test_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
         test_edge_cases(eng, oracle)
         for op in OPS:
             test_synth_every_type_pair(eng, oracle, synth, op)
+        if mode == "nomerge":
+            test_tiny_passthrough_containers(eng, oracle)  # k_copy itself at sixteen items per wave
     finally:
         eng.close()
 
