@@ -10,6 +10,8 @@ import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libroaring_hip.so")
+if os.environ.get("RHIP_LIB_VARIANT"):  # a diagnostic build beside the product library (croaring_amd/build.py)
+    LIB_PATH = os.path.join(PKG, f"libroaring_hip_{os.environ['RHIP_LIB_VARIANT']}.so")
 
 
 class RoaringHipError(RuntimeError):
@@ -71,6 +73,15 @@ SYMBOLS = [
     ("rhip_pairwise_multi", _vp, [_vp, _sz, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     ("rhip_pairwise_multi_begin", _vp, [_vp, _sz, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     ("rhip_pairwise_cardinality", _i, [_vp, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
+    ("rhip_pairlist_create", _vp, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    ("rhip_pairlist_all_pairs", _vp, [_vp, _vp]),
+    ("rhip_pairlist_successive", _vp, [_vp, _vp]),
+    ("rhip_pairlist_size", _sz, [_vp]),
+    ("rhip_pairlist_pairs", _i, [_vp, _vp, _vp]),
+    ("rhip_pairlist_free", None, [_vp]),
+    ("rhip_pairwise_list_begin", _vp, [_vp, _sz, _vp, _vp, _vp]),
+    ("rhip_pairwise_list", _vp, [_vp, _sz, _vp, _vp, _vp]),
+    ("rhip_pairwise_list_cardinality", _i, [_vp, _i, _vp, _vp]),
     ("rhip_pairwise_predicate", _i, [_vp, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     ("rhip_pairwise_inplace", _i, [_vp, _i, _vp, _vp, _sz, _vp, _vp]),
     ("rhip_pool_select", _vp, [_vp, _sz, _vp, _sz, _vp, _vp]),

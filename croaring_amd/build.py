@@ -35,7 +35,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     extra = os.environ.get("RHIP_EXTRA_FLAGS", "").split()  # diagnostic builds, e.g. -DRHIP_PHASES
     force = force or bool(extra)
-    objdir = os.path.join(PKG, "build")
+    # RHIP_BUILD_VARIANT=name: the diagnostic build goes to libroaring_hip_<name>.so (loaded with RHIP_LIB_VARIANT=name),
+    # beside the product library instead of over it -- A/B measurements of a compile-time switch in one GPU call
+    variant = os.environ.get("RHIP_BUILD_VARIANT", "")
+    out = os.path.join(PKG, f"libroaring_hip_{variant}.so") if variant else OUT
+    objdir = os.path.join(PKG, "build", variant) if variant else os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
     objs, rebuilt = [], False
     for src in SOURCES:
@@ -50,12 +54,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
             subprocess.run(cmd, check=True)
             rebuilt = True
         objs.append(obj)
-    if rebuilt or not os.path.exists(OUT):
-        cmd = [hipcc, "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", *objs, "-o", OUT]
+    if rebuilt or not os.path.exists(out):
+        cmd = [hipcc, "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", *objs, "-o", out]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -312,7 +312,7 @@ __device__ __forceinline__ void usmall_body(uint32_t* __restrict__ lds, uint32_t
             const uint32_t cnt = carry + nxs - (tot >> 16) + ynew;         // values in the window now
             __builtin_amdgcn_wave_barrier();
             const uint32_t nfull = cnt >> 3;
-            for (uint32_t j = lane; j < nfull; j += 64) po4[(out_base >> 3) + j] = ((const uint4*)ST)[j];
+            for (uint32_t j = lane; j < nfull; j += 64) out_store16(&po4[(out_base >> 3) + j], ((const uint4*)ST)[j]);
             carry = cnt & 7u;
             uint16_t keep = 0;
             if (lane < carry) keep = ST[8u * nfull + lane];
@@ -321,7 +321,7 @@ __device__ __forceinline__ void usmall_body(uint32_t* __restrict__ lds, uint32_t
             out_base += 8u * nfull;
         }
         __builtin_amdgcn_wave_barrier();
-        if (carry && lane == 0) po4[out_base >> 3] = ((const uint4*)ST)[0];  // (the slot is padded to 16 bytes)
+        if (carry && lane == 0) out_store16(&po4[out_base >> 3], ((const uint4*)ST)[0]);  // (the slot is padded to 16 bytes)
         PH(2);
         if (lane == 0) O.meta[t.out] = pack_meta(T_ARRAY, nx + nnew - ndel, 0);
         __builtin_amdgcn_wave_barrier();  // LDS is reused by the next item
@@ -442,7 +442,7 @@ __device__ __forceinline__ void filter_body(uint32_t* __restrict__ lds, uint32_t
                 if ((keepmask >> h) & 1u) ST[pos++] = (uint16_t)vals[h];
             __builtin_amdgcn_wave_barrier();
             const uint32_t filled = carry + tot, nfull = filled >> 3;
-            for (uint32_t j = lane; j < nfull; j += 64) po4[(run >> 3) + j] = ((const uint4*)ST)[j];
+            for (uint32_t j = lane; j < nfull; j += 64) out_store16(&po4[(run >> 3) + j], ((const uint4*)ST)[j]);
             carry = filled & 7u;
             uint16_t keep = 0;
             if (lane < carry) keep = ST[8u * nfull + lane];
@@ -452,7 +452,7 @@ __device__ __forceinline__ void filter_body(uint32_t* __restrict__ lds, uint32_t
         }
         if (!cardmode) {
             __builtin_amdgcn_wave_barrier();
-            if (carry && lane == 0) po4[run >> 3] = ((const uint4*)ST)[0];  // (the slot is padded to 16 bytes)
+            if (carry && lane == 0) out_store16(&po4[run >> 3], ((const uint4*)ST)[0]);  // (the slot is padded to 16 bytes)
             run += carry;
         }
         PH(2);
@@ -544,7 +544,7 @@ __device__ __forceinline__ void ba_body(uint32_t* __restrict__ lds, uint32_t bid
         if ((OP == OP_ITEM ? op == OP_OR : OP == OP_OR) || card > 4096u) {
             u32x4* __restrict__ po = (u32x4*)outp;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) po[i * 64 + lane] = va[i];
+            for (int i = 0; i < 8; ++i) out_store16(&po[i * 64 + lane], va[i]);
             if (lane == 0) O.meta[t.out] = pack_meta(T_BITSET, card, 0);
             __builtin_amdgcn_wave_barrier();  // the image is zeroed again by the next item
             continue;
@@ -630,7 +630,7 @@ __device__ __forceinline__ void wave_extract_array(uint32_t* __restrict__ img, u
     __builtin_amdgcn_wave_barrier();
     const uint32_t n16 = (2u * rc + 15u) >> 4;
     uint4* __restrict__ po = (uint4*)outp;
-    for (uint32_t i = lane; i < n16; i += 64) po[i] = ((const uint4*)img)[i];
+    for (uint32_t i = lane; i < n16; i += 64) out_store16(&po[i], ((const uint4*)img)[i]);
 }
 
 // ------------------------------------------------------------------ wave-private LDS image kernel (K6, K10, K11)
@@ -736,7 +736,7 @@ __device__ __forceinline__ void wave_body(uint32_t* __restrict__ lds, uint32_t b
 #pragma unroll
             for (int i = 0; i < 8; ++i) xv[i] = ((const uint4*)img)[i * 64 + lane];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) po[i * 64 + lane] = xv[i];
+            for (int i = 0; i < 8; ++i) out_store16(&po[i * 64 + lane], xv[i]);
         } else if (rc) {
             wave_extract_array(img, lane, rc, outp);
         }

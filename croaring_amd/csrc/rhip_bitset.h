@@ -140,7 +140,7 @@ __device__ __forceinline__ void bba_body(uint32_t* __restrict__ lds, uint32_t bi
         if (card > 4096u) {
             u32x4* __restrict__ po = (u32x4*)outp;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) po[i * 64 + lane] = va[i];
+            for (int i = 0; i < 8; ++i) out_store16(&po[i * 64 + lane], va[i]);
             if (lane == 0) O.meta[t.out] = pack_meta(T_BITSET, card, 0);
             continue;
         }
@@ -165,7 +165,7 @@ __device__ __forceinline__ void bba_body(uint32_t* __restrict__ lds, uint32_t bi
             __builtin_amdgcn_wave_barrier();
             const uint32_t n16 = (2u * card + 15u) >> 4;
             uint4* __restrict__ po = (uint4*)outp;
-            for (uint32_t i = lane; i < n16; i += 64) po[i] = ((const uint4*)st16)[i];
+            for (uint32_t i = lane; i < n16; i += 64) out_store16(&po[i], ((const uint4*)st16)[i]);
         }
         if (lane == 0) O.meta[t.out] = pack_meta(T_ARRAY, card, 0);
         __builtin_amdgcn_wave_barrier();  // the staging buffer is reused by the next item
@@ -207,7 +207,7 @@ __device__ __forceinline__ void copy_body(uint32_t* __restrict__ lds, uint32_t b
         if (__ballot(have && t.n16 > (1u << lsh)) == 0) {  // every item fits its lanes
             if (have && li < t.n16) {
                 const uint8_t* base = (t.src & COPY_FROM_B) ? arenaB : arenaA;
-                ((uint4*)(O.arena + t.offo))[li] = ((const uint4*)(base + (t.src & ~COPY_FROM_B)))[li];
+                out_store16(&((uint4*)(O.arena + t.offo))[li], ((const uint4*)(base + (t.src & ~COPY_FROM_B)))[li]);
             }
         } else {
             const u64 huge = __ballot(have && t.n16 > 16u);
@@ -221,7 +221,7 @@ __device__ __forceinline__ void copy_body(uint32_t* __restrict__ lds, uint32_t b
                     const uint32_t n16 = __shfl(t.n16, (int)(j << lsh));
                     if (i0 + j < n && gl < n16) {
                         const uint8_t* base = (src & COPY_FROM_B) ? arenaB : arenaA;
-                        ((uint4*)(O.arena + offo))[gl] = ((const uint4*)(base + (src & ~COPY_FROM_B)))[gl];
+                        out_store16(&((uint4*)(O.arena + offo))[gl], ((const uint4*)(base + (src & ~COPY_FROM_B)))[gl]);
                     }
                 } else {
                     for (uint32_t g = 0; g < 4; ++g) {
@@ -232,7 +232,7 @@ __device__ __forceinline__ void copy_body(uint32_t* __restrict__ lds, uint32_t b
                         const uint8_t* base = (src & COPY_FROM_B) ? arenaB : arenaA;
                         const uint4* __restrict__ ps = (const uint4*)(base + (src & ~COPY_FROM_B));
                         uint4* __restrict__ po = (uint4*)(O.arena + offo);
-                        for (uint32_t i = lane; i < n16; i += 64) po[i] = ps[i];
+                        for (uint32_t i = lane; i < n16; i += 64) out_store16(&po[i], ps[i]);
                     }
                 }
             }

@@ -234,6 +234,32 @@ __device__ int decide_type(int op, int ta, int tb, uint32_t ca, uint32_t cb, boo
     }
 }
 
+// ------------------------------------------------------------------ result stores
+// A result payload is written once and not read again by the batch that writes it, while the OPERANDS of a realdata
+// batch are re-read by every pair they appear in (weather_sept_85: ~85 times, a 7.6 MB working set against 4 MB of L2
+// per XCD): results leave with non-temporal stores so that a gigabyte of them does not push the operands out.
+// (-DRHIP_NT_OUT=0: plain stores, for A/B measurements.)
+#ifndef RHIP_NT_OUT
+#define RHIP_NT_OUT 1
+#endif
+typedef unsigned int rhip_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void out_store16(uint4* __restrict__ p, const uint4 v) {
+#if RHIP_NT_OUT
+    rhip_v4u t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, (rhip_v4u*)p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void out_store16(rhip_v4u* __restrict__ p, const rhip_v4u v) {
+#if RHIP_NT_OUT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // ------------------------------------------------------------------ which operand is the MEMBERSHIP / image side
 // The image kernels treat their operands asymmetrically: X is rasterised (8 KiB image: LDS for the filter, registers for
 // the union kernels), Y is streamed against it.  One definition, used by the planning kernels (X-grouped queues, below)

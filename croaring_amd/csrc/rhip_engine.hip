@@ -260,6 +260,7 @@ struct rhip_pool_s {
     std::vector<uint32_t> h_n;      // per-bitmap container count
     uint32_t max_n = 0;             // largest of them
     bool host_w = false;
+    uint64_t bounds_gen = 0;        // which fetch_bounds() filled the mirrors above (a prepared pair list remembers it)
     int8_t census[3] = {1, 1, 1};   // does the pool hold bitset / array / run containers (1 until known otherwise)
     PoolView view() const {
         PoolView v;
@@ -276,6 +277,25 @@ struct rhip_pool_s {
         bm_start.release(); key.release(); type.release(); card.release(); nruns.release(); off.release();
         arena.release();
     }
+};
+
+// sums over a pair list that size a batch (plan()): planning units, matched / candidate containers, result-slot bytes
+struct PairSums {
+    uint64_t nu_a = 0, nu_b = 0, s_mn = 0, s_na = 0, s_nb = 0, s_wmin = 0, s_wa = 0, s_wb = 0;
+};
+// A PREPARED pair list (include/roaring_hip.h, rhip_pairlist_*): the indices resident on the device, the sums above
+// computed once.  The reference has no pair list at all -- its benchmark walks the bitmaps (benchmarks/benchmark.cpp:
+// 2035-2091) -- so validating, summing and copying one is input preparation, not part of the set operation.
+struct rhip_pairlist_s {
+    rhip_ctx_t* ctx = nullptr;
+    rhip_pool_t *A = nullptr, *B = nullptr;
+    size_t npairs = 0;
+    std::vector<uint32_t> lhs, rhs;  // host copy: explicit-unit batches, the cardinality read-back, re-validation
+    DBuf d_idx;                      // lhs | rhs (u32 each) on the device
+    PairSums sums;
+    uint64_t genA = 0, genB = 0;     // the pools' bounds_gen the sums were taken from (0: never)
+    int in_use = 0;                  // batches in flight that read d_idx
+    bool free_deferred = false;
 };
 
 static void ensure_dir(rhip_pool_t* P, uint32_t n_bitmaps, uint64_t n_cont) {
@@ -1019,6 +1039,8 @@ static void fetch_bounds(rhip_pool_t* P) {
         P->h_n[b] = (uint32_t)(P->h_bm_start[b + 1] - P->h_bm_start[b]);
         P->max_n = std::max(P->max_n, P->h_n[b]);
     }
+    static uint64_t next_gen = 0;  // (process-wide: a recycled pool at the same address never repeats a number)
+    P->bounds_gen = __atomic_add_fetch(&next_gen, 1, __ATOMIC_RELAXED);
     P->host_w = true;
 }
 
@@ -1112,8 +1134,31 @@ struct OpSet {
     bool has(int o) const { for (int i = 0; i < n; ++i) if (op[i] == o) return true; return false; }
     int kop() const { return n == 1 ? op[0] : (int)OP_ITEM; }  // kernel argument: the op, or "read it from the item"
 };
+PairSums pair_sums(rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs, const uint32_t* rhs) {
+    PairSums S;
+    const uint32_t* nAv = A->h_n.data();
+    const uint32_t* nBv = B->h_n.data();
+    const uint64_t* wAv = A->h_w.data();
+    const uint64_t* wBv = B->h_w.data();
+    const uint32_t nbmA = A->n_bitmaps, nbmB = B->n_bitmaps;
+    for (size_t i = 0; i < npairs; ++i) {
+        const uint32_t l = lhs[i], r = rhs[i];
+        if (l >= nbmA || r >= nbmB) { set_err("pair %zu: bitmap index out of range", i); throw (int)RHIP_ERR_ARG; }
+        const uint64_t nA = nAv[l], nB = nBv[r], wA = wAv[l], wB = wBv[r];
+        S.nu_a += (nA + 255) / 256;
+        S.nu_b += (nB + 255) / 256;
+        S.s_mn += nA < nB ? nA : nB;
+        S.s_na += nA; S.s_nb += nB;
+        S.s_wmin += wA < wB ? wA : wB;
+        S.s_wa += wA; S.s_wb += wB;
+    }
+    return S;
+}
+// L != nullptr: the batch runs over a prepared pair list (lhs / rhs are its host copies): its sums are taken as they
+// are while the operand pools' mirrors are the ones they were computed from, and with implicit units nothing is staged
+// at all -- the planning kernels read the list's own device copy.
 Plan plan(rhip_ctx_t* c, const OpSet& ops, rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs,
-          const uint32_t* rhs, int cardmode, int slot, hipStream_t s, HostClock* clk = nullptr) {
+          const uint32_t* rhs, int cardmode, int slot, hipStream_t s, HostClock* clk = nullptr, rhip_pairlist_t* L = nullptr) {
     // (s = the stream the planning kernels may use instead of the main one; taken below if the batch is not a huge one)
     rhip_ctx_s::SlotScratch& SS = c->ss[slot];
     Plan P;
@@ -1140,27 +1185,17 @@ Plan plan(rhip_ctx_t* c, const OpSet& ops, rhip_pool_t* A, rhip_pool_t* B, size_
     size_t NU = 0;
     uint64_t ub_match = 0, ub = 0, bound = 0;
     {
-        const uint32_t* nAv = A->h_n.data();
-        const uint32_t* nBv = B->h_n.data();
-        const uint64_t* wAv = A->h_w.data();
-        const uint64_t* wBv = B->h_w.data();
-        const uint32_t nbmA = A->n_bitmaps, nbmB = B->n_bitmaps;
-        uint64_t nu_a = 0, nu_b = 0, s_mn = 0, s_na = 0, s_nb = 0, s_wmin = 0, s_wa = 0, s_wb = 0;
-        for (size_t i = 0; i < npairs; ++i) {
-            const uint32_t l = lhs[i], r = rhs[i];
-            if (l >= nbmA || r >= nbmB) { set_err("pair %zu: bitmap index out of range", i); throw (int)RHIP_ERR_ARG; }
-            const uint64_t nA = nAv[l], nB = nBv[r], wA = wAv[l], wB = wBv[r];
-            nu_a += (nA + 255) / 256;
-            nu_b += (nB + 255) / 256;
-            s_mn += nA < nB ? nA : nB;
-            s_na += nA; s_nb += nB;
-            s_wmin += wA < wB ? wA : wB;
-            s_wa += wA; s_wb += wB;
+        PairSums S;
+        if (L && L->genA == A->bounds_gen && L->genB == B->bounds_gen) {
+            S = L->sums;
+        } else {
+            S = pair_sums(A, B, npairs, lhs, rhs);
+            if (L) { L->sums = S; L->genA = A->bounds_gen; L->genB = B->bounds_gen; }
         }
-        NU = (size_t)(ops.n * (nu_a + (btiles ? nu_b : 0)));
-        ub_match = (uint64_t)ops.n * s_mn;
-        ub = n_b0 * s_mn + n_b1 * s_na + n_b2 * (s_na + s_nb);
-        bound = n_b0 * s_wmin + n_b1 * s_wa + n_b2 * (s_wa + s_wb);
+        NU = (size_t)(ops.n * (S.nu_a + (btiles ? S.nu_b : 0)));
+        ub_match = (uint64_t)ops.n * S.s_mn;
+        ub = n_b0 * S.s_mn + n_b1 * S.s_na + n_b2 * (S.s_na + S.s_nb);
+        bound = n_b0 * S.s_wmin + n_b1 * S.s_wa + n_b2 * (S.s_wa + S.s_wb);
     }
     if (implicit) NU = nvirt * (btiles ? 2 : 1);
     if (NU >= 0x7FFFFFF0ull) { set_err("batch too large: %zu planning units", NU); throw (int)RHIP_ERR_ARG; }
@@ -1170,9 +1205,10 @@ Plan plan(rhip_ctx_t* c, const OpSet& ops, rhip_pool_t* A, rhip_pool_t* B, size_
     const size_t o_lhs = 0, o_rhs = o_lhs + 4 * npairs, o_pair0 = (o_rhs + 4 * npairs + 7) & ~(size_t)7,
                  o_upair = o_pair0 + (implicit ? 0 : 8 * (nvirt + 1)), o_utile = o_upair + (implicit ? 0 : 4 * NU),
                  stage_bytes = o_utile + (implicit ? 0 : 4 * NU);
-    c->ensure_stage(slot, stage_bytes + 16);
-    char* hs = (char*)c->h_stage[slot];
-    if (npairs) {
+    const bool prestaged = L && implicit;  // the two index lists are all an implicit-unit batch stages
+    if (!prestaged) c->ensure_stage(slot, stage_bytes + 16);
+    char* hs = prestaged ? nullptr : (char*)c->h_stage[slot];
+    if (npairs && !prestaged) {
         memcpy(hs + o_lhs, lhs, 4 * npairs);
         memcpy(hs + o_rhs, rhs, 4 * npairs);
     }
@@ -1286,7 +1322,10 @@ Plan plan(rhip_ctx_t* c, const OpSet& ops, rhip_pool_t* A, rhip_pool_t* B, size_
     P.d_rhs = (uint32_t*)(dp + o_rhs);
     P.d_upair = (uint32_t*)(dp + o_upair);
     P.d_utile = (uint32_t*)(dp + o_utile);
-    if (c->stage_kernel && c->h_stage_dev[slot] && stage_bytes <= (1u << 20)) {
+    if (prestaged) {
+        P.d_lhs = L->d_idx.as<uint32_t>();
+        P.d_rhs = P.d_lhs + npairs;
+    } else if (c->stage_kernel && c->h_stage_dev[slot] && stage_bytes <= (1u << 20)) {
         const uint32_t n16 = (uint32_t)((stage_bytes + 15) >> 4);  // (staging and plan_in are 16 bytes longer than that)
         if (n16)  // (an empty pair list has nothing to stage, and a zero-block launch is an error)
             hipLaunchKernelGGL(k_stage_in, dim3((n16 + 255) / 256), dim3(256), 0, s, (const uint4*)c->h_stage_dev[slot],
@@ -1469,19 +1508,8 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
     } else if (has_wave)
         hipLaunchKernelGGL(k_wave, dim3(bounded_grid(nm)), dim3(256), 0, on(2), VA.arena, VB.arena, O,
                            c->ss[P.slot].q[CLS_WAVE].as<FatItem>(), ranges + 2 * SEC_WAVE, op);
-    if (!multi && has_runs && !genw_merged) launch_genw_general(on(!has_filt ? 1 : !has_wave ? 2 : 1));
-    if (has_ba && !P.grouped) {  // bitset (op) array, behind the few general items of its stream: andnot has no k_wave items, so that
-                   // stream is free; or / xor: the filter's stream
-        hipStream_t sb = on(multi ? 0 : (op == OP_ANDNOT ? 2 : 1));  // (multi-op: behind the interval kernel)
-        const FatItem* qb = c->ss[P.slot].q[CLS_BA].as<FatItem>();
-        const unsigned gb = bounded_grid(nm);
-        GenItem* rq = c->ss[P.slot].q[CLS_RETRY].as<GenItem>();
-        if (multi) hipLaunchKernelGGL(k_ba<OP_ITEM>, dim3(gb), dim3(256), 0, sb, VA.arena, VB.arena, O, qb, ranges + 2 * SEC_BA, rq, retry_count);
-        else if (op == OP_OR) hipLaunchKernelGGL(k_ba<OP_OR>, dim3(gb), dim3(256), 0, sb, VA.arena, VB.arena, O, qb, ranges + 2 * SEC_BA, rq, retry_count);
-        else if (op == OP_XOR) hipLaunchKernelGGL(k_ba<OP_XOR>, dim3(gb), dim3(256), 0, sb, VA.arena, VB.arena, O, qb, ranges + 2 * SEC_BA, rq, retry_count);
-        else hipLaunchKernelGGL(k_ba<OP_ANDNOT>, dim3(gb), dim3(256), 0, sb, VA.arena, VB.arena, O, qb, ranges + 2 * SEC_BA, rq, retry_count);
-        if (fork && op != OP_OR) HIPCHK(hipEventRecord(c->ev_ba, sb));  // "k_ba done" for the retry pass
-    }
+    // The main stream's own kernels are issued right after the big image kernels: the host's launches are what the device
+    // waits for in a forked batch (~25 API calls), and k_probe / k_usmall are on its critical path, the few general items are not.
     if (has_bb) {
         unsigned grid = persistent_grid(nm, 4, 256 * 32);
         if (c->timing) { HIPCHK(hipEventRecord(c->evs[P.slot][2], s)); c->bb_timed[P.slot] = true; }
@@ -1494,22 +1522,6 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
         }
         if (c->timing) HIPCHK(hipEventRecord(c->evs[P.slot][3], s));
         if (fork && has_retry && has_runs) HIPCHK(hipEventRecord(c->ev_runs, s));  // "k_bb done" for the retry pass on aux0
-    }
-    if (has_retry) {
-        // results that need the LDS image path after all: bitset x bitset results that must become
-        // arrays (card <= 4096), interval results that must become bitsets
-        hipStream_t sr = has_runs ? on(0) : s;
-        if (fork && has_runs && has_bb) HIPCHK(hipStreamWaitEvent(sr, c->ev_runs, 0));
-        if (fork && has_ba && !P.grouped && op != OP_OR) HIPCHK(hipStreamWaitEvent(sr, c->ev_ba, 0));  // k_ba re-queues its rare array results
-        rhip_ctx_s::SlotScratch& SS = c->ss[P.slot];
-        if (genw_merged)  // one stream: the general class and the re-queued results in one launch, after their producers
-            hipLaunchKernelGGL(k_genw<true>, dim3(4 * bounded_grid(nm, 512)), dim3(64), 0, sr, VA.arena, VB.arena, O,
-                               SS.q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, 0,
-                               c->pair_acc.as<u64>(), (const GenItem*)SS.q[CLS_RETRY].as<GenItem>(), (const uint32_t*)retry_count);
-        else
-            hipLaunchKernelGGL(k_genw<false>, dim3(4 * bounded_grid(nm, 512)), dim3(64), 0, sr, VA.arena, VB.arena, O,
-                               SS.q[CLS_RETRY].as<GenItem>(), (const u64*)nullptr, retry_count, op, 0,
-                               c->pair_acc.as<u64>(), (const GenItem*)nullptr, (const uint32_t*)nullptr);
     }
     if (has_wave && any_union)  // or / xor of a short array with a long one, by rank: light, beside k_wave
         hipLaunchKernelGGL(k_usmall, dim3(bounded_grid(nm)), dim3(256), 0, s, VA.arena, VB.arena, O,
@@ -1531,6 +1543,35 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
     if (has_copy)
         hipLaunchKernelGGL(k_copy, dim3(bounded_grid(P.copy_per_wave == 16 ? (P.ub_cand + 3) / 4 : P.ub_cand)), dim3(256), 0, s, VA.arena, VB.arena, O,
                            c->ss[P.slot].q[CLS_COPY].as<CopyItem>(), ranges + 2 * SEC_COPY, P.copy_per_wave);
+    if (!multi && has_runs && !genw_merged) launch_genw_general(on(!has_filt ? 1 : !has_wave ? 2 : 1));
+    if (has_ba && !P.grouped) {  // bitset (op) array, behind the few general items of its stream: andnot has no k_wave items, so that
+                   // stream is free; or / xor: the filter's stream
+        hipStream_t sb = on(multi ? 0 : (op == OP_ANDNOT ? 2 : 1));  // (multi-op: behind the interval kernel)
+        const FatItem* qb = c->ss[P.slot].q[CLS_BA].as<FatItem>();
+        const unsigned gb = bounded_grid(nm);
+        GenItem* rq = c->ss[P.slot].q[CLS_RETRY].as<GenItem>();
+        if (multi) hipLaunchKernelGGL(k_ba<OP_ITEM>, dim3(gb), dim3(256), 0, sb, VA.arena, VB.arena, O, qb, ranges + 2 * SEC_BA, rq, retry_count);
+        else if (op == OP_OR) hipLaunchKernelGGL(k_ba<OP_OR>, dim3(gb), dim3(256), 0, sb, VA.arena, VB.arena, O, qb, ranges + 2 * SEC_BA, rq, retry_count);
+        else if (op == OP_XOR) hipLaunchKernelGGL(k_ba<OP_XOR>, dim3(gb), dim3(256), 0, sb, VA.arena, VB.arena, O, qb, ranges + 2 * SEC_BA, rq, retry_count);
+        else hipLaunchKernelGGL(k_ba<OP_ANDNOT>, dim3(gb), dim3(256), 0, sb, VA.arena, VB.arena, O, qb, ranges + 2 * SEC_BA, rq, retry_count);
+        if (fork && op != OP_OR) HIPCHK(hipEventRecord(c->ev_ba, sb));  // "k_ba done" for the retry pass
+    }
+    if (has_retry) {
+        // results that need the LDS image path after all: bitset x bitset results that must become
+        // arrays (card <= 4096), interval results that must become bitsets
+        hipStream_t sr = has_runs ? on(0) : s;
+        if (fork && has_runs && has_bb) HIPCHK(hipStreamWaitEvent(sr, c->ev_runs, 0));
+        if (fork && has_ba && !P.grouped && op != OP_OR) HIPCHK(hipStreamWaitEvent(sr, c->ev_ba, 0));  // k_ba re-queues its rare array results
+        rhip_ctx_s::SlotScratch& SS = c->ss[P.slot];
+        if (genw_merged)  // one stream: the general class and the re-queued results in one launch, after their producers
+            hipLaunchKernelGGL(k_genw<true>, dim3(4 * bounded_grid(nm, 512)), dim3(64), 0, sr, VA.arena, VB.arena, O,
+                               SS.q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, 0,
+                               c->pair_acc.as<u64>(), (const GenItem*)SS.q[CLS_RETRY].as<GenItem>(), (const uint32_t*)retry_count);
+        else
+            hipLaunchKernelGGL(k_genw<false>, dim3(4 * bounded_grid(nm, 512)), dim3(64), 0, sr, VA.arena, VB.arena, O,
+                               SS.q[CLS_RETRY].as<GenItem>(), (const u64*)nullptr, retry_count, op, 0,
+                               c->pair_acc.as<u64>(), (const GenItem*)nullptr, (const uint32_t*)nullptr);
+    }
     if (fork)
         for (int a = 0; a < rhip_ctx_s::N_AUX; ++a)
             if (used[a]) {
@@ -1614,11 +1655,13 @@ struct rhip_batch_s {
     bool may_bb;
     const u64* ranges;  // the batch's section ranges (device)
     bool grouped;       // its filter / union items are in the X-grouped queue
+    rhip_pairlist_t* L; // the prepared pair list the batch reads (its device copy), or NULL
 };
 
 // Everything of a pairwise call up to and including the launch of k_tail: nothing here waits for the device.
 static rhip_batch_t* pairwise_begin_ops(rhip_ctx_t* c, size_t n_ops, const rhip_op* ops_, rhip_pool_t* A, rhip_pool_t* B,
-                                        size_t npairs, const uint32_t* lhs, const uint32_t* rhs, rhip_pool_t* reuse) {
+                                        size_t npairs, const uint32_t* lhs, const uint32_t* rhs, rhip_pool_t* reuse,
+                                        rhip_pairlist_t* L = nullptr) {
     rhip_pool_t* R = nullptr;
     try {
         if (!c) { set_err("null context"); throw (int)RHIP_ERR_ARG; }
@@ -1652,7 +1695,7 @@ static rhip_batch_t* pairwise_begin_ops(rhip_ctx_t* c, size_t n_ops, const rhip_
         hipStream_t ps = s;
         if (c->plan_overlap && c->overlap && c->in_flight() > 0)
             ps = c->aux[(ops.n == 1 && (op == OP_OR || op == OP_XOR)) ? 1 : 2];
-        Plan P = plan(c, ops, A, B, npairs, lhs, rhs, 0, slot, ps, &clk);
+        Plan P = plan(c, ops, A, B, npairs, lhs, rhs, 0, slot, ps, &clk, L);
         if (P.plan_stream != s) {
             HIPCHK(hipEventRecord(c->ev_plan[slot], P.plan_stream));
             HIPCHK(hipStreamWaitEvent(s, c->ev_plan[slot], 0));
@@ -1686,11 +1729,12 @@ static rhip_batch_t* pairwise_begin_ops(rhip_ctx_t* c, size_t n_ops, const rhip_
         if (c->timing) HIPCHK(hipEventRecord(c->evs[slot][1], s));
         HIPCHK(hipGetLastError());  // a refused launch anywhere above must not pass silently
         clk.lap(3);
-        rhip_batch_t* b = new rhip_batch_s{c, R, A, B, seq, slot, P.may_bb, P.ranges(), P.grouped};
+        rhip_batch_t* b = new rhip_batch_s{c, R, A, B, seq, slot, P.may_bb, P.ranges(), P.grouped, L};
         c->slot_busy[slot] = true;
         R->pending = true;
         ++A->in_use;
         ++B->in_use;
+        if (L) ++L->in_use;
         return b;
     } catch (int e) {
         last_status() = e;
@@ -1723,8 +1767,13 @@ extern "C" rhip_pool_t* rhip_pairwise_end(rhip_batch_t* b) {
     const int slot = b->slot;
     --b->A->in_use;
     --b->B->in_use;
+    rhip_pairlist_t* bl = b->L;
+    if (bl) --bl->in_use;
     auto drop_deferred = [](rhip_pool_t* X) {
         if (X->free_deferred && X->in_use == 0) { X->release(); delete X; }
+    };
+    auto drop_list = [](rhip_pairlist_t* X) {  // (after the wait below: nothing reads its device copy any more)
+        if (X && X->free_deferred && X->in_use == 0) { X->d_idx.release(); delete X; }
     };
     try {
         DeviceGuard dguard_(c->device);
@@ -1755,6 +1804,7 @@ extern "C" rhip_pool_t* rhip_pairwise_end(rhip_batch_t* b) {
         delete b;
         drop_deferred(A);  // (the batch has completed: nothing reads the operands any more)
         if (B != A) drop_deferred(B);
+        drop_list(bl);
         clk.lap(5);
         return R;
     } catch (int e) {
@@ -1767,6 +1817,7 @@ extern "C" rhip_pool_t* rhip_pairwise_end(rhip_batch_t* b) {
         delete b;
         drop_deferred(A);
         if (B != A) drop_deferred(B);
+        drop_list(bl);
         return nullptr;
     }
 }
@@ -1777,8 +1828,8 @@ extern "C" rhip_pool_t* rhip_pairwise(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A
     return b ? rhip_pairwise_end(b) : nullptr;
 }
 
-extern "C" int rhip_pairwise_cardinality(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A, rhip_pool_t* B, size_t npairs,
-                                         const uint32_t* lhs, const uint32_t* rhs, uint64_t* out) {
+static int pairwise_cardinality_impl(rhip_ctx_t* c, rhip_op op_, rhip_pool_t* A, rhip_pool_t* B, size_t npairs,
+                                     const uint32_t* lhs, const uint32_t* rhs, uint64_t* out, rhip_pairlist_t* L) {
     try {
         if (!c) { set_err("null context"); throw (int)RHIP_ERR_ARG; }
         int op = (int)op_;
@@ -1795,7 +1846,7 @@ extern "C" int rhip_pairwise_cardinality(rhip_ctx_t* c, rhip_op op_, rhip_pool_t
             if ((e = rhip_pool_cardinalities(B, cB.data())) != 0) throw e;
         }
         if (c->timing) HIPCHK(hipEventRecord(c->ev[0], s));
-        Plan P = plan(c, OpSet{}, A, B, npairs, lhs, rhs, 1, rhip_ctx_s::SYNC_SLOT, s);
+        Plan P = plan(c, OpSet{}, A, B, npairs, lhs, rhs, 1, rhip_ctx_s::SYNC_SLOT, s, nullptr, L);
         OutView O{};
         PoolView VA = A->view(), VB = B->view();
         run_kernels(c, OpSet{}, VA, VB, O, P, 1);
@@ -1813,6 +1864,95 @@ extern "C" int rhip_pairwise_cardinality(rhip_ctx_t* c, rhip_op op_, rhip_pool_t
         }
         return RHIP_OK;
     } catch (int e) { return e; }
+}
+
+extern "C" int rhip_pairwise_cardinality(rhip_ctx_t* c, rhip_op op, rhip_pool_t* A, rhip_pool_t* B, size_t npairs,
+                                         const uint32_t* lhs, const uint32_t* rhs, uint64_t* out) {
+    return pairwise_cardinality_impl(c, op, A, B, npairs, lhs, rhs, out, nullptr);
+}
+
+// ------------------------------------------------------------------ prepared pair lists (roaring_hip.h)
+static rhip_pairlist_t* pairlist_make(rhip_ctx_t* c, rhip_pool_t* A, rhip_pool_t* B, std::vector<uint32_t>&& lhs,
+                                      std::vector<uint32_t>&& rhs) {
+    rhip_pairlist_t* L = nullptr;
+    try {
+        if (!c) { set_err("null context"); throw (int)RHIP_ERR_ARG; }
+        check_pair_args(A, B, lhs.size(), lhs.data(), rhs.data());
+        DeviceGuard dguard_(c->device);
+        L = new rhip_pairlist_s();
+        L->ctx = c; L->A = A; L->B = B;
+        L->npairs = lhs.size();
+        L->lhs = std::move(lhs);
+        L->rhs = std::move(rhs);
+        fetch_bounds(A);
+        fetch_bounds(B);
+        L->sums = pair_sums(A, B, L->npairs, L->lhs.data(), L->rhs.data());  // (range-checks every index)
+        L->genA = A->bounds_gen; L->genB = B->bounds_gen;
+        L->d_idx.ensure(8 * L->npairs + 16);
+        if (L->npairs) {
+            HIPCHK(hipMemcpyAsync(L->d_idx.p, L->lhs.data(), 4 * L->npairs, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync((char*)L->d_idx.p + 4 * L->npairs, L->rhs.data(), 4 * L->npairs, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+        return L;
+    } catch (int e) {
+        last_status() = e;
+        if (L) { L->d_idx.release(); delete L; }
+        return nullptr;
+    }
+}
+extern "C" rhip_pairlist_t* rhip_pairlist_create(rhip_ctx_t* c, rhip_pool_t* A, rhip_pool_t* B, size_t npairs,
+                                                 const uint32_t* lhs, const uint32_t* rhs) {
+    if (npairs && (!lhs || !rhs)) { set_err("null pair index array"); last_status() = RHIP_ERR_ARG; return nullptr; }
+    return pairlist_make(c, A, B, std::vector<uint32_t>(lhs, lhs + npairs), std::vector<uint32_t>(rhs, rhs + npairs));
+}
+extern "C" rhip_pairlist_t* rhip_pairlist_all_pairs(rhip_ctx_t* c, rhip_pool_t* A) {
+    if (!A) { set_err("null pool"); last_status() = RHIP_ERR_ARG; return nullptr; }
+    const uint64_t n = A->n_bitmaps, np = n * (n ? n - 1 : 0) / 2;
+    if (np >= 0x3FFFFFF0ull) { set_err("too many pairs"); last_status() = RHIP_ERR_ARG; return nullptr; }
+    std::vector<uint32_t> l, r;
+    l.reserve((size_t)np); r.reserve((size_t)np);
+    for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t j = i + 1; j < n; ++j) { l.push_back(i); r.push_back(j); }
+    return pairlist_make(c, A, A, std::move(l), std::move(r));
+}
+extern "C" rhip_pairlist_t* rhip_pairlist_successive(rhip_ctx_t* c, rhip_pool_t* A) {
+    if (!A) { set_err("null pool"); last_status() = RHIP_ERR_ARG; return nullptr; }
+    std::vector<uint32_t> l, r;
+    for (uint32_t i = 0; i + 1 < A->n_bitmaps; ++i) { l.push_back(i); r.push_back(i + 1); }
+    return pairlist_make(c, A, A, std::move(l), std::move(r));
+}
+extern "C" size_t rhip_pairlist_size(const rhip_pairlist_t* L) { return L ? L->npairs : 0; }
+extern "C" int rhip_pairlist_pairs(const rhip_pairlist_t* L, uint32_t* lhs, uint32_t* rhs) {
+    if (!L) { set_err("null pair list"); return RHIP_ERR_ARG; }
+    if (lhs && L->npairs) memcpy(lhs, L->lhs.data(), 4 * L->npairs);
+    if (rhs && L->npairs) memcpy(rhs, L->rhs.data(), 4 * L->npairs);
+    return RHIP_OK;
+}
+extern "C" void rhip_pairlist_free(rhip_pairlist_t* L) {
+    if (!L) return;
+    if (L->in_use > 0) { L->free_deferred = true; return; }  // released by the last batch that reads it (rhip_pairwise_end)
+    L->d_idx.release();
+    delete L;
+}
+extern "C" rhip_batch_t* rhip_pairwise_list_begin(rhip_ctx_t* c, size_t n_ops, const rhip_op* ops, rhip_pairlist_t* L,
+                                                 rhip_pool_t* reuse) {
+    if (!L || L->free_deferred) {
+        set_err("null (or freed) pair list");
+        last_status() = RHIP_ERR_ARG;
+        if (reuse && !(reuse->pending || reuse->in_use)) { reuse->release(); delete reuse; }  // consumed, as everywhere
+        return nullptr;
+    }
+    return pairwise_begin_ops(c, n_ops, ops, L->A, L->B, L->npairs, L->lhs.data(), L->rhs.data(), reuse, L);
+}
+extern "C" rhip_pool_t* rhip_pairwise_list(rhip_ctx_t* c, size_t n_ops, const rhip_op* ops, rhip_pairlist_t* L,
+                                           rhip_pool_t* reuse) {
+    rhip_batch_t* b = rhip_pairwise_list_begin(c, n_ops, ops, L, reuse);
+    return b ? rhip_pairwise_end(b) : nullptr;
+}
+extern "C" int rhip_pairwise_list_cardinality(rhip_ctx_t* c, rhip_op op, rhip_pairlist_t* L, uint64_t* out) {
+    if (!L || L->free_deferred) { set_err("null (or freed) pair list"); return RHIP_ERR_ARG; }
+    return pairwise_cardinality_impl(c, op, L->A, L->B, L->npairs, L->lhs.data(), L->rhs.data(), out, L);
 }
 
 // host-side phase clock of rhip_pairwise, microseconds accumulated since the last reset: [0] pair-list passes,

@@ -14,6 +14,17 @@
 #pragma once
 #include "rhip_array.h"
 
+// the streamed operand of an item (all by value: a reference to a work item would put it on the stack)
+struct YSide { u64 off; uint32_t n; bool in_a; };
+__device__ __forceinline__ YSide filt_y_side(int op, uint32_t types, uint32_t ca, uint32_t cb, u64 offa, u64 offb) {
+    const bool ya = filt_y_is_a(op, types & 0xFF, types >> 8, ca, cb);
+    return YSide{ya ? offa : offb, ya ? ca : cb, ya};
+}
+__device__ __forceinline__ YSide union_y_side(int op, uint32_t types, uint32_t ca, uint32_t cb, u64 offa, u64 offb) {
+    const bool xa = union_x_is_a(op, types & 0xFF, types >> 8, ca, cb);
+    return YSide{xa ? offb : offa, xa ? cb : ca, !xa};
+}
+
 // ------------------------------------------------------------------ grouped filter
 // As filter_body (rhip_array.h), but the 8 KiB LDS image of X survives from item to item.
 template <bool STAGED>
@@ -31,10 +42,24 @@ __device__ __forceinline__ void filter_g_body(uint32_t* __restrict__ lds, uint32
     const uint32_t wend = w + chunk < n ? w + chunk : n;
     if (w >= wend) return;
     const uint8_t* cur_x = nullptr;  // the container whose image the wave holds
-    FatItem tnext = q[w];
+    // Two items ahead: the work item after next is fetched (scalar loads: w is wave-uniform) while the FIRST 512 values of
+    // the next item's Y are already in flight -- item -> pointer -> payload is a chain of two dependent round trips that
+    // a wave walking eight items in a row would otherwise wait out eight times.
+    FatItem tnext = q[w], tnext2 = q[w + 1 < wend ? w + 1 : wend - 1];  // (clamped index: no conditional copy of an item)
+    uint4 ycur = make_uint4(0, 0, 0, 0);
+    {
+        const YSide y = filt_y_side(item_op(kop, tnext.types), tnext.types, tnext.ca, tnext.cb, tnext.offa, tnext.offb);
+        if (8 * lane < y.n) ycur = ((const uint4*)((y.in_a ? arenaA : arenaB) + y.off))[lane];
+    }
     for (; w < wend; ++w) {
         const FatItem t = tnext;
-        if (w + 1 < wend) tnext = q[w + 1];  // next work item in flight while this one is processed
+        tnext = tnext2;
+        tnext2 = q[w + 2 < wend ? w + 2 : wend - 1];
+        uint4 ynext = make_uint4(0, 0, 0, 0);
+        if (w + 1 < wend) {
+            const YSide y = filt_y_side(item_op(kop, tnext.types), tnext.types, tnext.ca, tnext.cb, tnext.offa, tnext.offb);
+            if (8 * lane < y.n) ynext = ((const uint4*)((y.in_a ? arenaA : arenaB) + y.off))[lane];
+        }
         const int op = item_op(kop, t.types);
         const uint8_t ta = (uint8_t)(t.types & 0xFF), tb = (uint8_t)(t.types >> 8);
         const uint32_t ca = t.ca, cb = t.cb;
@@ -46,8 +71,8 @@ __device__ __forceinline__ void filter_g_body(uint32_t* __restrict__ lds, uint32
         const bool keep_present = op == OP_AND;
         const uint4* __restrict__ y4 = (const uint4*)yp;
         const uint4* __restrict__ x4 = (const uint4*)xp;
-        uint4 yfirst = make_uint4(0, 0, 0, 0);
-        if (8 * lane < ny) yfirst = y4[lane];  // first 512 values of Y: in flight while X is staged (if it is)
+        const uint4 yfirst = ycur;  // first 512 values of Y: loaded while the previous item was worked on
+        ycur = ynext;
         if (xp != cur_x) {
             cur_x = xp;
             if (x_bitset) {
@@ -107,7 +132,7 @@ __device__ __forceinline__ void filter_g_body(uint32_t* __restrict__ lds, uint32
                 if ((keepmask >> h) & 1u) ST[pos++] = (uint16_t)vals[h];
             __builtin_amdgcn_wave_barrier();
             const uint32_t filled = carry + tot, nfull = filled >> 3;
-            for (uint32_t j = lane; j < nfull; j += 64) po4[(run >> 3) + j] = ((const uint4*)ST)[j];
+            for (uint32_t j = lane; j < nfull; j += 64) out_store16(&po4[(run >> 3) + j], ((const uint4*)ST)[j]);
             carry = filled & 7u;
             uint16_t keep = 0;
             if (lane < carry) keep = ST[8u * nfull + lane];
@@ -117,7 +142,7 @@ __device__ __forceinline__ void filter_g_body(uint32_t* __restrict__ lds, uint32
         }
         if (!cardmode) {
             __builtin_amdgcn_wave_barrier();
-            if (carry && lane == 0) po4[run >> 3] = ((const uint4*)ST)[0];  // (the slot is padded to 16 bytes)
+            if (carry && lane == 0) out_store16(&po4[run >> 3], ((const uint4*)ST)[0]);  // (the slot is padded to 16 bytes)
             run += carry;
         }
         if (cardmode) {
@@ -183,7 +208,7 @@ __device__ __forceinline__ void wave_extract_groups(const u32x4 (&r)[8], const u
     __builtin_amdgcn_wave_barrier();
     const uint32_t n16 = (2u * rc + 15u) >> 4;
     uint4* __restrict__ po = (uint4*)outp;
-    for (uint32_t i = lane; i < n16; i += 64) po[i] = ((const uint4*)img)[i];
+    for (uint32_t i = lane; i < n16; i += 64) out_store16(&po[i], ((const uint4*)img)[i]);
 }
 
 template <int OP>
@@ -204,10 +229,22 @@ __device__ __forceinline__ void union_g_body(uint32_t* __restrict__ lds, uint32_
     u32x4 vx[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) vx[i] = (u32x4)(0u);
-    FatItem tnext = q[w];
+    // two items ahead, as in filter_g_body: the next item's first 512 values of Y are in flight while this one is worked on
+    FatItem tnext = q[w], tnext2 = q[w + 1 < wend ? w + 1 : wend - 1];  // (clamped index: no conditional copy of an item)
+    uint4 ycur = make_uint4(0, 0, 0, 0);
+    {
+        const YSide y = union_y_side(item_op(OP, tnext.types), tnext.types, tnext.ca, tnext.cb, tnext.offa, tnext.offb);
+        if (8 * lane < y.n) ycur = ((const uint4*)((y.in_a ? arenaA : arenaB) + y.off))[lane];
+    }
     for (; w < wend; ++w) {
         const FatItem t = tnext;
-        if (w + 1 < wend) tnext = q[w + 1];
+        tnext = tnext2;
+        tnext2 = q[w + 2 < wend ? w + 2 : wend - 1];
+        uint4 ynext = make_uint4(0, 0, 0, 0);
+        if (w + 1 < wend) {
+            const YSide y = union_y_side(item_op(OP, tnext.types), tnext.types, tnext.ca, tnext.cb, tnext.offa, tnext.offb);
+            if (8 * lane < y.n) ynext = ((const uint4*)((y.in_a ? arenaA : arenaB) + y.off))[lane];
+        }
         const int op = item_op(OP, t.types);
         const uint8_t ta = (uint8_t)(t.types & 0xFF), tb = (uint8_t)(t.types >> 8);
         const uint32_t ca = t.ca, cb = t.cb;
@@ -216,8 +253,8 @@ __device__ __forceinline__ void union_g_body(uint32_t* __restrict__ lds, uint32_
         const uint32_t cx = x_is_a ? ca : cb, cy = x_is_a ? cb : ca;
         const uint8_t* xp = x_is_a ? arenaA + t.offa : arenaB + t.offb;
         const uint4* __restrict__ y4 = (const uint4*)(x_is_a ? arenaB + t.offb : arenaA + t.offa);
-        uint4 yfirst = make_uint4(0, 0, 0, 0);
-        if (8 * lane < cy) yfirst = y4[lane];  // first 512 values of Y: in flight while the image is prepared
+        const uint4 yfirst = ycur;
+        ycur = ynext;
         const uint4 z = make_uint4(0, 0, 0, 0);
         if (xp != cur_x) {
             cur_x = xp;
@@ -280,7 +317,7 @@ __device__ __forceinline__ void union_g_body(uint32_t* __restrict__ lds, uint32_
         if (rc && ty == T_BITSET) {
             u32x4* __restrict__ po = (u32x4*)outp;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) po[i * 64 + lane] = r[i];
+            for (int i = 0; i < 8; ++i) out_store16(&po[i * 64 + lane], r[i]);
         } else if (rc) {
             __builtin_amdgcn_wave_barrier();  // every lane has read its groups of Y's image: it is the staging buffer now
             wave_extract_groups(r, cnt, img, lane, rc, outp);

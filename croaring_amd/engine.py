@@ -264,6 +264,56 @@ class Engine:
             raise RoaringHipError(f"pairwise_begin {op} failed: " + err)
         return Batch(self, h, (A, B))
 
+    # ---- prepared pair lists (rhip_pairlist_*): a list used more than once is validated / summed / uploaded once ----
+    def pairlist(self, A: "Pool", lhs, B: Optional["Pool"] = None, rhs=None) -> "PairList":
+        B = A if B is None else B
+        lhs, rhs = _pair_ids(lhs, rhs)
+        h = self.lib.rhip_pairlist_create(self.h, A.h, B.h, lhs.size, lhs.ctypes.data, rhs.ctypes.data)
+        if not h:
+            raise RoaringHipError("pairlist failed: " + self._err())
+        return PairList(self, h, (A, B))
+
+    def pairlist_all_pairs(self, A: "Pool") -> "PairList":
+        """All unordered pairs (i < j) of one pool, row by row -- the reference benchmark's all-pairs loops."""
+        h = self.lib.rhip_pairlist_all_pairs(self.h, A.h)
+        if not h:
+            raise RoaringHipError("pairlist_all_pairs failed: " + self._err())
+        return PairList(self, h, (A, A))
+
+    def pairlist_successive(self, A: "Pool") -> "PairList":
+        """Successive bitmaps (i, i + 1) -- the reference benchmark's successive_* loops."""
+        h = self.lib.rhip_pairlist_successive(self.h, A.h)
+        if not h:
+            raise RoaringHipError("pairlist_successive failed: " + self._err())
+        return PairList(self, h, (A, A))
+
+    def _ops_codes(self, ops):
+        ops = [ops] if isinstance(ops, str) else list(ops)
+        return ops, (C.c_int * len(ops))(*[OPS[o] for o in ops])
+
+    def pairwise_list(self, ops, plist: "PairList", reuse: Optional["Pool"] = None) -> "Pool":
+        """`pairwise` (ops = one name) or `pairwise_multi` (a list of names) over a prepared pair list."""
+        return self.pairwise_list_begin(ops, plist, reuse).end()
+
+    def pairwise_list_begin(self, ops, plist: "PairList", reuse: Optional["Pool"] = None) -> "Batch":
+        ops, codes = self._ops_codes(ops)
+        rh = None
+        if reuse is not None:
+            rh, reuse.h = reuse.h, None  # consumed
+        h = self.lib.rhip_pairwise_list_begin(self.h, len(ops), codes, plist.h, rh)
+        if not h:
+            err = self._err()
+            if reuse is not None and "still in flight" in err:
+                reuse.h = rh
+            raise RoaringHipError(f"pairwise_list_begin {ops} failed: " + err)
+        return Batch(self, h, (plist,) + tuple(plist._operands))
+
+    def pairwise_list_cardinality(self, op: str, plist: "PairList") -> np.ndarray:
+        out = np.zeros(len(plist), dtype=np.uint64)
+        if self.lib.rhip_pairwise_list_cardinality(self.h, OPS[op], plist.h, out.ctypes.data) != 0:
+            raise RoaringHipError(f"pairwise_list_cardinality {op} failed: " + self._err())
+        return out
+
     def pairwise_cardinality(self, op: str, A: "Pool", lhs, B: Optional["Pool"] = None, rhs=None) -> np.ndarray:
         """roaring_bitmap_{and,or,xor,andnot}_cardinality batched."""
         B = A if B is None else B
@@ -424,6 +474,34 @@ class PartialChunks:
         if self.p is not None:
             self.eng.lib.rhip_partials_free(self.eng.h, C.byref(self.p))
             self.p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class PairList:
+    """A prepared pair list (rhip_pairlist_t); keeps its operand pools alive."""
+
+    def __init__(self, engine: "Engine", handle, operands):
+        self.engine, self.h, self._operands = engine, handle, operands
+
+    def __len__(self) -> int:
+        return int(self.engine.lib.rhip_pairlist_size(self.h))
+
+    def pairs(self):
+        n = len(self)
+        lhs, rhs = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)
+        if self.engine.lib.rhip_pairlist_pairs(self.h, lhs.ctypes.data, rhs.ctypes.data) != 0:
+            raise RoaringHipError(self.engine._err())
+        return lhs, rhs
+
+    def free(self):
+        if getattr(self, "h", None) and self.engine is not None and self.engine.h:
+            self.engine.lib.rhip_pairlist_free(self.h)
+        self.h = None
 
     def __del__(self):
         try:

@@ -183,6 +183,32 @@ rhip_pool_t *rhip_pairwise_multi(rhip_ctx_t *ctx, size_t n_ops, const rhip_op *o
 rhip_batch_t *rhip_pairwise_multi_begin(rhip_ctx_t *ctx, size_t n_ops, const rhip_op *ops, rhip_pool_t *A,
                                         rhip_pool_t *B, size_t npairs, const uint32_t *lhs, const uint32_t *rhs,
                                         rhip_pool_t *reuse);
+/* ---- prepared pair lists --------------------------------------------------------------------------------------------
+ * The reference has no pair list: its benchmark walks the bitmaps -- every op of every unordered pair, or of
+ * successive bitmaps (benchmarks/benchmark.cpp:2035-2091, "successive_*" / "*_all_pairs" loops) -- and a query engine
+ * evaluates the same pairs again and again with different ops.  A pair list that is used more than once is prepared
+ * ONCE: validated, its indices resident on the device, the sums that size a batch (container counts, result-slot
+ * bounds) taken.  Batches over it then skip the host's pass over the pairs and the staging copy -- 25-40 us of a
+ * 20 000-pair call -- and are otherwise exactly rhip_pairwise / _multi / _cardinality: same kernels, same results.
+ * The operand pools must outlive the list; if one of them is updated in place (or recycled) the list re-validates itself
+ * at its next use.  rhip_pairlist_free while batches over the list are in flight is deferred to the last of them. */
+typedef struct rhip_pairlist_s rhip_pairlist_t;
+rhip_pairlist_t *rhip_pairlist_create(rhip_ctx_t *ctx, rhip_pool_t *A, rhip_pool_t *B, size_t npairs,
+                                      const uint32_t *lhs, const uint32_t *rhs);
+/* all unordered pairs (i, j), i < j, of one pool, row by row: n (n - 1) / 2 pairs */
+rhip_pairlist_t *rhip_pairlist_all_pairs(rhip_ctx_t *ctx, rhip_pool_t *A);
+/* successive bitmaps (i, i + 1): n - 1 pairs */
+rhip_pairlist_t *rhip_pairlist_successive(rhip_ctx_t *ctx, rhip_pool_t *A);
+size_t rhip_pairlist_size(const rhip_pairlist_t *list);
+/* the pairs themselves (lhs / rhs: rhip_pairlist_size entries each; either may be NULL) */
+int rhip_pairlist_pairs(const rhip_pairlist_t *list, uint32_t *lhs, uint32_t *rhs);
+void rhip_pairlist_free(rhip_pairlist_t *list);
+/* rhip_pairwise_multi_begin / rhip_pairwise_multi / rhip_pairwise_cardinality over a prepared list (n_ops = 1: rhip_pairwise) */
+rhip_batch_t *rhip_pairwise_list_begin(rhip_ctx_t *ctx, size_t n_ops, const rhip_op *ops, rhip_pairlist_t *list,
+                                       rhip_pool_t *reuse);
+rhip_pool_t *rhip_pairwise_list(rhip_ctx_t *ctx, size_t n_ops, const rhip_op *ops, rhip_pairlist_t *list,
+                                rhip_pool_t *reuse);
+int rhip_pairwise_list_cardinality(rhip_ctx_t *ctx, rhip_op op, rhip_pairlist_t *list, uint64_t *out);
 /* roaring_bitmap_{and,or,xor,andnot}_cardinality (roaring.h:231,258,270,264;
  * src/roaring.c:3048-3107): nothing is materialised. */
 int rhip_pairwise_cardinality(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *A, rhip_pool_t *B, size_t npairs,

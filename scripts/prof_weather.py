@@ -35,11 +35,12 @@ if len(sys.argv) > 3 and sys.argv[3] == "pipe":
     dt = (time.perf_counter() - t0) / 24
     print(op, name, "pipelined min ms", dt * 1e3, "host us/batch:", [round(x / 24, 1) for x in eng.host_clock()][:6])
     sys.exit(0)
+plist = eng.pairlist_all_pairs(pool) if os.environ.get("LIST", "0") == "1" else None  # LIST=1: prepared pair list
 for it in range(12):
     if it == 2:
         eng.host_clock(True)
     t = time.perf_counter()
-    res = eng.pairwise(op, pool, lhs, pool, rhs, reuse=res)
+    res = eng.pairwise_list(op, plist, reuse=res) if plist is not None else eng.pairwise(op, pool, lhs, pool, rhs, reuse=res)
     ts.append(time.perf_counter() - t)
 hc = [round(x / 10, 1) for x in eng.host_clock()]
 print(op, name, "min ms", min(ts) * 1e3, "mean(last 10) ms", sum(ts[2:]) / 10 * 1e3,

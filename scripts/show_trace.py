@@ -3,7 +3,7 @@ import csv, glob, sys
 for name in sys.argv[1:]:
     f = glob.glob(f'gpurun_out/prof_r2/{name}/*kernel_trace.csv')[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-    idx = [i for i, r in enumerate(rows) if 'k_count' in r['Kernel_Name'] or 'k_plan' in r['Kernel_Name']]
+    idx = [i for i, r in enumerate(rows) if "k_count" in r["Kernel_Name"] or "k_plan" in r["Kernel_Name"]]
     i0, i1 = idx[-2], idx[-1]
     t0 = int(rows[i0]['Start_Timestamp'])
     print('==', name)

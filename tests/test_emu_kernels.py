@@ -246,6 +246,10 @@ def test_emu_tiny_interval_pairs(emu, oracle):
     G.test_tiny_interval_pairs(emu, oracle)
 
 
+def test_emu_prepared_pair_lists(emu, oracle, synth):
+    G.test_prepared_pair_lists(emu, oracle, synth)
+
+
 def test_emu_tiny_passthrough_containers(emu, oracle):
     G.test_tiny_passthrough_containers(emu, oracle)
 
@@ -279,6 +283,8 @@ def test_emu_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
         G.test_synth_every_type_pair(eng, oracle, synth, "andnot")
         if mode == "nomerge":
             G.test_tiny_passthrough_containers(eng, oracle)
+        if mode == "1":
+            G.test_prepared_pair_lists(eng, oracle, synth)
         if mode in ("fork", "nomerge"):
             G.test_synth_every_type_pair(eng, oracle, synth, "and")
             G.test_synth_every_type_pair(eng, oracle, synth, "or")

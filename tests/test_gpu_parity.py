@@ -680,6 +680,73 @@ def test_tiny_interval_pairs(engine, oracle):
         oracle.free(h)
 
 
+def test_prepared_pair_lists(engine, oracle, synth):
+    """rhip_pairlist_*: a pair list prepared once (validated, summed, resident on the device); batches over it are
+    byte-identical to the ad-hoc calls -- single op, several ops in one batch, cardinalities, two batches in flight,
+    the all-pairs / successive generators (benchmarks/benchmark.cpp:2035-2091) -- and the list re-validates itself when
+    an operand pool changes under it (in-place update)."""
+    bufs, _, _ = synth
+    pool = engine.pool_from_serialized(bufs)
+    n = len(bufs)
+    rng = np.random.default_rng(4242)
+    lhs = rng.integers(0, n, 300).astype(np.uint32)
+    rhs = rng.integers(0, n, 300).astype(np.uint32)
+    pl = engine.pairlist(pool, lhs, pool, rhs)
+    assert len(pl) == 300 and all(np.array_equal(a, b) for a, b in zip(pl.pairs(), (lhs, rhs)))
+    for op in OPS:
+        want = engine.pairwise(op, pool, lhs, pool, rhs)
+        got = engine.pairwise_list(op, pl)
+        assert np.array_equal(got.serialize_many()[0], want.serialize_many()[0]), op
+        assert np.array_equal(engine.pairwise_list_cardinality(op, pl), want.cardinalities()), op
+        got = engine.pairwise_list(op, pl, reuse=got)  # recycled result pool
+        assert np.array_equal(got.serialize_many()[0], want.serialize_many()[0]), op
+    wm = engine.pairwise_multi(["xor", "and", "or"], pool, lhs, pool, rhs)
+    gm = engine.pairwise_list(["xor", "and", "or"], pl)
+    assert np.array_equal(gm.serialize_many()[0], wm.serialize_many()[0])
+    b1 = engine.pairwise_list_begin("or", pl)
+    b2 = engine.pairwise_list_begin(["andnot"], pl)
+    pl_small = engine.pairlist(pool, lhs[:5], pool, rhs[:5])
+    b3 = engine.pairwise_list_begin("and", pl_small)
+    pl_small.free()  # deferred: b3 still reads it
+    r2, r1, r3 = b2.end(), b1.end(), b3.end()
+    assert np.array_equal(r1.serialize_many()[0], engine.pairwise("or", pool, lhs, pool, rhs).serialize_many()[0])
+    assert np.array_equal(r2.serialize_many()[0], engine.pairwise("andnot", pool, lhs, pool, rhs).serialize_many()[0])
+    assert np.array_equal(r3.serialize_many()[0], engine.pairwise("and", pool, lhs[:5], pool, rhs[:5]).serialize_many()[0])
+    # generators
+    ns = 48
+    small = engine.pool_from_serialized(bufs[100:100 + ns])
+    ap = engine.pairlist_all_pairs(small)
+    L, R = all_pairs(ns)
+    assert all(np.array_equal(a, b) for a, b in zip(ap.pairs(), (L, R)))
+    assert np.array_equal(engine.pairwise_list("xor", ap).serialize_many()[0],
+                          engine.pairwise("xor", small, L, small, R).serialize_many()[0])
+    sc = engine.pairlist_successive(pool)
+    k = np.arange(n - 1, dtype=np.uint32)
+    assert all(np.array_equal(a, b) for a, b in zip(sc.pairs(), (k, k + 1)))
+    assert np.array_equal(engine.pairwise_list("andnot", sc).serialize_many()[0],
+                          engine.pairwise("andnot", pool, k, pool, k + 1).serialize_many()[0])
+    # an operand updated in place under the list: the next batch over it sees the new pool (bounds re-taken)
+    p2 = engine.pool_from_serialized(bufs)
+    pl2 = engine.pairlist(p2, lhs, p2, rhs)
+    engine.pairwise_list("or", pl2)
+    upd = np.arange(0, n, 3, dtype=np.uint32)
+    engine.pairwise_inplace("or", p2, upd, p2, (upd + 1) % n)
+    got = engine.pairwise_list("or", pl2)
+    want = engine.pairwise("or", p2, lhs, p2, rhs)
+    assert np.array_equal(got.serialize_many()[0], want.serialize_many()[0])
+    hs = [oracle.deserialize(b) for b in bufs]
+    for i in upd[:20]:
+        o = oracle.op("or", hs[i], hs[(i + 1) % n])
+        assert p2.serialize(int(i)) == oracle.serialize(o)
+        oracle.free(o)
+    for h in hs:
+        oracle.free(h)
+    # errors: an index out of range is refused when the list is made
+    with pytest.raises(Exception):
+        engine.pairlist(pool, np.array([0, n], np.uint32), pool, np.array([0, 0], np.uint32))
+    assert len(engine.pairwise_list("and", engine.pairlist(pool, np.zeros(0, np.uint32), pool, np.zeros(0, np.uint32)))) == 0
+
+
 def test_tiny_passthrough_containers(engine, oracle):
     """Pass-through containers of sparse bitmaps: the pool averages well under 96 payload bytes per container, so k_copy
     takes SIXTEEN items per wave (four lanes each).  Bitmaps with disjoint key sets (everything passes through under or /
@@ -827,6 +894,8 @@ def test_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
             test_synth_every_type_pair(eng, oracle, synth, op)
         if mode == "nomerge":
             test_tiny_passthrough_containers(eng, oracle)  # k_copy itself at sixteen items per wave
+        if mode == "1":
+            test_prepared_pair_lists(eng, oracle, synth)   # a prepared list whose batches stage explicit units
     finally:
         eng.close()
 
