@@ -1316,6 +1316,7 @@ Plan plan(rhip_ctx_t* c, const OpSet& ops, rhip_pool_t* A, rhip_pool_t* B, size_
     }
     // (Letting the planning kernels read two short index lists in place from the pinned staging area was measured:
     // the PCIe round trips inside k_count / k_emit cost 25 us more per batch than the copy command they replace.)
+    if (clk) clk->lap(6);  // ([6]: sizing + scratch; [1]: the staging of the batch description alone)
     char* dp = (char*)SS.plan_in.p;
     P.d_pair0 = (u64*)(dp + o_pair0);
     P.d_lhs = (uint32_t*)(dp + o_lhs);
