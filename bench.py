@@ -526,38 +526,38 @@ def run_ormany_x10(args, eng, D: Dist):
 
 def run_shard_stages(args, eng, D: Dist, n_bitmaps: int):
     """What ONE rank of an N-rank group would pay for the sharded or_many, measured on one GPU: stage 1
-    (rhip_many_partials_dense over the bitmaps b mod N == 0, into a world = N send table) and stage 3
+    (rhip_many_partials_dense over rank 0's pool -- the bitmaps b mod N == 0 -- into a world = N send table) and stage 3
     (rhip_many_finalize_dense over a world = N receive table), each timed to completion.  The all-to-all between them
     is what a single GPU cannot show.  Beside each N: DESIGN 7a's model for the same two stages."""
     import torch
     import croaring_amd
     from croaring_amd.distributed import dense_block, shard_ids
-    blob, offs = croaring_amd.synth_sparse_portable(0, 1, n_bitmaps)
-    pool = eng.pool_from_blob(blob, offs)
-    del blob
     dev = eng.torch_device()
     rows = {}
     for N in (1, 2, 4, 8):
+        # rank 0's own pool, as bench.py --gpus N builds it: bitmaps 0, N, 2 N, ... (no selection list: the whole pool)
+        blob, offs = croaring_amd.synth_sparse_portable(0, N, (n_bitmaps + N - 1) // N)
+        pool = eng.pool_from_blob(blob, offs)
+        del blob
         B = dense_block(4096, N)
-        ids = shard_ids(n_bitmaps, 0, N) if N > 1 else None
         with eng.torch_stream():
             table = torch.empty((N * B, 1024), dtype=torch.int64, device=dev)
         t1, t3 = [], []
-        for it in range(7):
+        for it in range(9):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            eng.many_partials_dense("or", pool, ids, 4096, N, table.data_ptr())
+            eng.many_partials_dense("or", pool, None, 4096, N, table.data_ptr())
             eng.synchronize()
             ta = time.perf_counter()
             res = eng.many_finalize_dense("or", False, N, 0, B, table.data_ptr())  # (rows of N "sources": this rank's own, N times over)
             tb = time.perf_counter()
             res.free()
-            if it >= 2:
+            if it >= 3:
                 t1.append(ta - t0)
                 t3.append(tb - ta)
         rows[str(N)] = {"stage1_ms": float(np.median(t1)) * 1e3, "stage3_ms": float(np.median(t3)) * 1e3,
                         "model_stage1_ms": 0.10 + 0.69 / N, "model_stage3_ms": 0.03}
-    pool.free()
+        pool.free()
     return rows
 
 

@@ -58,6 +58,7 @@ struct DBuf {
     void* base = nullptr;  // the allocation; p = base + skew
     size_t skew = 0;       // set before the first ensure(): see rhip_ctx_s::arena_skew
     size_t round_to = 0;   // allocations at least this large are rounded up to a multiple of it
+    bool pow2_large = false;  // allocations of 1 GiB and more take the next power of two, no slack (see rhip_ctx_s::arena_pow2)
     uint64_t gen = 0;      // bumped by every (re)allocation: "is this still the memory I initialised?"
     void ensure(size_t n) {
         if (n <= cap) return;
@@ -67,6 +68,11 @@ struct DBuf {
         cap = 0;
         size_t want = n + n / 8 + 256;
         if (round_to && want + skew >= round_to) want = (want + skew + round_to - 1) / round_to * round_to - skew;
+        if (pow2_large && n + skew >= (1ull << 30)) {
+            want = 1ull << 30;
+            while (want < n + skew) want <<= 1;
+            want -= skew;
+        }
         hipError_t e = hipMalloc(&base, want + skew);
         if (e != hipSuccess) {
             base = nullptr;
@@ -164,6 +170,13 @@ struct rhip_ctx_s {
     uint64_t dense_pipe = 0, dense_pipe_seq = 0;  // open dense many-way pipeline (rhip_many_partials_dense .. _finalize_dense), 0 = none
     size_t arena_skew = 0;  // result arenas start this many bytes into their allocation (RHIP_ARENA_SKEW)
     size_t arena_round = 0; // RHIP_ARENA_ROUND_MB
+    // Result arenas (and the synthetic bitset pool) of 1 GiB and more are allocated as POWERS OF TWO.  The bitset x bitset
+    // kernel streams two operands and one result in lockstep, and its time on C2 depends on how the driver's buddy
+    // allocator composes the buffers out of physical blocks (round 4, scripts/arena_place.hip, profiles/r04_arena_*):
+    // 8 / 16 GiB arenas beside an 8 GiB pool -- one naturally aligned block each -- gave 4.35-4.42 ms in 16 of 16 fresh
+    // allocations; 9.4 GB arenas (8 G + 1 G + 256 M + ... blocks) 4.37 or 4.64 ms, 7.8 GiB ones 3.97-4.40, by where the
+    // pieces happened to land.  A power of two costs address space (at most 2 x), never traffic.  RHIP_ARENA_POW2=0: off.
+    bool arena_pow2 = true;
     bool debug_plan = false;  // RHIP_DEBUG_PLAN=1: one line per batch on stderr (bounds, fork / merge decision)
     bool merge_classes = true;  // RHIP_MERGE_CLASSES=0: a small batch launches its class kernels one by one
     uint64_t merge_max_items = 256u << 10;  // ... "small" = at most that many matched container pairs (upper bound)
@@ -357,6 +370,7 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_DEBUG_PLAN")) c->debug_plan = e[0] == '1';
         if (const char* e = getenv("RHIP_MERGE_MAX_K")) c->merge_max_items = strtoull(e, nullptr, 0) << 10;
         if (const char* e = getenv("RHIP_ARENA_ROUND_MB")) c->arena_round = (size_t)strtoull(e, nullptr, 0) << 20;
+        if (const char* e = getenv("RHIP_ARENA_POW2")) c->arena_pow2 = !(e[0] == '0');
         if (const char* e = getenv("RHIP_ARENA_SKEW")) c->arena_skew = (size_t)strtoull(e, nullptr, 0) & ~(size_t)255;
         if (const char* e = getenv("RHIP_GROUP_X")) c->group_x = atoi(e);
         if (const char* e = getenv("RHIP_XG_CHUNK")) c->group_chunk = (uint32_t)std::max(1, atoi(e));
@@ -767,7 +781,12 @@ extern "C" rhip_pool_t* rhip_pool_synth_bitset(rhip_ctx_t* ctx, uint32_t n_bitma
         if (n_containers > 65536 || P->n_cont >= 0xFFFFFFF0ull) { set_err("bad synth shape"); throw (int)RHIP_ERR_ARG; }
         ensure_dir(P, n_bitmaps, P->n_cont);
         P->arena_used = P->n_cont * 8192ull + 64;
-        P->arena.ensure(P->arena_used);
+        {   // (a payload that IS a power of two -- 256 x 4096 containers = 8 GiB -- is allocated as exactly that: the 64 bytes
+            // of slack would double it, and no kernel reads past the last container of a bitset-only pool)
+            const uint64_t pay = P->n_cont * 8192ull;
+            P->arena.pow2_large = ctx->arena_pow2;
+            P->arena.ensure((ctx->arena_pow2 && pay >= (1ull << 30) && (pay & (pay - 1)) == 0) ? pay : P->arena_used);
+        }
         hipLaunchKernelGGL(k_synth_fill, dim3(256 * 16), dim3(256), 0, ctx->stream, P->arena.as<u64>(), n_bitmaps,
                            n_containers, (u64)seed);
         if (P->n_cont)
@@ -1714,6 +1733,7 @@ static rhip_batch_t* pairwise_begin_ops(rhip_ctx_t* c, size_t n_ops, const rhip_
         ensure_dir(R, (uint32_t)(npairs * n_ops), P.ub_cand);
         R->arena.skew = c->arena_skew;
         R->arena.round_to = c->arena_round;
+        R->arena.pow2_large = c->arena_pow2;
         R->arena.ensure(P.arena_bound + 64);
         OutView O{};
         O.key = CO.key; O.meta = c->ss[slot].o_meta.as<u64>(); O.off = CO.off; O.slot = nullptr;

@@ -103,6 +103,25 @@ uint64_t roaring64_bitmap_xor_cardinality(const roaring64_bitmap_t *r1, const ro
 uint64_t roaring64_bitmap_andnot_cardinality(const roaring64_bitmap_t *r1, const roaring64_bitmap_t *r2);     /* :515 */
 roaring64_bitmap_t *roaring64_bitmap_flip(const roaring64_bitmap_t *r, uint64_t min, uint64_t max);           /* :531 */
 
+/* ---- the reference's allocator hook (include/roaring/memory.h:29-38, src/memory.c:44-46) --------------------------
+ * The drop-ins above allocate every result through the reference's own roaring_malloc / roaring_aligned_malloc and
+ * release containers through roaring_free / roaring_aligned_free (resolved from the host program), so a memory hook the
+ * program installed with roaring_init_memory_hook is honoured in both directions.
+ * rhip_install_pinned_allocator installs a hook of this library's: a page-locked, device-mapped arena of `arena_bytes`
+ * (hipHostMalloc; 0 = 256 MiB) with size-class free lists -- every container the reference allocates afterwards is a
+ * valid DMA source / target; requests above 24 KiB, and all of them once the arena is full, fall through to the C
+ * library.  Call it before the first bitmap is created (blocks allocated earlier are still freed correctly: the hook
+ * tells its own blocks from the C library's by address).  0 on success; RHIP_ERR_ARG when the reference's
+ * roaring_init_memory_hook is not visible in the process, RHIP_ERR_ALLOC without a HIP device.
+ * rhip_pinned_allocator_stats: {arena bytes, bytes in use, blocks served from the arena, requests passed to the C library}. */
+int rhip_install_pinned_allocator(size_t arena_bytes);
+int rhip_pinned_allocator_stats(unsigned long long out[4]);
+
+/* Deliberately NOT drop-in symbols (they stay the reference's): roaring_bitmap_get_cardinality (roaring.h:537),
+ * roaring_bitmap_portable_deserialize_safe / _serialize / _size_in_bytes (roaring.h:746, 791, 807), point operations,
+ * iterators: host-trivial or latency-bound per call.  Their batched device forms are rhip_pool_cardinalities,
+ * rhip_pool_from_portable / _from_blob, rhip_pool_portable_serialize(_many) in roaring_hip.h. */
+
 #ifdef __cplusplus
 }
 #endif

@@ -182,7 +182,15 @@ int main(int argc, char** argv) {
         return 0;
     }
     const std::string pool_way = getenv("POOL_WAY") ? getenv("POOL_WAY") : "malloc";
-    Arena poolA = alloc_arena(pool_way, (u64)NBM * NC * 8192ull);
+    // SIZE_MODE=bench: pool and arenas sized as the engine's DBuf::ensure sizes them (n + n / 8 + 256) instead of exactly
+    const bool bench_size = getenv("SIZE_MODE") && !strcmp(getenv("SIZE_MODE"), "bench");
+    auto sized = [&](u64 n) { return bench_size ? n + n / 8 + 256 : n; };
+    // POOL_BYTES / ARENA_BYTES: allocation sizes in bytes (at least what is needed), overriding SIZE_MODE
+    const u64 pool_bytes = getenv("POOL_BYTES") ? strtoull(getenv("POOL_BYTES"), nullptr, 0) : sized((u64)NBM * NC * 8192ull + 64);
+    const u64 arena_bytes = getenv("ARENA_BYTES") ? strtoull(getenv("ARENA_BYTES"), nullptr, 0) : sized(nitems * 8192ull + 4096);
+    if (pool_bytes < (u64)NBM * NC * 8192ull || arena_bytes < nitems * 8192ull) { printf("POOL_BYTES / ARENA_BYTES too small\n"); return 1; }
+    printf("pool %llu bytes, arenas %llu bytes\n", (unsigned long long)pool_bytes, (unsigned long long)arena_bytes);
+    Arena poolA = alloc_arena(pool_way, pool_bytes);
     A = (uint8_t*)poolA.p;
     CK(hipMalloc(&meta, nitems * 8)); CK(hipMalloc(&q, nitems * sizeof(BBItem)));
     CK(hipMalloc(&rq, 1024 * sizeof(GenItem))); CK(hipMalloc(&rc, 64)); CK(hipMalloc(&qr, 64)); CK(hipMalloc(&acc, 8192));
@@ -212,7 +220,7 @@ int main(int argc, char** argv) {
     std::vector<Arena> kept;
     for (int t = 0; t < trials; ++t) {
         for (const std::string& way : wl) {
-            Arena a = alloc_arena(way, nitems * 8192ull + 4096);
+            Arena a = alloc_arena(way, arena_bytes);
             OutView O; O.key = nullptr; O.meta = meta; O.off = nullptr; O.arena = (uint8_t*)a.p; O.slot = nullptr;
             float best = 1e30f, first = 0;
             for (int r = 0; r < 3; ++r) {
