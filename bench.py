@@ -59,8 +59,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--arena-tries", type=int, default=12,
-                    help="start-up allocations of result pools, the two fastest kept (0: take the first; see Engine.pairwise_placed)")
+    ap.add_argument("--arena-tries", type=int, default=0,
+                    help="diagnostic: caller-side start-up allocations of result pools, the two fastest kept (Engine.pairwise_placed). "
+                         "0 (default): nothing -- the library places a large result arena by measurement itself (RHIP_ARENA_TRIES)")
     ap.add_argument("--pool", type=int, default=256, help="bitmaps in the pool")
     ap.add_argument("--containers", type=int, default=4096, help="bitset containers per bitmap")
     ap.add_argument("--pairs", type=int, default=250, help="bitmap pairs per batched call")
@@ -613,6 +614,7 @@ def main():
 
     pool = eng.pool_synth_bitset(args.pool, args.containers, SEED + 1000003 * rank)
     results = {"and": None, "or": None}
+    placement = {}
     bb_ms, bb_pairs = [], []
 
     def step(i: int, timed: bool):
@@ -631,7 +633,10 @@ def main():
         for r in range(args.rounds):
             for j, op in enumerate(("and", "or")):
                 lhs, rhs = schedule(((i * args.rounds + r) * 2 + j) * args.pairs, args.pairs, args.pool)
+                fresh = results[op] is None
                 b = eng.pairwise_begin(op, pool, lhs, pool, rhs, reuse=results[op])
+                if fresh:  # the library has just placed this result pool's arena (warm-up, untimed): keep its probe rates
+                    placement[op] = eng.last_placement()
                 results[op] = None
                 if pending is not None:
                     finish(pending)
@@ -695,10 +700,12 @@ def main():
                    "timed_region_s": dt,
                    "algorithmic_GBps": total_ops * args.containers * BB_BYTES_PER_PAIR / dt / 1e9,
                    "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective",
-                   "result_arena_startup": {"tries": args.arena_tries, "k_bb_ms_of_each_try": arena_probe,
-                                            "note": "untimed, before warm-up: the two recycled result pools are the two "
-                                                    "fastest of `tries` fresh allocations (physical page placement moves "
-                                                    "k_bb by 6 %; Engine.pairwise_placed)"}},
+                   "result_arena_placement": {"by": "library (rhip place_arena, untimed warm-up)" if args.arena_tries == 0 else "caller (Engine.pairwise_placed)",
+                                              "probe_GBps_of_each_candidate": placement if args.arena_tries == 0 else None,
+                                              "k_bb_ms_of_each_try": arena_probe or None,
+                                              "note": "the two recycled result pools: each arena is the fastest of the candidates the library "
+                                                      "probed when it allocated it (the physical distance between operand and result stream "
+                                                      "moves k_bb by up to 17 %, DESIGN 4a); RHIP_ARENA_TRIES=0 takes the first allocation"}},
         "roofline": {"bound": "hbm", "kernel": "k_bb (bitset x bitset fused op+popcount)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": ms_kernel,

@@ -101,6 +101,7 @@ SYMBOLS = [
     ("rhip_ctx_set_class_stats", None, [_vp, _i]),
     ("rhip_last_class_stats", _i, [_vp, C.POINTER(ClassStats), _i]),
     ("rhip_debug_host_clock", _i, [_vp, C.POINTER(C.c_double), _i]),
+    ("rhip_debug_last_placement", _i, [_vp, C.POINTER(C.c_float), _i]),
 ]
 
 _lib = None

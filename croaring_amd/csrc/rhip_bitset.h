@@ -179,6 +179,31 @@ __global__ __launch_bounds__(256) void k_bba(const uint8_t* __restrict__ arenaA,
 }
 
 
+// ------------------------------------------------------------------ placement probe (rhip_engine.hip, place_arena)
+// The access pattern of k_bb without a queue: wave-item i reads two 8 KiB containers of the operand arena -- at item
+// order and at a permuted position, as the left and right operands of a batch do -- and writes their OR to slot i of a
+// candidate result arena, all non-temporal.  Its time tells how the candidate's PHYSICAL pages sit relative to the
+// operand's (the same kernel streams at 5.4, 5.8 or 6.3 TB/s depending on that distance).
+__global__ __launch_bounds__(256) void k_place_probe(const uint8_t* __restrict__ arenaA, u64 a_items, uint8_t* __restrict__ out, u64 n_slots,
+                                                     u64 stride) {
+    // every stride-th slot of the WHOLE candidate (an allocation is composed of several physical blocks, each at its own
+    // distance from the operand: probing its first gigabyte says nothing about the rest)
+    const uint32_t lane = lane_id();
+    const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 i = wave_uniform((uint32_t)(((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6)) * stride; i < n_slots; i += nwaves * stride) {
+        const u32x4* __restrict__ pa = (const u32x4*)(arenaA + (i % a_items) * 8192ull);
+        const u32x4* __restrict__ pb = (const u32x4*)(arenaA + ((i * 97ull + 4096ull * 33ull) % a_items) * 8192ull);
+        u32x4 va[8], vb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) va[k] = __builtin_nontemporal_load(pa + k * 64 + lane);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) vb[k] = __builtin_nontemporal_load(pb + k * 64 + lane);
+        u32x4* __restrict__ po = (u32x4*)(out + i * 8192ull);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(va[k] | vb[k], po + k * 64 + lane);
+    }
+}
+
 // ------------------------------------------------------------------ pass-through copy
 // The item says where from, where to, how much -- no directory loads.  A wave takes `per_wave` items at a time: FOUR
 // (a quarter-wave each, 16 bytes per lane, while none of them exceeds 256 bytes; else the whole wave copies them one

@@ -59,6 +59,7 @@ struct DBuf {
     size_t skew = 0;       // set before the first ensure(): see rhip_ctx_s::arena_skew
     size_t round_to = 0;   // allocations at least this large are rounded up to a multiple of it
     bool pow2_large = false;  // allocations of 1 GiB and more take the next power of two, no slack (see rhip_ctx_s::arena_pow2)
+    bool exact = false;       // no slack at all (place_arena: the candidates' sizes decide how the driver composes them)
     uint64_t gen = 0;      // bumped by every (re)allocation: "is this still the memory I initialised?"
     void ensure(size_t n) {
         if (n <= cap) return;
@@ -68,6 +69,7 @@ struct DBuf {
         cap = 0;
         size_t want = n + n / 8 + 256;
         if (round_to && want + skew >= round_to) want = (want + skew + round_to - 1) / round_to * round_to - skew;
+        if (exact) want = (n + 4095) & ~(size_t)4095;
         if (pow2_large && n + skew >= (1ull << 30)) {
             want = 1ull << 30;
             while (want < n + skew) want <<= 1;
@@ -177,6 +179,16 @@ struct rhip_ctx_s {
     // allocations; 9.4 GB arenas (8 G + 1 G + 256 M + ... blocks) 4.37 or 4.64 ms, 7.8 GiB ones 3.97-4.40, by where the
     // pieces happened to land.  A power of two costs address space (at most 2 x), never traffic.  RHIP_ARENA_POW2=0: off.
     bool arena_pow2 = true;
+    // MEASURED placement of large result arenas (place_arena below): when a result arena of at least arena_place_min bytes
+    // has to be allocated and the left operand pool is large as well, up to arena_tries candidates are allocated (all kept
+    // alive until the choice is made, so that each gets different physical pages), a probe with k_bb's access pattern is
+    // timed on each against the operand pool, the fastest is kept -- or the first that streams at arena_good_gbps.  The
+    // caller does nothing; a recycled result pool (`reuse`) keeps its placement.  RHIP_ARENA_TRIES (0 / 1: off),
+    // RHIP_ARENA_PLACE_MIN_MB.
+    int arena_tries = 10;
+    uint64_t arena_place_min = 2ull << 30;
+    double arena_good_gbps = 6250.0;
+    std::vector<float> last_placement;  // probe GB/s of the candidates of the last placement (rhip_debug_last_placement)
     bool debug_plan = false;  // RHIP_DEBUG_PLAN=1: one line per batch on stderr (bounds, fork / merge decision)
     bool merge_classes = true;  // RHIP_MERGE_CLASSES=0: a small batch launches its class kernels one by one
     uint64_t merge_max_items = 256u << 10;  // ... "small" = at most that many matched container pairs (upper bound)
@@ -371,6 +383,8 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_MERGE_MAX_K")) c->merge_max_items = strtoull(e, nullptr, 0) << 10;
         if (const char* e = getenv("RHIP_ARENA_ROUND_MB")) c->arena_round = (size_t)strtoull(e, nullptr, 0) << 20;
         if (const char* e = getenv("RHIP_ARENA_POW2")) c->arena_pow2 = !(e[0] == '0');
+        if (const char* e = getenv("RHIP_ARENA_TRIES")) c->arena_tries = atoi(e);
+        if (const char* e = getenv("RHIP_ARENA_PLACE_MIN_MB")) c->arena_place_min = (uint64_t)strtoull(e, nullptr, 0) << 20;
         if (const char* e = getenv("RHIP_ARENA_SKEW")) c->arena_skew = (size_t)strtoull(e, nullptr, 0) & ~(size_t)255;
         if (const char* e = getenv("RHIP_GROUP_X")) c->group_x = atoi(e);
         if (const char* e = getenv("RHIP_XG_CHUNK")) c->group_chunk = (uint32_t)std::max(1, atoi(e));
@@ -1678,6 +1692,69 @@ struct rhip_batch_s {
     rhip_pairlist_t* L; // the prepared pair list the batch reads (its device copy), or NULL
 };
 
+// Measured placement of a large result arena (rhip_ctx_s::arena_tries).  The physical address of device memory is not
+// visible to a process, and it is what decides: with the operand pool and the result arena in ONE 128 GiB allocation the
+// bitset kernel of C2 takes 4.62-4.66 ms while the arena starts within ~24 GiB behind the pool, 3.91-3.98 ms in 5-6 GiB
+// wide windows further out (distances 27-31, 66-71, 82-87, 98-103 ... GiB) and 4.32-4.38 ms everywhere else
+// (profiles/r04_arena_distance.txt) -- the address hash that spreads a stream over the HBM channels also decides how often
+// the lockstep read and write streams of the kernel meet in one channel.  So the candidates are MEASURED: each is
+// allocated, probed with the kernel's own access pattern against the operand pool it will be written beside, and the
+// fastest is kept; the others are released.  Only when `arena` needs a new allocation of >= arena_place_min bytes, the
+// operand arena holds >= 64 MiB and no batch is in flight; a few milliseconds, once per result pool.
+static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool_t* A) {
+    const u64 a_items = A->arena.cap / 8192ull;
+    const u64 n_slots = need / 8192ull;
+    const u64 stride = std::max<u64>(1, n_slots / ((2ull << 30) / 8192ull));  // ~2 GiB of the candidate is written, spread over all of it
+    const u64 n_items = (n_slots + stride - 1) / stride;
+    hipStream_t s = c->stream;
+    struct Cand { DBuf buf; float gbps = 0; };
+    std::vector<Cand> cands;
+    c->last_placement.clear();
+    hipEvent_t e0 = c->ev[0], e1 = c->ev[1];
+    int best = -1;
+    for (int t = 0; t < c->arena_tries; ++t) {
+        Cand cd;
+        cd.buf.skew = arena.skew;
+        cd.buf.round_to = arena.round_to;
+        // Exactly the bytes needed: the driver composes an allocation out of naturally aligned power-of-two blocks, largest
+        // first -- 8 000 MiB = 4 G + 2 G + 1 G + ...; with the usual 12.5 % of slack (9.4 GB = 8 G + ...) or as a power of two
+        // the first block is an 8 GiB-aligned 8 GiB one, whose distance to an 8 GiB operand block is a multiple of 8 GiB:
+        // never inside a fast window (scripts/arena_place.hip: 0 of 40 such allocations fast, 15 of 28 exact ones).
+        cd.buf.pow2_large = false;
+        cd.buf.exact = true;
+        try {
+            cd.buf.ensure(need);
+        } catch (int) {
+            if (best >= 0) break;  // out of memory for another candidate: choose among those there are
+            throw;
+        }
+        float ms_best = 1e30f;
+        for (int r = 0; r < 3; ++r) {  // (the first pass touches the pages)
+            HIPCHK(hipEventRecord(e0, s));
+            hipLaunchKernelGGL(k_place_probe, dim3(8192), dim3(256), 0, s, A->arena.as<uint8_t>(), a_items, cd.buf.as<uint8_t>(), n_slots, stride);
+            HIPCHK(hipEventRecord(e1, s));
+            HIPCHK(hipEventSynchronize(e1));
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            if (r && ms < ms_best) ms_best = ms;
+        }
+        cd.gbps = (float)((double)n_items * 24576.0 / (double)ms_best / 1e6);
+        c->last_placement.push_back(cd.gbps);
+        cands.push_back(cd);
+        if (best < 0 || cd.gbps > cands[best].gbps) best = (int)cands.size() - 1;
+        if (cd.gbps >= c->arena_good_gbps) break;
+    }
+    for (int k = 0; k < (int)cands.size(); ++k)
+        if (k != best) cands[k].buf.release();
+    arena.release();
+    const bool p2 = arena.pow2_large;
+    const uint64_t g = arena.gen;
+    arena = cands[best].buf;
+    arena.pow2_large = p2;
+    arena.exact = false;
+    arena.gen = g + 1;
+}
+
 // Everything of a pairwise call up to and including the launch of k_tail: nothing here waits for the device.
 static rhip_batch_t* pairwise_begin_ops(rhip_ctx_t* c, size_t n_ops, const rhip_op* ops_, rhip_pool_t* A, rhip_pool_t* B,
                                         size_t npairs, const uint32_t* lhs, const uint32_t* rhs, rhip_pool_t* reuse,
@@ -1734,6 +1811,11 @@ static rhip_batch_t* pairwise_begin_ops(rhip_ctx_t* c, size_t n_ops, const rhip_
         R->arena.skew = c->arena_skew;
         R->arena.round_to = c->arena_round;
         R->arena.pow2_large = c->arena_pow2;
+        // (a batch of this size plans on the main stream, so the probes below are ordered behind everything enqueued so far
+        // -- the batches in flight included -- and run alone)
+        if (c->arena_tries > 1 && P.arena_bound + 64 > R->arena.cap && P.arena_bound + 64 >= c->arena_place_min &&
+            A->arena.cap >= (64ull << 20) && P.plan_stream == s)
+            place_arena(c, R->arena, P.arena_bound + 64, A);
         R->arena.ensure(P.arena_bound + 64);
         OutView O{};
         O.key = CO.key; O.meta = c->ss[slot].o_meta.as<u64>(); O.off = CO.off; O.slot = nullptr;
@@ -1983,6 +2065,14 @@ extern "C" int rhip_pairwise_list_cardinality(rhip_ctx_t* c, rhip_op op, rhip_pa
 extern "C" void rhip_debug_set_arena_skew(rhip_ctx_t* c, unsigned long long bytes) { c->arena_skew = (size_t)bytes & ~(size_t)255; }
 extern "C" void rhip_debug_set_arena_round(rhip_ctx_t* c, unsigned long long bytes) { c->arena_round = (size_t)bytes; }
 extern "C" unsigned long long rhip_debug_pool_arena(rhip_pool_t* P) { return (unsigned long long)(uintptr_t)P->arena.p; }
+// probe rates (GB/s) of the candidates of the context's last measured arena placement, in allocation order; returns
+// how many there were (0: no placement has happened)
+extern "C" int rhip_debug_last_placement(rhip_ctx_t* c, float* out, int capacity) {
+    if (!c) return 0;
+    const int n = (int)c->last_placement.size();
+    for (int k = 0; k < n && k < capacity; ++k) out[k] = c->last_placement[k];
+    return n;
+}
 extern "C" int rhip_debug_host_clock(rhip_ctx_t* c, double out[8], int reset) {
     if (!c || !out) return RHIP_ERR_ARG;
     for (int i = 0; i < 8; ++i) out[i] = c->hclk[i];

@@ -83,6 +83,12 @@ class Engine:
         self.lib.rhip_debug_host_clock(self.h, out, 1 if reset else 0)
         return list(out)
 
+    def last_placement(self) -> list:
+        """Probe rates (GB/s) of the candidate result arenas of the last measured placement (rhip_debug_last_placement)."""
+        out = (C.c_float * 32)()
+        n = self.lib.rhip_debug_last_placement(self.h, out, 32)
+        return [round(float(out[k]), 1) for k in range(min(n, 32))]
+
     def set_timing(self, on: bool):
         self.lib.rhip_ctx_set_timing(self.h, 1 if on else 0)
 

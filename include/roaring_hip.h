@@ -339,6 +339,12 @@ int rhip_last_class_stats(rhip_ctx_t *ctx, rhip_class_stats_t *out, int capacity
  * The wait polls a completion word the last kernel writes into pinned memory; RHIP_SPIN_WAIT=0 in the environment
  * (read at rhip_ctx_create) makes it block on the stream instead. */
 int rhip_debug_host_clock(rhip_ctx_t *ctx, double out_us[8], int reset);
+/* Large result arenas are placed by measurement (a result arena of >= 2 GiB written beside an operand pool of >= 64 MiB:
+ * up to RHIP_ARENA_TRIES = 10 candidate allocations are probed with the bitset kernel's access pattern and the fastest
+ * is kept -- the physical distance between the operand and the result stream moves that kernel by up to 17 %, and a
+ * process cannot see physical addresses).  This returns the probe rates (GB/s) of the candidates of the
+ * context's last placement, in allocation order, and how many there were. */
+int rhip_debug_last_placement(rhip_ctx_t *ctx, float *out_gbps, int capacity);
 
 #ifdef __cplusplus
 }

@@ -102,8 +102,20 @@ int main(int argc, char** argv) {
         // deterministic function of skew here (at least with physically contiguous memory); `trials` fresh slabs.
         const std::string sway = ways.size() > 5 ? ways.substr(5) : "contig";
         const u64 poolb = (u64)NBM * NC * 8192ull, resb = nitems * 8192ull;
-        const u64 skews[] = {0, 4096, 65536, 1ull << 20, 2ull << 20, 3ull << 20, 16ull << 20, 32ull << 20, 48ull << 20, 128ull << 20,
-                             256ull << 20, 384ull << 20, 512ull << 20, 768ull << 20, 1024ull << 20, 1536ull << 20, 2048ull << 20};
+        std::vector<u64> skews = {0, 4096, 65536, 1ull << 20, 2ull << 20, 3ull << 20, 16ull << 20, 32ull << 20, 48ull << 20, 128ull << 20,
+                                  256ull << 20, 384ull << 20, 512ull << 20, 768ull << 20, 1024ull << 20, 1536ull << 20, 2048ull << 20};
+        // SLAB_GIB=n: the slab is n GiB (a power of two: one buddy block if the driver has one) and the arena is tried at
+        // whole-GiB distances behind the pool, as far as the slab reaches
+        u64 slab_bytes = poolb + resb + (2048ull << 20) + 4096;
+        if (getenv("SLAB_GIB")) {
+            slab_bytes = strtoull(getenv("SLAB_GIB"), nullptr, 0) << 30;
+            skews.clear();
+            // SLAB_STEP_MIB: distance step (default 1 GiB); SLAB_FROM_GIB / SLAB_TO_GIB: range of distances behind the pool
+            const u64 step = (getenv("SLAB_STEP_MIB") ? strtoull(getenv("SLAB_STEP_MIB"), nullptr, 0) : 1024ull) << 20;
+            const u64 from = (getenv("SLAB_FROM_GIB") ? strtoull(getenv("SLAB_FROM_GIB"), nullptr, 0) : 0ull) << 30;
+            const u64 to = getenv("SLAB_TO_GIB") ? strtoull(getenv("SLAB_TO_GIB"), nullptr, 0) << 30 : ~0ull;
+            for (u64 d = from; poolb + d + resb <= slab_bytes && d <= to; d += step) skews.push_back(d);
+        }
         CK(hipMalloc(&meta, nitems * 8)); CK(hipMalloc(&q, nitems * sizeof(BBItem)));
         CK(hipMalloc(&rq, 1024 * sizeof(GenItem))); CK(hipMalloc(&rc, 64)); CK(hipMalloc(&qr, 64)); CK(hipMalloc(&acc, 8192));
         std::vector<BBItem> h(nitems);
@@ -119,7 +131,7 @@ int main(int argc, char** argv) {
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         std::vector<Arena> slabs;
         for (int t = 0; t < trials; ++t) {
-            Arena sl = alloc_arena(sway, poolb + resb + (2048ull << 20) + 4096);
+            Arena sl = alloc_arena(sway, slab_bytes);
             slabs.push_back(sl);
             A = (uint8_t*)sl.p;
             hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (u64*)A, poolb / 8);
@@ -135,7 +147,8 @@ int main(int argc, char** argv) {
                     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
                     if (r && ms < best) best = ms;
                 }
-                printf("  %llu:%.3f", (unsigned long long)(skew >> 12), best);
+                if (getenv("SLAB_GIB")) printf("  %.3fG:%.3f", (double)skew / (double)(1ull << 30), best);
+                else printf("  %llu:%.3f", (unsigned long long)(skew >> 12), best);
                 fflush(stdout);
             }
             printf("   (skew in 4 KiB pages : ms)\n");
