@@ -198,6 +198,7 @@ struct rhip_ctx_s {
     uint64_t group_min_reuse = 64;  // (C5: 47 partners per container by this bound, almost all interval pairs -- grouping costs it 4 %)
     uint64_t group_min_items = 16u << 10;
     uint32_t group_chunk = 8;    // RHIP_XG_CHUNK: items a wave of the grouped kernels walks in a row, at least
+    bool spin_join = true;       // RHIP_SPIN_JOIN=0: forked class kernels are joined with events in front of k_tail (k_join_signal)
     bool copy_wide = true;       // RHIP_COPY_WIDE=0: k_copy always takes four items per wave
     int many_pf = 4;  // RHIP_MANY_PF: payload groups per lane k_many_l1 loads ahead (2 / 4 / 8)
     int many_ch = 0;  // RHIP_MANY_CH: members per unit (tests of the multi-chunk / multi-unit paths on small inputs); 0 = by size
@@ -389,6 +390,7 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_GROUP_X")) c->group_x = atoi(e);
         if (const char* e = getenv("RHIP_XG_CHUNK")) c->group_chunk = (uint32_t)std::max(1, atoi(e));
         if (const char* e = getenv("RHIP_COPY_WIDE")) c->copy_wide = !(e[0] == '0');
+        if (const char* e = getenv("RHIP_SPIN_JOIN")) c->spin_join = !(e[0] == '0');
         if (const char* e = getenv("RHIP_MANY_CH")) c->many_ch = std::max(1, std::min(1024, atoi(e)));
         memset(c->h_pinned, 0, 4096);
         {
@@ -1080,7 +1082,7 @@ static void fetch_bounds(rhip_pool_t* P) {
 // device scratch of one call (inside ctx->misc, all of it cleared by k_count): u64 words
 struct PlanScratch {
     size_t n_scan_tiles, n_tail_tiles;
-    size_t w_scan_status, w_tail_status, w_tail_part, w_tickets, w_retry, w_ranges, n_words;
+    size_t w_scan_status, w_tail_status, w_tail_part, w_tickets, w_retry, w_ranges, w_join, n_words;
     void layout(size_t n_scan_elems, size_t ub_cand) {
         n_scan_tiles = (n_scan_elems + SCAN_TILE - 1) / SCAN_TILE + 1;
         n_tail_tiles = (ub_cand + TAIL_TILE - 1) / TAIL_TILE + 1;
@@ -1094,6 +1096,7 @@ struct PlanScratch {
         w_tickets = w; w += 2 * 16;
         w_retry = w; w += 16;
         w_ranges = w; w += (2 * N_SEC + 3 + 15) & ~15;  // (+ 3: the group boundaries of a grouped batch)
+        w_join = w; w += 16;  // "auxiliary stream a has finished its class kernels" (k_join_signal -> k_tail)
         n_words = w;
     }
 };
@@ -1119,6 +1122,7 @@ struct Plan {
     LbState scan_lb() const { return LbState{words + sc.w_scan_status, (uint32_t*)(words + sc.w_tickets)}; }
     LbState tail_lb() const { return LbState{words + sc.w_tail_status, (uint32_t*)(words + sc.w_tickets + 16)}; }
     u64* tail_part() const { return words + sc.w_tail_part; }
+    u64* join_flags() const { return words + sc.w_join; }
 };
 
 void check_pair_args(rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs, const uint32_t* rhs) {
@@ -1425,8 +1429,11 @@ unsigned bounded_grid(uint64_t ub_items, unsigned max_blocks = 1u << 16) {
     const uint64_t need = (ub_items + 4 * ITEMS_PER_WAVE - 1) / (4 * ITEMS_PER_WAVE);
     return (unsigned)std::min<uint64_t>(std::max<uint64_t>(need, 1), max_blocks);
 }
+// join_mask != nullptr: the auxiliary streams are not joined with events -- each ends with k_join_signal and *join_mask says
+// which flags the caller's tail kernel has to wait for (k_tail above)
 void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const PoolView& VB, const OutView& O, const Plan& P,
-                 int cardmode) {
+                 int cardmode, uint32_t* join_mask = nullptr) {
+    if (join_mask) *join_mask = 0;
     hipStream_t s = c->stream;
     const int op = ops.kop();  // the batch's op, or OP_ITEM: a multi-op batch, every work item carries its own
     const bool multi = ops.n > 1;
@@ -1609,8 +1616,13 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
     if (fork)
         for (int a = 0; a < rhip_ctx_s::N_AUX; ++a)
             if (used[a]) {
-                HIPCHK(hipEventRecord(c->ev_join[a], c->aux[a]));
-                HIPCHK(hipStreamWaitEvent(s, c->ev_join[a], 0));
+                if (join_mask) {
+                    hipLaunchKernelGGL(k_join_signal, dim3(1), dim3(64), 0, c->aux[a], P.join_flags() + a);
+                    *join_mask |= 1u << a;
+                } else {
+                    HIPCHK(hipEventRecord(c->ev_join[a], c->aux[a]));
+                    HIPCHK(hipStreamWaitEvent(s, c->ev_join[a], 0));
+                }
             }
 }
 
@@ -1821,14 +1833,16 @@ static rhip_batch_t* pairwise_begin_ops(rhip_ctx_t* c, size_t n_ops, const rhip_
         O.key = CO.key; O.meta = c->ss[slot].o_meta.as<u64>(); O.off = CO.off; O.slot = nullptr;
         O.arena = R->arena.as<uint8_t>();
         PoolView VA = A->view(), VB = B->view();
-        run_kernels(c, ops, VA, VB, O, P, 0);
+        const unsigned tail_blocks = (unsigned)std::max<uint64_t>(1, (P.ub_cand + TAIL_TILE - 1) / TAIL_TILE);
+        uint32_t join_mask = 0;
+        run_kernels(c, ops, VA, VB, O, P, 0, (c->spin_join && tail_blocks <= 1024u) ? &join_mask : nullptr);
         // drop empty results, build the result directory, totals
         DirOut D{R->bm_start.as<u64>(), R->key.as<u64>(), R->type.as<uint8_t>(), R->card.as<uint32_t>(),
                  R->nruns.as<uint32_t>(), R->off.as<u64>()};
         const uint64_t seq = ++c->seq;
-        hipLaunchKernelGGL(k_tail, dim3((unsigned)std::max<uint64_t>(1, (P.ub_cand + TAIL_TILE - 1) / TAIL_TILE)), dim3(256), 0,
+        hipLaunchKernelGGL(k_tail, dim3(tail_blocks), dim3(256), 0,
                            s, P.ranges(), CO, O.meta, D, (uint32_t)(npairs * n_ops), P.tail_lb(), P.tail_part(),
-                           (Stats*)c->slot_stats(slot), (u64*)c->done_flag(slot), (u64)seq);
+                           (Stats*)c->slot_stats(slot), (u64*)c->done_flag(slot), (u64)seq, (const u64*)P.join_flags(), join_mask);
         if (c->timing) HIPCHK(hipEventRecord(c->evs[slot][1], s));
         HIPCHK(hipGetLastError());  // a refused launch anywhere above must not pass silently
         clk.lap(3);

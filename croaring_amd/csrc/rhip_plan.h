@@ -623,9 +623,27 @@ struct DirOut {
 #define TAIL_READY (1ull << 63)
 constexpr uint32_t TAIL_PER_THREAD = 8;
 constexpr uint32_t TAIL_TILE = 256 * TAIL_PER_THREAD;  // candidates per block
+// Join without events (round 4).  The class kernels of a forked batch run on up to three auxiliary streams; joining them
+// into the main stream with events costs three barrier packets in front of this kernel -- 20 us between the end of the
+// last class kernel and the start of the tail, on every forked batch (profiles/r04_timelines.txt).  Instead every
+// auxiliary stream ends with k_join_signal, and the tail is launched on the main stream WITHOUT waiting: its blocks
+// wait here for the flags of the streams in `join_mask`, then take an acquire fence (the class kernels' results were
+// released at the end of their kernels, on other XCDs) before they read a meta word.  The host uses this form only
+// while the tail's grid is small (<= 1024 blocks): blocks that wait hold wave slots, and the kernels they wait for must
+// still find theirs.
+__global__ void k_join_signal(u64* flag) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) lb_store(flag, 1ull);
+}
 __global__ __launch_bounds__(256) void k_tail(const u64* __restrict__ ranges, CandOut C, const u64* __restrict__ meta,
                                               DirOut R, uint32_t n_pairs, LbState lb, u64* __restrict__ part,
-                                              Stats* __restrict__ host_stats, u64* host_flag, u64 seq) {
+                                              Stats* __restrict__ host_stats, u64* host_flag, u64 seq,
+                                              const u64* join_flags, uint32_t join_mask) {
+    if (join_mask) {
+        if (threadIdx.x < 8u && ((join_mask >> threadIdx.x) & 1u))
+            while (lb_load(&join_flags[threadIdx.x]) == 0ull) __builtin_amdgcn_s_sleep(16);
+        __syncthreads();
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
     __shared__ u64 sm[4];
     __shared__ uint32_t s_tile;
     __shared__ u64 s_prefix;

@@ -52,7 +52,7 @@ struct hipemu_event {
 };
 typedef hipemu_event* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
-enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0 };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipHostMallocPortable = 1, hipHostMallocMapped = 2 };
 
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
@@ -235,6 +235,7 @@ static inline unsigned mbcnt(unsigned mask, unsigned add, int hi) {
 #define __builtin_amdgcn_mbcnt_hi(m, a) hipemu::mbcnt((m), (a), 1)
 // (only ever applied to values the whole wave shares: the emulated lanes each keep their own copy)
 #define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
 
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }

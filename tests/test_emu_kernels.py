@@ -113,6 +113,15 @@ def test_emu_dropin_entry_points(emu, ref):
     GC.test_dropin_lazy_family(lib, ref)
 
 
+def test_emu_pinned_allocator_hook(emu, ref):
+    """tests/hook_child.py against the emulator build (the arena is plain host memory there: the allocator, the hook
+    plumbing and the drop-ins' use of the reference's roaring_malloc / roaring_free are what is tested)."""
+    import os, subprocess, sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hook_child.py")
+    p = subprocess.run([sys.executable, child, "emu"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "hook ok" in p.stdout, (p.stdout + p.stderr)[-3000:]
+
+
 def test_emu_pool_reshaping(emu, oracle):
     """rhip_pool_select / rhip_pairwise_inplace / run_optimize / remove_run_compression / predicates."""
     import test_gpu_poolops as GP

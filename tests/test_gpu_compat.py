@@ -129,6 +129,16 @@ def test_dropin_reentrant(hip, ref):
             ref.free(b)
 
 
+def test_pinned_allocator_hook(ref):
+    """rhip_install_pinned_allocator: the library's page-locked arena installed as the reference's memory hook; bitmaps
+    built by the reference, operated on by the drop-ins, freed by the reference (tests/hook_child.py, a process of its
+    own: the hook is process-wide)."""
+    import os, subprocess, sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hook_child.py")
+    p = subprocess.run([sys.executable, child, "hip"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "hook ok" in p.stdout, (p.stdout + p.stderr)[-3000:]
+
+
 def test_dropin_many(hip, ref):
     rng = np.random.default_rng(6)
     for it in range(10):

@@ -54,16 +54,20 @@ def test_reference_cpp_unit_against_dropin():
     64map*.bin / addoffsetinput.bin fixtures it reads are the verbatim copies under tests/golden/)."""
     if not os.path.exists(BIN_CPPUNIT):
         pytest.skip("oracle/_ref/cpp_unit_dropin not prebuilt")
-    if not os.environ.get("RHIP_SLOW_HARNESS"):
-        # 4 million per-call device round trips = 7.5 GPU-minutes; result recorded in
-        # profiles/r01_dropin_cpp_unit.txt (69 tests, 0 failed).  Set RHIP_SLOW_HARNESS=1 to re-run.
-        pytest.skip("slow (7.5 min): set RHIP_SLOW_HARNESS=1")
+    # The whole file is 4 million per-call device round trips (7 minutes: profiles/r03_dropin_harnesses.txt, 69 tests,
+    # 0 failed).  By default a 40-second SLICE runs: the shim starts no test after that many seconds, prints every
+    # test's time, and what ran must pass.  RHIP_SLOW_HARNESS=1 runs all of it.
     env = dict(os.environ, RHIP_COMPAT_STATS="1")
+    full = bool(os.environ.get("RHIP_SLOW_HARNESS"))
+    if not full:
+        env["SHIM_MAX_SECONDS"] = "40"
     p = subprocess.run([BIN_CPPUNIT], capture_output=True, text=True, timeout=1500, env=env)
     tail = (p.stdout + p.stderr)[-3000:]
-    m = re.search(r"(\d+) tests, (\d+) failed", p.stdout)
+    m = re.search(r"(\d+) tests, (\d+) failed \((\d+) run", p.stdout)
     assert m, tail
-    assert int(m.group(1)) >= 60 and int(m.group(2)) == 0 and p.returncode == 0, tail
+    assert int(m.group(2)) == 0 and p.returncode == 0, tail
+    assert int(m.group(3)) >= (60 if full else 5), tail
+    print("\n".join(l for l in p.stderr.splitlines() if "OK ]" in l or "NOT RUN" in l)[-2500:])
 
 
 BIN_64 = os.path.join(ROOT, "oracle", "_ref", "roaring64_unit_dropin")
