@@ -1136,9 +1136,9 @@ void check_pair_args(rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32
 }
 
 template <int OP>
-void launch_bb(rhip_ctx_t* c, unsigned grid, const PoolView& A, const PoolView& B, const OutView& O, const Plan& P,
+void launch_bb(rhip_ctx_t* c, hipStream_t st, unsigned grid, const PoolView& A, const PoolView& B, const OutView& O, const Plan& P,
                int cardmode) {
-    hipLaunchKernelGGL(k_bb<OP>, dim3(grid), dim3(256), 0, c->stream, A.arena, B.arena, O, c->ss[P.slot].q[CLS_BB].as<BBItem>(),
+    hipLaunchKernelGGL(k_bb<OP>, dim3(grid), dim3(256), 0, st, A.arena, B.arena, O, c->ss[P.slot].q[CLS_BB].as<BBItem>(),
                        P.ranges() + 2 * SEC_BB, cardmode, c->pair_acc.as<u64>(), c->ss[P.slot].q[CLS_RETRY].as<GenItem>(),
                        P.retry_count());
 }
@@ -1430,7 +1430,7 @@ unsigned bounded_grid(uint64_t ub_items, unsigned max_blocks = 1u << 16) {
     return (unsigned)std::min<uint64_t>(std::max<uint64_t>(need, 1), max_blocks);
 }
 // join_mask != nullptr: the auxiliary streams are not joined with events -- each ends with k_join_signal and *join_mask says
-// which flags the caller's tail kernel has to wait for (k_tail above)
+// which flags the caller's k_join_wait has to wait for (rhip_plan.h)
 void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const PoolView& VB, const OutView& O, const Plan& P,
                  int cardmode, uint32_t* join_mask = nullptr) {
     if (join_mask) *join_mask = 0;
@@ -1498,22 +1498,37 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
         }
         return;
     }
+    // Stream roles of a forked batch (round 4).  The batch ends when its LONGEST kernel does -- the image kernel: k_filter(_g)
+    // under and / andnot / cardinality, k_union_g / k_wave under or / xor -- so that kernel stays on the MAIN stream:
+    // it starts right behind k_emit (a kernel on an auxiliary stream starts ~16 us later: the fork is a cross-queue
+    // dependency) and the tail starts right behind it (no signal kernel, no barrier packet on the critical path).  The
+    // light chain k_bb -> k_usmall / k_probe -> k_bba -> k_copy, which used to own the main stream, takes the auxiliary
+    // stream the image kernel vacated.
     bool used[rhip_ctx_s::N_AUX] = {false, false, false};
-    auto on = [&](int a) -> hipStream_t {
-        if (!fork) return s;
+    const int crit = !fork ? -1 : has_filt ? 1 : (has_wave || has_ba) ? 2 : -1;
+    auto on_aux = [&](int a) -> hipStream_t {
         if (!used[a]) {
             HIPCHK(hipStreamWaitEvent(c->aux[a], c->ev_fork, 0));
             used[a] = true;
         }
         return c->aux[a];
     };
+    auto on = [&](int a) -> hipStream_t {
+        if (!fork || a == crit) return s;
+        return on_aux(a);
+    };
     if (fork) HIPCHK(hipEventRecord(c->ev_fork, s));
+    const hipStream_t lst = (fork && crit >= 0) ? on_aux(crit) : s;  // the stream of the light chain
     if (has_runs) {
         // interval algebra, three size classes in one launch: short lists four pairs per wave (most of a sparse
         // run-compressed batch), long lists one pair per wave.  Few items as a rule, so few blocks (an empty block of an
         // LDS-heavy kernel still queues for a slot); many items simply loop.
         rhip_ctx_s::SlotScratch& SS = c->ss[P.slot];
-        const unsigned g1 = bounded_grid(nm, 4096), g2 = bounded_grid(nm, 2048), g3 = bounded_grid(nm, 2048);
+        // (forked: at most 2 048 blocks in all -- the queues are short as a rule and every block of this LDS-heavy kernel,
+        // empty or not, has to find a slot beside the image kernels: with 8 192 the kernel's last blocks ran 400 us after
+        // its first on weather `or`, and the retry pass waits for them; 1 024 + 512 + 512 blocks still fill the machine
+        // when the interval pairs ARE the batch -- C5)
+        const unsigned g1 = bounded_grid(nm, fork ? 1024 : 4096), g2 = bounded_grid(nm, fork ? 512 : 2048), g3 = bounded_grid(nm, fork ? 512 : 2048);
         IvlQueues IQ{{SS.q[CLS_RUNS16].as<GenItem>(), SS.q[CLS_RUNS16W].as<GenItem>(), SS.q[CLS_RUNS].as<GenItem>()},
                      {ranges + 2 * SEC_RUNS16, ranges + 2 * SEC_RUNS16W, ranges + 2 * SEC_RUNS}};
         hipLaunchKernelGGL(k_ivl_all, dim3(g1 + g2 + g3), dim3(256), 0, on(0), VA.arena, VB.arena, O, IQ, g1, g2, op,
@@ -1551,43 +1566,46 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
                            c->ss[P.slot].q[CLS_WAVE].as<FatItem>(), ranges + 2 * SEC_WAVE, op);
     // The main stream's own kernels are issued right after the big image kernels: the host's launches are what the device
     // waits for in a forked batch (~25 API calls), and k_probe / k_usmall are on its critical path, the few general items are not.
+    const bool need_bb_event = fork && has_retry && has_bb;  // the retry pass (another stream) consumes what k_bb re-queues
     if (has_bb) {
         unsigned grid = persistent_grid(nm, 4, 256 * 32);
-        if (c->timing) { HIPCHK(hipEventRecord(c->evs[P.slot][2], s)); c->bb_timed[P.slot] = true; }
+        if (c->timing) { HIPCHK(hipEventRecord(c->evs[P.slot][2], lst)); c->bb_timed[P.slot] = true; }
         switch (op) {
-            case OP_ITEM: launch_bb<OP_ITEM>(c, grid, VA, VB, O, P, cardmode); break;
-            case OP_AND: launch_bb<OP_AND>(c, grid, VA, VB, O, P, cardmode); break;
-            case OP_OR: launch_bb<OP_OR>(c, grid, VA, VB, O, P, cardmode); break;
-            case OP_XOR: launch_bb<OP_XOR>(c, grid, VA, VB, O, P, cardmode); break;
-            default: launch_bb<OP_ANDNOT>(c, grid, VA, VB, O, P, cardmode); break;
+            case OP_ITEM: launch_bb<OP_ITEM>(c, lst, grid, VA, VB, O, P, cardmode); break;
+            case OP_AND: launch_bb<OP_AND>(c, lst, grid, VA, VB, O, P, cardmode); break;
+            case OP_OR: launch_bb<OP_OR>(c, lst, grid, VA, VB, O, P, cardmode); break;
+            case OP_XOR: launch_bb<OP_XOR>(c, lst, grid, VA, VB, O, P, cardmode); break;
+            default: launch_bb<OP_ANDNOT>(c, lst, grid, VA, VB, O, P, cardmode); break;
         }
-        if (c->timing) HIPCHK(hipEventRecord(c->evs[P.slot][3], s));
-        if (fork && has_retry && has_runs) HIPCHK(hipEventRecord(c->ev_runs, s));  // "k_bb done" for the retry pass on aux0
+        if (c->timing) HIPCHK(hipEventRecord(c->evs[P.slot][3], lst));
+        if (need_bb_event) HIPCHK(hipEventRecord(c->ev_runs, lst));  // "k_bb done"
     }
-    if (has_wave && any_union)  // or / xor of a short array with a long one, by rank: light, beside k_wave
-        hipLaunchKernelGGL(k_usmall, dim3(bounded_grid(nm)), dim3(256), 0, s, VA.arena, VB.arena, O,
+    if (has_wave && any_union)  // or / xor of a short array with a long one, by rank: 170 us alone on weather -- a stream of
+                                // its own when the filter's is free (or / xor), else the light chain
+        hipLaunchKernelGGL(k_usmall, dim3(bounded_grid(nm)), dim3(256), 0, (fork && crit == 2) ? on_aux(1) : lst, VA.arena, VB.arena, O,
                            c->ss[P.slot].q[CLS_USMALL].as<FatItem>(), ranges + 2 * SEC_USMALL, op);
     if (has_filt)  // short streamed arrays: no LDS, 8 waves per SIMD -- co-resides with the LDS-bound kernels
-        hipLaunchKernelGGL(k_probe, dim3(bounded_grid(nm)), dim3(256), 0, s, VA.arena, VB.arena, O,
+        hipLaunchKernelGGL(k_probe, dim3(bounded_grid(nm)), dim3(256), 0, lst, VA.arena, VB.arena, O,
                            c->ss[P.slot].q[CLS_PROBE].as<FatItem>(), ranges + 2 * SEC_PROBE, op, cardmode, c->pair_acc.as<u64>());
     if (has_bba) {  // bitset pairs expected to give arrays
         if (multi)
-            hipLaunchKernelGGL(k_bba<OP_ITEM>, dim3(bounded_grid(nm)), dim3(256), 0, s, VA.arena, VB.arena, O,
+            hipLaunchKernelGGL(k_bba<OP_ITEM>, dim3(bounded_grid(nm)), dim3(256), 0, lst, VA.arena, VB.arena, O,
                                c->ss[P.slot].q[CLS_BBA].as<BBItem>(), ranges + 2 * SEC_BBA);
         else if (op == OP_AND)
-            hipLaunchKernelGGL(k_bba<OP_AND>, dim3(bounded_grid(nm)), dim3(256), 0, s, VA.arena, VB.arena, O,
+            hipLaunchKernelGGL(k_bba<OP_AND>, dim3(bounded_grid(nm)), dim3(256), 0, lst, VA.arena, VB.arena, O,
                                c->ss[P.slot].q[CLS_BBA].as<BBItem>(), ranges + 2 * SEC_BBA);
         else
-            hipLaunchKernelGGL(k_bba<OP_ANDNOT>, dim3(bounded_grid(nm)), dim3(256), 0, s, VA.arena, VB.arena, O,
+            hipLaunchKernelGGL(k_bba<OP_ANDNOT>, dim3(bounded_grid(nm)), dim3(256), 0, lst, VA.arena, VB.arena, O,
                                c->ss[P.slot].q[CLS_BBA].as<BBItem>(), ranges + 2 * SEC_BBA);
     }
     if (has_copy)
-        hipLaunchKernelGGL(k_copy, dim3(bounded_grid(P.copy_per_wave == 16 ? (P.ub_cand + 3) / 4 : P.ub_cand)), dim3(256), 0, s, VA.arena, VB.arena, O,
+        hipLaunchKernelGGL(k_copy, dim3(bounded_grid(P.copy_per_wave == 16 ? (P.ub_cand + 3) / 4 : P.ub_cand)), dim3(256), 0, lst, VA.arena, VB.arena, O,
                            c->ss[P.slot].q[CLS_COPY].as<CopyItem>(), ranges + 2 * SEC_COPY, P.copy_per_wave);
-    if (!multi && has_runs && !genw_merged) launch_genw_general(on(!has_filt ? 1 : !has_wave ? 2 : 1));
+    // (or / xor: at the end of the light chain, whose stream is idle by then; and / cardinality: the union stream, idle)
+    if (!multi && has_runs && !genw_merged) launch_genw_general(!has_filt ? lst : on(!has_wave ? 2 : 1));
     if (has_ba && !P.grouped) {  // bitset (op) array, behind the few general items of its stream: andnot has no k_wave items, so that
                    // stream is free; or / xor: the filter's stream
-        hipStream_t sb = on(multi ? 0 : (op == OP_ANDNOT ? 2 : 1));  // (multi-op: behind the interval kernel)
+        hipStream_t sb = multi ? on(0) : op == OP_ANDNOT ? on(2) : lst;  // (multi-op: behind the interval kernel; or / xor: the light chain -- k_usmall has the filter's stream)
         const FatItem* qb = c->ss[P.slot].q[CLS_BA].as<FatItem>();
         const unsigned gb = bounded_grid(nm);
         GenItem* rq = c->ss[P.slot].q[CLS_RETRY].as<GenItem>();
@@ -1600,8 +1618,8 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
     if (has_retry) {
         // results that need the LDS image path after all: bitset x bitset results that must become
         // arrays (card <= 4096), interval results that must become bitsets
-        hipStream_t sr = has_runs ? on(0) : s;
-        if (fork && has_runs && has_bb) HIPCHK(hipStreamWaitEvent(sr, c->ev_runs, 0));
+        hipStream_t sr = fork ? on_aux(0) : s;  // (behind the interval kernel, which re-queues too; never the image kernel's stream)
+        if (need_bb_event) HIPCHK(hipStreamWaitEvent(sr, c->ev_runs, 0));
         if (fork && has_ba && !P.grouped && op != OP_OR) HIPCHK(hipStreamWaitEvent(sr, c->ev_ba, 0));  // k_ba re-queues its rare array results
         rhip_ctx_s::SlotScratch& SS = c->ss[P.slot];
         if (genw_merged)  // one stream: the general class and the re-queued results in one launch, after their producers
@@ -1835,14 +1853,15 @@ static rhip_batch_t* pairwise_begin_ops(rhip_ctx_t* c, size_t n_ops, const rhip_
         PoolView VA = A->view(), VB = B->view();
         const unsigned tail_blocks = (unsigned)std::max<uint64_t>(1, (P.ub_cand + TAIL_TILE - 1) / TAIL_TILE);
         uint32_t join_mask = 0;
-        run_kernels(c, ops, VA, VB, O, P, 0, (c->spin_join && tail_blocks <= 1024u) ? &join_mask : nullptr);
+        run_kernels(c, ops, VA, VB, O, P, 0, c->spin_join ? &join_mask : nullptr);
+        if (join_mask) hipLaunchKernelGGL(k_join_wait, dim3(1), dim3(64), 0, s, (const u64*)P.join_flags(), join_mask);
         // drop empty results, build the result directory, totals
         DirOut D{R->bm_start.as<u64>(), R->key.as<u64>(), R->type.as<uint8_t>(), R->card.as<uint32_t>(),
                  R->nruns.as<uint32_t>(), R->off.as<u64>()};
         const uint64_t seq = ++c->seq;
         hipLaunchKernelGGL(k_tail, dim3(tail_blocks), dim3(256), 0,
                            s, P.ranges(), CO, O.meta, D, (uint32_t)(npairs * n_ops), P.tail_lb(), P.tail_part(),
-                           (Stats*)c->slot_stats(slot), (u64*)c->done_flag(slot), (u64)seq, (const u64*)P.join_flags(), join_mask);
+                           (Stats*)c->slot_stats(slot), (u64*)c->done_flag(slot), (u64)seq);
         if (c->timing) HIPCHK(hipEventRecord(c->evs[slot][1], s));
         HIPCHK(hipGetLastError());  // a refused launch anywhere above must not pass silently
         clk.lap(3);

@@ -624,26 +624,23 @@ struct DirOut {
 constexpr uint32_t TAIL_PER_THREAD = 8;
 constexpr uint32_t TAIL_TILE = 256 * TAIL_PER_THREAD;  // candidates per block
 // Join without events (round 4).  The class kernels of a forked batch run on up to three auxiliary streams; joining them
-// into the main stream with events costs three barrier packets in front of this kernel -- 20 us between the end of the
-// last class kernel and the start of the tail, on every forked batch (profiles/r04_timelines.txt).  Instead every
-// auxiliary stream ends with k_join_signal, and the tail is launched on the main stream WITHOUT waiting: its blocks
-// wait here for the flags of the streams in `join_mask`, then take an acquire fence (the class kernels' results were
-// released at the end of their kernels, on other XCDs) before they read a meta word.  The host uses this form only
-// while the tail's grid is small (<= 1024 blocks): blocks that wait hold wave slots, and the kernels they wait for must
-// still find theirs.
+// into the main stream with events costs three barrier packets in front of the tail -- 20 us between the end of the
+// last class kernel and the start of k_tail, on every forked batch (profiles/r04_timelines.txt).  Instead every
+// auxiliary stream ends with k_join_signal and the main stream runs k_join_wait in front of k_tail: ONE wave that waits
+// for the flags of the streams in `mask` (the kernel boundary behind it is the acquire the tail needs: the class
+// kernels' results were released at the end of their kernels, possibly on other XCDs).  One wave holds one slot, so
+// the kernels it waits for always find theirs.  (Waiting inside k_tail itself saves the 5 us of that boundary but keeps
+// every block of the tail resident while it waits: a four-op batch on weather_sept_85 went 1.6 -> 2.4 ms.)
 __global__ void k_join_signal(u64* flag) {
     if (threadIdx.x == 0 && blockIdx.x == 0) lb_store(flag, 1ull);
 }
+__global__ void k_join_wait(const u64* flags, uint32_t mask) {
+    if (blockIdx.x == 0 && threadIdx.x < 8u && ((mask >> threadIdx.x) & 1u))
+        while (lb_load(&flags[threadIdx.x]) == 0ull) __builtin_amdgcn_s_sleep(8);
+}
 __global__ __launch_bounds__(256) void k_tail(const u64* __restrict__ ranges, CandOut C, const u64* __restrict__ meta,
                                               DirOut R, uint32_t n_pairs, LbState lb, u64* __restrict__ part,
-                                              Stats* __restrict__ host_stats, u64* host_flag, u64 seq,
-                                              const u64* join_flags, uint32_t join_mask) {
-    if (join_mask) {
-        if (threadIdx.x < 8u && ((join_mask >> threadIdx.x) & 1u))
-            while (lb_load(&join_flags[threadIdx.x]) == 0ull) __builtin_amdgcn_s_sleep(16);
-        __syncthreads();
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    }
+                                              Stats* __restrict__ host_stats, u64* host_flag, u64 seq) {
     __shared__ u64 sm[4];
     __shared__ uint32_t s_tile;
     __shared__ u64 s_prefix;
