@@ -20,6 +20,9 @@ for st, seg in zip(stats, segs):
     for k, v in st["classes"].items():
         pat = NAMES.get(k, k)
         ds = [x for n, xs in dur.items() if n.startswith(pat) for x in xs]
+        if not ds and k in ("k_wave", "k_ba"):  # an X-grouped batch: both classes are served by ONE k_union_g launch
+            ds = [x for n, xs in dur.items() if n.startswith("k_union_g") for x in xs]
+            k = k + " (in k_union_g)"
         us = sum(ds) / len(ds) / 1e3 if ds else None
         if k.startswith("k_ivl") or k == "k_genw":
             pass  # (k_ivl_all serves three classes in one launch, k_genw is launched twice: durations are per launch)
