@@ -198,7 +198,11 @@ struct rhip_ctx_s {
     uint64_t group_min_reuse = 64;  // (C5: 47 partners per container by this bound, almost all interval pairs -- grouping costs it 4 %)
     uint64_t group_min_items = 16u << 10;
     uint32_t group_chunk = 8;    // RHIP_XG_CHUNK: items a wave of the grouped kernels walks in a row, at least
-    bool spin_join = true;       // RHIP_SPIN_JOIN=0: forked class kernels are joined with events in front of k_tail (k_join_signal)
+    // Forked class kernels are joined by flags (k_join_signal / k_join_wait, rhip_plan.h) instead of events -- only where
+    // kernels of different streams really run side by side: rhip_ctx_create tests that (k_conc_probe) and falls back to
+    // events where they do not (a tool that serialises kernels: rocprofv3 --pmc).  RHIP_SPIN_JOIN=0: always events.
+    bool spin_join = true;
+    u64* join_timeout_word() const { return (u64*)((char*)h_pinned + PINNED_JOIN_TIMEOUT_OFF); }
     bool copy_wide = true;       // RHIP_COPY_WIDE=0: k_copy always takes four items per wave
     int many_pf = 4;  // RHIP_MANY_PF: payload groups per lane k_many_l1 loads ahead (2 / 4 / 8)
     int many_ch = 0;  // RHIP_MANY_CH: members per unit (tests of the multi-chunk / multi-unit paths on small inputs); 0 = by size
@@ -207,7 +211,7 @@ struct rhip_ctx_s {
     void* h_pinned = nullptr;  // small pinned readback area
     // completion word of the pairwise path (inside h_pinned): k_tail's last block writes the call's sequence number
     // after the statistics; the host polls it (the stream's completion signal costs an interrupt / wake-up)
-    static constexpr size_t PINNED_STATS_OFF = 1024, PINNED_STATS_STRIDE = 192, PINNED_FLAG_OFF = 2048;
+    static constexpr size_t PINNED_STATS_OFF = 1024, PINNED_STATS_STRIDE = 192, PINNED_FLAG_OFF = 2048, PINNED_JOIN_TIMEOUT_OFF = 3072;
     uint64_t seq = 0;
     bool spin_wait = true;
     int explicit_units = 0;  // RHIP_EXPLICIT_UNITS=1: always stage the unit arrays; =2: implicit units, but never four per wave (tests of those paths)
@@ -390,9 +394,23 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_GROUP_X")) c->group_x = atoi(e);
         if (const char* e = getenv("RHIP_XG_CHUNK")) c->group_chunk = (uint32_t)std::max(1, atoi(e));
         if (const char* e = getenv("RHIP_COPY_WIDE")) c->copy_wide = !(e[0] == '0');
-        if (const char* e = getenv("RHIP_SPIN_JOIN")) c->spin_join = !(e[0] == '0');
+        bool spin_join_forced = false;  // RHIP_SPIN_JOIN=2: on without the self-test (the emulator runs kernels one by one)
+        if (const char* e = getenv("RHIP_SPIN_JOIN")) { c->spin_join = !(e[0] == '0'); spin_join_forced = e[0] == '2'; }
         if (const char* e = getenv("RHIP_MANY_CH")) c->many_ch = std::max(1, std::min(1024, atoi(e)));
         memset(c->h_pinned, 0, 4096);
+        if (c->spin_join && !spin_join_forced) {
+            // do kernels of two streams overlap here?  (k_conc_probe: bounded wait on the main stream for a flag that a
+            // kernel launched 300 us later on an auxiliary stream sets; both words live in the pinned area)
+            u64* w = (u64*)((char*)c->h_pinned + 3200);  // [0] flag, [1] verdict
+            hipLaunchKernelGGL(k_conc_probe, dim3(1), dim3(64), 0, c->stream, (const u64*)w, w + 1);
+            const auto t0 = std::chrono::steady_clock::now();
+            while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 300.0) {}
+            hipLaunchKernelGGL(k_join_signal, dim3(1), dim3(64), 0, c->aux[0], w);
+            const bool ok = hipStreamSynchronize(c->stream) == hipSuccess && hipStreamSynchronize(c->aux[0]) == hipSuccess;
+            if (!ok || __atomic_load_n(w + 1, __ATOMIC_ACQUIRE) != 1ull) c->spin_join = false;
+            (void)hipGetLastError();
+            w[0] = w[1] = 0;
+        }
         {
             std::lock_guard<std::mutex> lk(g_ctx_mu);
             c->gen = ++g_ctx_gen;
@@ -1854,7 +1872,7 @@ static rhip_batch_t* pairwise_begin_ops(rhip_ctx_t* c, size_t n_ops, const rhip_
         const unsigned tail_blocks = (unsigned)std::max<uint64_t>(1, (P.ub_cand + TAIL_TILE - 1) / TAIL_TILE);
         uint32_t join_mask = 0;
         run_kernels(c, ops, VA, VB, O, P, 0, c->spin_join ? &join_mask : nullptr);
-        if (join_mask) hipLaunchKernelGGL(k_join_wait, dim3(1), dim3(64), 0, s, (const u64*)P.join_flags(), join_mask);
+        if (join_mask) hipLaunchKernelGGL(k_join_wait, dim3(1), dim3(64), 0, s, (const u64*)P.join_flags(), join_mask, c->join_timeout_word());
         // drop empty results, build the result directory, totals
         DirOut D{R->bm_start.as<u64>(), R->key.as<u64>(), R->type.as<uint8_t>(), R->card.as<uint32_t>(),
                  R->nruns.as<uint32_t>(), R->off.as<u64>()};
@@ -1916,6 +1934,13 @@ extern "C" rhip_pool_t* rhip_pairwise_end(rhip_batch_t* b) {
         HostClock clk(c);
         Stats st;
         finish_stats(c, nullptr, &st, b->may_bb, b->seq, slot);
+        if (__atomic_load_n(c->join_timeout_word(), __ATOMIC_ACQUIRE)) {  // k_join_wait gave up (rhip_plan.h)
+            __atomic_store_n(c->join_timeout_word(), 0ull, __ATOMIC_RELEASE);
+            c->spin_join = false;
+            set_err("the class kernels of a forked batch did not finish within 10 s of its image kernel: kernels of different "
+                    "streams are not running side by side (a tool that serialises them?); later batches of this context join with events");
+            throw (int)RHIP_ERR_DEVICE;
+        }
         if (c->class_stats) {  // (diagnostics: the slot's queues and meta words are intact until its next batch)
             rhip_ctx_s::SlotScratch& SS = c->ss[slot];
             ClassQueues CQ{SS.q[CLS_BB].as<BBItem>(), SS.q[CLS_BBA].as<BBItem>(),

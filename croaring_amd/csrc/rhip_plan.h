@@ -634,9 +634,29 @@ constexpr uint32_t TAIL_TILE = 256 * TAIL_PER_THREAD;  // candidates per block
 __global__ void k_join_signal(u64* flag) {
     if (threadIdx.x == 0 && blockIdx.x == 0) lb_store(flag, 1ull);
 }
-__global__ void k_join_wait(const u64* flags, uint32_t mask) {
-    if (blockIdx.x == 0 && threadIdx.x < 8u && ((mask >> threadIdx.x) & 1u))
-        while (lb_load(&flags[threadIdx.x]) == 0ull) __builtin_amdgcn_s_sleep(8);
+// (Bounded: ~10 s of s_sleep.  A wait that never ends would be a hang with no message; one that gives up leaves a
+// mark the host turns into an error -- see rhip_pairwise_end.)
+__global__ void k_join_wait(const u64* flags, uint32_t mask, u64* timed_out) {
+    if (blockIdx.x == 0 && threadIdx.x < 8u && ((mask >> threadIdx.x) & 1u)) {
+        u64 spins = 0;
+        while (lb_load(&flags[threadIdx.x]) == 0ull) {
+            __builtin_amdgcn_s_sleep(127);
+            if (++spins > 2500000ull) { lb_store(timed_out, 1ull); break; }
+        }
+    }
+}
+// Self-test of a context (rhip_ctx_create): do kernels of two streams run SIDE BY SIDE here?  This kernel waits (bounded:
+// ~5 ms) for a flag that a kernel launched later, on another stream, sets.  Under a tool that serialises kernel
+// execution (rocprofv3 --pmc does) it runs alone, times out, and the context joins its streams with events instead.
+__global__ void k_conc_probe(const u64* flag, u64* out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        u64 seen = 2;
+        for (uint32_t i = 0; i < 20000u; ++i) {
+            if (lb_load(flag) != 0ull) { seen = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        lb_store(out, seen);
+    }
 }
 __global__ __launch_bounds__(256) void k_tail(const u64* __restrict__ ranges, CandOut C, const u64* __restrict__ meta,
                                               DirOut R, uint32_t n_pairs, LbState lb, u64* __restrict__ part,

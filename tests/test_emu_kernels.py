@@ -281,6 +281,7 @@ def test_emu_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
         pytest.skip("hipemu needs the ROCm clang++ to compile the kernels for the host")
     if mode == "fork":       # the stand-alone class kernels (a small batch otherwise runs them as ONE launch, k_classes)
         monkeypatch.setenv("RHIP_FORK_MIN_MB", "0")
+        monkeypatch.setenv("RHIP_SPIN_JOIN", "2")  # (the emulator runs kernels one by one: no self-test, the flag join forced on)
     elif mode == "nomerge":
         monkeypatch.setenv("RHIP_MERGE_CLASSES", "0")
     else:
@@ -316,6 +317,7 @@ def test_emu_grouped_queues(oracle, synth, monkeypatch, mode):
     monkeypatch.setenv("RHIP_GROUP_X", "2")
     if mode == "groupfork":
         monkeypatch.setenv("RHIP_FORK_MIN_MB", "0")
+        monkeypatch.setenv("RHIP_SPIN_JOIN", "2")
     eng = emu_engine()
     try:
         G.grouped_body(eng, oracle, synth)
