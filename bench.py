@@ -243,17 +243,23 @@ class Dist:
         return float(t.item())
 
 
-def timed_calls(D: Dist, fn, reps=10, min_s=0.05):
-    """>= reps repetitions (and >= min_s in total) of fn, each bracketed by a barrier; returns (min, median) of the
-    max-over-ranks wall time."""
+def timed_calls(D: Dist, fn, reps=20, min_s=0.05):
+    """>= reps repetitions (and >= min_s in total) of fn; returns (min, median) of the wall time of a call.  fn is a
+    SYNCHRONOUS call (it returns when its results are complete), so on one GPU the calls are simply issued one after the
+    other, as a caller would; with several ranks every call is bracketed by a barrier and the slowest rank counts."""
     fn()
+    fn()
+    sync = D.world > 1
     ts, t_all = [], time.perf_counter()
     while len(ts) < reps or time.perf_counter() - t_all < min_s:
-        D.barrier()
+        if sync:
+            D.barrier()
         t0 = time.perf_counter()
         fn()
-        D.barrier()
-        ts.append(D.max(time.perf_counter() - t0))
+        if sync:
+            D.barrier()
+        dt = time.perf_counter() - t0
+        ts.append(D.max(dt) if sync else dt)
         if len(ts) >= 200:
             break
     return float(np.min(ts)), float(np.median(ts))

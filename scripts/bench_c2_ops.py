@@ -15,7 +15,8 @@ for op in ("and", "or", "xor", "andnot"):
     ts, ks = [], []
     res = None
     for i in range(3):
-        res = eng.pairwise(op, pool, *bench.schedule(i * 250, 250, 256), reuse=res)
+        l0, r0 = bench.schedule(i * 250, 250, 256)
+        res = eng.pairwise(op, pool, l0, pool, r0, reuse=res)
     eng.synchronize()
     for i in range(7):
         lhs, rhs = bench.schedule(i * 250, 250, 256)

@@ -10,10 +10,15 @@ DST = os.path.join(ROOT, "profiles")
 
 def cp(src, dst):
     if os.path.exists(src):
+        if os.path.getsize(src) == 0:  # (round 3 committed an empty r03_c2_ops.jsonl that DESIGN cited: never again)
+            raise SystemExit(f"collect_profiles: {src} is EMPTY -- the step that writes it failed; fix it before citing it")
         shutil.copy(src, os.path.join(DST, dst))
         print("  ", dst)
 
 cp(os.path.join(SRC, "bench.json"), f"{TAG}_bench.json")
+cp(os.path.join(SRC, "bench_detail.json"), f"{TAG}_bench_detail.json")
+cp(os.path.join(SRC, "quick_all.txt"), f"{TAG}_quick_all.txt")
+cp(os.path.join(SRC, "pmc_l2.md"), f"{TAG}_pmc_l2.md")
 for f, d in (("c2_ops.jsonl", "c2_ops"), ("quick_c3.jsonl", "quick_c3"), ("class_throughput.jsonl", "class_throughput"),
              ("poolops.jsonl", "poolops"), ("per_kernel_c3.jsonl", "per_kernel_c3"), ("multi.txt", "multi_ops")):
     cp(os.path.join(SRC, f), f"{TAG}_{d}" + (".txt" if f.endswith(".txt") else ".jsonl"))
