@@ -16,18 +16,25 @@ typing, directory compaction.  Inputs are resident in HBM before the timed regio
 N > 1: every rank runs the same schedule on its own pool (pairwise ops shard with no data-path collective,
 SURVEY §8e): scaling = "weak".
 
-config.secondary (same line, measured after the timed region of the headline):
+config.secondary_summary (same line, measured after the timed region of the headline; one compact row per configuration
+-- [ms per batch, fraction of the HBM peak, checksum ok, ...] -- so that the line stays ~4 KB; every other figure of a row
+goes to stderr as `BENCH_DETAIL {...}` and to gpurun_out/bench_detail.json):
   c3_* / c1_*   realdata weather_sept_85 / census1881 (tests/golden bundles): ALL unordered pairs, one batched call
-                per op (and / or / xor / andnot / and_cardinality), wall time of the whole call; the SURVEY §8d
-                checksums are asserted; pairs are partitioned over ranks (strong scaling); CRoaring on 1 host core
-                beside it.
+                per op (and / or / xor / andnot / and_cardinality) over a PREPARED pair list (rhip_pairlist_*), wall time
+                of the whole call, calls issued back to back; the SURVEY §8d checksums are asserted; pairs are
+                partitioned over ranks (strong scaling); CRoaring on 1 host core beside it.
   c4_or_many    BASELINE configs[3]: roaring_bitmap_or_many over 100 000 seeded sparse bitmaps (pcg32 generator in
                 the library), bitmaps b mod N on rank b mod N, key-owner exchange over RCCL (strong scaling).
-  c5_*          BASELINE configs[4]: roaring64, wikileaks-noquotes x 10 buckets, all pairs and/or + 200-way union.
+  c4x10_or_many the same generator at 10^6 bitmaps (16.4 GB): the many-way row large enough for N GPUs to split;
+                cardinality checked against the reference's (tests/golden/c4x10_or_many.npz).
+  c4_shard_stages  (N = 1 only) what ONE rank of 2 / 4 / 8 pays for the sharded or_many, measured on this GPU.
+  c5_*          BASELINE configs[4]: roaring64, wikileaks-noquotes x 10 buckets, all pairs and/or + the 200-way union
+                (N > 1: sharded b mod N through the 48-bit-key exchange, cardinality asserted).
 
-Extra keys: "roofline" (bitset x bitset kernel vs the 8 TB/s HBM peak, from HIP events on the engine's stream) and
-"cpu_baseline" (CRoaring itself -- oracle/_ref -- or the C port when the prebuilt reference is absent, on a bounded
-sample of the same workload on the host cores: 1 core, all cores, best T, and the ISA variants when prebuilt).
+Extra keys: "roofline" (bitset x bitset kernel vs the 8 TB/s HBM peak, from HIP events on the engine's stream; the two
+result arenas are placed by the LIBRARY when it allocates them -- config.result_arena_placement lists the probe rates)
+and "cpu_baseline" (CRoaring itself -- oracle/_ref -- or the C port when the prebuilt reference is absent, on a bounded
+sample of the same workload on rank 0's host cores, at every N: 1 core, best T of a sweep, the ISA variants).
 """
 from __future__ import annotations
 
@@ -649,13 +656,17 @@ def main():
                 pending = (op, b)
         finish(pending)
 
-    # Untimed start-up: the two result pools the steps recycle.  A multi-GiB arena is fast or 6 % slower for the bitset
-    # kernel depending on the physical pages it got (Engine.pairwise_placed): a few allocations, the best one kept.
+    # (diagnostic, --arena-tries > 0: the CALLER picks the two result pools by measurement, Engine.pairwise_placed -- round 3's
+    # start-up; by default the library places each result arena itself when it allocates it)
     arena_probe = []
     if args.arena_tries > 0:
         lhs, rhs = schedule(0, args.pairs, args.pool)
         (results["and"], results["or"]), arena_probe = eng.pairwise_placed("or", pool, lhs, pool, rhs, tries=args.arena_tries,
                                                                            keep=2, timing_after=True)
+    if results["and"] is None:
+        # untimed start-up, whatever --warmup says: the first step allocates (and the library places) the two result pools
+        # that every later step recycles -- allocation is not part of a step
+        step(0, False)
     for i in range(args.warmup):
         step(i, False)
     D.barrier()
