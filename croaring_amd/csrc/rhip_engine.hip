@@ -1862,7 +1862,7 @@ static rhip_batch_t* pairwise_begin_ops(rhip_ctx_t* c, size_t n_ops, const rhip_
         // (a batch of this size plans on the main stream, so the probes below are ordered behind everything enqueued so far
         // -- the batches in flight included -- and run alone)
         if (c->arena_tries > 1 && P.arena_bound + 64 > R->arena.cap && P.arena_bound + 64 >= c->arena_place_min &&
-            A->arena.cap >= (64ull << 20) && P.plan_stream == s)
+            A->arena.cap >= std::min<uint64_t>(64ull << 20, std::max<uint64_t>(c->arena_place_min, 8192)) && P.plan_stream == s)
             place_arena(c, R->arena, P.arena_bound + 64, A);
         R->arena.ensure(P.arena_bound + 64);
         OutView O{};

@@ -303,6 +303,21 @@ def test_emu_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
         eng.close()
 
 
+def test_emu_arena_placement_forced(oracle, synth, monkeypatch):
+    """place_arena on small arenas (RHIP_ARENA_PLACE_MIN_MB=0) through the emulator: the candidate bookkeeping -- allocate,
+    probe, keep one, release the rest, hand the winner to the result pool -- not the timings, is what this covers."""
+    from emu import build_emu, emu_engine
+    if not __import__("os").path.exists(build_emu.CXX):
+        pytest.skip("hipemu needs the ROCm clang++ to compile the kernels for the host")
+    monkeypatch.setenv("RHIP_ARENA_PLACE_MIN_MB", "0")
+    monkeypatch.setenv("RHIP_ARENA_TRIES", "3")
+    eng = emu_engine()
+    try:
+        G.arena_placement_body(eng, oracle, synth)
+    finally:
+        eng.close()
+
+
 def test_emu_batches_in_flight(emu, oracle, synth):
     G.test_batches_in_flight(emu, oracle, synth)
 

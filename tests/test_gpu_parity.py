@@ -900,6 +900,49 @@ def test_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
         eng.close()
 
 
+@pytest.mark.gpu
+def test_arena_placement_forced(oracle, synth, monkeypatch):
+    """The measured placement of result arenas (place_arena: candidates allocated, probed with k_place_probe against the
+    operand pool, the fastest kept, the others released) forced onto SMALL arenas with RHIP_ARENA_PLACE_MIN_MB=0: results
+    byte-identical, recycled pools keep working, the probe rates are reported.  (At full size the C2 tests and bench.py
+    go through it by themselves.)"""
+    import croaring_amd
+    monkeypatch.setenv("RHIP_ARENA_PLACE_MIN_MB", "0")
+    monkeypatch.setenv("RHIP_ARENA_TRIES", "4")
+    eng = croaring_amd.Engine()
+    try:
+        arena_placement_body(eng, oracle, synth)
+    finally:
+        eng.close()
+
+
+def arena_placement_body(eng, oracle, synth):
+    bufs, _, _ = synth
+    pool = eng.pool_from_serialized(bufs)
+    n = len(bufs)
+    rng = np.random.default_rng(31)
+    lhs = rng.integers(0, n, 200).astype(np.uint32)
+    rhs = rng.integers(0, n, 200).astype(np.uint32)
+    res = None
+    for op in OPS:
+        res = eng.pairwise(op, pool, lhs, pool, rhs, reuse=res)  # (the recycled arena grows under or / xor: placed again)
+        blob, offs = res.serialize_many()
+        raw = blob.tobytes()
+        for k in range(0, 200, 7):
+            oa, ob = oracle.deserialize(bufs[lhs[k]]), oracle.deserialize(bufs[rhs[k]])
+            oo = oracle.op(op, oa, ob)
+            assert raw[int(offs[k]):int(offs[k + 1])] == oracle.serialize(oo), (op, k)
+            for h in (oa, ob, oo):
+                oracle.free(h)
+    rates = eng.last_placement()
+    assert 1 <= len(rates) <= 4 and all(r > 0 for r in rates), rates
+    b1 = eng.pairwise_begin("xor", pool, lhs, pool, rhs)  # a fresh result pool while another batch is in flight
+    b2 = eng.pairwise_begin("or", pool, lhs, pool, rhs)
+    r2, r1 = b2.end(), b1.end()
+    assert np.array_equal(r1.serialize_many()[0], eng.pairwise("xor", pool, lhs, pool, rhs).serialize_many()[0])
+    assert np.array_equal(r2.serialize_many()[0], eng.pairwise("or", pool, lhs, pool, rhs).serialize_many()[0])
+
+
 def grouped_body(eng, oracle, synth):
     """Everything with an image-class item, through the X-grouped queues (k_filter_g / k_union_g)."""
     test_edge_cases(eng, oracle)
