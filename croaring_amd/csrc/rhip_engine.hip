@@ -1756,7 +1756,10 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
     const u64 n_items = (n_slots + stride - 1) / stride;
     hipStream_t s = c->stream;
     struct Cand { DBuf buf; float gbps = 0; };
-    std::vector<Cand> cands;
+    struct Cands : std::vector<Cand> {  // (a HIP error in the middle of the search must not leak the candidates it leaves behind)
+        int keep = -1;
+        ~Cands() { for (int k = 0; k < (int)size(); ++k) if (k != keep) (*this)[k].buf.release(); }
+    } cands;
     c->last_placement.clear();
     hipEvent_t e0 = c->ev[0], e1 = c->ev[1];
     int best = -1;
@@ -1776,24 +1779,24 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
             if (best >= 0) break;  // out of memory for another candidate: choose among those there are
             throw;
         }
+        cands.push_back(cd);
+        Cand& cur = cands.back();
         float ms_best = 1e30f;
         for (int r = 0; r < 3; ++r) {  // (the first pass touches the pages)
             HIPCHK(hipEventRecord(e0, s));
-            hipLaunchKernelGGL(k_place_probe, dim3(8192), dim3(256), 0, s, A->arena.as<uint8_t>(), a_items, cd.buf.as<uint8_t>(), n_slots, stride);
+            hipLaunchKernelGGL(k_place_probe, dim3(8192), dim3(256), 0, s, A->arena.as<uint8_t>(), a_items, cur.buf.as<uint8_t>(), n_slots, stride);
             HIPCHK(hipEventRecord(e1, s));
             HIPCHK(hipEventSynchronize(e1));
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, e0, e1));
             if (r && ms < ms_best) ms_best = ms;
         }
-        cd.gbps = (float)((double)n_items * 24576.0 / (double)ms_best / 1e6);
-        c->last_placement.push_back(cd.gbps);
-        cands.push_back(cd);
-        if (best < 0 || cd.gbps > cands[best].gbps) best = (int)cands.size() - 1;
-        if (cd.gbps >= c->arena_good_gbps) break;
+        cur.gbps = (float)((double)n_items * 24576.0 / (double)ms_best / 1e6);
+        c->last_placement.push_back(cur.gbps);
+        if (best < 0 || cur.gbps > cands[best].gbps) best = (int)cands.size() - 1;
+        if (cur.gbps >= c->arena_good_gbps) break;
     }
-    for (int k = 0; k < (int)cands.size(); ++k)
-        if (k != best) cands[k].buf.release();
+    cands.keep = best;  // (the others are released when `cands` goes out of scope)
     arena.release();
     const bool p2 = arena.pow2_large;
     const uint64_t g = arena.gen;
