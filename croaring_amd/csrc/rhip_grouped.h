@@ -326,8 +326,12 @@ __device__ __forceinline__ void union_g_body(uint32_t* __restrict__ lds, uint32_
         __builtin_amdgcn_wave_barrier();  // the image is zeroed again by the next item
     }
 }
+// (-DRHIP_UNION_WAVES=5: variant build, five waves per SIMD if the compiler fits the kernel into 96 VGPRs)
+#ifndef RHIP_UNION_WAVES
+#define RHIP_UNION_WAVES 4
+#endif
 template <int OP>
-__global__ __launch_bounds__(256, 4) void k_union_g(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+__global__ __launch_bounds__(256, RHIP_UNION_WAVES) void k_union_g(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                                  OutView O, const FatItem* __restrict__ q, const u64* __restrict__ xr,
                                                  uint32_t cmin) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[8192];

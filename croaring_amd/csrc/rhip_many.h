@@ -636,8 +636,13 @@ __device__ __forceinline__ bool many_image_full(const uint32_t* acc, BlockScratc
 }
 
 // PF = 16-byte payload groups per lane loaded ahead of the LDS atomics (RHIP_MANY_PF selects 2 / 4 / 8; default 4)
+// (-DRHIP_MANY_WAVES=5, a variant build for A/B runs -- croaring_amd/build.py RHIP_BUILD_VARIANT: five waves per SIMD at 96
+// VGPRs and 24 bytes of scratch per lane; compiled in round 4, not yet measured)
+#ifndef RHIP_MANY_WAVES
+#define RHIP_MANY_WAVES 1
+#endif
 template <int PF>
-__global__ __launch_bounds__(256) void k_many_l1(PoolView P, ManyView V, ManyOut MO, int op) {
+__global__ __launch_bounds__(256, RHIP_MANY_WAVES) void k_many_l1(PoolView P, ManyView V, ManyOut MO, int op) {
     __shared__ __attribute__((aligned(16))) uint32_t acc[2048];
     __shared__ __attribute__((aligned(16))) uint32_t tmp[2048];
     __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];
