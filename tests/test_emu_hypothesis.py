@@ -135,6 +135,11 @@ def test_batched_all_pairs_match_the_oracle(emu, oracle, bms, op):
     rhs = np.tile(np.arange(n, dtype=np.uint32), n)
     res = emu.pairwise(op, pool, lhs, pool, rhs)
     cards = emu.pairwise_cardinality(op, pool, lhs, pool, rhs)
+    # the same batch over a PREPARED pair list (rhip_pairlist_*): no host pass, no staging -- identical bytes
+    plist = emu.pairlist(pool, lhs, pool, rhs)
+    assert np.array_equal(emu.pairwise_list(op, plist).serialize_many()[0], res.serialize_many()[0])
+    assert np.array_equal(emu.pairwise_list_cardinality(op, plist), cards)
+    plist.free()
     for k in range(lhs.size):
         want = oracle.op(op, hs[lhs[k]], hs[rhs[k]])
         assert res.serialize(k) == oracle.serialize(want), (op, int(lhs[k]), int(rhs[k]))
