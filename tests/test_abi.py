@@ -64,3 +64,35 @@ def test_product_does_not_reference_oracle():
                 assert "hipemu" not in txt and "rhip_emu" not in txt, f  # the CPU emulator is test-only too
     out = os.popen(f"readelf -d {os.path.join(pkg, 'libroaring_hip.so')}").read()
     assert "oracle" not in out and "croaring_ref" not in out
+
+
+def test_headers_compile_as_c_and_cpp(tmp_path):
+    """include/*.h are what a binding compiles against: plain C11 and C++17, no HIP or torch types, every round-4 entry
+    point (prepared pair lists, the allocator hook) callable as INTEGRATION.md shows."""
+    import shutil
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('''
+#include "roaring_hip.h"
+#include "roaring_hip_compat.h"
+int main(void) {
+    rhip_ctx_t *ctx = 0; rhip_pool_t *pool = 0; rhip_op ops[4] = {RHIP_AND, RHIP_OR, RHIP_XOR, RHIP_ANDNOT};
+    rhip_pairlist_t *all = rhip_pairlist_all_pairs(ctx, pool);
+    rhip_pool_t *four = rhip_pairwise_list(ctx, 4, ops, all, 0);
+    rhip_batch_t *b = rhip_pairwise_list_begin(ctx, 1, ops, all, 0);
+    unsigned long long cards[1]; float rates[4];
+    (void)rhip_pairwise_list_cardinality(ctx, RHIP_AND, all, (uint64_t *)cards);
+    (void)rhip_debug_last_placement(ctx, rates, 4);
+    (void)rhip_install_pinned_allocator(0);
+    (void)four; (void)b;
+    rhip_pairlist_free(all);
+    return 0;
+}
+''')
+    inc = os.path.join(ROOT, "include")
+    for cc, std, lang in (("gcc", "-std=c11", "c"), ("g++", "-std=c++17", "c++")):
+        if not shutil.which(cc):
+            continue
+        p = subprocess.run([cc, std, "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", lang, "-I", inc, str(src)],
+                           capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
