@@ -36,6 +36,11 @@ def row(k, label):
 
 
 pl = d["config"]["result_arena_placement"]["probe_GBps_of_each_candidate"]
+_f = json.load(open(P(f"{TAG}_bench_final_code.json")))
+_r = _f["config"]["secondary_summary"]["rows"]
+FINAL = (f"weather `and` {_r['c3_and'][0]:.3f} / {_r['c3_and'][1]:.3f}, `or` {_r['c3_or'][0]:.3f} / {_r['c3_or'][1]:.3f}, `xor` {_r['c3_xor'][0]:.3f} / {_r['c3_xor'][1]:.3f}, "
+         f"`andnot` {_r['c3_andnot'][0]:.3f} / {_r['c3_andnot'][1]:.3f}; census1881 `and` {_r['c1_and'][0]:.3f}; C5 `and` {_r['c5_and'][0]:.3f}, `or` {_r['c5_or'][0]:.3f}; "
+         f"C4 {_r['c4_or_many'][0]:.3f}; C4 x 10 {_r['c4x10_or_many'][0]:.2f}; C2 `k_bb` {_f['roofline']['frac']:.3f} of peak.")
 t = []
 t.append(f"""**Headline (`bench.py`, C2, N = 1, driver contract).** {d['value']:,.0f} set-ops/s = {d['config']['algorithmic_GBps'] / 1e3:.2f} TB/s algorithmic over a
 {d['config']['timed_region_s']:.2f} s timed region ({d['ms_per_step']:.1f} ms per step of 3 000 ops).  Dominant kernel `k_bb`: {r['achieved'] / 1e3:.2f} TB/s = **{r['frac']:.3f} of the 8 TB/s
@@ -60,6 +65,9 @@ t.append(f"""
 (`and` / `andnot` write 8 GiB arenas, `or` / `xor` 16 GiB ones -- their slot bound is the sum of both operands -- and the
 cardinality forms write nothing: 16 384 B per pair.  Which physical pages an arena gets moves `k_bb` between 3.9 and 4.7 ms;
 §3 and `profiles/{TAG}_arena_distance.txt` say what was found out about it.)
+
+**On the final code** (`profiles/{TAG}_bench_final_code.json`: `bench.py --no-cpu --steps 10`, the realdata calls issued back
+to back; median ms / of the HBM peak): {FINAL}
 
 **Realdata, ALL unordered pairs in one batched call per op** (`bench.py`, detail in `profiles/{TAG}_bench_detail.json`: wall time
 of the whole call incl. planning and the final wait over a PREPARED pair list (`rhip_pairlist_all_pairs`), median (min) of >= 10
