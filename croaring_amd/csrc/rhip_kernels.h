@@ -14,7 +14,8 @@
 //   k_bb               K1-K3: bitset (x) bitset {and,or,xor,andnot} fused with popcount, one wave per container
 //                      pair, 16 x 16-byte loads in flight per lane
 //   k_bba              bitset (x) bitset whose and / andnot is expected to be an array: one pass, array written
-//   k_copy             pass-through containers (roaring.c:914-941 clone paths), four short ones per wave
+//   k_copy             pass-through containers (roaring.c:914-941 clone paths), four short ones per wave -- sixteen
+//                      when the pools hold tiny containers
 //   k_probe            K9/K12 for a streamed array of <= 256 values: pivot search straight from global / L2, no LDS
 //   k_filter           K8/K12: array filtered by membership (and / andnot), wave-private LDS image, wave per pair
 //   k_usmall           K10/K11 for a short operand (<= 255 values): rank merge into the long array
@@ -28,6 +29,10 @@
 //                      arrays: wave-private LDS image (runs: toggle bits + prefix-xor), op + popcount + run counting,
 //                      result re-typed by the reference's rules (Appendix A) and extracted with prefix sums
 //   k_tail             drops empty results, builds the result directory, totals + completion word to pinned memory
+//   k_join_signal / k_join_wait   join of a forked batch's auxiliary streams by flags (one-wave gate in front of k_tail);
+//                      k_conc_probe: the context's self-test that kernels of two streams really overlap
+//   k_place_probe      k_bb's access pattern without a queue: times a candidate result arena against the operand pool
+//                      (measured placement of large result arenas)
 //   k_many_*           group-by-key OR/XOR accumulation for or_many / xor_many
 //   k_compact          directory compaction of the flip / many-way paths
 #pragma once
