@@ -184,10 +184,12 @@ struct rhip_ctx_s {
     // alive until the choice is made, so that each gets different physical pages), a probe with k_bb's access pattern is
     // timed on each against the operand pool, the fastest is kept -- or the first that streams at arena_good_gbps.  The
     // caller does nothing; a recycled result pool (`reuse`) keeps its placement.  RHIP_ARENA_TRIES (0 / 1: off),
-    // RHIP_ARENA_PLACE_MIN_MB.
+    // RHIP_ARENA_PLACE_MIN_MB.  The search goes on for up to arena_tries more candidates while the best so far is below
+    // arena_fair_gbps.
     int arena_tries = 10;
     uint64_t arena_place_min = 2ull << 30;
     double arena_good_gbps = 6250.0;
+    double arena_fair_gbps = 5850.0;  // (probe scale: slow band 5.2-5.7 TB/s, mid 5.9-6.1, fast windows 6.2-6.4)
     std::vector<float> last_placement;  // probe GB/s of the candidates of the last placement (rhip_debug_last_placement)
     bool debug_plan = false;  // RHIP_DEBUG_PLAN=1: one line per batch on stderr (bounds, fork / merge decision)
     bool merge_classes = true;  // RHIP_MERGE_CLASSES=0: a small batch launches its class kernels one by one
@@ -1763,7 +1765,11 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
     c->last_placement.clear();
     hipEvent_t e0 = c->ev[0], e1 = c->ev[1];
     int best = -1;
-    for (int t = 0; t < c->arena_tries; ++t) {
+    // arena_tries candidates -- and up to as many again while even the best of them is in the slow band: consecutive
+    // allocations are neighbours (one process of round 4 drew ten slow candidates in a row), and with the losers still
+    // alive the driver has to hand out pages further away
+    for (int t = 0; t < 2 * c->arena_tries; ++t) {
+        if (t >= c->arena_tries && best >= 0 && cands[best].gbps >= c->arena_fair_gbps) break;
         Cand cd;
         cd.buf.skew = arena.skew;
         cd.buf.round_to = arena.round_to;
