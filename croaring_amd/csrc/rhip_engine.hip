@@ -1770,6 +1770,10 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
     // alive the driver has to hand out pages further away
     for (int t = 0; t < 2 * c->arena_tries; ++t) {
         if (t >= c->arena_tries && best >= 0 && cands[best].gbps >= c->arena_fair_gbps) break;
+        if (best >= 0) {  // never run the device out of memory for one more candidate
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < need + need / 4 + (1ull << 30)) { (void)hipGetLastError(); break; }
+        }
         Cand cd;
         cd.buf.skew = arena.skew;
         cd.buf.round_to = arena.round_to;
@@ -1782,7 +1786,8 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
         try {
             cd.buf.ensure(need);
         } catch (int) {
-            if (best >= 0) break;  // out of memory for another candidate: choose among those there are
+            (void)hipGetLastError();  // (the failed hipMalloc must not surface as the batch's own error later)
+            if (best >= 0) break;     // out of memory for another candidate: choose among those there are
             throw;
         }
         cands.push_back(cd);
