@@ -745,6 +745,18 @@ def test_prepared_pair_lists(engine, oracle, synth):
     with pytest.raises(Exception):
         engine.pairlist(pool, np.array([0, n], np.uint32), pool, np.array([0, 0], np.uint32))
     assert len(engine.pairwise_list("and", engine.pairlist(pool, np.zeros(0, np.uint32), pool, np.zeros(0, np.uint32)))) == 0
+    # a list that has been freed while a batch still read it cannot start another batch; a NULL list is refused
+    pl3 = engine.pairlist(pool, lhs[:4], pool, rhs[:4])
+    bb = engine.pairwise_list_begin("or", pl3)
+    h3 = pl3.h
+    pl3.free()                         # deferred
+    pl3.h = h3
+    with pytest.raises(Exception):
+        engine.pairwise_list("and", pl3)
+    pl3.h = None
+    assert len(bb.end()) == 4          # (the last batch over it releases the list)
+    import ctypes
+    assert not engine.lib.rhip_pairwise_list(engine.h, 1, (ctypes.c_int * 1)(0), None, None)
 
 
 def test_tiny_passthrough_containers(engine, oracle):
