@@ -80,6 +80,8 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true", help="skip config.secondary (realdata, C4, C5)")
     ap.add_argument("--no-x10", action="store_true", help="skip the 10^6-bitmap or_many row (16 GB of images built on the host, ~20 s)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
+    ap.add_argument("--cpu-baseline-only", action="store_true",
+                    help="internal: run the cpu_baseline leg alone and print its JSON (rank 0 does this in a fresh process at N > 1)")
     return ap.parse_args()
 
 
@@ -588,6 +590,9 @@ def claim_stdout():
 
 def main():
     args = parse_args()
+    if args.cpu_baseline_only:  # (no torch, no HIP, no NCCL in this process: only the CPU reference and its worker processes)
+        print(json.dumps(cpu_baseline(args, args.cpu_seconds)), flush=True)
+        return
     maybe_spawn(args)
     real_stdout = claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
@@ -783,7 +788,21 @@ def main():
             "note": "realdata: ALL unordered pairs in one batched call per op over a prepared pair list; pairs partitioned over ranks"}
     # cpu_baseline: rank 0's host cores, whatever the world size (the other ranks wait at the barrier below)
     if rank == 0 and not args.no_cpu:
-        cb = cpu_baseline(args, args.cpu_seconds)
+        if world == 1:
+            cb = cpu_baseline(args, args.cpu_seconds)
+        else:
+            # N > 1: in a fresh process -- the sweep forks worker processes, and forking a process that holds an RCCL
+            # communicator is not something to find out about inside the scaling run; bounded, and a failure is a row
+            import subprocess
+            try:
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-seconds", str(args.cpu_seconds),
+                                    "--containers", str(args.containers)], capture_output=True, text=True, timeout=180,
+                                   env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")})
+                cb = json.loads(p.stdout.strip().split("\n")[-1])
+            except Exception as e:
+                cb = None
+                out["cpu_baseline"] = {"error": str(e)[:160]}
+    if rank == 0 and not args.no_cpu and cb is not None:
         detail["cpu_baseline_full"] = cb
         out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "host_threads")}
         out["cpu_baseline"]["one_core_ops_per_s"] = round(cb["one_core"]["ops_per_s_median"], 1)
@@ -792,7 +811,7 @@ def main():
         out["cpu_baseline"]["note"] = ("CRoaring is malloc-bound here: every op allocates and writes a 32 MiB result, so worker processes "
                                        "stop scaling at ~16 on this host (page faults, not cores)")
         out["cpu_baseline"]["sample"] = cb["sample"][:300]
-    elif rank == 0:
+    elif rank == 0 and "cpu_baseline" not in out:
         out["cpu_baseline"] = None
     D.barrier()
     if rank == 0:
