@@ -76,7 +76,16 @@ struct DBuf {
             want -= skew;
         }
         hipError_t e = hipMalloc(&base, want + skew);
+        if (e != hipSuccess && want > n + 256) {
+            // the rounded request (slack, round_to, next power of two: up to 2 x n) did not fit: what the caller
+            // asked for may still.  hipMalloc's failure is sticky until read.
+            (void)hipGetLastError();
+            base = nullptr;
+            want = (n + 255) & ~(size_t)255;
+            e = hipMalloc(&base, want + skew);
+        }
         if (e != hipSuccess) {
+            (void)hipGetLastError();
             base = nullptr;
             set_err("hipMalloc(%zu) failed: %s", want + skew, hipGetErrorString(e));
             throw (int)RHIP_ERR_ALLOC;
@@ -207,7 +216,11 @@ struct rhip_ctx_s {
     u64* join_timeout_word() const { return (u64*)((char*)h_pinned + PINNED_JOIN_TIMEOUT_OFF); }
     bool copy_wide = true;       // RHIP_COPY_WIDE=0: k_copy always takes four items per wave
     int many_pf = 4;  // RHIP_MANY_PF: payload groups per lane k_many_l1 loads ahead (2 / 4 / 8)
-    int many_ch = 0;  // RHIP_MANY_CH: members per unit (tests of the multi-chunk / multi-unit paths on small inputs); 0 = by size
+    int many_ch = 0;  // RHIP_MANY_CH: members per piece (tests of the multi-chunk / cut-group paths on small inputs); 0 = by size
+    uint64_t many_slots = 1024;  // RHIP_MANY_SLOTS: pieces of a large call = workgroups of k_many_l1 resident at once (4 per CU)
+    uint64_t many_t = 8192;      // RHIP_MANY_T: members per workgroup of k_many_hist / k_many_scatter
+    int many_reverse = 0;        // RHIP_MANY_REVERSE (tests): k_many_scatter fills its reservations backwards
+    bool many_hist_dirty = false;  // a call failed between k_many_hist and k_many_keyscan: the histogram is not all zero
     static constexpr size_t PINNED_MANY_FLAG_OFF = 2304, PINNED_MANY_TOT_OFF = 2560, PINNED_MANY_ERR_OFF = 2816;
     DBuf sel[5];  // pool_select / pool_convert scratch
     void* h_pinned = nullptr;  // small pinned readback area
@@ -287,6 +300,7 @@ struct rhip_pool_s {
     std::vector<uint64_t> h_w;      // per-bitmap result-slot bound (k_bitmap_bounds), see fetch_bounds
     std::vector<uint64_t> h_wm;     // the same bound as the many-way path needs it (runs by rounded cardinality)
     uint64_t wm_total = 0;          // sum of h_wm
+    bool has_long_runs = false;     // some run container's payload exceeds 8192 bytes (a pass-through slot can then exceed a bitset's)
     uint64_t n_keys_distinct = 0;   // 32-bit pools: distinct container keys in the pool (fetch_bounds)
     uint64_t max_key = 0;           // largest container key in the pool
     std::vector<uint32_t> h_n;      // per-bitmap container count
@@ -398,7 +412,10 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_COPY_WIDE")) c->copy_wide = !(e[0] == '0');
         bool spin_join_forced = false;  // RHIP_SPIN_JOIN=2: on without the self-test (the emulator runs kernels one by one)
         if (const char* e = getenv("RHIP_SPIN_JOIN")) { c->spin_join = !(e[0] == '0'); spin_join_forced = e[0] == '2'; }
-        if (const char* e = getenv("RHIP_MANY_CH")) c->many_ch = std::max(1, std::min(1024, atoi(e)));
+        if (const char* e = getenv("RHIP_MANY_CH")) c->many_ch = std::max(1, std::min(1 << 20, atoi(e)));
+        if (const char* e = getenv("RHIP_MANY_SLOTS")) c->many_slots = (uint64_t)std::max(1, atoi(e));
+        if (const char* e = getenv("RHIP_MANY_T")) c->many_t = (uint64_t)std::max(1024, atoi(e));
+        if (const char* e = getenv("RHIP_MANY_REVERSE")) c->many_reverse = atoi(e);
         memset(c->h_pinned, 0, 4096);
         if (c->spin_join && !spin_join_forced) {
             // do kernels of two streams overlap here?  (k_conc_probe: bounded wait on the main stream for a flag that a
@@ -1057,7 +1074,7 @@ static void fetch_bounds(rhip_pool_t* P) {
     rhip_ctx_t* c = P->ctx;
     P->h_w.assign((size_t)P->n_bitmaps, 0);
     P->h_wm.assign((size_t)P->n_bitmaps, 0);
-    uint32_t census[3] = {0, 0, 0};
+    uint32_t census[4] = {0, 0, 0, 0};
     uint64_t nkeys = P->n_cont;
     if (P->n_bitmaps && P->n_cont) {
         const size_t nb = (size_t)P->n_bitmaps;
@@ -1080,11 +1097,12 @@ static void fetch_bounds(rhip_pool_t* P) {
         }
         HIPCHK(hipMemcpyAsync(P->h_w.data(), dw, 8 * nb, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(P->h_wm.data(), dwm, 8 * nb, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(census, dcensus, 12, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(census, dcensus, 16, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(&P->max_key, dnk + 1, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     for (int t = 0; t < 3; ++t) P->census[t] = census[t] ? 1 : 0;
+    P->has_long_runs = census[3] != 0;
     P->n_keys_distinct = nkeys;
     P->wm_total = 0;
     for (uint64_t w : P->h_wm) P->wm_total += w;

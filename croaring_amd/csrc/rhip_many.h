@@ -3,20 +3,34 @@
 //
 // The reference folds bitmap after bitmap into a growing answer ("for every key, OR all
 // containers with that key into one 8 KiB accumulator, then canonicalise",
-// roaring.c:2600-2682 + 2845-2856).  Here the same computation is a group-by-key with ONE host wait at the end:
-//   k_many_gather   every member container of the selected bitmaps becomes (key, 64-bit DESCRIPTOR): payload offset,
-//                   type, size -- everything the accumulation needs, so nothing gathers from the pool directory later;
-//                   also clears the scan / totals scratch of the call
-//   (stable radix sort by key: members of one key stay in input-bitmap order)
-//   k_many_groups   ONE look-back pass: group heads, group starts / keys, per-group cardinality bound (a second
-//                   look-back sum, read off at the heads), positions of the last full-run / bitset member of a group
-//   k_many_units    ONE look-back pass over the groups: units of <= ch members per group, result-slot offsets
-//   k_many_l1       one workgroup per unit: the array members of the unit are ONE flattened stream of 16-byte payload
-//                   groups (every lane holds eight values whatever the cardinalities), four loads per lane in flight
-//                   while the previous four feed the LDS atomics; bitset members: owner-thread word OR; run members:
-//                   toggle + prefix-xor rasterisation.  Groups with one unit are canonicalised straight from LDS,
-//                   groups with several write 8 KiB partial chunks
-//   k_many_l2       combines the partial chunks of multi-unit groups (same shape as the multi-GPU exchange)
+// roaring.c:2600-2682 + 2845-2856; every step inserts into the answer's sorted directory,
+// roaring_array.c:348-367).  Here the same computation is a group-by-key with ONE host wait at the end.
+//
+// Grouping, 16-bit keys (32-bit bitmaps) -- a COUNTING SORT over the key space, three launches, no library call:
+//   k_many_hist     every member container of the selected bitmaps is counted into an LDS histogram over its key
+//                   (count | result-slot weight), blocks flush their non-empty bins to the global histogram; also clears
+//                   the scan / totals scratch of the call
+//   k_many_keyscan  ONE workgroup walks the key space: non-empty bins become groups (start, key, partial-chunk slots,
+//                   result-slot offset) and per-key scatter cursors; the histogram is returned to zero for the next call
+//   k_many_scatter  the same member sets again: LDS count per key -> ONE global reservation per (block, key) -> every
+//                   member's 64-bit DESCRIPTOR (payload offset, type, size: everything the accumulation needs) lands in
+//                   its group.  The order inside a group is whatever the atomics give, so every member also carries its
+//                   TAG (position in the gathered order): the one place where the reference's result depends on the
+//                   fold order (the type of a FULL union) is replayed from the tags (full_union_decide).
+// Grouping, 48-bit keys (roaring64): k_many_gather -> stable radix sort by key (rocPRIM) -> k_many_groups (one look-back
+// pass: group heads, starts, keys, slot weights) -> k_many_units (look-back: partial-chunk slots, result-slot offsets);
+// tags are the positions themselves.
+//
+// Accumulation, both:
+//   k_many_l1       the grouped member list is cut into PIECES of `per` consecutive members (the host picks per = M /
+//                   resident workgroups: every workgroup gets the same number of members whatever the group sizes, a
+//                   100 000-member group is just 32 pieces); a workgroup walks the groups of its piece.  The array
+//                   members are ONE flattened stream of 16-byte payload groups (every lane holds eight values whatever
+//                   the cardinalities), four loads per lane in flight while the previous four feed the LDS atomics;
+//                   bitset members: owner-thread word OR; run members: toggle + prefix-xor rasterisation.  A group
+//                   inside one piece is canonicalised straight from LDS, a group cut by piece boundaries writes 8 KiB
+//                   partial chunks
+//   k_many_l2       combines the partial chunks of cut groups (same shape as the multi-GPU exchange)
 //   k_many_copy     single-member groups keep their container unchanged
 //   k_many_tail     ONE look-back pass: drops empty (xor) results, writes the result directory, totals and the
 //                   completion word into pinned host memory
@@ -51,24 +65,33 @@ __device__ __forceinline__ uint32_t md_payload(u64 d) {
 
 // device-side totals of one call (inside the zeroed scratch words); the last kernel copies them to pinned memory
 struct ManyTotals {
-    u64 n_groups, n_units, slot_bytes, kept, bytes_in, bytes_out, n_type[3], max_key, err;
+    u64 n_groups, n_partials, slot_bytes, kept, bytes_in, bytes_out, n_type[3], max_key, err;
 };
 #define MANY_ERR_KEYSPACE 1ull
 
 struct ManyView {
-    const u64* skey;        // [M] sorted member keys
-    const u64* sdesc;       // [M] member descriptors, same order
-    const u64* gstart;      // [G+1] first member of each group
-    const u64* ustart;      // [G+1] first unit of each group
-    const u64* pstart;      // [G+1] first partial-chunk slot of each group (groups with several units)
-    const ManyTotals* tot;  // n_groups / n_units live here
-    uint32_t ch;            // members per unit (upper bound, <= 1024)
+    const u64* sdesc;       // [M] member descriptors, grouped by key
+    const uint32_t* sord;   // [M] tag (position in the gathered order) of every member; null: the members of a group ARE
+                            //     in gathered order and a member's tag is its position
+    u64* rdesc;             // [M] scratch of the full-union replay (a group only ever uses its own range)
+    const u64* gstart;      // [G+1] first member of each group; gstart[G] = M
+    const u64* pstart;      // [G+1] first partial-chunk slot of each group (groups cut by piece boundaries)
+    const ManyTotals* tot;  // n_groups lives here
+    u64 per;                // members per piece
 };
 struct ManyZero {   // scratch the first kernel of a call clears for the later ones
     u64* words; u64 n_words;
     uint32_t* glast; u64 n_glast;
     u64* table; u64 n_table;   // dense stage-1 table of the sharded form (u64 words), may be null
 };
+// result-slot weight of a member, in 16-byte units: the slot of a group is its one member's weight, or the sum of its
+// members' weights capped at a bitset (512).  The same figure as the host's per-bitmap bound (k_bitmap_bounds' wmany:
+// runs weighed by their cardinality rounded up to a multiple of 256) -- the arena is sized from the sum of those.
+__device__ __forceinline__ uint32_t many_weight16(uint32_t ty, uint32_t card, uint32_t nruns) {
+    return slot_bound((uint8_t)ty, ty == T_RUN ? ((card + 255u) & ~255u) : card, nruns) >> 4;
+}
+// pieces a group [gs, ge) is cut into by the piece boundaries (multiples of per)
+__device__ __forceinline__ u64 many_group_pieces(u64 gs, u64 ge, u64 per) { return (ge - 1) / per - gs / per + 1; }
 
 // members of the selected bitmaps -> (key, descriptor).  ids == null: every bitmap of the pool, one thread per container.
 __global__ __launch_bounds__(256) void k_many_gather(PoolView P, const uint32_t* __restrict__ ids,
@@ -93,6 +116,192 @@ __global__ __launch_bounds__(256) void k_many_gather(PoolView P, const uint32_t*
             mkey[d0 + (i - c0)] = P.key[i];
             mdesc[d0 + (i - c0)] = md_pack(P.off[i], P.type[i], P.card[i], P.nruns[i]);
         }
+    }
+}
+
+// ------------------------------------------------------------------ grouping by counting sort (16-bit keys)
+// The members of a call in GATHERED order: member t (its tag) is container `t` of the pool (ids == null), or container
+// bm_start[ids[s]] + (t - sel_start[s]) of the s-th selected bitmap.  A workgroup's share: `per_block` consecutive members
+// (ids == null) or `per_block` consecutive selected bitmaps, a wave per bitmap.  k_many_hist and k_many_scatter iterate
+// the same way (nothing else depends on the split).
+struct ManySel {
+    const uint32_t* ids;
+    const u64* sel_start;  // [nsel + 1]
+    uint32_t nsel;
+    u64 M;
+    u64 per_block;
+};
+constexpr uint32_t MC_THREADS = 1024;
+constexpr uint32_t MC_W1 = 8192;    // keys per LDS window of k_many_hist (u64 bins: 64 KiB)
+constexpr uint32_t MC_W3 = 16384;   // keys per LDS window of k_many_scatter (u32 bins: 64 KiB)
+constexpr uint32_t MC_WCAP = 8192;  // a block's flushed slot weight per key is capped here (>= any single weight's use: 512)
+
+template <class F>
+__device__ __forceinline__ void many_for_members(const PoolView& P, const ManySel& S, F f) {
+    if (!S.ids) {
+        const u64 lo = (u64)blockIdx.x * S.per_block, hi = lo + S.per_block < S.M ? lo + S.per_block : S.M;
+        for (u64 t = lo + threadIdx.x; t < hi; t += MC_THREADS) f(t, t);
+        return;
+    }
+    const u64 s0 = (u64)blockIdx.x * S.per_block, s1 = s0 + S.per_block < S.nsel ? s0 + S.per_block : S.nsel;
+    for (u64 s = s0 + (threadIdx.x >> 6); s < s1; s += MC_THREADS / 64) {
+        const uint32_t b = S.ids[s];
+        const u64 c0 = P.bm_start[b], c1 = P.bm_start[b + 1], d0 = S.sel_start[s];
+        for (u64 i = c0 + lane_id(); i < c1; i += 64) f(i, d0 + (i - c0));
+    }
+}
+
+// hist[k] = members with key k | (slot weight, 16-byte units) << 32, accumulated on top of an all-zero array
+// (k_many_keyscan returns it to zero); hist[KS] = payload bytes of all members.
+__global__ __launch_bounds__(MC_THREADS) void k_many_hist(PoolView P, ManySel S, uint32_t KS, u64* __restrict__ hist, ManyZero Z) {
+    __shared__ u64 h[MC_W1];
+    __shared__ u64 s_bytes[MC_THREADS / 64];
+    const u64 gid = (u64)blockIdx.x * MC_THREADS + threadIdx.x, nth = (u64)gridDim.x * MC_THREADS;
+    for (u64 i = gid; i < Z.n_words; i += nth) Z.words[i] = 0;
+    for (u64 i = gid; i < Z.n_glast; i += nth) Z.glast[i] = 0;
+    for (u64 i = gid; i < Z.n_table; i += nth) Z.table[i] = 0;
+    u64 bytes = 0;
+    for (uint32_t w0 = 0; w0 < KS; w0 += MC_W1) {
+        for (uint32_t i = threadIdx.x; i < MC_W1; i += MC_THREADS) h[i] = 0;
+        __syncthreads();
+        many_for_members(P, S, [&](u64 c, u64) {
+            const uint32_t k = ((uint32_t)P.key[c] & 0xFFFFu) - w0;
+            if (k < MC_W1) {
+                const uint32_t ty = P.type[c], cd = P.card[c], nr = P.nruns[c];
+                atomicAdd(&h[k], 1ull | ((u64)many_weight16(ty, cd, nr) << 32));
+                bytes += payload_bytes((uint8_t)ty, cd, nr);
+            }
+        });
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < MC_W1 && w0 + i < KS; i += MC_THREADS) {
+            const u64 v = h[i];
+            if (v) {
+                const u64 w = (v >> 32) > MC_WCAP ? (u64)MC_WCAP : (v >> 32);
+                atomicAdd(&hist[w0 + i], (v & 0xFFFFFFFFull) | (w << 32));
+            }
+        }
+        __syncthreads();
+    }
+    bytes = wave_sum64(bytes);
+    if (lane_id() == 0) s_bytes[threadIdx.x >> 6] = bytes;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 b = 0;
+        for (uint32_t w = 0; w < MC_THREADS / 64; ++w) b += s_bytes[w];
+        if (b) atomicAdd(&hist[KS], b);
+    }
+}
+
+// exclusive prefix sums of two values over the 1024 threads of the block; totals through ta / tb
+__device__ __forceinline__ void blk1024_exscan2(uint32_t& a, uint32_t& b, uint32_t* sw /* [32] LDS */, uint32_t* ta, uint32_t* tb) {
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t ia = wave_incl_scan(a), ib = wave_incl_scan(b);
+    __syncthreads();
+    if (lane == 63) { sw[wave] = ia; sw[16 + wave] = ib; }
+    __syncthreads();
+    uint32_t oa = 0, ob = 0, sa = 0, sb = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; ++w) {
+        const uint32_t x = sw[w], y = sw[16 + w];
+        if (w < wave) { oa += x; ob += y; }
+        sa += x; sb += y;
+    }
+    a = oa + ia - a; b = ob + ib - b;
+    *ta = sa; *tb = sb;
+}
+
+// ONE workgroup over the key space: groups in key order.  gstart / gkey / pstart / off as the accumulation kernels read
+// them, kc[k] = first member position of key k | group index << 32 (k_many_scatter's cursor), totals; hist back to zero.
+__global__ __launch_bounds__(MC_THREADS) void k_many_keyscan(u64* __restrict__ hist, uint32_t KS, u64 per, int force_typed,
+                                                            u64* __restrict__ gstart, u64* __restrict__ gkey,
+                                                            u64* __restrict__ pstart, u64* __restrict__ off,
+                                                            u64* __restrict__ kc, ManyTotals* __restrict__ tot) {
+    __shared__ uint32_t sw[32];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t chunk = (KS + MC_THREADS - 1) / MC_THREADS;
+    const uint32_t b0 = tid * chunk < KS ? tid * chunk : KS, b1 = b0 + chunk < KS ? b0 + chunk : KS;
+    uint32_t ng = 0, nm = 0;
+    for (uint32_t b = b0; b < b1; ++b) {
+        const uint32_t c = (uint32_t)hist[b];
+        if (c) { ++ng; nm += c; }
+    }
+    uint32_t G, M;
+    blk1024_exscan2(ng, nm, sw, &G, &M);  // (ng, nm: groups / members in front of this thread's bins)
+    uint32_t np = 0, ns = 0;
+    {
+        u64 m = nm;
+        for (uint32_t b = b0; b < b1; ++b) {
+            const u64 v = hist[b];
+            const uint32_t c = (uint32_t)v;
+            if (!c) continue;
+            const u64 nu = many_group_pieces(m, m + c, per);
+            np += nu > 1 ? (uint32_t)nu : 0u;
+            const uint32_t w = (uint32_t)(v >> 32);
+            ns += (c == 1 && !force_typed) ? w : (w > 512u ? 512u : w);
+            m += c;
+        }
+    }
+    uint32_t NP, NS;
+    blk1024_exscan2(np, ns, sw, &NP, &NS);
+    {
+        u64 m = nm, g = ng, pp = np, sl = ns;
+        for (uint32_t b = b0; b < b1; ++b) {
+            const u64 v = hist[b];
+            const uint32_t c = (uint32_t)v;
+            if (!c) continue;
+            hist[b] = 0;
+            gstart[g] = m; gkey[g] = b; pstart[g] = pp; off[g] = 16ull * sl;
+            kc[b] = m | (g << 32);
+            const u64 nu = many_group_pieces(m, m + c, per);
+            pp += nu > 1 ? nu : 0;
+            const uint32_t w = (uint32_t)(v >> 32);
+            sl += (c == 1 && !force_typed) ? w : (w > 512u ? 512u : w);
+            if (g + 1 == G) tot->max_key = b;
+            m += c; ++g;
+        }
+    }
+    if (tid == 0) {
+        gstart[G] = M; pstart[G] = NP; off[G] = 16ull * NS;
+        tot->n_groups = G; tot->n_partials = NP; tot->slot_bytes = 16ull * NS;
+        tot->bytes_in = hist[KS];
+        hist[KS] = 0;
+    }
+}
+
+// every member's descriptor (and tag) into its group.  glast[2g], glast[2g+1] = tag + 1 of the group's LAST (in gathered
+// order) full-run member and LAST bitset member (0 = none), for the replay of roaring_bitmap_or_many's full-union typing.
+// reverse != 0 (tests): a block fills its reservations from the top -- the order inside a group must not matter.
+__global__ __launch_bounds__(MC_THREADS) void k_many_scatter(PoolView P, ManySel S, uint32_t KS, u64* __restrict__ kc,
+                                                            u64* __restrict__ sdesc, uint32_t* __restrict__ sord,
+                                                            uint32_t* __restrict__ glast, int reverse) {
+    __shared__ uint32_t h[MC_W3];
+    for (uint32_t w0 = 0; w0 < KS; w0 += MC_W3) {
+        for (uint32_t i = threadIdx.x; i < MC_W3; i += MC_THREADS) h[i] = 0;
+        __syncthreads();
+        many_for_members(P, S, [&](u64 c, u64) {
+            const uint32_t k = ((uint32_t)P.key[c] & 0xFFFFu) - w0;
+            if (k < MC_W3) atomicAdd(&h[k], 1u);
+        });
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < MC_W3 && w0 + i < KS; i += MC_THREADS) {
+            const uint32_t c = h[i];
+            if (c) h[i] = (uint32_t)atomicAdd(&kc[w0 + i], (u64)c) + (reverse ? c : 0u);
+        }
+        __syncthreads();
+        many_for_members(P, S, [&](u64 c, u64 t) {
+            const uint32_t kk = (uint32_t)P.key[c] & 0xFFFFu, k = kk - w0;
+            if (k < MC_W3) {
+                const uint32_t pos = reverse ? atomicSub(&h[k], 1u) - 1u : atomicAdd(&h[k], 1u);
+                const uint32_t ty = P.type[c], cd = P.card[c];
+                sdesc[pos] = md_pack(P.off[c], ty, cd, P.nruns[c]);
+                sord[pos] = (uint32_t)t;
+                if (ty == T_BITSET || (ty == T_RUN && cd == 65536u)) {
+                    const u64 g = kc[kk] >> 32;
+                    atomicMax(&glast[2 * g + (ty == T_BITSET ? 1u : 0u)], (uint32_t)t + 1u);
+                }
+            }
+        });
+        __syncthreads();
     }
 }
 
@@ -198,17 +407,16 @@ __global__ __launch_bounds__(256) void k_many_groups(const u64* __restrict__ ske
     if (threadIdx.x == 0) atomicAdd(&tot->bytes_in, s_bytes[0] + s_bytes[1] + s_bytes[2] + s_bytes[3]);
 }
 
-// per group: number of units, partial-chunk slots (the units of a group that has several) and the result-slot size
-// (upper bound on the canonical result payload); look-back sums give the first unit / first partial slot of the group
-// and the byte offset of its result slot.  Element G (one past the last group) carries the totals.
-// Chain a carries units and partial slots packed in one word (units < 2^33, partial slots < 2^29).
+// per group (48-bit-key path): partial-chunk slots (the pieces of a group that piece boundaries cut) and the result-slot
+// size (upper bound on the canonical result payload); look-back sums give the first partial slot of the group and the
+// byte offset of its result slot.  Element G (one past the last group) carries the totals.
 __global__ __launch_bounds__(256) void k_many_units(const u64* __restrict__ sdesc, const u64* __restrict__ gstart,
-                                                    const u64* __restrict__ gcs, uint32_t ch, int force_typed, ManyLb lb,
-                                                    u64* __restrict__ ustart, u64* __restrict__ pstart,
-                                                    u64* __restrict__ off, ManyTotals* __restrict__ tot) {
-    __shared__ uint32_t s_u[32], s_s[32], s_p[32];
+                                                    const u64* __restrict__ gcs, u64 per, int force_typed, ManyLb lb,
+                                                    u64* __restrict__ pstart, u64* __restrict__ off,
+                                                    ManyTotals* __restrict__ tot) {
+    __shared__ uint32_t s_s[32], s_p[32];
     __shared__ uint32_t s_tile;
-    __shared__ u64 s_pu, s_pp, s_ps;
+    __shared__ u64 s_pp, s_ps, s_tp, s_ts;
     if (threadIdx.x == 0) s_tile = atomicAdd(lb.ticket, 1u);
     __syncthreads();
     const uint32_t tile = s_tile;
@@ -216,14 +424,15 @@ __global__ __launch_bounds__(256) void k_many_units(const u64* __restrict__ sdes
     if ((u64)tile * MANY_TILE > G) return;  // (element G is the sentinel)
     const uint32_t wv = threadIdx.x >> 6, lane = lane_id();
     const u64 tbase = (u64)tile * MANY_TILE + threadIdx.x;
-    uint32_t nun[8], sl[8], uex[8], sex[8], pex[8];
+    uint32_t np[8], sl[8], sex[8], pex[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const u64 g = tbase + 256ull * k;
-        nun[k] = 0; sl[k] = 0;
+        np[k] = 0; sl[k] = 0;
         if (g < G) {
-            const u64 gs = gstart[g], cnt = gstart[g + 1] - gs;
-            nun[k] = (uint32_t)((cnt + ch - 1) / ch);
+            const u64 gs = gstart[g], ge = gstart[g + 1], cnt = ge - gs;
+            const u64 nu = many_group_pieces(gs, ge, per);
+            np[k] = nu > 1 ? (uint32_t)nu : 0u;
             uint32_t sz;
             if (cnt == 1 && !force_typed) {
                 sz = align16(md_payload(sdesc[gs]));
@@ -236,54 +445,37 @@ __global__ __launch_bounds__(256) void k_many_units(const u64* __restrict__ sdes
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const uint32_t np = nun[k] > 1u ? nun[k] : 0u;
-        const uint32_t iu = wave_incl_scan(nun[k]), is = wave_incl_scan(sl[k]), ip = wave_incl_scan(np);
-        uex[k] = iu - nun[k]; sex[k] = is - sl[k]; pex[k] = ip - np;
-        const uint32_t tu = __shfl(iu, 63), ts = __shfl(is, 63), tp = __shfl(ip, 63);
-        if (lane == 0) { s_u[4 * k + wv] = tu; s_s[4 * k + wv] = ts; s_p[4 * k + wv] = tp; }
+        const uint32_t is = wave_incl_scan(sl[k]), ip = wave_incl_scan(np[k]);
+        sex[k] = is - sl[k]; pex[k] = ip - np[k];
+        const uint32_t ts = __shfl(is, 63), tp = __shfl(ip, 63);
+        if (lane == 0) { s_s[4 * k + wv] = ts; s_p[4 * k + wv] = tp; }
     }
-    __syncthreads();
-    if (wv == 0) {
-        const uint32_t vu = lane < 32 ? s_u[lane] : 0u, vp = lane < 32 ? s_p[lane] : 0u;
-        const uint32_t iu = wave_incl_scan(vu), ip = wave_incl_scan(vp);
-        if (lane < 32) { s_u[lane] = iu - vu; s_p[lane] = ip - vp; }
-        const u64 agg = ((u64)__shfl(iu, 63) << 29) | (u64)__shfl(ip, 63);
-        const u64 pfx = lb_exclusive_prefix(lb.status_a, tile, agg);
-        if (lane == 0) { s_pu = pfx >> 29; s_pp = pfx & ((1ull << 29) - 1ull); }
-    } else if (wv == 1) {
-        const uint32_t vs = lane < 32 ? s_s[lane] : 0u;
-        const uint32_t is = wave_incl_scan(vs);
-        if (lane < 32) s_s[lane] = is - vs;
-        const u64 pfx = lb_exclusive_prefix(lb.status_b, tile, (u64)__shfl(is, 63));
-        if (lane == 0) s_ps = pfx;
-    }
-    __syncthreads();
+    many_two_scans(s_p, s_s, lb, tile, &s_pp, &s_ps, &s_tp, &s_ts);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const u64 g = tbase + 256ull * k;
         if (g <= G) {
-            const u64 pu = s_pu + s_u[4 * k + wv] + uex[k], ps = 16ull * (s_ps + s_s[4 * k + wv] + sex[k]);
-            ustart[g] = pu;
-            pstart[g] = s_pp + s_p[4 * k + wv] + pex[k];
+            const u64 pp = s_pp + s_p[4 * k + wv] + pex[k], ps = 16ull * (s_ps + s_s[4 * k + wv] + sex[k]);
+            pstart[g] = pp;
             off[g] = ps;
-            if (g == G) { tot->n_units = pu; tot->slot_bytes = ps; }
+            if (g == G) { tot->n_partials = pp; tot->slot_bytes = ps; }
         }
     }
 }
 
-// unit -> group lookup: largest g with ustart[g] <= u
-__device__ __forceinline__ uint32_t unit_group(const u64* __restrict__ ustart, uint32_t G, u64 u) {
-    u64 lo = 0, hi = G;  // ustart[G] = total units
+// group of member position m: largest g with gstart[g] <= m (gstart[G] = M > m)
+__device__ __forceinline__ uint32_t many_group_of(const u64* __restrict__ gstart, uint32_t G, u64 m) {
+    u64 lo = 0, hi = G;
     while (lo + 1 < hi) {
         u64 mid = (lo + hi) >> 1;
-        if (ustart[mid] <= u) lo = mid;
+        if (gstart[mid] <= m) lo = mid;
         else hi = mid;
     }
     return (uint32_t)lo;
 }
 
 // ------------------------------------------------------------------ accumulation of one unit into an LDS image
-constexpr uint32_t MANY_CHUNK = 512;  // members staged at a time (a unit has at most 1024)
+constexpr uint32_t MANY_CHUNK = 512;  // members staged at a time
 struct ManyLists {  // bitset / run members of the chunk (relative member indices), listed by the staging pass
     uint32_t n_bitset, n_run, n_g16, pad;
     uint16_t bitset[MANY_CHUNK], run[MANY_CHUNK];
@@ -493,8 +685,9 @@ struct ManyOut {
     int exact_or_many;  // 1: reproduce roaring_bitmap_or_many's run-vs-bitset choice for FULL containers
     uint32_t world, dense_b;
     u64 key_space;
-    const uint32_t* glast;  // [2 G] last full-run / last bitset member of every group (k_many_groups)
+    const uint32_t* glast;  // [2 G] tag + 1 of the last full-run / last bitset member of every group (0 = none)
     u64 first_lo, first_hi, second_lo, second_hi;  // container index ranges of ids[0] and ids[1]
+                                                   // (their members' tags: 0 + i and (first_hi - first_lo) + i)
     ManyTotals* tot;
 };
 // row of group g's chunk in a partial mode; ~0 = the key does not fit the dense table (error recorded)
@@ -520,34 +713,74 @@ __device__ __forceinline__ bool many_key_in(const PoolView& P, u64 lo, u64 hi, u
 // Given that the final union IS full, the outcome follows from member metadata plus ONE question:
 // "is the union already full after the last bitset member?" -- answered by re-accumulating that prefix (the caller
 // does that, through the same accumulation code as everything else: the answer "2" below).
-// Returns 1 for a full run, 0 for a (full) bitset, 2: full run iff the union of members [gs, *replay_end) is full.
-__device__ __forceinline__ int full_union_decide(const PoolView& P, const ManyView& V, const ManyOut& MO, uint32_t g,
-                                                 u64 gs, u64* replay_end) {
-    const u64 d0 = V.sdesc[gs], d1 = V.sdesc[gs + 1];
-    // the first two members come from ids[0] and ids[1] iff both of those bitmaps hold the key (the sort is stable)
+// "First", "last", "after" mean the GATHERED order (the fold order of the reference): a member's tag.  In the sorted
+// (48-bit) path a member's tag is its position; in the counting path the positions inside a group are arbitrary and
+// the tags are read from V.sord.
+// Returns 1 for a full run, 0 for a (full) bitset, 2: full run iff the union of the members with tag <= *replay_tag is
+// full.  Block-uniform (metadata only); `red` is LDS scratch of 4 u64.
+__device__ int full_union_decide(const PoolView& P, const ManyView& V, const ManyOut& MO, uint32_t g, u64 gs, u64 ge,
+                                 u64* red, u64* replay_tag) {
     const u64 key = MO.O.key[g];
-    const bool first = many_key_in(P, MO.first_lo, MO.first_hi, key) && many_key_in(P, MO.second_lo, MO.second_hi, key);
+    // the first two members come from ids[0] and ids[1] iff both of those bitmaps hold the key
+    const u64 j0 = lower_bound(P.key, MO.first_lo, MO.first_hi, key), j1 = lower_bound(P.key, MO.second_lo, MO.second_hi, key);
+    const bool first = j0 < MO.first_hi && P.key[j0] == key && j1 < MO.second_hi && P.key[j1] == key;
+    u64 d0, d1 = 0, tprev;  // tprev: tag of the last member the reference's FIRST step consumes
+    if (!V.sord) {
+        d0 = V.sdesc[gs]; d1 = V.sdesc[gs + 1];
+        tprev = first ? gs + 1 : gs;
+    } else if (first) {
+        d0 = md_pack(P.off[j0], P.type[j0], P.card[j0], P.nruns[j0]);
+        d1 = md_pack(P.off[j1], P.type[j1], P.card[j1], P.nruns[j1]);
+        tprev = (MO.first_hi - MO.first_lo) + (j1 - MO.second_lo);
+    } else {  // the group's first member in gathered order: smallest tag
+        u64 best = ~0ull;
+        for (u64 i = gs + threadIdx.x; i < ge; i += blockDim.x) {
+            const u64 c = ((u64)V.sord[i] << 32) | (i - gs);
+            best = c < best ? c : best;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const u64 x = __shfl_xor(best, o);
+            best = x < best ? x : best;
+        }
+        __syncthreads();
+        if (lane_id() == 0) red[threadIdx.x >> 6] = best;
+        __syncthreads();
+        for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) best = red[w] < best ? red[w] : best;
+        __syncthreads();
+        d0 = V.sdesc[gs + (best & 0xFFFFFFFFull)];
+        tprev = best >> 32;
+    }
     auto isB = [&](u64 d) { return md_type(d) == T_BITSET; };
     auto isRF = [&](u64 d) { return md_type(d) == T_RUN && md_full(d); };
-    u64 start;  // first member handled by the generic lazy_or_inplace step
     if (first) {  // roaring_bitmap_lazy_or(x0, x1), roaring.c:2529-2548
         if (isB(d0) || isB(d1)) { if (isRF(d0) || isRF(d1)) return 1; }
         else if (isRF(d1)) return 1;
-        start = gs + 2;
     } else {
         if (isRF(d0)) return 1;                       // container_is_full -> every step skipped
         if (isB(d0) && md_full(d0)) return 0;         // known-full bitset: skipped, repair keeps a bitset
-        start = gs + 1;
     }
-    // Any full run among the members [start, ge) wins (it is never skipped: the accumulator's cardinality is unknown
-    // or below 65536 when it arrives); otherwise the LAST bitset member decides.  Both positions were recorded by
-    // k_many_groups (member index + 1).
-    const uint32_t lrf = MO.glast[2 * (u64)g], lb_all = MO.glast[2 * (u64)g + 1];
-    if (lrf && (u64)lrf - 1u >= start) return 1;
-    const uint32_t lb = (lb_all && (u64)lb_all - 1u >= start) ? lb_all : 0u;
-    if (!lb) return 0;
-    *replay_end = (u64)lb;  // union of members [gs, last bitset member] full?
+    // Any full run among the later members wins (it is never skipped: the accumulator's cardinality is unknown
+    // or below 65536 when it arrives); otherwise the LAST bitset member decides.  Both tags (+ 1) were recorded by the
+    // grouping kernels.
+    const uint32_t lrf = MO.glast[2 * (u64)g], lb = MO.glast[2 * (u64)g + 1];
+    if (lrf && (u64)lrf - 1u > tprev) return 1;
+    if (!lb || (u64)lb - 1u <= tprev) return 0;
+    *replay_tag = (u64)lb - 1u;  // union of the members up to the last bitset member full?
     return 2;
+}
+// the members of group [gs, ge) with tag <= tag as a descriptor range: in place (sorted path), or compacted into the
+// group's range of V.rdesc (any order: the question is only whether their union is full)
+__device__ const u64* many_replay_members(const ManyView& V, u64 gs, u64 ge, u64 tag, uint32_t* cnt /* LDS */, u64* m0, u64* m1) {
+    if (!V.sord) { *m0 = gs; *m1 = tag + 1; return V.sdesc; }
+    __syncthreads();
+    if (threadIdx.x == 0) *cnt = 0;
+    __syncthreads();
+    for (u64 i = gs + threadIdx.x; i < ge; i += blockDim.x)
+        if ((u64)V.sord[i] <= tag) V.rdesc[gs + atomicAdd(cnt, 1u)] = V.sdesc[i];
+    __syncthreads();
+    *m0 = gs; *m1 = gs + *cnt;
+    return V.rdesc;
 }
 // the result of a group whose union is full: one run {0, 0xFFFF}, or the all-ones bitset
 __device__ __forceinline__ void many_emit_full(const ManyOut& MO, uint32_t g, bool as_run) {
@@ -600,10 +833,10 @@ __device__ __forceinline__ void many_emit(const uint32_t r[8], int ty, uint32_t 
 // What to do with the finished LDS image of group g (members [gs, ge)): partial modes store the chunk; otherwise it is
 // canonicalised -- card <= 4096 -> array, else bitset (container_repair_after_lazy, containers.h:344-371); empty ->
 // dropped by the tail.  Returns true when the caller must first answer full_union_decide's question by accumulating
-// the members [gs, *replay_end) and calling many_emit_full(.., union is full).
+// the members with tag <= *replay_tag (many_replay_members) and calling many_emit_full(.., union is full).
 __device__ __forceinline__ bool many_finalize(uint32_t* acc, uint16_t* stage, const ManyOut& MO, uint32_t g,
                                               BlockScratch* sc, const PoolView& P, const ManyView& V, u64 gs, u64 ge,
-                                              u64* replay_end) {
+                                              u64* red, u64* replay_tag) {
     const uint32_t tid = threadIdx.x;
     uint4 r0 = ((uint4*)acc)[2 * tid], r1 = ((uint4*)acc)[2 * tid + 1];
     if (MO.partial_mode) {
@@ -617,7 +850,7 @@ __device__ __forceinline__ bool many_finalize(uint32_t* acc, uint16_t* stage, co
     uint32_t r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
     const uint32_t rc = blk_sum(popc4(r0) + popc4(r1), sc->wsum);
     if (rc == 65536u && MO.exact_or_many && ge - gs >= 2) {
-        const int dec = full_union_decide(P, V, MO, g, gs, replay_end);  // (block-uniform: metadata only)
+        const int dec = full_union_decide(P, V, MO, g, gs, ge, red, replay_tag);  // (block-uniform: metadata only)
         if (dec == 2) return true;
         many_emit_full(MO, g, dec == 1);
         return false;
@@ -648,56 +881,61 @@ __global__ __launch_bounds__(256, RHIP_MANY_WAVES) void k_many_l1(PoolView P, Ma
     __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];
     __shared__ BlockScratch sc;
     __shared__ ManyLists ml;
+    __shared__ u64 red[4];
+    __shared__ uint32_t s_cnt;
     const uint32_t G = (uint32_t)V.tot->n_groups;
-    const u64 U = V.tot->n_units;
-    for (u64 u = blockIdx.x; u < U; u += gridDim.x) {
-        const uint32_t g = unit_group(V.ustart, G, u);
-        const u64 gs = V.gstart[g], ge = V.gstart[g + 1];
-        const u64 nu = V.ustart[g + 1] - V.ustart[g];
-        if (nu == 1 && (ge - gs) == 1 && !MO.force_typed && !MO.partial_mode) continue;  // pass-through copy path
-        const u64 per = (ge - gs + nu - 1) / nu;  // the group's members in nu equal shares (<= ch each)
-        u64 a0 = gs + (u - V.ustart[g]) * per;
-        u64 a1 = (a0 + per < ge) ? a0 + per : ge;
-        // One accumulation site for the unit's members and -- rarely -- for the replay of a full union's prefix
-        for (bool replay = false;;) {
-            __syncthreads();
-            lds_zero(acc);
-            __syncthreads();
-            many_accumulate<PF>(acc, tmp, P.arena, V.sdesc, a0, a1, replay ? (int)OP_OR : op, &sc, &ml);
-            if (replay) {
-                many_emit_full(MO, g, many_image_full(acc, &sc));
-                break;
+    if (!G) return;
+    const u64 M = V.gstart[G], per = V.per;
+    for (u64 piece = blockIdx.x; piece * per < M; piece += gridDim.x) {
+        const u64 lo = piece * per, hi = lo + per < M ? lo + per : M;
+        for (uint32_t g = many_group_of(V.gstart, G, lo); g < G; ++g) {
+            const u64 gs = V.gstart[g], ge = V.gstart[g + 1];
+            if (gs >= hi) break;
+            const u64 q0 = gs / per, nu = (ge - 1) / per - q0 + 1;  // pieces the group is cut into
+            if (nu == 1 && (ge - gs) == 1 && !MO.force_typed && !MO.partial_mode) continue;  // pass-through copy path
+            const u64* desc = V.sdesc;
+            u64 a0 = gs > lo ? gs : lo, a1 = ge < hi ? ge : hi;
+            // One accumulation site for the piece's members and -- rarely -- for the replay of a full union's prefix
+            for (bool replay = false;;) {
+                __syncthreads();
+                lds_zero(acc);
+                __syncthreads();
+                many_accumulate<PF>(acc, tmp, P.arena, desc, a0, a1, replay ? (int)OP_OR : op, &sc, &ml);
+                if (replay) {
+                    many_emit_full(MO, g, many_image_full(acc, &sc));
+                    break;
+                }
+                if (nu != 1) {
+                    uint4* po = (uint4*)(MO.partial + (V.pstart[g] + (piece - q0)) * 1024ull);
+                    po[2 * threadIdx.x] = ((uint4*)acc)[2 * threadIdx.x];
+                    po[2 * threadIdx.x + 1] = ((uint4*)acc)[2 * threadIdx.x + 1];
+                    break;
+                }
+                u64 rtag = 0;
+                if (!many_finalize(acc, stage, MO, g, &sc, P, V, gs, ge, red, &rtag)) break;
+                replay = true;
+                desc = many_replay_members(V, gs, ge, rtag, &s_cnt, &a0, &a1);
             }
-            if (nu != 1) {
-                uint4* po = (uint4*)(MO.partial + (V.pstart[g] + (u - V.ustart[g])) * 1024ull);
-                po[2 * threadIdx.x] = ((uint4*)acc)[2 * threadIdx.x];
-                po[2 * threadIdx.x + 1] = ((uint4*)acc)[2 * threadIdx.x + 1];
-                break;
-            }
-            u64 rend = 0;
-            if (!many_finalize(acc, stage, MO, g, &sc, P, V, gs, ge, &rend)) break;
-            replay = true;
-            a0 = gs;
-            a1 = rend;
         }
     }
 }
 
-// combine the partial chunks of multi-unit groups
+// combine the partial chunks of the groups that piece boundaries cut
 __global__ __launch_bounds__(256) void k_many_l2(PoolView P, ManyView V, ManyOut MO, int op) {
     __shared__ __attribute__((aligned(16))) uint32_t acc[2048];
     __shared__ __attribute__((aligned(16))) uint32_t tmp[2048];
     __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];
     __shared__ BlockScratch sc;
     __shared__ ManyLists ml;
+    __shared__ u64 red[4];
+    __shared__ uint32_t s_cnt;
     const uint32_t G = (uint32_t)V.tot->n_groups;
     const uint32_t tid = threadIdx.x;
-    if (V.tot->n_units == (u64)G) return;  // no group has more than one unit
+    if (V.tot->n_partials == 0) return;  // no group was cut
     for (uint32_t g = blockIdx.x; g < G; g += gridDim.x) {
-        const u64 u0 = V.ustart[g], u1 = V.ustart[g + 1];
-        if (u1 - u0 < 2) continue;
+        const u64 p0 = V.pstart[g], np = V.pstart[g + 1] - p0;
+        if (np < 2) continue;
         uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
-        const u64 p0 = V.pstart[g], np = u1 - u0;
         for (u64 u = 0; u < np; u += 8) {  // eight chunks' loads in flight (one at a time: 15 GB/s for the one block)
             uint4 a[8], b[8];
 #pragma unroll
@@ -716,13 +954,15 @@ __global__ __launch_bounds__(256) void k_many_l2(PoolView P, ManyView V, ManyOut
         ((uint4*)acc)[2 * tid] = r0;
         ((uint4*)acc)[2 * tid + 1] = r1;
         __syncthreads();
-        const u64 gs = V.gstart[g];
-        u64 rend = 0;
-        if (many_finalize(acc, stage, MO, g, &sc, P, V, gs, V.gstart[g + 1], &rend)) {
+        const u64 gs = V.gstart[g], ge = V.gstart[g + 1];
+        u64 rtag = 0;
+        if (many_finalize(acc, stage, MO, g, &sc, P, V, gs, ge, red, &rtag)) {
+            u64 m0, m1;
+            const u64* desc = many_replay_members(V, gs, ge, rtag, &s_cnt, &m0, &m1);
             __syncthreads();
             lds_zero(acc);
             __syncthreads();
-            many_accumulate<2>(acc, tmp, P.arena, V.sdesc, gs, rend, OP_OR, &sc, &ml);
+            many_accumulate<2>(acc, tmp, P.arena, desc, m0, m1, OP_OR, &sc, &ml);
             many_emit_full(MO, g, many_image_full(acc, &sc));
         }
     }
