@@ -220,7 +220,6 @@ struct rhip_ctx_s {
     uint64_t many_slots = 1024;  // RHIP_MANY_SLOTS: pieces of a large call = workgroups of k_many_l1 resident at once (4 per CU)
     uint64_t many_t = 8192;      // RHIP_MANY_T: members per workgroup of k_many_hist / k_many_scatter
     int many_reverse = 0;        // RHIP_MANY_REVERSE (tests): k_many_scatter fills its reservations backwards
-    bool many_hist_dirty = false;  // a call failed between k_many_hist and k_many_keyscan: the histogram is not all zero
     static constexpr size_t PINNED_MANY_FLAG_OFF = 2304, PINNED_MANY_TOT_OFF = 2560, PINNED_MANY_ERR_OFF = 2816;
     DBuf sel[5];  // pool_select / pool_convert scratch
     void* h_pinned = nullptr;  // small pinned readback area

@@ -123,23 +123,28 @@ __global__ __launch_bounds__(256) void k_many_gather(PoolView P, const uint32_t*
 // The members of a call in GATHERED order: member t (its tag) is container `t` of the pool (ids == null), or container
 // bm_start[ids[s]] + (t - sel_start[s]) of the s-th selected bitmap.  A workgroup's share: `per_block` consecutive members
 // (ids == null) or `per_block` consecutive selected bitmaps, a wave per bitmap.  k_many_hist and k_many_scatter iterate
-// the same way (nothing else depends on the split).
+// the same way: row b of the count matrix is workgroup b's.
 struct ManySel {
     const uint32_t* ids;
     const u64* sel_start;  // [nsel + 1]
     uint32_t nsel;
     u64 M;
     u64 per_block;
+    uint32_t n_blocks;     // workgroups that hold members = rows of the count matrix
 };
 constexpr uint32_t MC_THREADS = 1024;
 constexpr uint32_t MC_W1 = 8192;    // keys per LDS window of k_many_hist (u64 bins: 64 KiB)
 constexpr uint32_t MC_W3 = 16384;   // keys per LDS window of k_many_scatter (u32 bins: 64 KiB)
-constexpr uint32_t MC_WCAP = 8192;  // a block's flushed slot weight per key is capped here (>= any single weight's use: 512)
+// count matrix entry: members of (workgroup, key) in bits 0..16, their slot weight (capped) in bits 17..31
+constexpr uint32_t MC_CNT_BITS = 17, MC_CNT_MASK = (1u << MC_CNT_BITS) - 1u, MC_W_CAP = (1u << (32 - MC_CNT_BITS)) - 1u;
+constexpr uint32_t MC_MAX_PER_BLOCK = MC_CNT_MASK;  // members of one workgroup
 
+// f(container index, tag) for every member of this workgroup with UNROLL independent iterations in flight
 template <class F>
 __device__ __forceinline__ void many_for_members(const PoolView& P, const ManySel& S, F f) {
     if (!S.ids) {
         const u64 lo = (u64)blockIdx.x * S.per_block, hi = lo + S.per_block < S.M ? lo + S.per_block : S.M;
+#pragma unroll 4
         for (u64 t = lo + threadIdx.x; t < hi; t += MC_THREADS) f(t, t);
         return;
     }
@@ -151,16 +156,17 @@ __device__ __forceinline__ void many_for_members(const PoolView& P, const ManySe
     }
 }
 
-// hist[k] = members with key k | (slot weight, 16-byte units) << 32, accumulated on top of an all-zero array
-// (k_many_keyscan returns it to zero); hist[KS] = payload bytes of all members.
-__global__ __launch_bounds__(MC_THREADS) void k_many_hist(PoolView P, ManySel S, uint32_t KS, u64* __restrict__ hist, ManyZero Z) {
+// Row blockIdx of the count matrix mat[n_blocks][KS]: this workgroup's members per key (count | capped slot weight).
+// Every entry of the row is written (zeros included): the matrix needs no clearing.  Also clears the scan / totals
+// scratch of the call.
+__global__ __launch_bounds__(MC_THREADS) void k_many_hist(PoolView P, ManySel S, uint32_t KS, uint32_t* __restrict__ mat,
+                                                         ManyZero Z) {
     __shared__ u64 h[MC_W1];
-    __shared__ u64 s_bytes[MC_THREADS / 64];
     const u64 gid = (u64)blockIdx.x * MC_THREADS + threadIdx.x, nth = (u64)gridDim.x * MC_THREADS;
     for (u64 i = gid; i < Z.n_words; i += nth) Z.words[i] = 0;
     for (u64 i = gid; i < Z.n_glast; i += nth) Z.glast[i] = 0;
     for (u64 i = gid; i < Z.n_table; i += nth) Z.table[i] = 0;
-    u64 bytes = 0;
+    if (blockIdx.x >= S.n_blocks) return;  // (blocks beyond the member blocks only help clearing)
     for (uint32_t w0 = 0; w0 < KS; w0 += MC_W1) {
         for (uint32_t i = threadIdx.x; i < MC_W1; i += MC_THREADS) h[i] = 0;
         __syncthreads();
@@ -169,17 +175,149 @@ __global__ __launch_bounds__(MC_THREADS) void k_many_hist(PoolView P, ManySel S,
             if (k < MC_W1) {
                 const uint32_t ty = P.type[c], cd = P.card[c], nr = P.nruns[c];
                 atomicAdd(&h[k], 1ull | ((u64)many_weight16(ty, cd, nr) << 32));
-                bytes += payload_bytes((uint8_t)ty, cd, nr);
             }
         });
         __syncthreads();
+        uint32_t* __restrict__ row = mat + (u64)blockIdx.x * KS + w0;
         for (uint32_t i = threadIdx.x; i < MC_W1 && w0 + i < KS; i += MC_THREADS) {
             const u64 v = h[i];
-            if (v) {
-                const u64 w = (v >> 32) > MC_WCAP ? (u64)MC_WCAP : (v >> 32);
-                atomicAdd(&hist[w0 + i], (v & 0xFFFFFFFFull) | (w << 32));
-            }
+            const uint32_t w = (v >> 32) > MC_W_CAP ? MC_W_CAP : (uint32_t)(v >> 32);
+            row[i] = (uint32_t)v | (w << MC_CNT_BITS);
         }
+        __syncthreads();
+    }
+}
+
+// The key space in tiles of 64 keys; a workgroup = 16 waves = 16 SEGMENTS of the matrix's rows over the tile's keys.
+// (1) column sums: every wave adds up its rows (loads only), the segment totals meet in LDS; (2) wave 0: non-empty keys
+// become groups in key order -- two look-back chains over the key tiles: (groups, members), then, with a group's first
+// member known, (partial-chunk slots, result-slot units) -- and writes gstart / gkey / pstart / off as the accumulation
+// kernels read them, kstart[k] = first member position of key k, kgrp[k] = its group, and the totals; (3) every wave
+// walks its rows again: rel[b][k] = members of key k in workgroups < b.
+struct ManyKeyLb { u64* status_a; u64* status_b; uint32_t* ticket; };
+constexpr uint32_t MC_KT = 64, MC_SEG = 16;
+__global__ __launch_bounds__(MC_KT * MC_SEG) void k_many_keyscan(const uint32_t* __restrict__ mat, uint32_t* __restrict__ rel,
+                                                                uint32_t n_blocks, uint32_t KS, u64 per, int force_typed,
+                                                                ManyKeyLb lb, u64* __restrict__ gstart, u64* __restrict__ gkey,
+                                                                u64* __restrict__ pstart, u64* __restrict__ off,
+                                                                uint32_t* __restrict__ kstart, uint32_t* __restrict__ kgrp,
+                                                                ManyTotals* __restrict__ tot) {
+    __shared__ uint32_t s_cnt[MC_SEG][MC_KT], s_w[MC_SEG][MC_KT];
+    __shared__ uint32_t s_tile;
+    if (threadIdx.x == 0) s_tile = atomicAdd(lb.ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile, n_tiles = (KS + MC_KT - 1u) / MC_KT;
+    if (tile >= n_tiles) return;
+    const uint32_t seg = threadIdx.x >> 6, lane = lane_id(), k = tile * MC_KT + lane;
+    const uint32_t rows = (n_blocks + MC_SEG - 1u) / MC_SEG;
+    const uint32_t r0 = seg * rows < n_blocks ? seg * rows : n_blocks, r1 = r0 + rows < n_blocks ? r0 + rows : n_blocks;
+    const bool kin = k < KS;
+    const uint32_t* __restrict__ col = mat + (kin ? k : 0u);
+    uint32_t cnt = 0, wsum = 0;
+    {
+        uint32_t b = r0;
+        for (; b + 8 <= r1; b += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = col[(u64)(b + j) * KS];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { cnt += v[j] & MC_CNT_MASK; wsum += v[j] >> MC_CNT_BITS; }
+        }
+        for (; b < r1; ++b) {
+            const uint32_t v = col[(u64)b * KS];
+            cnt += v & MC_CNT_MASK; wsum += v >> MC_CNT_BITS;
+        }
+        if (!kin) { cnt = 0; wsum = 0; }
+    }
+    s_cnt[seg][lane] = cnt;
+    s_w[seg][lane] = wsum;
+    __syncthreads();
+    uint32_t before = 0;  // members of the key in earlier segments
+    for (uint32_t q = 0; q < seg; ++q) before += s_cnt[q][lane];
+    if (seg == 0) {
+        uint32_t tc = 0, tw = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < MC_SEG; ++q) { tc += s_cnt[q][lane]; tw += s_w[q][lane]; }
+        // ---- chain a: groups | members in front of this key
+        const uint32_t isg = tc ? 1u : 0u;
+        const uint32_t ig = wave_incl_scan(isg), im = wave_incl_scan(tc);
+        const uint32_t tg = wave_lane<63>(ig), tm = wave_lane<63>(im);
+        const u64 pa = lb_exclusive_prefix(lb.status_a, tile, ((u64)tg << 32) | tm);
+        const u64 g = (pa >> 32) + ig - isg, gs = (pa & 0xFFFFFFFFull) + im - tc, ge = gs + tc;
+        const u64 Gt = (pa >> 32) + tg, Mt = (pa & 0xFFFFFFFFull) + tm;  // groups / members up to and including this tile
+        // ---- chain b: partial-chunk slots | result-slot units in front of this group
+        uint32_t np = 0, sl = 0;
+        if (tc) {
+            const u64 nu = many_group_pieces(gs, ge, per);
+            np = nu > 1 ? (uint32_t)nu : 0u;
+            sl = (tc == 1 && !force_typed) ? tw : (tw > 512u ? 512u : tw);
+        }
+        const uint32_t ip = wave_incl_scan(np), is = wave_incl_scan(sl);
+        const uint32_t tp = wave_lane<63>(ip), ts = wave_lane<63>(is);
+        const u64 pb = lb_exclusive_prefix(lb.status_b, tile, ((u64)tp << 32) | ts);  // (slot units < 2^32: 65 536 groups x 8 192)
+        const u64 pp = (pb >> 32) + ip - np, ss = (pb & 0xFFFFFFFFull) + is - sl;
+        if (kin) { kstart[k] = (uint32_t)gs; kgrp[k] = (uint32_t)g; }
+        if (tc) {
+            gstart[g] = gs; gkey[g] = k; pstart[g] = pp; off[g] = 16ull * ss;
+            if (g + 1 == Gt) atomicMax(&tot->max_key, (u64)k);  // (one per non-empty tile: the last group so far)
+        }
+        if (tile == n_tiles - 1 && lane == 0) {  // the last tile closes the lists
+            const u64 NP = (pb >> 32) + tp, NS = (pb & 0xFFFFFFFFull) + ts;
+            gstart[Gt] = Mt; pstart[Gt] = NP; off[Gt] = 16ull * NS;
+            tot->n_groups = Gt; tot->n_partials = NP; tot->slot_bytes = 16ull * NS;
+        }
+    }
+    if (kin) {
+        uint32_t* __restrict__ out = rel + k;
+        uint32_t run = before, b = r0;
+        for (; b + 8 <= r1; b += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = col[(u64)(b + j) * KS];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { out[(u64)(b + j) * KS] = run; run += v[j] & MC_CNT_MASK; }
+        }
+        for (; b < r1; ++b) {
+            out[(u64)b * KS] = run;
+            run += col[(u64)b * KS] & MC_CNT_MASK;
+        }
+    }
+}
+
+// every member's descriptor (and tag) into its group: position = kstart[key] + rel[workgroup][key] (members of the key in
+// earlier workgroups) + rank inside the workgroup (an LDS cursor) -- no global atomics.  glast[2g], glast[2g+1] = tag + 1
+// of the group's LAST (in gathered order) full-run member and LAST bitset member (0 = none), for the replay of
+// roaring_bitmap_or_many's full-union typing.  reverse != 0 (tests): a workgroup fills its ranges from the top -- the
+// order inside a group must not matter.
+__global__ __launch_bounds__(MC_THREADS) void k_many_scatter(PoolView P, ManySel S, uint32_t KS, const uint32_t* __restrict__ rel,
+                                                            const uint32_t* __restrict__ kstart, const uint32_t* __restrict__ kgrp,
+                                                            u64* __restrict__ sdesc, uint32_t* __restrict__ sord,
+                                                            uint32_t* __restrict__ glast, ManyTotals* __restrict__ tot, int reverse) {
+    __shared__ uint32_t h[MC_W3];
+    __shared__ u64 s_bytes[MC_THREADS / 64];
+    u64 bytes = 0;
+    for (uint32_t w0 = 0; w0 < KS; w0 += MC_W3) {
+        const uint32_t* __restrict__ row = rel + (u64)blockIdx.x * KS + w0;
+        const uint32_t* __restrict__ nxt = blockIdx.x + 1 < S.n_blocks ? row + KS : nullptr;  // (reverse: the range's end)
+        for (uint32_t i = threadIdx.x; i < MC_W3 && w0 + i < KS; i += MC_THREADS) {
+            uint32_t base = kstart[w0 + i] + row[i];
+            if (reverse)  // end of this workgroup's range of the key = start of the next workgroup's (or of the next key)
+                base = nxt ? kstart[w0 + i] + nxt[i] : (w0 + i + 1 < KS ? kstart[w0 + i + 1] : (uint32_t)S.M);
+            h[i] = base;
+        }
+        __syncthreads();
+        many_for_members(P, S, [&](u64 c, u64 t) {
+            const uint32_t kk = (uint32_t)P.key[c] & 0xFFFFu, k = kk - w0;
+            if (k < MC_W3) {
+                const uint32_t pos = reverse ? atomicSub(&h[k], 1u) - 1u : atomicAdd(&h[k], 1u);
+                const uint32_t ty = P.type[c], cd = P.card[c], nr = P.nruns[c];
+                sdesc[pos] = md_pack(P.off[c], ty, cd, nr);
+                sord[pos] = (uint32_t)t;
+                bytes += payload_bytes((uint8_t)ty, cd, nr);
+                if (ty == T_BITSET || (ty == T_RUN && cd == 65536u))
+                    atomicMax(&glast[2 * (u64)kgrp[kk] + (ty == T_BITSET ? 1u : 0u)], (uint32_t)t + 1u);
+            }
+        });
         __syncthreads();
     }
     bytes = wave_sum64(bytes);
@@ -188,120 +326,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_many_hist(PoolView P, ManySel S,
     if (threadIdx.x == 0) {
         u64 b = 0;
         for (uint32_t w = 0; w < MC_THREADS / 64; ++w) b += s_bytes[w];
-        if (b) atomicAdd(&hist[KS], b);
-    }
-}
-
-// exclusive prefix sums of two values over the 1024 threads of the block; totals through ta / tb
-__device__ __forceinline__ void blk1024_exscan2(uint32_t& a, uint32_t& b, uint32_t* sw /* [32] LDS */, uint32_t* ta, uint32_t* tb) {
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    const uint32_t ia = wave_incl_scan(a), ib = wave_incl_scan(b);
-    __syncthreads();
-    if (lane == 63) { sw[wave] = ia; sw[16 + wave] = ib; }
-    __syncthreads();
-    uint32_t oa = 0, ob = 0, sa = 0, sb = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < 16; ++w) {
-        const uint32_t x = sw[w], y = sw[16 + w];
-        if (w < wave) { oa += x; ob += y; }
-        sa += x; sb += y;
-    }
-    a = oa + ia - a; b = ob + ib - b;
-    *ta = sa; *tb = sb;
-}
-
-// ONE workgroup over the key space: groups in key order.  gstart / gkey / pstart / off as the accumulation kernels read
-// them, kc[k] = first member position of key k | group index << 32 (k_many_scatter's cursor), totals; hist back to zero.
-__global__ __launch_bounds__(MC_THREADS) void k_many_keyscan(u64* __restrict__ hist, uint32_t KS, u64 per, int force_typed,
-                                                            u64* __restrict__ gstart, u64* __restrict__ gkey,
-                                                            u64* __restrict__ pstart, u64* __restrict__ off,
-                                                            u64* __restrict__ kc, ManyTotals* __restrict__ tot) {
-    __shared__ uint32_t sw[32];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t chunk = (KS + MC_THREADS - 1) / MC_THREADS;
-    const uint32_t b0 = tid * chunk < KS ? tid * chunk : KS, b1 = b0 + chunk < KS ? b0 + chunk : KS;
-    uint32_t ng = 0, nm = 0;
-    for (uint32_t b = b0; b < b1; ++b) {
-        const uint32_t c = (uint32_t)hist[b];
-        if (c) { ++ng; nm += c; }
-    }
-    uint32_t G, M;
-    blk1024_exscan2(ng, nm, sw, &G, &M);  // (ng, nm: groups / members in front of this thread's bins)
-    uint32_t np = 0, ns = 0;
-    {
-        u64 m = nm;
-        for (uint32_t b = b0; b < b1; ++b) {
-            const u64 v = hist[b];
-            const uint32_t c = (uint32_t)v;
-            if (!c) continue;
-            const u64 nu = many_group_pieces(m, m + c, per);
-            np += nu > 1 ? (uint32_t)nu : 0u;
-            const uint32_t w = (uint32_t)(v >> 32);
-            ns += (c == 1 && !force_typed) ? w : (w > 512u ? 512u : w);
-            m += c;
-        }
-    }
-    uint32_t NP, NS;
-    blk1024_exscan2(np, ns, sw, &NP, &NS);
-    {
-        u64 m = nm, g = ng, pp = np, sl = ns;
-        for (uint32_t b = b0; b < b1; ++b) {
-            const u64 v = hist[b];
-            const uint32_t c = (uint32_t)v;
-            if (!c) continue;
-            hist[b] = 0;
-            gstart[g] = m; gkey[g] = b; pstart[g] = pp; off[g] = 16ull * sl;
-            kc[b] = m | (g << 32);
-            const u64 nu = many_group_pieces(m, m + c, per);
-            pp += nu > 1 ? nu : 0;
-            const uint32_t w = (uint32_t)(v >> 32);
-            sl += (c == 1 && !force_typed) ? w : (w > 512u ? 512u : w);
-            if (g + 1 == G) tot->max_key = b;
-            m += c; ++g;
-        }
-    }
-    if (tid == 0) {
-        gstart[G] = M; pstart[G] = NP; off[G] = 16ull * NS;
-        tot->n_groups = G; tot->n_partials = NP; tot->slot_bytes = 16ull * NS;
-        tot->bytes_in = hist[KS];
-        hist[KS] = 0;
-    }
-}
-
-// every member's descriptor (and tag) into its group.  glast[2g], glast[2g+1] = tag + 1 of the group's LAST (in gathered
-// order) full-run member and LAST bitset member (0 = none), for the replay of roaring_bitmap_or_many's full-union typing.
-// reverse != 0 (tests): a block fills its reservations from the top -- the order inside a group must not matter.
-__global__ __launch_bounds__(MC_THREADS) void k_many_scatter(PoolView P, ManySel S, uint32_t KS, u64* __restrict__ kc,
-                                                            u64* __restrict__ sdesc, uint32_t* __restrict__ sord,
-                                                            uint32_t* __restrict__ glast, int reverse) {
-    __shared__ uint32_t h[MC_W3];
-    for (uint32_t w0 = 0; w0 < KS; w0 += MC_W3) {
-        for (uint32_t i = threadIdx.x; i < MC_W3; i += MC_THREADS) h[i] = 0;
-        __syncthreads();
-        many_for_members(P, S, [&](u64 c, u64) {
-            const uint32_t k = ((uint32_t)P.key[c] & 0xFFFFu) - w0;
-            if (k < MC_W3) atomicAdd(&h[k], 1u);
-        });
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < MC_W3 && w0 + i < KS; i += MC_THREADS) {
-            const uint32_t c = h[i];
-            if (c) h[i] = (uint32_t)atomicAdd(&kc[w0 + i], (u64)c) + (reverse ? c : 0u);
-        }
-        __syncthreads();
-        many_for_members(P, S, [&](u64 c, u64 t) {
-            const uint32_t kk = (uint32_t)P.key[c] & 0xFFFFu, k = kk - w0;
-            if (k < MC_W3) {
-                const uint32_t pos = reverse ? atomicSub(&h[k], 1u) - 1u : atomicAdd(&h[k], 1u);
-                const uint32_t ty = P.type[c], cd = P.card[c];
-                sdesc[pos] = md_pack(P.off[c], ty, cd, P.nruns[c]);
-                sord[pos] = (uint32_t)t;
-                if (ty == T_BITSET || (ty == T_RUN && cd == 65536u)) {
-                    const u64 g = kc[kk] >> 32;
-                    atomicMax(&glast[2 * g + (ty == T_BITSET ? 1u : 0u)], (uint32_t)t + 1u);
-                }
-            }
-        });
-        __syncthreads();
+        if (b) atomicAdd(&tot->bytes_in, b);
     }
 }
 

@@ -226,14 +226,22 @@ def test_emu_sparse_many_and_dense_shards(emu, oracle):
     G.sparse_many_body(emu, oracle, n=400, worlds=(1, 3))
 
 
-@pytest.mark.parametrize("ch", ["1024", "3"])
+@pytest.mark.parametrize("ch", ["1024", "3", "rev"])
 def test_emu_many_unit_shapes(oracle, synth, monkeypatch, ch):
-    """RHIP_MANY_CH forces the unit size of the many-way path: 1024 = units of more than one 512-member staging
-    chunk (key 0 of the sparse set has one member per bitmap), 3 = nearly every group split over partial chunks."""
+    """RHIP_MANY_CH forces the piece size of the many-way path: 1024 = pieces of more than one 512-member staging
+    chunk (key 0 of the sparse set has one member per bitmap), 3 = nearly every group cut into partial chunks;
+    "rev": the counting sort's scatter fills its reservations backwards in workgroups of 1 024 members -- the order
+    inside a group is arbitrary on the GPU (atomics), and the emulator's is otherwise always the gathered order: the
+    full-union typing must come from the members' tags."""
     from emu import build_emu, emu_engine
     if not __import__("os").path.exists(build_emu.CXX):
         pytest.skip("hipemu needs the ROCm clang++ to compile the kernels for the host")
-    monkeypatch.setenv("RHIP_MANY_CH", ch)
+    if ch == "rev":
+        monkeypatch.setenv("RHIP_MANY_REVERSE", "1")
+        monkeypatch.setenv("RHIP_MANY_T", "1024")
+        monkeypatch.setenv("RHIP_MANY_CH", "5")
+    else:
+        monkeypatch.setenv("RHIP_MANY_CH", ch)
     eng = emu_engine()
     try:
         G.sparse_many_body(eng, oracle, n=700 if ch == "1024" else 150, worlds=(2,))
