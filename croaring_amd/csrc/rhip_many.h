@@ -139,16 +139,24 @@ constexpr uint32_t MC_W3 = 16384;   // keys per LDS window of k_many_scatter (u3
 constexpr uint32_t MC_CNT_BITS = 17, MC_CNT_MASK = (1u << MC_CNT_BITS) - 1u, MC_W_CAP = (1u << (32 - MC_CNT_BITS)) - 1u;
 constexpr uint32_t MC_MAX_PER_BLOCK = MC_CNT_MASK;  // members of one workgroup
 
-// f(container index, tag) for every member of this workgroup with UNROLL independent iterations in flight
+// Row of the count matrix (= share of the members) workgroup b takes.  Workgroup b runs on XCD b % 8 (observed, not
+// promised: a speed matter only): the workgroups of one XCD take CONSECUTIVE rows, so that what they scatter into a
+// group -- a few members per (row, key), adjacent for adjacent rows -- meets in ONE L2 and leaves as whole lines
+// (with rows dealt round-robin every 8-byte descriptor left its L2 as a partial line: k_many_scatter 142 us on C4).
+__device__ __forceinline__ uint32_t many_row(uint32_t b, uint32_t n) {
+    const uint32_t q = n >> 3, r = n & 7u, x = b & 7u;
+    return x * q + (x < r ? x : r) + (b >> 3);
+}
+// f(container index, tag) for every member of row `row`
 template <class F>
-__device__ __forceinline__ void many_for_members(const PoolView& P, const ManySel& S, F f) {
+__device__ __forceinline__ void many_for_members(const PoolView& P, const ManySel& S, uint32_t row, F f) {
     if (!S.ids) {
-        const u64 lo = (u64)blockIdx.x * S.per_block, hi = lo + S.per_block < S.M ? lo + S.per_block : S.M;
+        const u64 lo = (u64)row * S.per_block, hi = lo + S.per_block < S.M ? lo + S.per_block : S.M;
 #pragma unroll 4
         for (u64 t = lo + threadIdx.x; t < hi; t += MC_THREADS) f(t, t);
         return;
     }
-    const u64 s0 = (u64)blockIdx.x * S.per_block, s1 = s0 + S.per_block < S.nsel ? s0 + S.per_block : S.nsel;
+    const u64 s0 = (u64)row * S.per_block, s1 = s0 + S.per_block < S.nsel ? s0 + S.per_block : S.nsel;
     for (u64 s = s0 + (threadIdx.x >> 6); s < s1; s += MC_THREADS / 64) {
         const uint32_t b = S.ids[s];
         const u64 c0 = P.bm_start[b], c1 = P.bm_start[b + 1], d0 = S.sel_start[s];
@@ -167,10 +175,11 @@ __global__ __launch_bounds__(MC_THREADS) void k_many_hist(PoolView P, ManySel S,
     for (u64 i = gid; i < Z.n_glast; i += nth) Z.glast[i] = 0;
     for (u64 i = gid; i < Z.n_table; i += nth) Z.table[i] = 0;
     if (blockIdx.x >= S.n_blocks) return;  // (blocks beyond the member blocks only help clearing)
+    const uint32_t myrow = many_row(blockIdx.x, S.n_blocks);
     for (uint32_t w0 = 0; w0 < KS; w0 += MC_W1) {
         for (uint32_t i = threadIdx.x; i < MC_W1; i += MC_THREADS) h[i] = 0;
         __syncthreads();
-        many_for_members(P, S, [&](u64 c, u64) {
+        many_for_members(P, S, myrow, [&](u64 c, u64) {
             const uint32_t k = ((uint32_t)P.key[c] & 0xFFFFu) - w0;
             if (k < MC_W1) {
                 const uint32_t ty = P.type[c], cd = P.card[c], nr = P.nruns[c];
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_many_hist(PoolView P, ManySel S,
             }
         });
         __syncthreads();
-        uint32_t* __restrict__ row = mat + (u64)blockIdx.x * KS + w0;
+        uint32_t* __restrict__ row = mat + (u64)myrow * KS + w0;
         for (uint32_t i = threadIdx.x; i < MC_W1 && w0 + i < KS; i += MC_THREADS) {
             const u64 v = h[i];
             const uint32_t w = (v >> 32) > MC_W_CAP ? MC_W_CAP : (uint32_t)(v >> 32);
@@ -296,9 +305,10 @@ __global__ __launch_bounds__(MC_THREADS) void k_many_scatter(PoolView P, ManySel
     __shared__ uint32_t h[MC_W3];
     __shared__ u64 s_bytes[MC_THREADS / 64];
     u64 bytes = 0;
+    const uint32_t myrow = many_row(blockIdx.x, S.n_blocks);
     for (uint32_t w0 = 0; w0 < KS; w0 += MC_W3) {
-        const uint32_t* __restrict__ row = rel + (u64)blockIdx.x * KS + w0;
-        const uint32_t* __restrict__ nxt = blockIdx.x + 1 < S.n_blocks ? row + KS : nullptr;  // (reverse: the range's end)
+        const uint32_t* __restrict__ row = rel + (u64)myrow * KS + w0;
+        const uint32_t* __restrict__ nxt = myrow + 1 < S.n_blocks ? row + KS : nullptr;  // (reverse: the range's end)
         for (uint32_t i = threadIdx.x; i < MC_W3 && w0 + i < KS; i += MC_THREADS) {
             uint32_t base = kstart[w0 + i] + row[i];
             if (reverse)  // end of this workgroup's range of the key = start of the next workgroup's (or of the next key)
@@ -306,7 +316,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_many_scatter(PoolView P, ManySel
             h[i] = base;
         }
         __syncthreads();
-        many_for_members(P, S, [&](u64 c, u64 t) {
+        many_for_members(P, S, myrow, [&](u64 c, u64 t) {
             const uint32_t kk = (uint32_t)P.key[c] & 0xFFFFu, k = kk - w0;
             if (k < MC_W3) {
                 const uint32_t pos = reverse ? atomicSub(&h[k], 1u) - 1u : atomicAdd(&h[k], 1u);
