@@ -218,7 +218,7 @@ struct rhip_ctx_s {
     int many_pf = 4;  // RHIP_MANY_PF: payload groups per lane k_many_l1 loads ahead (2 / 4 / 8)
     int many_ch = 0;  // RHIP_MANY_CH: members per piece (tests of the multi-chunk / cut-group paths on small inputs); 0 = by size
     uint64_t many_slots = 1024;  // RHIP_MANY_SLOTS: pieces of a large call = workgroups of k_many_l1 resident at once (4 per CU)
-    uint64_t many_t = 8192;      // RHIP_MANY_T: members per workgroup of k_many_hist / k_many_scatter
+    uint64_t many_t = 0;         // RHIP_MANY_T: members per workgroup of k_many_hist / k_many_scatter; 0 = one workgroup per CU
     int many_reverse = 0;        // RHIP_MANY_REVERSE (tests): k_many_scatter fills its reservations backwards
     static constexpr size_t PINNED_MANY_FLAG_OFF = 2304, PINNED_MANY_TOT_OFF = 2560, PINNED_MANY_ERR_OFF = 2816;
     DBuf sel[5];  // pool_select / pool_convert scratch

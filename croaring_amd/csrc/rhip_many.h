@@ -147,20 +147,41 @@ __device__ __forceinline__ uint32_t many_row(uint32_t b, uint32_t n) {
     const uint32_t q = n >> 3, r = n & 7u, x = b & 7u;
     return x * q + (x < r ? x : r) + (b >> 3);
 }
-// f(container index, tag) for every member of row `row`
-template <class F>
+// One member's directory entry, loaded whole: the grouping kernels are chains of dependent loads unless a thread has
+// many of them in flight (k_many_scatter: 99 -> us on C4 with eight members' loads issued before the first is used).
+struct ManyRec { uint32_t key, ty, cd, nr; u64 off; };
+template <bool WITH_OFF>
+__device__ __forceinline__ ManyRec many_load(const PoolView& P, u64 c) {
+    ManyRec r;
+    r.key = (uint32_t)P.key[c] & 0xFFFFu; r.ty = P.type[c]; r.cd = P.card[c]; r.nr = P.nruns[c];
+    r.off = WITH_OFF ? P.off[c] : 0ull;
+    return r;
+}
+// f(record, tag) for every member of row `row`; eight members per thread in flight
+template <bool WITH_OFF, class F>
 __device__ __forceinline__ void many_for_members(const PoolView& P, const ManySel& S, uint32_t row, F f) {
     if (!S.ids) {
         const u64 lo = (u64)row * S.per_block, hi = lo + S.per_block < S.M ? lo + S.per_block : S.M;
-#pragma unroll 4
-        for (u64 t = lo + threadIdx.x; t < hi; t += MC_THREADS) f(t, t);
+        for (u64 base = lo + threadIdx.x; base < hi; base += 8ull * MC_THREADS) {
+            ManyRec r[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const u64 t = base + (u64)j * MC_THREADS;
+                r[j] = many_load<WITH_OFF>(P, t < hi ? t : hi - 1);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const u64 t = base + (u64)j * MC_THREADS;
+                if (t < hi) f(r[j], t);
+            }
+        }
         return;
     }
     const u64 s0 = (u64)row * S.per_block, s1 = s0 + S.per_block < S.nsel ? s0 + S.per_block : S.nsel;
     for (u64 s = s0 + (threadIdx.x >> 6); s < s1; s += MC_THREADS / 64) {
         const uint32_t b = S.ids[s];
         const u64 c0 = P.bm_start[b], c1 = P.bm_start[b + 1], d0 = S.sel_start[s];
-        for (u64 i = c0 + lane_id(); i < c1; i += 64) f(i, d0 + (i - c0));
+        for (u64 i = c0 + lane_id(); i < c1; i += 64) f(many_load<WITH_OFF>(P, i), d0 + (i - c0));
     }
 }
 
@@ -179,12 +200,9 @@ __global__ __launch_bounds__(MC_THREADS) void k_many_hist(PoolView P, ManySel S,
     for (uint32_t w0 = 0; w0 < KS; w0 += MC_W1) {
         for (uint32_t i = threadIdx.x; i < MC_W1; i += MC_THREADS) h[i] = 0;
         __syncthreads();
-        many_for_members(P, S, myrow, [&](u64 c, u64) {
-            const uint32_t k = ((uint32_t)P.key[c] & 0xFFFFu) - w0;
-            if (k < MC_W1) {
-                const uint32_t ty = P.type[c], cd = P.card[c], nr = P.nruns[c];
-                atomicAdd(&h[k], 1ull | ((u64)many_weight16(ty, cd, nr) << 32));
-            }
+        many_for_members<false>(P, S, myrow, [&](const ManyRec& r, u64) {
+            const uint32_t k = r.key - w0;
+            if (k < MC_W1) atomicAdd(&h[k], 1ull | ((u64)many_weight16(r.ty, r.cd, r.nr) << 32));
         });
         __syncthreads();
         uint32_t* __restrict__ row = mat + (u64)myrow * KS + w0;
@@ -316,16 +334,15 @@ __global__ __launch_bounds__(MC_THREADS) void k_many_scatter(PoolView P, ManySel
             h[i] = base;
         }
         __syncthreads();
-        many_for_members(P, S, myrow, [&](u64 c, u64 t) {
-            const uint32_t kk = (uint32_t)P.key[c] & 0xFFFFu, k = kk - w0;
+        many_for_members<true>(P, S, myrow, [&](const ManyRec& r, u64 t) {
+            const uint32_t k = r.key - w0;
             if (k < MC_W3) {
                 const uint32_t pos = reverse ? atomicSub(&h[k], 1u) - 1u : atomicAdd(&h[k], 1u);
-                const uint32_t ty = P.type[c], cd = P.card[c], nr = P.nruns[c];
-                sdesc[pos] = md_pack(P.off[c], ty, cd, nr);
+                sdesc[pos] = md_pack(r.off, r.ty, r.cd, r.nr);
                 sord[pos] = (uint32_t)t;
-                bytes += payload_bytes((uint8_t)ty, cd, nr);
-                if (ty == T_BITSET || (ty == T_RUN && cd == 65536u))
-                    atomicMax(&glast[2 * (u64)kgrp[kk] + (ty == T_BITSET ? 1u : 0u)], (uint32_t)t + 1u);
+                bytes += payload_bytes((uint8_t)r.ty, r.cd, r.nr);
+                if (r.ty == T_BITSET || (r.ty == T_RUN && r.cd == 65536u))
+                    atomicMax(&glast[2 * (u64)kgrp[r.key] + (r.ty == T_BITSET ? 1u : 0u)], (uint32_t)t + 1u);
             }
         });
         __syncthreads();
@@ -571,10 +588,34 @@ __device__ void many_raster_runs(uint32_t* dst, const uint8_t* __restrict__ aren
 // Accumulate the members [m0, m1) (at most MANY_CHUNK of them) into the LDS image acc.
 // `tmp` (8 KiB) first holds the staging tables of the array stream -- g16[j] = number of 16-byte payload groups of the
 // chunk's array members in front of member j, and the members' descriptors -- and later the rasterised run members.
-template <int PF>
+// One 16-byte payload group (eight sorted values, the first nv of them valid) into the swizzled image.  No branch per
+// value: an invalid value contributes the mask 0 (x | 0 = x ^ 0 = x), and a wave whose 64 groups are all full -- nearly
+// every step: only a member's last group is ragged -- skips the validity selects altogether.  The swizzle of both halves
+// of a dword is ONE xor: (d >> 5) & 0x03E003E0 is ((v >> 10) & 31) << 5 for either half.  (Round 5: the loop used to
+// test the op and the validity with three scalar branches and an exec-mask save / restore per value.)
+template <int OP>
+__device__ __forceinline__ void many_scatter8(uint32_t* acc, const uint4& x, uint32_t nv) {
+    const uint32_t dd[4] = {x.x, x.y, x.z, x.w};
+    const bool all_full = __ballot(nv != 8u) == 0ull;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t d = dd[q] ^ ((dd[q] >> 5) & 0x03E003E0u);
+        const uint32_t w0 = (d >> 5) & 2047u, w1 = d >> 21;
+        uint32_t b0 = 1u << (d & 31u), b1 = 1u << ((d >> 16) & 31u);
+        if (!all_full) {
+            b0 = (uint32_t)(2 * q) < nv ? b0 : 0u;
+            b1 = (uint32_t)(2 * q + 1) < nv ? b1 : 0u;
+        }
+        if (OP == OP_OR) { atomicOr(&acc[w0], b0); atomicOr(&acc[w1], b1); }
+        else { atomicXor(&acc[w0], b0); atomicXor(&acc[w1], b1); }
+    }
+}
+
+template <int PF, int OP>
 __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* tmp, const uint8_t* __restrict__ arena,
-                                      const u64* __restrict__ sdesc, u64 m0, u64 m1, int op, BlockScratch* sc,
+                                      const u64* __restrict__ sdesc, u64 m0, u64 m1, BlockScratch* sc,
                                       ManyLists* ml) {
+    constexpr int op = OP;
     const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const uint32_t nm = (uint32_t)(m1 - m0);
     uint32_t* g16 = tmp;                          // [MANY_CHUNK + 1]
@@ -645,17 +686,7 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
 #pragma unroll
             for (int p = 0; p < PF; ++p) fetch(c + PF + p, nxt[p], nn[p]);
 #pragma unroll
-            for (int p = 0; p < PF; ++p) {
-                const uint32_t dd[4] = {cur[p].x, cur[p].y, cur[p].z, cur[p].w};
-#pragma unroll
-                for (int h = 0; h < 8; ++h) {
-                    if ((uint32_t)h < cn[p]) {
-                        const uint32_t v = (dd[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
-                        if (op == OP_OR) atomicOr(&acc[mswz(v >> 5)], 1u << (v & 31));
-                        else atomicXor(&acc[mswz(v >> 5)], 1u << (v & 31));
-                    }
-                }
-            }
+            for (int p = 0; p < PF; ++p) many_scatter8<OP>(acc, cur[p], cn[p]);
 #pragma unroll
             for (int p = 0; p < PF; ++p) { cur[p] = nxt[p]; cn[p] = nn[p]; }
         }
@@ -703,11 +734,11 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
 }
 
 // Accumulate the members [m0, m1) into the LDS image acc (zeroed by the caller), MANY_CHUNK members at a time.
-template <int PF>
+template <int PF, int OP>
 __device__ __forceinline__ void many_accumulate(uint32_t* acc, uint32_t* tmp, const uint8_t* __restrict__ arena,
-                                const u64* __restrict__ sdesc, u64 m0, u64 m1, int op, BlockScratch* sc, ManyLists* ml) {
+                                const u64* __restrict__ sdesc, u64 m0, u64 m1, BlockScratch* sc, ManyLists* ml) {
     for (u64 c0 = m0; c0 < m1; c0 += MANY_CHUNK)
-        many_accumulate_chunk<PF>(acc, tmp, arena, sdesc, c0, (c0 + MANY_CHUNK < m1) ? c0 + MANY_CHUNK : m1, op, sc, ml);
+        many_accumulate_chunk<PF, OP>(acc, tmp, arena, sdesc, c0, (c0 + MANY_CHUNK < m1) ? c0 + MANY_CHUNK : m1, sc, ml);
 }
 
 struct ManyOut {
@@ -909,8 +940,8 @@ __device__ __forceinline__ bool many_image_full(const uint32_t* acc, BlockScratc
 #ifndef RHIP_MANY_WAVES
 #define RHIP_MANY_WAVES 1
 #endif
-template <int PF>
-__global__ __launch_bounds__(256, RHIP_MANY_WAVES) void k_many_l1(PoolView P, ManyView V, ManyOut MO, int op) {
+template <int PF, int OP>
+__global__ __launch_bounds__(256, RHIP_MANY_WAVES) void k_many_l1(PoolView P, ManyView V, ManyOut MO) {
     __shared__ __attribute__((aligned(16))) uint32_t acc[2048];
     __shared__ __attribute__((aligned(16))) uint32_t tmp[2048];
     __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];
@@ -935,7 +966,7 @@ __global__ __launch_bounds__(256, RHIP_MANY_WAVES) void k_many_l1(PoolView P, Ma
                 __syncthreads();
                 lds_zero(acc);
                 __syncthreads();
-                many_accumulate<PF>(acc, tmp, P.arena, desc, a0, a1, replay ? (int)OP_OR : op, &sc, &ml);
+                many_accumulate<PF, OP>(acc, tmp, P.arena, desc, a0, a1, &sc, &ml);  // (a replay only happens under OP_OR)
                 if (replay) {
                     many_emit_full(MO, g, many_image_full(acc, &sc));
                     break;
@@ -997,7 +1028,7 @@ __global__ __launch_bounds__(256) void k_many_l2(PoolView P, ManyView V, ManyOut
             __syncthreads();
             lds_zero(acc);
             __syncthreads();
-            many_accumulate<2>(acc, tmp, P.arena, desc, m0, m1, OP_OR, &sc, &ml);
+            many_accumulate<2, OP_OR>(acc, tmp, P.arena, desc, m0, m1, &sc, &ml);
             many_emit_full(MO, g, many_image_full(acc, &sc));
         }
     }
