@@ -38,6 +38,12 @@
 // every kernel takes its counts from device memory.
 #pragma once
 #include "rhip_kernels.h"
+#ifndef RHIP_ABL_SC   // ablation builds (scripts/r5/*.sh): 0 in the product
+#define RHIP_ABL_SC 0
+#endif
+#ifndef RHIP_ABL_L1
+#define RHIP_ABL_L1 0
+#endif
 
 // ------------------------------------------------------------------ member descriptors
 // bits 0..34  payload offset / 16 (arenas up to 512 GiB)
@@ -338,8 +344,15 @@ __global__ __launch_bounds__(MC_THREADS) void k_many_scatter(PoolView P, ManySel
             const uint32_t k = r.key - w0;
             if (k < MC_W3) {
                 const uint32_t pos = reverse ? atomicSub(&h[k], 1u) - 1u : atomicAdd(&h[k], 1u);
+#if RHIP_ABL_SC == 1   /* ablation builds only (scripts/r5): the kernel without its stores */
+                if (pos == 0xFFFFFFFFu) { sdesc[0] = md_pack(r.off, r.ty, r.cd, r.nr); sord[0] = (uint32_t)t; }
+#elif RHIP_ABL_SC == 2  /* non-temporal stores */
+                __builtin_nontemporal_store(md_pack(r.off, r.ty, r.cd, r.nr), &sdesc[pos]);
+                __builtin_nontemporal_store((uint32_t)t, &sord[pos]);
+#else
                 sdesc[pos] = md_pack(r.off, r.ty, r.cd, r.nr);
                 sord[pos] = (uint32_t)t;
+#endif
                 bytes += payload_bytes((uint8_t)r.ty, r.cd, r.nr);
                 if (r.ty == T_BITSET || (r.ty == T_RUN && r.cd == 65536u))
                     atomicMax(&glast[2 * (u64)kgrp[r.key] + (r.ty == T_BITSET ? 1u : 0u)], (uint32_t)t + 1u);
@@ -595,6 +608,10 @@ __device__ void many_raster_runs(uint32_t* dst, const uint8_t* __restrict__ aren
 // test the op and the validity with three scalar branches and an exec-mask save / restore per value.)
 template <int OP>
 __device__ __forceinline__ void many_scatter8(uint32_t* acc, const uint4& x, uint32_t nv) {
+#if RHIP_ABL_L1 == 1  /* ablation builds only: the member stream without its LDS atomics */
+    if ((x.x ^ x.y ^ x.z ^ x.w) == 0x12345678u && nv == 77u) atomicOr(&acc[0], 1u);
+    return;
+#endif
     const uint32_t dd[4] = {x.x, x.y, x.z, x.w};
     const bool all_full = __ballot(nv != 8u) == 0ull;
 #pragma unroll
@@ -606,8 +623,14 @@ __device__ __forceinline__ void many_scatter8(uint32_t* acc, const uint4& x, uin
             b0 = (uint32_t)(2 * q) < nv ? b0 : 0u;
             b1 = (uint32_t)(2 * q + 1) < nv ? b1 : 0u;
         }
+#if RHIP_ABL_L1 == 3 || RHIP_ABL_L1 == 4  /* ablation builds only (wrong results): plain stores instead of atomics */
+        ((volatile uint32_t*)acc)[w0] = b0; ((volatile uint32_t*)acc)[w1] = b1;
+#elif RHIP_ABL_L1 == 5 || RHIP_ABL_L1 == 6  /* ablation: byte stores */
+        ((volatile uint8_t*)acc)[w0 * 4 + (d & 3u)] = (uint8_t)b0; ((volatile uint8_t*)acc)[w1 * 4 + ((d >> 16) & 3u)] = (uint8_t)b1;
+#else
         if (OP == OP_OR) { atomicOr(&acc[w0], b0); atomicOr(&acc[w1], b1); }
         else { atomicXor(&acc[w0], b0); atomicXor(&acc[w1], b1); }
+#endif
     }
 }
 
@@ -645,19 +668,27 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
     if (tid == 0) { g16[nm] = carry; ml->n_g16 = carry; }
     __syncthreads();
     // ---- phase A: the array members as one flattened stream of 16-byte groups, LDS atomics (commutative: no ordering
-    // needed).  Wave w takes a contiguous quarter of the stream, 64 groups (1 KiB) per step, every lane eight values
-    // whatever the members' cardinalities; the member of a group is found by advancing a per-lane cursor over g16[]
-    // (consecutive steps are 64 groups apart: a couple of members).  FOUR steps are loaded ahead while the previous
-    // four feed the atomics: a member is a few hundred bytes at a random arena offset, so this loop is latency-bound
-    // unless enough loads overlap (one load round trip per four members and wave held k_many_l1 at 1.8 TB/s on the
-    // 100 000 sparse bitmaps of BASELINE config C4).
+    // needed).  The stream is cut into 32 equal ranges, one per OCTET of lanes (8 per wave): an octet walks its range
+    // eight groups = one 128-byte line per step, every lane eight values whatever the members' cardinalities.  A lane's
+    // groups are 8 apart, a member is ~32 groups long: a lane stays inside its member for several steps and keeps the
+    // member's base, end and cardinality in registers -- the LDS tables are read only when it crosses into the next
+    // member.  (Until round 5 a wave walked 64 consecutive groups per step: every lane crossed a member or two at every
+    // step, a chain of three to five dependent LDS reads in front of every load -- the kernel took 370 us with its loads
+    // or its atomics removed, neither being the bound.)  PF steps are loaded ahead while the previous PF feed the atomics.
     {
         const uint32_t T = carry;
-        const uint32_t nc = (T + 63u) >> 6;
-        const uint32_t c0 = wave * nc / 4u, c1 = (wave + 1u) * nc / 4u;
-        uint32_t m = 0;
-        if (c0 < c1) {  // cursor: largest member index with g16[m] <= first group of this lane
-            const uint32_t q = 64u * c0 + lane < T ? 64u * c0 + lane : T - 1u;
+        const uint32_t S = (((T + 31u) >> 5) + 7u) & ~7u;  // groups per octet range
+        const uint32_t oct = wave * 8u + (lane >> 3);
+        uint32_t q = oct * S + (lane & 7u);
+        const uint32_t qend = (oct + 1u) * S < T ? (oct + 1u) * S : T;
+        uint32_t m = 0, mstart = 0, mnext = 0, mcard = 0;
+        const uint4* __restrict__ mbase = (const uint4*)arena;
+        auto enter = [&]() {  // registers of member m
+            const u64 d = mdl[m];
+            mstart = g16[m]; mnext = g16[m + 1u]; mcard = md_n(d);
+            mbase = (const uint4*)(arena + md_off(d));
+        };
+        if (q < qend) {  // cursor: largest member index with g16[m] <= first group of this lane
             uint32_t lo = 0, hi = nm;
             while (lo + 1u < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
@@ -665,26 +696,34 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
                 else hi = mid;
             }
             m = lo;
+            enter();
         }
         uint4 cur[PF], nxt[PF];
         uint32_t cn[PF], nn[PF];
-        auto fetch = [&](uint32_t c, uint4& x, uint32_t& nv) {
-            const uint32_t q = 64u * c + lane;
+        auto fetch = [&](uint4& x, uint32_t& nv) {  // this lane's next group
             nv = 0;
             x = make_uint4(0, 0, 0, 0);
-            if (c < c1 && q < T) {
-                while (g16[m + 1u] <= q) ++m;  // (members without array payload span no groups and are stepped over)
-                const u64 d = mdl[m];
-                const uint32_t j = q - g16[m], card = md_n(d);
-                nv = card - 8u * j < 8u ? card - 8u * j : 8u;
-                x = ((const uint4*)(arena + md_off(d)))[j];
+            if (q < qend) {
+                if (q >= mnext) {
+                    do { ++m; } while (g16[m + 1u] <= q);  // (members without array payload span no groups and are stepped over)
+                    enter();
+                }
+                const uint32_t j = q - mstart;
+                nv = mcard - 8u * j < 8u ? mcard - 8u * j : 8u;
+#if RHIP_ABL_L1 == 2 || RHIP_ABL_L1 == 4 || RHIP_ABL_L1 == 6 /* ablation builds only: the LDS atomics without the member loads */
+                x = make_uint4(q * 2654435761u, q * 40503u + lane, (q + lane) * 2246822519u, q ^ (lane * 3266489917u));
+#else
+                x = mbase[j];
+#endif
             }
+            q += 8u;
         };
+        const uint32_t nsteps = S >> 3;
 #pragma unroll
-        for (int p = 0; p < PF; ++p) fetch(c0 + p, cur[p], cn[p]);
-        for (uint32_t c = c0; c < c1; c += PF) {
+        for (int p = 0; p < PF; ++p) fetch(cur[p], cn[p]);
+        for (uint32_t c = 0; c < nsteps; c += PF) {
 #pragma unroll
-            for (int p = 0; p < PF; ++p) fetch(c + PF + p, nxt[p], nn[p]);
+            for (int p = 0; p < PF; ++p) fetch(nxt[p], nn[p]);
 #pragma unroll
             for (int p = 0; p < PF; ++p) many_scatter8<OP>(acc, cur[p], cn[p]);
 #pragma unroll

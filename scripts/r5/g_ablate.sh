@@ -1,0 +1,10 @@
+# round 5, call g: ablations of k_many_scatter (stores off / non-temporal) and k_many_l1 (LDS atomics off / loads off)
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/r5g
+mkdir -p $O
+for v in "" sc1 sc2 l11 l12; do
+  RHIP_LIB_VARIANT=$v timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$v -o p -- python scripts/prof_c4.py 100000 > $O/prof_$v.log 2>&1
+  python scripts/trace_many.py $O/prof_$v "variant '${v:-product}'" | tee -a $O/timelines.txt
+  rm -f $(find $O/prof_$v -name "*kernel_trace.csv")
+done
