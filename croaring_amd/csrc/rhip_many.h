@@ -78,7 +78,7 @@ struct ManyTotals {
 struct ManyView {
     const u64* sdesc;       // [M] member descriptors, grouped by key
     const uint32_t* sord;   // [M] tag (position in the gathered order) of every member; null: the members of a group ARE
-                            //     in gathered order and a member's tag is its position
+                            //     in gathered order and a member's tag is its position (or MO.arrays_only: tags are never asked for)
     u64* rdesc;             // [M] scratch of the full-union replay (a group only ever uses its own range)
     const u64* gstart;      // [G+1] first member of each group; gstart[G] = M
     const u64* pstart;      // [G+1] first partial-chunk slot of each group (groups cut by piece boundaries)
@@ -158,9 +158,19 @@ __device__ __forceinline__ uint32_t many_row(uint32_t b, uint32_t n) {
 struct ManyRec { uint32_t key, ty, cd, nr; u64 off; };
 template <bool WITH_OFF>
 __device__ __forceinline__ ManyRec many_load(const PoolView& P, u64 c) {
+    // (non-temporal: the directory streams through once; what should stay in the L2 are the partly written lines of
+    // k_many_scatter's output, which only leave as whole lines if they survive until their neighbours arrive)
     ManyRec r;
+#if RHIP_ABL_SC == 3
     r.key = (uint32_t)P.key[c] & 0xFFFFu; r.ty = P.type[c]; r.cd = P.card[c]; r.nr = P.nruns[c];
     r.off = WITH_OFF ? P.off[c] : 0ull;
+#else
+    r.key = (uint32_t)__builtin_nontemporal_load(&P.key[c]) & 0xFFFFu;
+    r.ty = __builtin_nontemporal_load(&P.type[c]);
+    r.cd = __builtin_nontemporal_load(&P.card[c]);
+    r.nr = __builtin_nontemporal_load(&P.nruns[c]);
+    r.off = WITH_OFF ? __builtin_nontemporal_load(&P.off[c]) : 0ull;
+#endif
     return r;
 }
 // f(record, tag) for every member of row `row`; eight members per thread in flight
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_many_scatter(PoolView P, ManySel
                 __builtin_nontemporal_store((uint32_t)t, &sord[pos]);
 #else
                 sdesc[pos] = md_pack(r.off, r.ty, r.cd, r.nr);
-                sord[pos] = (uint32_t)t;
+                if (sord) sord[pos] = (uint32_t)t;
 #endif
                 bytes += payload_bytes((uint8_t)r.ty, r.cd, r.nr);
                 if (r.ty == T_BITSET || (r.ty == T_RUN && r.cd == 65536u))
@@ -540,7 +550,8 @@ __device__ __forceinline__ uint32_t many_group_of(const u64* __restrict__ gstart
 }
 
 // ------------------------------------------------------------------ accumulation of one unit into an LDS image
-constexpr uint32_t MANY_CHUNK = 512;  // members staged at a time
+constexpr uint32_t MANY_CHUNK = 1024;  // members staged at a time (four per thread)
+constexpr uint32_t MANY_TMP_WORDS = 3 * MANY_CHUNK + 8;  // g16[MANY_CHUNK + 1] | descriptors; later one rasterised run member (2048 words)
 struct ManyLists {  // bitset / run members of the chunk (relative member indices), listed by the staging pass
     uint32_t n_bitset, n_run, n_g16, pad;
     uint16_t bitset[MANY_CHUNK], run[MANY_CHUNK];
@@ -608,7 +619,7 @@ __device__ void many_raster_runs(uint32_t* dst, const uint8_t* __restrict__ aren
 // test the op and the validity with three scalar branches and an exec-mask save / restore per value.)
 template <int OP>
 __device__ __forceinline__ void many_scatter8(uint32_t* acc, const uint4& x, uint32_t nv) {
-#if RHIP_ABL_L1 == 1  /* ablation builds only: the member stream without its LDS atomics */
+#if RHIP_ABL_L1 == 1 || RHIP_ABL_L1 == 7  /* ablation builds only: the member stream without its LDS atomics */
     if ((x.x ^ x.y ^ x.z ^ x.w) == 0x12345678u && nv == 77u) atomicOr(&acc[0], 1u);
     return;
 #endif
@@ -645,25 +656,38 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
     u64* mdl = (u64*)(tmp + MANY_CHUNK + 2);      // [MANY_CHUNK] (8-byte aligned: MANY_CHUNK + 2 is even)
     __syncthreads();
     if (tid == 0) { ml->n_bitset = 0; ml->n_run = 0; }
-    many_swizzle_pass(acc);  // linear -> swizzled (ends with a barrier)
-    // ---- staging: descriptors, lists of the bitset / run members, prefix of the array members' 16-byte groups
-    uint32_t carry = 0;
+    __syncthreads();
+    // ---- staging: descriptors, lists of the bitset / run members, prefix of the array members' 16-byte groups.
+    // A thread takes four CONSECUTIVE members: their loads go out together and ONE block scan serves the chunk.
+    uint32_t carry;
+    {
+        u64 d[4];
+        uint32_t ng[4], mine = 0;
 #pragma unroll
-    for (uint32_t r = 0; r < MANY_CHUNK / 256; ++r) {
-        const uint32_t j = 256u * r + tid;
-        uint32_t ng = 0;
-        if (j < nm) {
-            const u64 d = sdesc[m0 + j];
-            mdl[j] = d;
-            const uint32_t ty = md_type(d);
-            if (ty == T_ARRAY) ng = (md_n(d) + 7u) >> 3;
-            else if (ty == T_BITSET) ml->bitset[atomicAdd(&ml->n_bitset, 1u)] = (uint16_t)j;
-            else ml->run[atomicAdd(&ml->n_run, 1u)] = (uint16_t)j;
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t j = 4u * tid + r;
+            d[r] = j < nm ? sdesc[m0 + j] : 0ull;
         }
-        uint32_t tot;
-        const uint32_t ex = blk_exscan(ng, sc->wsum, &tot);
-        if (j < nm) g16[j] = carry + ex;
-        carry += tot;
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t j = 4u * tid + r;
+            ng[r] = 0;
+            if (j < nm) {
+                mdl[j] = d[r];
+                const uint32_t ty = md_type(d[r]);
+                if (ty == T_ARRAY) ng[r] = (md_n(d[r]) + 7u) >> 3;
+                else if (ty == T_BITSET) ml->bitset[atomicAdd(&ml->n_bitset, 1u)] = (uint16_t)j;
+                else ml->run[atomicAdd(&ml->n_run, 1u)] = (uint16_t)j;
+            }
+            mine += ng[r];
+        }
+        uint32_t ex = blk_exscan(mine, sc->wsum, &carry);
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t j = 4u * tid + r;
+            if (j < nm) g16[j] = ex;
+            ex += ng[r];
+        }
     }
     if (tid == 0) { g16[nm] = carry; ml->n_g16 = carry; }
     __syncthreads();
@@ -686,7 +710,11 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
         auto enter = [&]() {  // registers of member m
             const u64 d = mdl[m];
             mstart = g16[m]; mnext = g16[m + 1u]; mcard = md_n(d);
+#if RHIP_ABL_L1 == 8  /* ablation: every member inside one MiB (cache-resident payloads) */
+            mbase = (const uint4*)(arena + (md_off(d) & 0xFFC00ull));
+#else
             mbase = (const uint4*)(arena + md_off(d));
+#endif
         };
         if (q < qend) {  // cursor: largest member index with g16[m] <= first group of this lane
             uint32_t lo = 0, hi = nm;
@@ -710,7 +738,7 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
                 }
                 const uint32_t j = q - mstart;
                 nv = mcard - 8u * j < 8u ? mcard - 8u * j : 8u;
-#if RHIP_ABL_L1 == 2 || RHIP_ABL_L1 == 4 || RHIP_ABL_L1 == 6 /* ablation builds only: the LDS atomics without the member loads */
+#if RHIP_ABL_L1 == 2 || RHIP_ABL_L1 == 4 || RHIP_ABL_L1 == 6 || RHIP_ABL_L1 == 7 /* ablation builds only: the LDS atomics without the member loads */
                 x = make_uint4(q * 2654435761u, q * 40503u + lane, (q + lane) * 2246822519u, q ^ (lane * 3266489917u));
 #else
                 x = mbase[j];
@@ -731,21 +759,22 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
         }
     }
     __syncthreads();
-    many_swizzle_pass(acc);  // swizzled -> linear
-    __syncthreads();
-    // ---- phase B: bitset members, thread-owned words, four members' loads in flight.  XOR / OR are commutative, so
-    // the arbitrary list order is fine.
+    // ---- phase B: bitset members, thread-owned words (through the swizzle: the image stays swizzled until the whole
+    // group is in), four members' loads in flight.  XOR / OR are commutative, so the arbitrary list order is fine.
     {
         const uint32_t nb = ml->n_bitset;
         if (nb) {
-            uint4 r0 = ((uint4*)acc)[2 * tid], r1 = ((uint4*)acc)[2 * tid + 1];
+            uint32_t r[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[k] = acc[mswz(8u * tid + k)];
+            uint4 r0 = make_uint4(r[0], r[1], r[2], r[3]), r1 = make_uint4(r[4], r[5], r[6], r[7]);
             for (uint32_t k = 0; k < nb; k += 4) {
                 uint4 a[4], b[4];
 #pragma unroll
                 for (uint32_t u = 0; u < 4; ++u) {
                     a[u] = make_uint4(0, 0, 0, 0); b[u] = a[u];
                     if (k + u < nb) {
-                        const uint4* __restrict__ g = (const uint4*)(arena + md_off(sdesc[m0 + ml->bitset[k + u]]));
+                        const uint4* __restrict__ g = (const uint4*)(arena + md_off(mdl[ml->bitset[k + u]]));
                         a[u] = g[2 * tid];
                         b[u] = g[2 * tid + 1];
                     }
@@ -753,31 +782,37 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
 #pragma unroll
                 for (uint32_t u = 0; u < 4; ++u) { r0 = op4(op, r0, a[u]); r1 = op4(op, r1, b[u]); }  // (x op 0 = x for or / xor)
             }
-            ((uint4*)acc)[2 * tid] = r0;
-            ((uint4*)acc)[2 * tid + 1] = r1;
+            const uint32_t w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[mswz(8u * tid + k)] = w[k];
         }
     }
     __syncthreads();
-    // ---- phase C: run members, rasterised one at a time into tmp (the staging tables are dead by now)
+    // ---- phase C: run members, rasterised one at a time into tmp (the staging tables are dead by now: the descriptor
+    // comes from global memory again)
     {
         const uint32_t nr = ml->n_run;
         for (uint32_t k = 0; k < nr; ++k) {
             many_raster_runs(tmp, arena, sdesc[m0 + ml->run[k]], sc);
-            uint4 r0 = ((uint4*)acc)[2 * tid], r1 = ((uint4*)acc)[2 * tid + 1];
-            uint4 x0 = ((uint4*)tmp)[2 * tid], x1 = ((uint4*)tmp)[2 * tid + 1];
-            ((uint4*)acc)[2 * tid] = op4(op, r0, x0);
-            ((uint4*)acc)[2 * tid + 1] = op4(op, r1, x1);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t x = tmp[8u * tid + q], i = mswz(8u * tid + q);
+                acc[i] = op == OP_OR ? (acc[i] | x) : (acc[i] ^ x);
+            }
             __syncthreads();
         }
     }
 }
 
-// Accumulate the members [m0, m1) into the LDS image acc (zeroed by the caller), MANY_CHUNK members at a time.
+// Accumulate the members [m0, m1) into the LDS image acc (ZEROED by the caller), MANY_CHUNK members at a time.
 template <int PF, int OP>
 __device__ __forceinline__ void many_accumulate(uint32_t* acc, uint32_t* tmp, const uint8_t* __restrict__ arena,
                                 const u64* __restrict__ sdesc, u64 m0, u64 m1, BlockScratch* sc, ManyLists* ml) {
+    // (the caller's image is all zero, which reads the same through the swizzle; it leaves in linear order)
     for (u64 c0 = m0; c0 < m1; c0 += MANY_CHUNK)
         many_accumulate_chunk<PF, OP>(acc, tmp, arena, sdesc, c0, (c0 + MANY_CHUNK < m1) ? c0 + MANY_CHUNK : m1, sc, ml);
+    __syncthreads();
+    many_swizzle_pass(acc);  // swizzled -> linear (ends with a barrier)
 }
 
 struct ManyOut {
@@ -788,6 +823,7 @@ struct ManyOut {
                         //    chunk of key k at row (k % world) * dense_b + k / world
     int force_typed;    // 1: single-member groups are typed by cardinality too
     int exact_or_many;  // 1: reproduce roaring_bitmap_or_many's run-vs-bitset choice for FULL containers
+    int arrays_only;    // 1: the pool holds array containers only (type census): a full union is a bitset, member tags are not kept
     uint32_t world, dense_b;
     u64 key_space;
     const uint32_t* glast;  // [2 G] tag + 1 of the last full-run / last bitset member of every group (0 = none)
@@ -825,6 +861,7 @@ __device__ __forceinline__ bool many_key_in(const PoolView& P, u64 lo, u64 hi, u
 // full.  Block-uniform (metadata only); `red` is LDS scratch of 4 u64.
 __device__ int full_union_decide(const PoolView& P, const ManyView& V, const ManyOut& MO, uint32_t g, u64 gs, u64 ge,
                                  u64* red, u64* replay_tag) {
+    if (MO.arrays_only) return 0;  // no bitset, no run among the members: the lazy accumulator stays a bitset (and no tags were kept)
     const u64 key = MO.O.key[g];
     // the first two members come from ids[0] and ids[1] iff both of those bitmaps hold the key
     const u64 j0 = lower_bound(P.key, MO.first_lo, MO.first_hi, key), j1 = lower_bound(P.key, MO.second_lo, MO.second_hi, key);
@@ -982,7 +1019,7 @@ __device__ __forceinline__ bool many_image_full(const uint32_t* acc, BlockScratc
 template <int PF, int OP>
 __global__ __launch_bounds__(256, RHIP_MANY_WAVES) void k_many_l1(PoolView P, ManyView V, ManyOut MO) {
     __shared__ __attribute__((aligned(16))) uint32_t acc[2048];
-    __shared__ __attribute__((aligned(16))) uint32_t tmp[2048];
+    __shared__ __attribute__((aligned(16))) uint32_t tmp[MANY_TMP_WORDS];
     __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];
     __shared__ BlockScratch sc;
     __shared__ ManyLists ml;
@@ -1028,7 +1065,7 @@ __global__ __launch_bounds__(256, RHIP_MANY_WAVES) void k_many_l1(PoolView P, Ma
 // combine the partial chunks of the groups that piece boundaries cut
 __global__ __launch_bounds__(256) void k_many_l2(PoolView P, ManyView V, ManyOut MO, int op) {
     __shared__ __attribute__((aligned(16))) uint32_t acc[2048];
-    __shared__ __attribute__((aligned(16))) uint32_t tmp[2048];
+    __shared__ __attribute__((aligned(16))) uint32_t tmp[MANY_TMP_WORDS];
     __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];
     __shared__ BlockScratch sc;
     __shared__ ManyLists ml;
