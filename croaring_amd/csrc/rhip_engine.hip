@@ -215,7 +215,7 @@ struct rhip_ctx_s {
     bool spin_join = true;
     u64* join_timeout_word() const { return (u64*)((char*)h_pinned + PINNED_JOIN_TIMEOUT_OFF); }
     bool copy_wide = true;       // RHIP_COPY_WIDE=0: k_copy always takes four items per wave
-    int many_pf = 4;  // RHIP_MANY_PF: payload groups per lane k_many_l1 loads ahead (2 / 4 / 8)
+    int many_pf = 2;  // RHIP_MANY_PF: payload groups per lane k_many_l1 loads ahead (2 / 4 / 8; round 5: 2 beats 4 by 4 % on C4 -- the memory system queues, more requests in flight only wait longer)
     int many_ch = 0;  // RHIP_MANY_CH: members per piece (tests of the multi-chunk / cut-group paths on small inputs); 0 = by size
     uint64_t many_slots = 1024;  // RHIP_MANY_SLOTS: pieces of a large call = workgroups of k_many_l1 resident at once (4 per CU)
     uint64_t many_t = 0;         // RHIP_MANY_T: members per workgroup of k_many_hist / k_many_scatter; 0 = one workgroup per CU

@@ -613,18 +613,25 @@ __device__ void many_raster_runs(uint32_t* dst, const uint8_t* __restrict__ aren
 // `tmp` (8 KiB) first holds the staging tables of the array stream -- g16[j] = number of 16-byte payload groups of the
 // chunk's array members in front of member j, and the members' descriptors -- and later the rasterised run members.
 // One 16-byte payload group (eight sorted values, the first nv of them valid) into the swizzled image.  No branch per
-// value: an invalid value contributes the mask 0 (x | 0 = x ^ 0 = x), and a wave whose 64 groups are all full -- nearly
-// every step: only a member's last group is ragged -- skips the validity selects altogether.  The swizzle of both halves
+// value: an invalid value contributes the mask 0 (x | 0 = x ^ 0 = x), and a wave none of whose groups is ragged (only a
+// member's last group can be) skips the validity selects altogether.  The swizzle of both halves
 // of a dword is ONE xor: (d >> 5) & 0x03E003E0 is ((v >> 10) & 31) << 5 for either half.  (Round 5: the loop used to
 // test the op and the validity with three scalar branches and an exec-mask save / restore per value.)
+// An array member in the stream of phase A: its payload seen as whole 128-byte LINES -- `lead` 16-byte slots in front of
+// its first group (the payload is 16-byte aligned, not line aligned), its ceil(card / 8) groups, padding to the end of the
+// last line.  A step of an octet of lanes is then exactly one line of one member: one memory request, no straddling
+// (with groups packed back to back a step touched two lines and a third of the second touches missed the L2: 20.7 M L2
+// requests and 2.07 GB from memory for 1.64 GB of payload on C4, `profiles/r05_many_l1_tcc.md`).
+__device__ __forceinline__ uint32_t many_lead(u64 d) { return (uint32_t)(d & 7ull); }  // (offset / 16) mod 8
+__device__ __forceinline__ uint32_t many_slots(u64 d) { return (many_lead(d) + ((md_n(d) + 7u) >> 3) + 7u) & ~7u; }
+
 template <int OP>
-__device__ __forceinline__ void many_scatter8(uint32_t* acc, const uint4& x, uint32_t nv) {
+__device__ __forceinline__ void many_scatter8(uint32_t* acc, const uint4& x, uint32_t nv, bool all_full) {
 #if RHIP_ABL_L1 == 1 || RHIP_ABL_L1 == 7  /* ablation builds only: the member stream without its LDS atomics */
     if ((x.x ^ x.y ^ x.z ^ x.w) == 0x12345678u && nv == 77u) atomicOr(&acc[0], 1u);
     return;
 #endif
     const uint32_t dd[4] = {x.x, x.y, x.z, x.w};
-    const bool all_full = __ballot(nv != 8u) == 0ull;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint32_t d = dd[q] ^ ((dd[q] >> 5) & 0x03E003E0u);
@@ -675,7 +682,7 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
             if (j < nm) {
                 mdl[j] = d[r];
                 const uint32_t ty = md_type(d[r]);
-                if (ty == T_ARRAY) ng[r] = (md_n(d[r]) + 7u) >> 3;
+                if (ty == T_ARRAY) ng[r] = many_slots(d[r]);
                 else if (ty == T_BITSET) ml->bitset[atomicAdd(&ml->n_bitset, 1u)] = (uint16_t)j;
                 else ml->run[atomicAdd(&ml->n_run, 1u)] = (uint16_t)j;
             }
@@ -705,18 +712,19 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
         const uint32_t oct = wave * 8u + (lane >> 3);
         uint32_t q = oct * S + (lane & 7u);
         const uint32_t qend = (oct + 1u) * S < T ? (oct + 1u) * S : T;
-        uint32_t m = 0, mstart = 0, mnext = 0, mcard = 0;
+        uint32_t m = 0, mnext = 0, mcard = 0;
+        int mfirst = 0;  // stream index of the member's first GROUP (its first slot + lead)
         const uint4* __restrict__ mbase = (const uint4*)arena;
         auto enter = [&]() {  // registers of member m
             const u64 d = mdl[m];
-            mstart = g16[m]; mnext = g16[m + 1u]; mcard = md_n(d);
+            mfirst = (int)(g16[m] + many_lead(d)); mnext = g16[m + 1u]; mcard = md_n(d);
 #if RHIP_ABL_L1 == 8  /* ablation: every member inside one MiB (cache-resident payloads) */
             mbase = (const uint4*)(arena + (md_off(d) & 0xFFC00ull));
 #else
             mbase = (const uint4*)(arena + md_off(d));
 #endif
         };
-        if (q < qend) {  // cursor: largest member index with g16[m] <= first group of this lane
+        if (q < qend) {  // cursor: largest member index with g16[m] <= first slot of this lane
             uint32_t lo = 0, hi = nm;
             while (lo + 1u < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
@@ -728,21 +736,23 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
         }
         uint4 cur[PF], nxt[PF];
         uint32_t cn[PF], nn[PF];
-        auto fetch = [&](uint4& x, uint32_t& nv) {  // this lane's next group
+        auto fetch = [&](uint4& x, uint32_t& nv) {  // this lane's next slot
             nv = 0;
             x = make_uint4(0, 0, 0, 0);
             if (q < qend) {
-                if (q >= mnext) {
-                    do { ++m; } while (g16[m + 1u] <= q);  // (members without array payload span no groups and are stepped over)
+                if (q >= mnext) {  // (octet-uniform: members start and end on line boundaries of the stream)
+                    do { ++m; } while (g16[m + 1u] <= q);  // (members without array payload span no slots and are stepped over)
                     enter();
                 }
-                const uint32_t j = q - mstart;
-                nv = mcard - 8u * j < 8u ? mcard - 8u * j : 8u;
+                const int j = (int)q - mfirst;  // group of the member (negative: lead slot)
+                if (j >= 0 && 8u * (uint32_t)j < mcard) {
+                    nv = mcard - 8u * (uint32_t)j < 8u ? mcard - 8u * (uint32_t)j : 8u;
 #if RHIP_ABL_L1 == 2 || RHIP_ABL_L1 == 4 || RHIP_ABL_L1 == 6 || RHIP_ABL_L1 == 7 /* ablation builds only: the LDS atomics without the member loads */
-                x = make_uint4(q * 2654435761u, q * 40503u + lane, (q + lane) * 2246822519u, q ^ (lane * 3266489917u));
+                    x = make_uint4(q * 2654435761u, q * 40503u + lane, (q + lane) * 2246822519u, q ^ (lane * 3266489917u));
 #else
-                x = mbase[j];
+                    x = mbase[j];
 #endif
+                }
             }
             q += 8u;
         };
@@ -753,7 +763,10 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
 #pragma unroll
             for (int p = 0; p < PF; ++p) fetch(nxt[p], nn[p]);
 #pragma unroll
-            for (int p = 0; p < PF; ++p) many_scatter8<OP>(acc, cur[p], cn[p]);
+            for (int p = 0; p < PF; ++p) {
+                const bool all_full = __ballot(cn[p] != 0u && cn[p] != 8u) == 0ull;  // (no ragged group in this step)
+                if (cn[p]) many_scatter8<OP>(acc, cur[p], cn[p], all_full);  // (lead / padding slots and lanes past the range sit out)
+            }
 #pragma unroll
             for (int p = 0; p < PF; ++p) { cur[p] = nxt[p]; cn[p] = nn[p]; }
         }
