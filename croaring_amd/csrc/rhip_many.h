@@ -31,7 +31,7 @@
 //                   inside one piece is canonicalised straight from LDS, a group cut by piece boundaries writes 8 KiB
 //                   partial chunks
 //   k_many_l2       combines the partial chunks of cut groups (same shape as the multi-GPU exchange)
-//   k_many_copy     single-member groups keep their container unchanged
+//                   (a single-member group keeps its container unchanged: copied by the workgroup that meets it)
 //   k_many_tail     ONE look-back pass: drops empty (xor) results, writes the result directory, totals and the
 //                   completion word into pinned host memory
 // Every buffer is sized on the host from upper bounds (members, distinct keys of the pool, per-bitmap payload bounds);
@@ -1023,6 +1023,29 @@ __device__ __forceinline__ bool many_image_full(const uint32_t* acc, BlockScratc
     return blk_sum(popc4(r0) + popc4(r1), sc->wsum) == 65536u;
 }
 
+// a single-member group keeps its container unchanged (type included): roaring.c:2660-2676.  The whole workgroup copies.
+__device__ __forceinline__ void many_pass_through(u64 d, const uint8_t* __restrict__ arena, const ManyOut& MO, uint32_t g,
+                                                  BlockScratch* sc) {
+    const uint32_t ty = md_type(d), n = md_n(d);
+    const uint32_t n16 = (md_payload(d) + 15u) >> 4;
+    const uint4* __restrict__ ps = (const uint4*)(arena + md_off(d));
+    uint4* __restrict__ po = (uint4*)(MO.O.arena + MO.O.off[g]);
+    uint32_t card = 0;  // runs: the descriptor has no exact cardinality, the runs do (sum of length + 1)
+    for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) {
+        const uint4 x = ps[i];
+        po[i] = x;
+        if (ty == T_RUN) {
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k)
+                if (4u * i + k < n) card += (w[k] >> 16) + 1u;
+        }
+    }
+    if (ty == T_RUN) card = blk_sum(card, sc->wsum);  // (block-uniform branch: the descriptor is)
+    else card = ty == T_ARRAY ? n : n + 1u;
+    if (threadIdx.x == 0) MO.O.meta[g] = pack_meta(ty, card, ty == T_RUN ? n : 0u);
+}
+
 // PF = 16-byte payload groups per lane loaded ahead of the LDS atomics (RHIP_MANY_PF selects 2 / 4 / 8; default 4)
 // (-DRHIP_MANY_WAVES=5, a variant build for A/B runs -- croaring_amd/build.py RHIP_BUILD_VARIANT: five waves per SIMD at 96
 // VGPRs and 24 bytes of scratch per lane; compiled in round 4, not yet measured)
@@ -1047,7 +1070,10 @@ __global__ __launch_bounds__(256, RHIP_MANY_WAVES) void k_many_l1(PoolView P, Ma
             const u64 gs = V.gstart[g], ge = V.gstart[g + 1];
             if (gs >= hi) break;
             const u64 q0 = gs / per, nu = (ge - 1) / per - q0 + 1;  // pieces the group is cut into
-            if (nu == 1 && (ge - gs) == 1 && !MO.force_typed && !MO.partial_mode) continue;  // pass-through copy path
+            if (nu == 1 && (ge - gs) == 1 && !MO.force_typed && !MO.partial_mode) {
+                many_pass_through(V.sdesc[gs], P.arena, MO, g, &sc);  // a single member keeps its container (roaring.c:2660-2676)
+                continue;
+            }
             const u64* desc = V.sdesc;
             u64 a0 = gs > lo ? gs : lo, a1 = ge < hi ? ge : hi;
             // One accumulation site for the piece's members and -- rarely -- for the replay of a full union's prefix
@@ -1120,35 +1146,6 @@ __global__ __launch_bounds__(256) void k_many_l2(PoolView P, ManyView V, ManyOut
             many_accumulate<2, OP_OR>(acc, tmp, P.arena, desc, m0, m1, &sc, &ml);
             many_emit_full(MO, g, many_image_full(acc, &sc));
         }
-    }
-}
-
-// single-member groups keep their container unchanged (type included): roaring.c:2660-2676
-__global__ __launch_bounds__(256) void k_many_copy(PoolView P, ManyView V, ManyOut MO) {
-    const uint32_t G = (uint32_t)V.tot->n_groups;
-    const uint32_t lane = lane_id();
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; g < G; g += nwaves) {
-        if (V.gstart[g + 1] - V.gstart[g] != 1) continue;
-        const u64 d = V.sdesc[V.gstart[g]];
-        const uint32_t ty = md_type(d), n = md_n(d);
-        const uint32_t n16 = (md_payload(d) + 15u) >> 4;
-        const uint4* __restrict__ ps = (const uint4*)(P.arena + md_off(d));
-        uint4* __restrict__ po = (uint4*)(MO.O.arena + MO.O.off[g]);
-        uint32_t card = 0;  // runs: the descriptor has no exact cardinality, the runs do (sum of length + 1)
-        for (uint32_t i = lane; i < n16; i += 64) {
-            const uint4 x = ps[i];
-            po[i] = x;
-            if (ty == T_RUN) {
-                const uint32_t w[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k)
-                    if (4u * i + k < n) card += (w[k] >> 16) + 1u;
-            }
-        }
-        if (ty == T_RUN) card = wave_sum(card);
-        else card = ty == T_ARRAY ? n : n + 1u;
-        if (lane == 0) MO.O.meta[g] = pack_meta(ty, card, ty == T_RUN ? n : 0u);
     }
 }
 
