@@ -80,6 +80,11 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true", help="skip config.secondary (realdata, C4, C5)")
     ap.add_argument("--no-x10", action="store_true", help="skip the 10^6-bitmap or_many row (16 GB of images built on the host, ~20 s)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
+    ap.add_argument("--reps", type=int, default=20, help="repetitions of every secondary batch (>= 20 in a measurement run)")
+    ap.add_argument("--ranks-share-device", action="store_true",
+                    help="DRY RUN of the N > 1 line on ONE GPU: every rank opens cuda:0, the process group is gloo and the "
+                         "many-way exchange is staged through host memory (croaring_amd.distributed).  Every statement of the "
+                         "multi-rank script runs except the collectives on RCCL; the line says so and is not a scaling number")
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="internal: run the cpu_baseline leg alone and print its JSON (rank 0 does this in a fresh process at N > 1)")
     return ap.parse_args()
@@ -229,8 +234,10 @@ def cpu_baseline(args, seconds: float):
 class Dist:
     """The little bit of torch.distributed the bench needs, degenerate at world 1."""
 
-    def __init__(self, rank, world, torch, dist):
+    def __init__(self, rank, world, torch, dist, reps=20, host_tensors=False):
         self.rank, self.world, self.torch, self.dist = rank, world, torch, dist
+        self.reps = reps
+        self.rdev = "cpu" if host_tensors else "cuda"  # where the scalars of max / sum live (gloo: host)
 
     def barrier(self):
         if self.world > 1:
@@ -240,25 +247,28 @@ class Dist:
     def max(self, x: float) -> float:
         if self.world == 1:
             return x
-        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.rdev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
     def sum(self, x: float) -> float:
         if self.world == 1:
             return x
-        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.rdev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
 
-def timed_calls(D: Dist, fn, reps=20, min_s=0.05):
+def timed_calls(D: Dist, fn, reps=None, min_s=0.05):
     """>= reps repetitions (and >= min_s in total) of fn; returns (min, median) of the wall time of a call.  fn is a
     SYNCHRONOUS call (it returns when its results are complete), so on one GPU the calls are simply issued one after the
     other, as a caller would; with several ranks every call is bracketed by a barrier and the slowest rank counts."""
     fn()
     fn()
     sync = D.world > 1
+    reps = D.reps if reps is None else reps
+    if reps < 20:
+        min_s = 0.0  # (a dry run: the statements, not the statistics)
     ts, t_all = [], time.perf_counter()
     while len(ts) < reps or time.perf_counter() - t_all < min_s:
         if sync:
@@ -328,7 +338,7 @@ def run_realdata(eng, D: Dist, name: str, tag: str, chk, is64=False, ops=("and",
                "matched_pairs_rank0": int(st["matched_pairs"]), "passthrough_rank0": int(st["passthrough"])}
         # the same batch with TWO calls in flight (rhip_pairwise_begin / _end): the host half of call i+1 overlaps
         # the kernels of call i; per-call period over 40 calls, result of the last one checked
-        n_pipe, n_warm = 40, 8
+        n_pipe, n_warm = max(4, 2 * D.reps), 8
         slots, prev = [res[0], None], None
         res[0] = None
         for it in range(-n_warm, n_pipe):  # warm-up: every slot's pinned staging exists before the clock starts
@@ -373,6 +383,42 @@ def run_realdata(eng, D: Dist, name: str, tag: str, chk, is64=False, ops=("and",
     tmin, tmed = timed_calls(D, lambda: eng.pairwise_list_cardinality("and", plist))
     out[f"{tag}_and_cardinality"] = {"pairs": int(L.size), "ops_per_s": L.size / tmed, "ms_batch_median": tmed * 1e3,
                                      "ms_batch_min": tmin * 1e3}
+    # The reference benchmark's own loop shape (benchmarks/benchmark.cpp:2035-2091 successive_and / successive_or): the
+    # n - 1 ADJACENT pairs, each result materialised, its cardinality taken, freed.  Here: one batch over
+    # rhip_pairlist_successive + the cardinalities read back.  199 pairs are almost pure fixed cost of a call -- this is
+    # the row where one CPU core is expected to be at least as fast, reported as it comes (rank 0 only: nothing to shard).
+    if not is64 and D.rank == 0:
+        slist = eng.pairlist_successive(pool)
+        n_succ = len(bufs) - 1
+        sl, sr = np.arange(n_succ, dtype=np.uint32), np.arange(1, n_succ + 1, dtype=np.uint32)
+        for op in ("and", "or"):
+            res = [None]
+            cards = [None]
+
+            def scall():
+                res[0] = eng.pairwise_list(op, slist, reuse=res[0])
+                cards[0] = res[0].cardinalities()
+            fn = scall
+            fn(); fn()
+            ts = []
+            for _ in range(max(D.reps, 3)):
+                t0 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t0)
+            tmed = float(np.median(ts))
+            row = {"pairs": n_succ, "ms_batch_median": tmed * 1e3, "ms_batch_min": float(np.min(ts)) * 1e3,
+                   "us_per_op": tmed * 1e6 / n_succ, "ops_per_s": n_succ / tmed, "checksum": int(cards[0].sum())}
+            if hs is not None:
+                rate = cpu_pairs_rate(chk, hs, sl, sr, op, budget=0.2)
+                row["cpu1_ops_per_s"] = rate
+                row["cpu1_us_per_op"] = 1e6 / rate
+                row["gpu_over_cpu1"] = (n_succ / tmed) / rate
+                want = sum(chk.cardinality(r) for r in (chk.op(op, hs[i], hs[i + 1]) for i in range(n_succ)))
+                row["checksum_ok"] = bool(want == row["checksum"])
+                assert row["checksum_ok"], f"{name} successive {op}: checksum differs from the reference"
+            res[0] = None
+            out[f"{tag}_successive_{op}"] = row
+        slist.free()
     if is64:
         # BASELINE configs[4]: the many-way aggregation of the roaring64 bitmaps.  world > 1: bitmaps b mod world on rank
         # b mod world, the 48-bit-key chunks to their owners through the sparse exchange (RCCL), owners finalize; the
@@ -405,6 +451,43 @@ def run_realdata(eng, D: Dist, name: str, tag: str, chk, is64=False, ops=("and",
         for h in hs:
             (chk.free64 if is64 else chk.free)(h)
     return out
+
+
+def run_dropin_percall(chk, name: str, n_calls: int = 200):
+    """Per-call latency of the CRoaring-named drop-in (include/roaring_hip_compat.h): ONE roaring_bitmap_and / _or on two
+    host-resident reference structs = upload of both operands, a batch of one, download, a reference-layout result.  The
+    CPU op it replaces beside it.  This is the compatibility path, not the product: the row exists so that the
+    loss is a number.  Needs the real reference (its structs are the operands)."""
+    import ctypes as C
+    import croaring_amd
+    from util import load_bundle
+    if getattr(chk, "name", "") != "reference":
+        return None
+    lib = croaring_amd.load()
+    bufs = load_bundle(name)
+    hs = [chk.deserialize(b) for b in bufs]
+    n = min(n_calls, len(hs) - 1)
+    row = {"calls": n, "operands": name}
+    for op in ("and", "or"):
+        f = getattr(lib, f"roaring_bitmap_{op}")
+        f.restype = C.c_void_p
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        for i in range(3):  # warm-up: the lane's context, pinned staging and pools exist
+            chk.free(f(hs[i], hs[i + 1]))
+        t0 = time.perf_counter()
+        for i in range(n):
+            r = f(hs[i], hs[i + 1])
+            chk.free(r)
+        t_gpu = (time.perf_counter() - t0) / n
+        t0 = time.perf_counter()
+        for i in range(n):
+            r = chk.op(op, hs[i], hs[i + 1])
+            chk.free(r)
+        t_cpu = (time.perf_counter() - t0) / n
+        row[op] = {"dropin_us_per_call": t_gpu * 1e6, "croaring_us_per_call": t_cpu * 1e6, "dropin_over_cpu": t_gpu / t_cpu}
+    for h in hs:
+        chk.free(h)
+    return row
 
 
 def _time_steps(D: Dist, step, steps: int, warmup: int):
@@ -604,15 +687,23 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    if torch.cuda.device_count() < world:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible")
-    torch.cuda.set_device(local_rank)
+    share = bool(args.ranks_share_device)
+    if not share and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible "
+                         "(--ranks-share-device runs the N-rank script on one GPU over gloo, as a dry run)")
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import croaring_amd
-    eng = croaring_amd.Engine(local_rank)
+    eng = croaring_amd.Engine(dev_index)
     eng.set_timing(True)
-    D = Dist(rank, world, torch, dist)
+    D = Dist(rank, world, torch, dist, reps=args.reps, host_tensors=share)
+    transport = ("gloo-staged (dry run: %d ranks share one GPU, exchange through host memory -- NOT a scaling number)" % world) if share \
+        else ("rccl" if world > 1 else "none (one rank)")
     chk = None
     if rank == 0 and not args.no_cpu:
         from oracle.pyoracle import best_checker
@@ -622,7 +713,7 @@ def main():
         row = run_ormany(args, eng, D, args.steps, args.warmup, chk)
         out = {"metric": METRIC, "value": row["ops_per_s"], "unit": "or_many-ops/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": row["ms_median"], "higher_is_better": True,
-               "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+               "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic", "transport": transport,
                "config": {"workload": f"C4 or_many over {args.bitmaps} sparse bitmaps x 32 array containers", **row}}
         if rank == 0:
             print(json.dumps(out), file=real_stdout, flush=True)
@@ -714,6 +805,7 @@ def main():
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
+        "transport": transport,
         "config": {"workload": f"C2 synthetic bitset-only: pool {args.pool} bitmaps x {args.containers} bitset "
                                f"containers (density 0.5), batched pairwise AND+OR, {args.pairs} pairs per call, "
                                f"{args.rounds} x (AND call + OR call) per step, two calls in flight "
@@ -741,7 +833,14 @@ def main():
         sec.update(run_realdata(eng, D, "weather_sept_85", "c3", chk))
         sec.update(run_realdata(eng, D, "census1881", "c1", chk))
         sec.update(run_realdata(eng, D, "wikileaks-noquotes x10 (roaring64)", "c5", chk, is64=True, ops=("and", "or")))
-        sec["c4_or_many"] = run_ormany(args, eng, D, steps=10, warmup=2, chk=chk)
+        if rank == 0 and chk is not None:
+            try:
+                r = run_dropin_percall(chk, "census1881")
+                if r:
+                    sec["dropin_percall_us"] = r
+            except Exception as e:  # (a compatibility row: its failure is reported, it does not take the line down)
+                sec["dropin_percall_us"] = {"error": str(e)[:160]}
+        sec["c4_or_many"] = run_ormany(args, eng, D, steps=max(3, min(10, args.reps)), warmup=2, chk=chk)
         # (the two rows below are evidence for the scaling model, not the headline: a failure in them is reported as a
         # row, it does not take the line down -- except a WRONG cardinality, which is asserted inside)
         if not args.no_x10:
@@ -767,6 +866,9 @@ def main():
             if "error" in r:
                 summ[k] = r["error"][:80]
                 continue
+            if k == "dropin_percall_us":
+                summ[k] = {o: [round(r[o]["dropin_us_per_call"], 1), round(r[o]["croaring_us_per_call"], 2)] for o in ("and", "or") if o in r}
+                continue
             if k == "c4_shard_stages":
                 summ[k] = {n: [round(v["stage1_ms"], 3), round(v["stage3_ms"], 3), round(v["model_stage1_ms"] + v["model_stage3_ms"], 3)]
                            for n, v in r.items()}
@@ -778,13 +880,18 @@ def main():
                 row += [round(r["ms_adhoc_list"], 4), round(r.get("ms_batch_pipelined2", 0.0), 4)]
             if "sharded_w1" in r:
                 row += [round(r["sharded_w1"]["vs_or_many"], 3)]
+            if "us_per_op" in r:
+                row += [round(r["us_per_op"], 3), None if "cpu1_us_per_op" not in r else round(r["cpu1_us_per_op"], 3)]
             summ[k] = row
         out["config"]["secondary_summary"] = {
             "rows": summ,
             "columns": "ms per batch (median, whole call: planning + kernels + wait) | fraction of the 8 TB/s HBM peak | checksum / "
                        "cardinality equal to the reference's | realdata only: ms with the pair list handed over per call instead of "
                        "prepared once, ms per call with two calls in flight | c4: sharded pipeline at world 1 / or_many | "
-                       "c4_shard_stages: N -> [stage 1 ms, stage 3 ms, DESIGN 7a model ms] for one rank of N on this GPU",
+                       "c4_shard_stages: N -> [stage 1 ms, stage 3 ms, DESIGN 7a model ms] for one rank of N on this GPU | "
+                       "*_successive_*: the n - 1 adjacent pairs as one batch + cardinalities read back (the reference benchmark's "
+                       "successive_and / _or loop), then us per op here, us per op of CRoaring on one core | dropin_percall_us: op -> "
+                       "[us per call through the CRoaring-named per-call drop-in, us per call of CRoaring]",
             "note": "realdata: ALL unordered pairs in one batched call per op over a prepared pair list; pairs partitioned over ranks"}
     # cpu_baseline: rank 0's host cores, whatever the world size (the other ranks wait at the barrier below)
     if rank == 0 and not args.no_cpu:
@@ -796,7 +903,8 @@ def main():
             import subprocess
             try:
                 p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-seconds", str(args.cpu_seconds),
-                                    "--containers", str(args.containers)], capture_output=True, text=True, timeout=180,
+                                    "--containers", str(args.containers), "--pool", str(args.pool), "--pairs", str(args.pairs)],
+                                   capture_output=True, text=True, timeout=180,
                                    env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")})
                 cb = json.loads(p.stdout.strip().split("\n")[-1])
             except Exception as e:
