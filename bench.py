@@ -129,9 +129,10 @@ _CPU = {}
 def _cpu_worker(a):
     tid, T, secs = a
     chk, hs, lhs, rhs = _CPU["chk"], _CPU["hs"], _CPU["lhs"], _CPU["rhs"]
-    done, k = 0, tid
+    done, k, n = 0, tid, len(lhs)
     end = time.perf_counter() + secs
     while time.perf_counter() < end:
+        k %= n  # (small containers: a worker outruns the 2^20-pair schedule within its window)
         for op in ("and", "or"):
             r = chk.op(op, hs[lhs[k]], hs[rhs[k]])  # materialise
             chk.cardinality(r)                        # consume, as benchmarks/benchmark.cpp:2048-2057 does
@@ -152,7 +153,7 @@ def _one_core(chk, hs, lhs, rhs, min_reps=10, min_s=0.2):
             chk.cardinality(r)
             chk.free(r)
         ts.append((time.perf_counter() - t0) / 2)
-        k += 1
+        k = (k + 1) % len(lhs)
     return float(np.min(ts)), float(np.median(ts))
 
 
@@ -906,10 +907,13 @@ def main():
                                     "--containers", str(args.containers), "--pool", str(args.pool), "--pairs", str(args.pairs)],
                                    capture_output=True, text=True, timeout=180,
                                    env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")})
-                cb = json.loads(p.stdout.strip().split("\n")[-1])
+                js = [l for l in p.stdout.split("\n") if l.startswith("{")]
+                if p.returncode != 0 or not js:
+                    raise RuntimeError(f"--cpu-baseline-only exited {p.returncode}: {p.stderr[-400:]!r}")
+                cb = json.loads(js[-1])
             except Exception as e:
                 cb = None
-                out["cpu_baseline"] = {"error": str(e)[:160]}
+                out["cpu_baseline"] = {"error": str(e)[:600]}
     if rank == 0 and not args.no_cpu and cb is not None:
         detail["cpu_baseline_full"] = cb
         out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "host_threads")}
