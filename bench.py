@@ -760,9 +760,17 @@ def main():
         lhs, rhs = schedule(0, args.pairs, args.pool)
         (results["and"], results["or"]), arena_probe = eng.pairwise_placed("or", pool, lhs, pool, rhs, tries=args.arena_tries,
                                                                            keep=2, timing_after=True)
+    fresh_ms = {}
     if results["and"] is None:
-        # untimed start-up, whatever --warmup says: the first step allocates (and the library places) the two result pools
-        # that every later step recycles -- allocation is not part of a step
+        # untimed start-up, whatever --warmup says: the two result pools that every later step recycles are allocated here --
+        # one SYNCHRONOUS call each (the library places a new arena only when no batch of the context is in flight).
+        # Allocation is not part of a step; what a caller WITHOUT `reuse` pays for it is reported: c2_fresh_result_pool_ms.
+        lhs, rhs = schedule(0, args.pairs, args.pool)
+        for op in ("and", "or"):
+            t_ = time.perf_counter()
+            results[op] = eng.pairwise(op, pool, lhs, pool, rhs)
+            fresh_ms[op] = (time.perf_counter() - t_) * 1e3
+            placement[op] = eng.last_placement()
         step(0, False)
     for i in range(args.warmup):
         step(i, False)
@@ -815,6 +823,9 @@ def main():
                    "timed_region_s": dt,
                    "algorithmic_GBps": total_ops * args.containers * BB_BYTES_PER_PAIR / dt / 1e9,
                    "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective",
+                   "c2_fresh_result_pool_ms": {"note": "one 250-pair call that has to allocate (and, >= 2 GiB, place) its result pool: what a "
+                                                       "caller that does not pass `reuse` pays per call; a steady-state call is ms_per_step / "
+                                                       f"{2 * args.rounds}", **{k: round(v, 2) for k, v in fresh_ms.items()}},
                    "result_arena_placement": {"by": "library (rhip place_arena, untimed warm-up)" if args.arena_tries == 0 else "caller (Engine.pairwise_placed)",
                                               "probe_GBps_of_each_candidate": placement if args.arena_tries == 0 else None,
                                               "k_bb_ms_of_each_try": arena_probe or None,

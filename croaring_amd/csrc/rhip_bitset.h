@@ -43,6 +43,39 @@ __device__ __forceinline__ void bb_body(uint32_t* __restrict__ lds, uint32_t bid
     const uint32_t lane = lane_id();
     const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
+    if (cardmode) {
+        // Cardinality only (bitset_container_and_justcard, bitset.c:421-430, under roaring_bitmap_and_cardinality,
+        // roaring.c:3048-3076): nothing is written but the pair's sum.  The queue is in pair order -- the 4 096
+        // container pairs of one bitmap pair are neighbours -- so a wave takes a CONTIGUOUS stretch of it and adds in a
+        // register, with one atomic per pair it meets instead of one per container pair (4 096 same-address 64-bit
+        // atomics per bitmap pair, 250 hot addresses per launch: the read-only form was slower per byte than `and`
+        // with its 8 GiB of stores).
+        const uint32_t w = wave_uniform((bid * blockDim.x + threadIdx.x) >> 6);
+        const uint32_t per = (n + nwaves - 1u) / nwaves;
+        const uint32_t i0 = w * per < n ? w * per : n, i1 = i0 + per < n ? i0 + per : n;
+        u64 acc = 0;
+        for (uint32_t i = i0; i < i1; ++i) {
+            const BBItem t = q[i];
+            const int op = item_op(OP, t.slot);
+            const u32x4* __restrict__ pa = (const u32x4*)(arenaA + t.offa);
+            const u32x4* __restrict__ pb = (const u32x4*)(arenaB + t.offb);
+            u32x4 va[8], vb[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) va[k] = __builtin_nontemporal_load(pa + k * 64 + lane);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) vb[k] = __builtin_nontemporal_load(pb + k * 64 + lane);
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cnt += vpopc(vop_any<OP>(op, va[k], vb[k]));
+            acc += cnt;  // per-lane partial sums: ONE wave reduction per pair, when its last item of this stretch is in
+            if (i + 1 == i1 || q[i + 1].out != t.out) {  // (wave-uniform: the items are)
+                const u64 s = wave_sum64(acc);
+                if (s && lane == 0) atomicAdd(&pair_acc[t.out], s);
+                acc = 0;
+            }
+        }
+        return;
+    }
     for (uint32_t w = wave_uniform((bid * blockDim.x + threadIdx.x) >> 6); w < n; w += nwaves) {
         const BBItem t = q[w];
         const int op = item_op(OP, t.slot);            // (OP_ITEM: the item's own op, wave-uniform)
@@ -65,16 +98,12 @@ __device__ __forceinline__ void bb_body(uint32_t* __restrict__ lds, uint32_t bid
         // OR; for and / xor / andnot unless the operands are too sparse for a result above 4096 values) the eight
         // stores are issued BEFORE the cardinality reduction resolves, so they overlap it.  If the result then turns
         // out to be an array (card <= 4096) the retry pass rewrites the slot; a smaller slot can never need a bitset.
-        if (!cardmode && (is_or || slot >= 8192u)) {
+        if (is_or || slot >= 8192u) {
             u32x4* __restrict__ po = (u32x4*)(O.arena + t.offo);
 #pragma unroll
             for (int i = 0; i < 8; ++i) __builtin_nontemporal_store(va[i], po + i * 64 + lane);
         }
         const uint32_t card = wave_sum(cnt);
-        if (cardmode) {
-            if (lane == 0 && card) atomicAdd(&pair_acc[t.out], (u64)card);
-            continue;
-        }
         // result typing: OR is always a bitset (containers.h:1015-1020); and/xor/andnot are a
         // bitset iff card > 4096 (mixed_intersection.c:305-325, mixed_xor.c:260-273,
         // mixed_andnot.c:482-497)

@@ -147,6 +147,7 @@ struct rhip_ctx_s {
     bool stage_kernel = true;  // small descriptions are pulled by k_stage_in (RHIP_STAGE_KERNEL=0: always a copy command)
     size_t h_stage_cap[N_SLOTS + 1] = {};
     bool slot_busy[N_SLOTS] = {};
+    bool slot_flagjoin[N_SLOTS] = {};  // the slot's batch joins its auxiliary streams by flags (k_join_wait)
     bool bb_timed[N_SLOTS + 1] = {};  // the slot's k_bb events were recorded by its current call (not in a merged launch)
     // device scratch of a pairwise batch (planning arrays, candidate directory, class queues, scan / tail words): one
     // set per slot, so that the planning kernels of a batch can run while the class kernels of the previous one do
@@ -195,6 +196,7 @@ struct rhip_ctx_s {
     // caller does nothing; a recycled result pool (`reuse`) keeps its placement.  RHIP_ARENA_TRIES (0 / 1: off),
     // RHIP_ARENA_PLACE_MIN_MB.  The search goes on for up to arena_tries more candidates while the best so far is below
     // arena_fair_gbps.
+    int arena_hold = 4;  // RHIP_ARENA_HOLD: candidates alive at once during a placement (the best so far + the latest losers)
     int arena_tries = 10;
     uint64_t arena_place_min = 2ull << 30;
     double arena_good_gbps = 6250.0;
@@ -213,6 +215,9 @@ struct rhip_ctx_s {
     // kernels of different streams really run side by side: rhip_ctx_create tests that (k_conc_probe) and falls back to
     // events where they do not (a tool that serialises kernels: rocprofv3 --pmc).  RHIP_SPIN_JOIN=0: always events.
     bool spin_join = true;
+    uint64_t join_spins = 60000;  // RHIP_JOIN_SPINS: the gate's bound, x ~3.4 us (0.2 s)
+    int join_force_fail = 0;      // RHIP_JOIN_FAIL=1 (tests): every gate reports a time-out
+    uint64_t join_recovered = 0;  // batches finished through the fallback (rhip_debug_join_recovered)
     u64* join_timeout_word() const { return (u64*)((char*)h_pinned + PINNED_JOIN_TIMEOUT_OFF); }
     bool copy_wide = true;       // RHIP_COPY_WIDE=0: k_copy always takes four items per wave
     int many_pf = 2;  // RHIP_MANY_PF: payload groups per lane k_many_l1 loads ahead (2 / 4 / 8; round 5: 2 beats 4 by 4 % on C4 -- the memory system queues, more requests in flight only wait longer)
@@ -404,6 +409,7 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_ARENA_ROUND_MB")) c->arena_round = (size_t)strtoull(e, nullptr, 0) << 20;
         if (const char* e = getenv("RHIP_ARENA_POW2")) c->arena_pow2 = !(e[0] == '0');
         if (const char* e = getenv("RHIP_ARENA_TRIES")) c->arena_tries = atoi(e);
+        if (const char* e = getenv("RHIP_ARENA_HOLD")) c->arena_hold = std::max(2, atoi(e));
         if (const char* e = getenv("RHIP_ARENA_PLACE_MIN_MB")) c->arena_place_min = (uint64_t)strtoull(e, nullptr, 0) << 20;
         if (const char* e = getenv("RHIP_ARENA_SKEW")) c->arena_skew = (size_t)strtoull(e, nullptr, 0) & ~(size_t)255;
         if (const char* e = getenv("RHIP_GROUP_X")) c->group_x = atoi(e);
@@ -411,6 +417,8 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_COPY_WIDE")) c->copy_wide = !(e[0] == '0');
         bool spin_join_forced = false;  // RHIP_SPIN_JOIN=2: on without the self-test (the emulator runs kernels one by one)
         if (const char* e = getenv("RHIP_SPIN_JOIN")) { c->spin_join = !(e[0] == '0'); spin_join_forced = e[0] == '2'; }
+        if (const char* e = getenv("RHIP_JOIN_SPINS")) c->join_spins = (uint64_t)std::max(0ll, atoll(e));
+        if (const char* e = getenv("RHIP_JOIN_FAIL")) c->join_force_fail = atoi(e);
         if (const char* e = getenv("RHIP_MANY_CH")) c->many_ch = std::max(1, std::min(1 << 20, atoi(e)));
         if (const char* e = getenv("RHIP_MANY_SLOTS")) c->many_slots = (uint64_t)std::max(1, atoi(e));
         if (const char* e = getenv("RHIP_MANY_T")) c->many_t = (uint64_t)std::max(1024, atoi(e));
@@ -1747,6 +1755,18 @@ void finish_stats(rhip_ctx_t* c, const Stats* dstats, Stats* out, bool had_bb, u
 }
 }  // namespace
 
+// what it takes to run a batch's k_tail once more (a flag join that gave up: rhip_pairwise_end)
+struct TailRedo {
+    bool armed = false;     // the batch joined its auxiliary streams by flags
+    CandOut CO{nullptr, nullptr, nullptr};
+    const u64* meta = nullptr;
+    DirOut D{};
+    uint32_t n_virt = 0;
+    LbState lb{nullptr, nullptr};
+    u64* part = nullptr;
+    unsigned blocks = 0;
+    size_t status_words = 0;  // look-back states + per-tile parts (contiguous from lb.status)
+};
 struct rhip_batch_s {
     rhip_ctx_t* c;
     rhip_pool_t* R;
@@ -1757,6 +1777,7 @@ struct rhip_batch_s {
     const u64* ranges;  // the batch's section ranges (device)
     bool grouped;       // its filter / union items are in the X-grouped queue
     rhip_pairlist_t* L; // the prepared pair list the batch reads (its device copy), or NULL
+    TailRedo redo;
 };
 
 // Measured placement of a large result arena (rhip_ctx_s::arena_tries).  The physical address of device memory is not
@@ -1767,7 +1788,11 @@ struct rhip_batch_s {
 // the lockstep read and write streams of the kernel meet in one channel.  So the candidates are MEASURED: each is
 // allocated, probed with the kernel's own access pattern against the operand pool it will be written beside, and the
 // fastest is kept; the others are released.  Only when `arena` needs a new allocation of >= arena_place_min bytes, the
-// operand arena holds >= 64 MiB and no batch is in flight; a few milliseconds, once per result pool.
+// operand arena holds >= 64 MiB and no batch of the context is in flight (the probes wait for the device: this is the one
+// place where rhip_pairwise_begin blocks, tens of milliseconds, once per NEW result pool -- a recycled pool keeps its
+// placement).  Transient footprint: at most arena_hold (4) candidates of `need` bytes alive at once besides the one being
+// allocated, and never more than half of the memory that was free when the search began (include/roaring_hip.h says so
+// to callers; RHIP_ARENA_TRIES=0 switches the search off).
 static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool_t* A) {
     const u64 a_items = A->arena.cap / 8192ull;
     const u64 n_slots = need / 8192ull;
@@ -1777,8 +1802,12 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
     struct Cand { DBuf buf; float gbps = 0; };
     struct Cands : std::vector<Cand> {  // (a HIP error in the middle of the search must not leak the candidates it leaves behind)
         int keep = -1;
+        size_t live() const { size_t n = 0; for (const Cand& x : *this) n += x.buf.base ? 1 : 0; return n; }
         ~Cands() { for (int k = 0; k < (int)size(); ++k) if (k != keep) (*this)[k].buf.release(); }
     } cands;
+    size_t free_at_start = 0, tot_mem = 0;
+    if (hipMemGetInfo(&free_at_start, &tot_mem) != hipSuccess) { (void)hipGetLastError(); free_at_start = 0; }
+    if (free_at_start < 2 * need) return;  // (no room to choose: the caller's ordinary allocation follows)
     c->last_placement.clear();
     hipEvent_t e0 = c->ev[0], e1 = c->ev[1];
     int best = -1;
@@ -1790,6 +1819,17 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
         if (best >= 0) {  // never run the device out of memory for one more candidate
             size_t fr = 0, tot = 0;
             if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < need + need / 4 + (1ull << 30)) { (void)hipGetLastError(); break; }
+            // ... and never hold more than arena_hold candidates (the best + the latest losers) at once: the transient
+            // footprint of one call is bounded by (arena_hold + 1) x need whatever arena_tries is, and by half of what
+            // was free when the search began (other contexts / ranks sharing the device allocate too)
+            while ((int)cands.live() >= c->arena_hold || (cands.live() + 1) * need > free_at_start / 2) {
+                int worst = -1;
+                for (int k = 0; k < (int)cands.size(); ++k)
+                    if (k != best && cands[k].buf.base && (worst < 0 || cands[k].gbps < cands[worst].gbps)) worst = k;
+                if (worst < 0) break;
+                cands[worst].buf.release();
+            }
+            if ((cands.live() + 1) * need > free_at_start / 2 && cands.live() >= 1) break;
         }
         Cand cd;
         cd.buf.skew = arena.skew;
@@ -1893,7 +1933,8 @@ static rhip_batch_t* pairwise_begin_ops(rhip_ctx_t* c, size_t n_ops, const rhip_
         // (a batch of this size plans on the main stream, so the probes below are ordered behind everything enqueued so far
         // -- the batches in flight included -- and run alone)
         if (c->arena_tries > 1 && P.arena_bound + 64 > R->arena.cap && P.arena_bound + 64 >= c->arena_place_min &&
-            A->arena.cap >= std::min<uint64_t>(64ull << 20, std::max<uint64_t>(c->arena_place_min, 8192)) && P.plan_stream == s)
+            A->arena.cap >= std::min<uint64_t>(64ull << 20, std::max<uint64_t>(c->arena_place_min, 8192)) && P.plan_stream == s &&
+            c->in_flight() == 0)
             place_arena(c, R->arena, P.arena_bound + 64, A);
         R->arena.ensure(P.arena_bound + 64);
         OutView O{};
@@ -1903,7 +1944,8 @@ static rhip_batch_t* pairwise_begin_ops(rhip_ctx_t* c, size_t n_ops, const rhip_
         const unsigned tail_blocks = (unsigned)std::max<uint64_t>(1, (P.ub_cand + TAIL_TILE - 1) / TAIL_TILE);
         uint32_t join_mask = 0;
         run_kernels(c, ops, VA, VB, O, P, 0, c->spin_join ? &join_mask : nullptr);
-        if (join_mask) hipLaunchKernelGGL(k_join_wait, dim3(1), dim3(64), 0, s, (const u64*)P.join_flags(), join_mask, c->join_timeout_word());
+        if (join_mask) hipLaunchKernelGGL(k_join_wait, dim3(1), dim3(64), 0, s, (const u64*)P.join_flags(), join_mask, c->join_timeout_word(),
+                                          (u64)c->join_spins, c->join_force_fail);
         // drop empty results, build the result directory, totals
         DirOut D{R->bm_start.as<u64>(), R->key.as<u64>(), R->type.as<uint8_t>(), R->card.as<uint32_t>(),
                  R->nruns.as<uint32_t>(), R->off.as<u64>()};
@@ -1914,8 +1956,15 @@ static rhip_batch_t* pairwise_begin_ops(rhip_ctx_t* c, size_t n_ops, const rhip_
         if (c->timing) HIPCHK(hipEventRecord(c->evs[slot][1], s));
         HIPCHK(hipGetLastError());  // a refused launch anywhere above must not pass silently
         clk.lap(3);
-        rhip_batch_t* b = new rhip_batch_s{c, R, A, B, seq, slot, P.may_bb, P.ranges(), P.grouped, L};
+        rhip_batch_t* b = new rhip_batch_s{c, R, A, B, seq, slot, P.may_bb, P.ranges(), P.grouped, L, TailRedo{}};
+        if (join_mask) {
+            TailRedo& T = b->redo;
+            T.armed = true; T.CO = CO; T.meta = O.meta; T.D = D; T.n_virt = (uint32_t)(npairs * n_ops);
+            T.lb = P.tail_lb(); T.part = P.tail_part(); T.blocks = tail_blocks;
+            T.status_words = 3 * P.sc.n_tail_tiles;
+        }
         c->slot_busy[slot] = true;
+        c->slot_flagjoin[slot] = join_mask != 0;
         R->pending = true;
         ++A->in_use;
         ++B->in_use;
@@ -1965,13 +2014,34 @@ extern "C" rhip_pool_t* rhip_pairwise_end(rhip_batch_t* b) {
         HostClock clk(c);
         Stats st;
         finish_stats(c, nullptr, &st, b->may_bb, b->seq, slot);
-        if (__atomic_load_n(c->join_timeout_word(), __ATOMIC_ACQUIRE)) {  // k_join_wait gave up (rhip_plan.h)
-            __atomic_store_n(c->join_timeout_word(), 0ull, __ATOMIC_RELEASE);
+        if (b->redo.armed && __atomic_load_n(c->join_timeout_word(), __ATOMIC_ACQUIRE)) {
+            // A gate of this context gave up (rhip_plan.h: kernels of different streams did not run side by side -- a
+            // tool that serialises them, a busy device): this batch's tail may have run before its class kernels had
+            // finished.  Nothing is lost: the class kernels' outputs are complete once their streams are idle, and the
+            // tail only reads them.  Wait the ordinary way, clear the tail's scratch, run it again.  The word is per
+            // context, so every flag-joined batch that ends while it is set takes this path (its tail may be the early
+            // one); it is cleared when no flag-joined batch is left in flight.  Later batches join with events.
             c->spin_join = false;
-            set_err("the class kernels of a forked batch did not finish within 10 s of its image kernel: kernels of different "
-                    "streams are not running side by side (a tool that serialises them?); later batches of this context join with events");
-            throw (int)RHIP_ERR_DEVICE;
+            for (int a = 0; a < rhip_ctx_s::N_AUX; ++a) HIPCHK(hipStreamSynchronize(c->aux[a]));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            const TailRedo& T = b->redo;
+            HIPCHK(hipMemsetAsync(T.lb.status, 0, 8 * T.status_words, c->stream));
+            HIPCHK(hipMemsetAsync(T.lb.ticket, 0, 8, c->stream));
+            const uint64_t seq2 = ++c->seq;
+            hipLaunchKernelGGL(k_tail, dim3(T.blocks), dim3(256), 0, c->stream, b->ranges, T.CO, T.meta, T.D, T.n_virt, T.lb, T.part,
+                               (Stats*)c->slot_stats(slot), (u64*)c->done_flag(slot), (u64)seq2);
+            HIPCHK(hipGetLastError());
+            wait_word(c, c->done_flag(slot), seq2);
+            memcpy(&st, c->slot_stats(slot), sizeof(Stats));
+            c->stats.matched_pairs = st.matched_pairs; c->stats.passthrough = st.passthrough;
+            c->stats.bytes_in = st.bytes_in; c->stats.bytes_out = st.bytes_out;
+            c->stats.n_bitset_pairs = st.n_bb; c->stats.result_containers = st.result_containers;
+            ++c->join_recovered;
+            bool more = false;  // another flag-joined batch still in flight?  (their batch objects are the callers'; count slots)
+            for (int k = 0; k < rhip_ctx_s::N_SLOTS; ++k) more = more || (k != slot && c->slot_busy[k] && c->slot_flagjoin[k]);
+            if (!more) __atomic_store_n(c->join_timeout_word(), 0ull, __ATOMIC_RELEASE);
         }
+        c->slot_flagjoin[slot] = false;
         if (c->class_stats) {  // (diagnostics: the slot's queues and meta words are intact until its next batch)
             rhip_ctx_s::SlotScratch& SS = c->ss[slot];
             ClassQueues CQ{SS.q[CLS_BB].as<BBItem>(), SS.q[CLS_BBA].as<BBItem>(),
@@ -2156,6 +2226,8 @@ extern "C" void rhip_debug_set_arena_round(rhip_ctx_t* c, unsigned long long byt
 extern "C" unsigned long long rhip_debug_pool_arena(rhip_pool_t* P) { return (unsigned long long)(uintptr_t)P->arena.p; }
 // probe rates (GB/s) of the candidates of the context's last measured arena placement, in allocation order; returns
 // how many there were (0: no placement has happened)
+// batches of this context that a flag join gave up on and that were finished through the fallback (rhip_pairwise_end)
+extern "C" unsigned long long rhip_debug_join_recovered(rhip_ctx_t* c) { return c ? (unsigned long long)c->join_recovered : 0ull; }
 extern "C" int rhip_debug_last_placement(rhip_ctx_t* c, float* out, int capacity) {
     if (!c) return 0;
     const int n = (int)c->last_placement.size();

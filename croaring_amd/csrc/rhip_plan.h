@@ -634,15 +634,19 @@ constexpr uint32_t TAIL_TILE = 256 * TAIL_PER_THREAD;  // candidates per block
 __global__ void k_join_signal(u64* flag) {
     if (threadIdx.x == 0 && blockIdx.x == 0) lb_store(flag, 1ull);
 }
-// (Bounded: ~10 s of s_sleep.  A wait that never ends would be a hang with no message; one that gives up leaves a
-// mark the host turns into an error -- see rhip_pairwise_end.)
-__global__ void k_join_wait(const u64* flags, uint32_t mask, u64* timed_out) {
+// (Bounded: max_spins x ~3.4 us of s_sleep, 0.2 s by default.  HIP does not promise that kernels of different streams run
+// side by side, so the gate may give up: it then leaves a mark, the tail behind it runs too early, and
+// rhip_pairwise_end -- which sees the mark -- waits for the auxiliary streams the ordinary way and runs the tail again:
+// the batch is finished correctly either way, a time-out only costs time.  force_fail (tests) reports a time-out
+// whatever the flags say.)
+__global__ void k_join_wait(const u64* flags, uint32_t mask, u64* timed_out, u64 max_spins, int force_fail) {
     if (blockIdx.x == 0 && threadIdx.x < 8u && ((mask >> threadIdx.x) & 1u)) {
         u64 spins = 0;
         while (lb_load(&flags[threadIdx.x]) == 0ull) {
             __builtin_amdgcn_s_sleep(127);
-            if (++spins > 2500000ull) { lb_store(timed_out, 1ull); break; }
+            if (++spins > max_spins) { lb_store(timed_out, 1ull); break; }
         }
+        if (force_fail) lb_store(timed_out, 1ull);
     }
 }
 // Self-test of a context (rhip_ctx_create): do kernels of two streams run SIDE BY SIDE here?  This kernel waits (bounded:

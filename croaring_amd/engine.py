@@ -83,6 +83,10 @@ class Engine:
         self.lib.rhip_debug_host_clock(self.h, out, 1 if reset else 0)
         return list(out)
 
+    def join_recovered(self) -> int:
+        """Batches of this context whose flag join gave up and that were finished through the event fallback."""
+        return int(self.lib.rhip_debug_join_recovered(self.h))
+
     def last_placement(self) -> list:
         """Probe rates (GB/s) of the candidate result arenas of the last measured placement (rhip_debug_last_placement)."""
         out = (C.c_float * 32)()

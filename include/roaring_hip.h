@@ -166,7 +166,16 @@ rhip_pool_t *rhip_pairwise(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *A, rhip_poo
  * begin order on the context's stream.  Until a batch has ended, its operand pools cannot be updated in place or
  * recycled (as `reuse` they are refused, RHIP_ERR_ARG); rhip_pool_free of an operand is accepted and DEFERRED -- the last
  * batch that reads the pool releases it when it ends; the batch's result cannot be an operand or the `reuse` of another
- * batch (RHIP_ERR_ARG); and any other call on the context simply waits for the batches in flight.  rhip_pairwise == begin followed by end. */
+ * batch (RHIP_ERR_ARG); and any other call on the context simply waits for the batches in flight.  rhip_pairwise == begin followed by end.
+ *
+ * Placement of a NEW large result arena.  When a call has to allocate a result arena of 2 GiB or more beside an operand
+ * pool of 64 MiB or more, and no batch of the context is in flight, the library does not take the first allocation: it
+ * allocates up to RHIP_ARENA_TRIES (10) candidates, times the bitset kernel's access pattern on each against the operand
+ * pool and keeps the fastest (which physical pages an arena gets moves that kernel by up to 17 %).  This is
+ * the one place where rhip_pairwise_begin WAITS for the device -- tens of milliseconds, once per new result pool -- and
+ * it transiently holds up to RHIP_ARENA_HOLD (4) candidates beside the one being allocated, never more than half of
+ * the device memory that was free when it began.  A pool handed back through `reuse` keeps its arena and its placement:
+ * steady-state callers never meet the search.  RHIP_ARENA_TRIES=0 (environment, read by rhip_ctx_create) turns it off. */
 #define RHIP_MAX_BATCHES_IN_FLIGHT 4
 typedef struct rhip_batch_s rhip_batch_t;
 rhip_batch_t *rhip_pairwise_begin(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *A, rhip_pool_t *B, size_t npairs,
@@ -345,6 +354,11 @@ int rhip_debug_host_clock(rhip_ctx_t *ctx, double out_us[8], int reset);
  * process cannot see physical addresses).  This returns the probe rates (GB/s) of the candidates of the
  * context's last placement, in allocation order, and how many there were. */
 int rhip_debug_last_placement(rhip_ctx_t *ctx, float *out_gbps, int capacity);
+/* Batches of this context whose flag join (the one-wave gate in front of the tail kernel of a forked batch) gave up --
+ * HIP does not promise that kernels of different streams run side by side -- and that were then finished through the
+ * fallback: the auxiliary streams waited for the ordinary way, the tail run again.  Such a batch returns the same result
+ * as any other; the reference's functions cannot fail for scheduling reasons (roaring.h:102-113) and neither do these. */
+unsigned long long rhip_debug_join_recovered(rhip_ctx_t *ctx);
 
 #ifdef __cplusplus
 }

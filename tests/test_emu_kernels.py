@@ -279,6 +279,25 @@ def test_emu_pairwise_placed(emu, oracle, synth):
     G.test_pairwise_placed(emu, oracle, synth)
 
 
+def test_emu_join_fallback(oracle, synth, monkeypatch):
+    """A forked batch whose flag gate reports a time-out (RHIP_JOIN_FAIL=1) is finished through the fallback of
+    rhip_pairwise_end -- streams waited for, the tail's scratch cleared, the tail run again -- with the same bytes."""
+    from emu import build_emu, emu_engine
+    if not __import__("os").path.exists(build_emu.CXX):
+        pytest.skip("hipemu needs the ROCm clang++ to compile the kernels for the host")
+    monkeypatch.setenv("RHIP_FORK_MIN_MB", "0")
+    monkeypatch.setenv("RHIP_SPIN_JOIN", "2")
+    monkeypatch.setenv("RHIP_JOIN_FAIL", "1")
+    eng = emu_engine()
+    try:
+        G.test_synth_every_type_pair(eng, oracle, synth, "or")
+        assert eng.join_recovered() >= 1
+        G.test_edge_cases(eng, oracle)
+        G.test_batches_in_flight(eng, oracle, synth)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("mode", ["1", "2", "fork", "nomerge"])
 def test_emu_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
     """Batches whose bitmaps all have <= 256 containers plan on implicit units (unit = pair / 2 pair + side), four
