@@ -37,7 +37,8 @@ def test_join_fallback(monkeypatch, mode):
         for op, want in CHECKSUMS.items():
             res = eng.pairwise(op, pool, lhs, pool, rhs)
             assert int(res.cardinalities().sum()) == want, op
-        assert eng.join_recovered() >= 1  # the first forked batch went through the fallback (later ones join with events)
+        if mode == "fail":  # (spins0: whether a gate really gives up depends on which stream finishes first)
+            assert eng.join_recovered() >= 1  # the first forked batch went through the fallback (later ones join with events)
         # bytes, against a context that never used flags
         monkeypatch.setenv("RHIP_SPIN_JOIN", "0")
         monkeypatch.delenv("RHIP_JOIN_FAIL", raising=False)
@@ -47,6 +48,7 @@ def test_join_fallback(monkeypatch, mode):
         sub_l, sub_r = lhs[::37].copy(), rhs[::37].copy()
         monkeypatch.setenv("RHIP_SPIN_JOIN", "2")
         monkeypatch.setenv("RHIP_JOIN_SPINS", "0")
+        monkeypatch.setenv("RHIP_JOIN_FAIL", "1")
         eng2 = croaring_amd.Engine(0)
         pool2, _ = _weather(eng2)
         a = eng2.pairwise("or", pool2, lhs, pool2, rhs)  # all pairs: a forked batch, through the fallback
