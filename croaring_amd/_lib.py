@@ -96,6 +96,7 @@ SYMBOLS = [
     ("rhip_many_finalize", _vp, [_vp, _i, _i, _u64, _vp, _vp]),
     ("rhip_many_partials_dense", _i, [_vp, _i, _vp, _sz, _vp, _u64, _u32, _vp]),
     ("rhip_many_finalize_dense", _vp, [_vp, _i, _i, _u32, _u32, _u64, _vp]),
+    ("rhip_many_sharded", _i, [_vp, _vp, _i, _vp, _sz, _vp, _u64, C.POINTER(_vp)]),
     ("rhip_last_stats", _i, [_vp, C.POINTER(Stats)]),
     ("rhip_ctx_set_timing", None, [_vp, _i]),
     ("rhip_ctx_set_class_stats", None, [_vp, _i]),

@@ -171,6 +171,8 @@ struct rhip_ctx_s {
     void ensure_stage(int slot, size_t n);
     int acquire_slot();
     DBuf many[20];
+    DBuf shard[9];  // rhip_many_sharded: send / receive tables and the sparse exchange's staging, kept between calls
+    int shard_force_collective = 0;  // RHIP_SHARD_FORCE_COLLECTIVE=1: issue the all-to-all on a one-rank communicator too (tests, timing)
     // many-way path: pinned staging of the selection (ids + member prefix), the event that says the device has read
     // it, totals / completion word / sticky error word inside h_pinned
     void* h_many = nullptr;
@@ -196,7 +198,6 @@ struct rhip_ctx_s {
     // caller does nothing; a recycled result pool (`reuse`) keeps its placement.  RHIP_ARENA_TRIES (0 / 1: off),
     // RHIP_ARENA_PLACE_MIN_MB.  The search goes on for up to arena_tries more candidates while the best so far is below
     // arena_fair_gbps.
-    int arena_hold = 4;  // RHIP_ARENA_HOLD: candidates alive at once during a placement (the best so far + the latest losers)
     int arena_tries = 10;
     uint64_t arena_place_min = 2ull << 30;
     double arena_good_gbps = 6250.0;
@@ -409,7 +410,6 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_ARENA_ROUND_MB")) c->arena_round = (size_t)strtoull(e, nullptr, 0) << 20;
         if (const char* e = getenv("RHIP_ARENA_POW2")) c->arena_pow2 = !(e[0] == '0');
         if (const char* e = getenv("RHIP_ARENA_TRIES")) c->arena_tries = atoi(e);
-        if (const char* e = getenv("RHIP_ARENA_HOLD")) c->arena_hold = std::max(2, atoi(e));
         if (const char* e = getenv("RHIP_ARENA_PLACE_MIN_MB")) c->arena_place_min = (uint64_t)strtoull(e, nullptr, 0) << 20;
         if (const char* e = getenv("RHIP_ARENA_SKEW")) c->arena_skew = (size_t)strtoull(e, nullptr, 0) & ~(size_t)255;
         if (const char* e = getenv("RHIP_GROUP_X")) c->group_x = atoi(e);
@@ -417,6 +417,7 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_COPY_WIDE")) c->copy_wide = !(e[0] == '0');
         bool spin_join_forced = false;  // RHIP_SPIN_JOIN=2: on without the self-test (the emulator runs kernels one by one)
         if (const char* e = getenv("RHIP_SPIN_JOIN")) { c->spin_join = !(e[0] == '0'); spin_join_forced = e[0] == '2'; }
+        if (const char* e = getenv("RHIP_SHARD_FORCE_COLLECTIVE")) c->shard_force_collective = atoi(e);
         if (const char* e = getenv("RHIP_JOIN_SPINS")) c->join_spins = (uint64_t)std::max(0ll, atoll(e));
         if (const char* e = getenv("RHIP_JOIN_FAIL")) c->join_force_fail = atoi(e);
         if (const char* e = getenv("RHIP_MANY_CH")) c->many_ch = std::max(1, std::min(1 << 20, atoi(e)));
@@ -461,6 +462,7 @@ extern "C" void rhip_ctx_destroy(rhip_ctx_t* c) {
     for (auto& hs : c->h_stage) if (hs) (void)hipHostFree(hs);
     for (auto* b : all) b->release();
     for (auto& b : c->many) b.release();
+    for (auto& b : c->shard) b.release();
     for (auto& b : c->sel) b.release();
     for (auto& b : c->partial_cache) { (void)hipFree(b.keys); (void)hipFree(b.words); }
     for (rhip_pool_t* R : c->many_free) { R->release(); delete R; }
@@ -1790,9 +1792,9 @@ struct rhip_batch_s {
 // fastest is kept; the others are released.  Only when `arena` needs a new allocation of >= arena_place_min bytes, the
 // operand arena holds >= 64 MiB and no batch of the context is in flight (the probes wait for the device: this is the one
 // place where rhip_pairwise_begin blocks, tens of milliseconds, once per NEW result pool -- a recycled pool keeps its
-// placement).  Transient footprint: at most arena_hold (4) candidates of `need` bytes alive at once besides the one being
-// allocated, and never more than half of the memory that was free when the search began (include/roaring_hip.h says so
-// to callers; RHIP_ARENA_TRIES=0 switches the search off).
+// placement).  Transient footprint: the candidates stay alive until the choice (a released block comes straight back as
+// the next candidate, and releasing mid-search is slow), so the search stops at half of the memory that was free when
+// it began (include/roaring_hip.h says so to callers; RHIP_ARENA_TRIES=0 switches the search off).
 static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool_t* A) {
     const u64 a_items = A->arena.cap / 8192ull;
     const u64 n_slots = need / 8192ull;
@@ -1819,17 +1821,11 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
         if (best >= 0) {  // never run the device out of memory for one more candidate
             size_t fr = 0, tot = 0;
             if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < need + need / 4 + (1ull << 30)) { (void)hipGetLastError(); break; }
-            // ... and never hold more than arena_hold candidates (the best + the latest losers) at once: the transient
-            // footprint of one call is bounded by (arena_hold + 1) x need whatever arena_tries is, and by half of what
-            // was free when the search began (other contexts / ranks sharing the device allocate too)
-            while ((int)cands.live() >= c->arena_hold || (cands.live() + 1) * need > free_at_start / 2) {
-                int worst = -1;
-                for (int k = 0; k < (int)cands.size(); ++k)
-                    if (k != best && cands[k].buf.base && (worst < 0 || cands[k].gbps < cands[worst].gbps)) worst = k;
-                if (worst < 0) break;
-                cands[worst].buf.release();
-            }
-            if ((cands.live() + 1) * need > free_at_start / 2 && cands.live() >= 1) break;
+            // ... and never hold more than half of what was free when the search began (other contexts / ranks sharing the
+            // device allocate too).  The search ENDS there: releasing a loser to make room costs ~0.5 s per 16 GiB block
+            // once another allocation follows it (a C2 `or` call that had to place its arena took 1.8 s holding four
+            // candidates, 5.6 s holding two, 14 ms when nothing was released before the choice) and hands the same pages out again
+            if ((cands.size() + 1) * need > free_at_start / 2) break;
         }
         Cand cd;
         cd.buf.skew = arena.skew;
@@ -2255,6 +2251,7 @@ extern "C" int rhip_debug_phases(rhip_ctx_t* c, unsigned long long out[32], int 
 #endif
 
 #include "rhip_many_host.inc"
+#include "rhip_sharded.inc"
 #include "rhip_synth.inc"
 #include "rhip_pool_ops.inc"
 #include "roaring_compat.inc"

@@ -428,6 +428,19 @@ class Engine:
             raise RoaringHipError("many_finalize failed: " + self._err())
         return Pool(self, h)
 
+    def many_sharded_native(self, nccl_comm: int, op: str, P: "Pool", ids=None, key_space: int = 0) -> "Pool":
+        """rhip_many_sharded: the sharded or_many / xor_many with the exchange done by the library itself over the
+        caller's ncclComm_t (an address).  Returns this rank's share (keys with key % world == rank)."""
+        out = C.c_void_p()
+        if ids is None:
+            rc = self.lib.rhip_many_sharded(self.h, nccl_comm, OPS[op], P.h, 0, None, int(key_space), C.byref(out))
+        else:
+            ids = _u32(ids)
+            rc = self.lib.rhip_many_sharded(self.h, nccl_comm, OPS[op], P.h, ids.size, ids.ctypes.data, int(key_space), C.byref(out))
+        if rc != 0 or not out.value:
+            raise RoaringHipError("many_sharded failed: " + self._err())
+        return Pool(self, out.value)
+
     def many_partials_dense(self, op: str, P: "Pool", ids, key_space: int, world: int, d_table: int) -> None:
         """Stage 1, dense exchange: ENQUEUES the reduction of P[ids] into the zero-filled table at device address
         d_table (world * ceil(key_space / world) rows of 1024 words; the chunk of key k at row (k % world) * B + k //

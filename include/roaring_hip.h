@@ -173,8 +173,8 @@ rhip_pool_t *rhip_pairwise(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *A, rhip_poo
  * allocates up to RHIP_ARENA_TRIES (10) candidates, times the bitset kernel's access pattern on each against the operand
  * pool and keeps the fastest (which physical pages an arena gets moves that kernel by up to 17 %).  This is
  * the one place where rhip_pairwise_begin WAITS for the device -- tens of milliseconds, once per new result pool -- and
- * it transiently holds up to RHIP_ARENA_HOLD (4) candidates beside the one being allocated, never more than half of
- * the device memory that was free when it began.  A pool handed back through `reuse` keeps its arena and its placement:
+ * its candidates stay allocated until the choice is made: the search stops when they reach half of the device memory
+ * that was free when it began (so a crowded device gets fewer candidates, not an out-of-memory error).  A pool handed back through `reuse` keeps its arena and its placement:
  * steady-state callers never meet the search.  RHIP_ARENA_TRIES=0 (environment, read by rhip_ctx_create) turns it off. */
 #define RHIP_MAX_BATCHES_IN_FLIGHT 4
 typedef struct rhip_batch_s rhip_batch_t;
@@ -313,6 +313,27 @@ int rhip_many_partials_dense(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *pool, siz
                              uint64_t key_space, uint32_t world, uint64_t *d_table);
 rhip_pool_t *rhip_many_finalize_dense(rhip_ctx_t *ctx, rhip_op op, int is64, uint32_t world, uint32_t rank,
                                       uint64_t keys_per_rank, const uint64_t *d_table);
+
+/* The whole sharded aggregation in one call, the exchange over RCCL included -- roaring_bitmap_or_many (roaring.h:304,
+ * src/roaring.c:775-790) / Roaring64Map::fastunion (cpp/roaring/roaring64map.hh:1549-1670) over bitmaps spread across
+ * the GPUs of a node, one process (and one rhip context) per GPU.  Every rank of the communicator calls it with ITS
+ * bitmaps (`local`, or the selection ids[0..n) of it; ids == NULL: all of them), the same op and the same key_space.
+ *   nccl_comm   an ncclComm_t of the caller (rccl.h:36) whose device is the context's; world and rank are read from it.
+ *               librccl is opened with dlopen at the first call (RHIP_RCCL_LIB overrides the name): this library has
+ *               no link-time dependency on it, and every other entry point works without it.
+ *   key_space   > 0: an exclusive upper bound of the container keys on EVERY rank (e.g. 4096): the dense exchange --
+ *               stage 1 writes the [world x ceil(key_space / world)] chunk table, ONE ncclAllToAll on the context's
+ *               stream moves it, stage 3 combines the rows; one host wait, at the very end.  A larger key anywhere
+ *               fails the call (RHIP_ERR_ARG).  0: the sparse exchange, any key width (roaring64 pools): the ranks'
+ *               key lists are all-gathered, the chunks each peer is owed are packed back to back and leave in one group
+ *               of ncclSend / ncclRecv.
+ *   owned       out: this rank's share of the result, a one-bitmap pool holding the container keys with
+ *               key % world == rank (the shares are disjoint: their serialized forms concatenate by key).
+ * Everything is enqueued on the context's stream (rhip_ctx_stream); the call returns when the share is complete.
+ * RCCL has no OR / XOR reduction and a ring all-reduce of 8 KiB chunks would be bound by one xGMI link: the
+ * personalised all-to-all keeps all point-to-point links busy.  Returns RHIP_OK or an error code. */
+int rhip_many_sharded(rhip_ctx_t *ctx, void *nccl_comm, rhip_op op, rhip_pool_t *local, size_t n, const uint32_t *ids,
+                      uint64_t key_space, rhip_pool_t **owned);
 
 /* ---- measurement hooks (bench.py) --------------------------------------- */
 /* algorithmic bytes and matched container pairs of the last

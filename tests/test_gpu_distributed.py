@@ -169,3 +169,62 @@ def test_many_sharded_nccl_world1_dense(engine, oracle):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def _rccl():
+    """librccl through ctypes: the test owns the communicator, as a C / Go caller of rhip_many_sharded would."""
+    import ctypes as C
+    import torch  # noqa  (its bundled librccl is then already in the process; dlopen by name finds it)
+    for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
+        try:
+            return C.CDLL(name, mode=C.RTLD_GLOBAL)
+        except OSError:
+            continue
+    pytest.skip("no librccl on this box")
+
+
+@pytest.mark.parametrize("key_space", [4096, 0])
+def test_many_sharded_c_abi_world1(engine, oracle, key_space):
+    """rhip_many_sharded (the C entry point: stage 1 -> RCCL exchange -> stage 3 inside the library) on a one-rank
+    communicator -- the only size one GPU allows: dense (with the all-to-all really issued) and sparse (all-gathers,
+    packing, grouped send / recv degenerate to the local copy), bytes equal to rhip_or_many / the oracle's or_many."""
+    import ctypes as C
+    import croaring_amd
+    from gen_inputs import random_bitmap
+    L = _rccl()
+
+    class UID(C.Structure):
+        _fields_ = [("b", C.c_char * 128)]
+    uid = UID()
+    L.ncclGetUniqueId.argtypes = [C.POINTER(UID)]
+    assert L.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UID, C.c_int]
+    assert L.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        rng = np.random.default_rng(11)
+        vals = [random_bitmap(rng) for _ in range(40)]
+        vals = [v[v < (4096 << 16)] for v in vals]  # keys below the dense key space
+        hs = [oracle.from_sorted(v) for v in vals]
+        bufs = [oracle.serialize(h) for h in hs]
+        import os
+        os.environ["RHIP_SHARD_FORCE_COLLECTIVE"] = "1"
+        eng = croaring_amd.Engine(0)
+        os.environ.pop("RHIP_SHARD_FORCE_COLLECTIVE")
+        try:
+            pool = eng.pool_from_serialized(bufs)
+            for op, fn in (("or", oracle.or_many), ("xor", oracle.xor_many)):
+                want = fn(hs)
+                got = eng.many_sharded_native(comm.value, op, pool, None, key_space)
+                hv = oracle.deserialize(got.serialize(0))
+                assert oracle.validate(hv)
+                assert np.array_equal(oracle.to_array(hv), oracle.to_array(want)), (op, key_space)
+                sub = [3, 17, 5, 5, 29]
+                ws = fn([hs[i] for i in sub])
+                gs = eng.many_sharded_native(comm.value, op, pool, sub, key_space)
+                assert np.array_equal(oracle.to_array(oracle.deserialize(gs.serialize(0))), oracle.to_array(ws))
+        finally:
+            eng.close()
+    finally:
+        L.ncclCommDestroy.argtypes = [C.c_void_p]
+        L.ncclCommDestroy(comm)
