@@ -174,3 +174,24 @@ def test_c2_full_size_sampled_bytes(engine, ref):
         del res
     for h in hs.values():
         ref.free(h)
+
+
+def test_c2_full_size_all_cardinalities(engine, ref):
+    """SURVEY 8d for C2: 'the oracle checks a sampled subset bit-for-bit and ALL ops by cardinality'.  The 250 pairs of
+    the bench schedule over the full 8 GiB pool, every op: the cardinality of every result bitmap (the materialising
+    call) and of the cardinality-only call equals CRoaring's roaring_bitmap_{and,or,xor,andnot}_cardinality on the same
+    serialized operands (all 256 bitmaps go through the reference: 8 GiB of host memory)."""
+    from bench import SEED, schedule
+    pool = engine.pool_synth_bitset(256, 4096, SEED)
+    lhs, rhs = schedule(0, 250, 256)
+    hs = [ref.deserialize(pool.serialize(b)) for b in range(256)]
+    try:
+        for op in OPS:
+            want = np.array([ref.op_cardinality(op, hs[int(a)], hs[int(b)]) for a, b in zip(lhs, rhs)], dtype=np.uint64)
+            res = engine.pairwise(op, pool, lhs, pool, rhs)
+            assert np.array_equal(res.cardinalities().astype(np.uint64), want), op
+            del res
+            assert np.array_equal(engine.pairwise_cardinality(op, pool, lhs, pool, rhs).astype(np.uint64), want), op + "_cardinality"
+    finally:
+        for h in hs:
+            ref.free(h)
