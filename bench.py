@@ -299,8 +299,18 @@ def cpu_pairs_rate(chk, hs, lhs, rhs, op, budget=0.4, is64=False):
     return n / (time.perf_counter() - t0)
 
 
+def _stored_traffic():
+    """profiles/realdata_traffic.json: HBM bytes per all-pairs batch and issue shares of its kernels, from rocprofv3 PMC
+    passes recorded earlier (scripts/gpu_final_r5.sh + scripts/summarize_realdata_traffic.py) -- NOT re-measured in this run."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "realdata_traffic.json")))
+    except Exception:
+        return {}
+
+
 def run_realdata(eng, D: Dist, name: str, tag: str, chk, is64=False, ops=("and", "or", "xor", "andnot")):
     from util import all_pairs, c5_inputs, load_bundle
+    traffic = _stored_traffic() if D.world == 1 else {}
     if is64:
         bufs = c5_inputs()
         pool = eng.pool_from_serialized64(bufs)
@@ -337,6 +347,19 @@ def run_realdata(eng, D: Dist, name: str, tag: str, chk, is64=False, ops=("and",
                "ms_batch_median": tmed * 1e3, "ms_batch_min": tmin * 1e3, "ms_adhoc_list": amed * 1e3, "alg_GBps": alg / tmed / 1e9,
                "frac": alg / tmed / 1e9 / HBM_PEAK_GBS, "checksum": int(csum), "checksum_ok": want is None or int(csum) == want,
                "matched_pairs_rank0": int(st["matched_pairs"]), "passthrough_rank0": int(st["passthrough"])}
+        # `frac` is ALGORITHMIC bytes over time -- on a 7.6 MB data set the operands live in the L2s, so it is
+        # not HBM utilisation.  The stored PMC pass says what really crossed the memory side per batch and what the batch's
+        # kernels spent their wave cycles on: that names the bound of the row.
+        tr = traffic.get(f"{tag}_{op}")
+        if tr:
+            hb = tr["hbm_read_bytes"] + tr["hbm_write_bytes"]
+            row["hbm_traffic_frac"] = hb / tmed / 1e9 / HBM_PEAK_GBS
+            row["hbm_traffic_over_algorithmic"] = hb / max(1.0, alg)
+            row["valu_share_of_wave_cycles"] = tr.get("valu_share_of_wave_cycles")
+            row["lds_bank_conflict_share"] = tr.get("lds_bank_conflict_share")
+            row["bound"] = "hbm" if row["hbm_traffic_frac"] >= 0.5 * row["frac"] and row["hbm_traffic_frac"] >= 0.3 else \
+                "issue + lds + latency (operands cache-resident; results stream to HBM)"
+            row["traffic_source"] = tr.get("source", "profiles/realdata_traffic.json") + " (recorded earlier, not re-measured in this run)"
         # the same batch with TWO calls in flight (rhip_pairwise_begin / _end): the host half of call i+1 overlaps
         # the kernels of call i; per-call period over 40 calls, result of the last one checked
         n_pipe, n_warm = max(4, 2 * D.reps), 8
@@ -889,7 +912,8 @@ def main():
             ok = r.get("checksum_ok", r.get("cardinality_ok"))
             row = [None if ms is None else round(ms, 4), None if r.get("frac") is None else round(r["frac"], 4), ok]
             if "ms_adhoc_list" in r:
-                row += [round(r["ms_adhoc_list"], 4), round(r.get("ms_batch_pipelined2", 0.0), 4)]
+                row += [round(r["ms_adhoc_list"], 4), round(r.get("ms_batch_pipelined2", 0.0), 4),
+                        None if "hbm_traffic_frac" not in r else round(r["hbm_traffic_frac"], 3)]
             if "sharded_w1" in r:
                 row += [round(r["sharded_w1"]["vs_or_many"], 3)]
             if "us_per_op" in r:
@@ -899,7 +923,8 @@ def main():
             "rows": summ,
             "columns": "ms per batch (median, whole call: planning + kernels + wait) | fraction of the 8 TB/s HBM peak | checksum / "
                        "cardinality equal to the reference's | realdata only: ms with the pair list handed over per call instead of "
-                       "prepared once, ms per call with two calls in flight | c4: sharded pipeline at world 1 / or_many | "
+                       "prepared once, ms per call with two calls in flight, HBM TRAFFIC (stored PMC pass) / time / 8 TB/s -- the "
+                       "second column counts algorithmic bytes, which on these cache-resident sets is not HBM utilisation | c4: sharded pipeline at world 1 / or_many | "
                        "c4_shard_stages: N -> [stage 1 ms, stage 3 ms, DESIGN 7a model ms] for one rank of N on this GPU | "
                        "*_successive_*: the n - 1 adjacent pairs as one batch + cardinalities read back (the reference benchmark's "
                        "successive_and / _or loop), then us per op here, us per op of CRoaring on one core | dropin_percall_us: op -> "
