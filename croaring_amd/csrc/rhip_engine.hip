@@ -291,7 +291,9 @@ struct rhip_pool_s {
     uint64_t arena_used = 0;
     bool pending = false;       // result of a batch that has begun and not ended: not usable yet
     int in_use = 0;             // batches in flight that read this pool as an operand: not recyclable yet
-    bool free_deferred = false; // rhip_pool_free arrived while in_use: the last batch to end frees it
+    bool free_deferred = false; // rhip_pool_free arrived while in_use / pinned: the last batch to end (or list to go) frees it
+    int list_pins = 0;          // prepared pair lists that hold this pool as an operand (rhip_pairlist_*): a freed pool must
+                                // not be dereferenced by the next rhip_pairwise_list call
     bool from_many = false;     // result of the many-way path: rhip_pool_free hands its buffers back to the context
     uint64_t ctx_gen = 0;       // ... the context it was made by, by GENERATION: an address can be reused by a later context
     uint64_t compact_mark = 0;  // arena_used right after the last compaction (0: never updated in place), see rhip_pairwise_inplace
@@ -347,7 +349,10 @@ struct rhip_pairlist_s {
     uint64_t genA = 0, genB = 0;     // the pools' bounds_gen the sums were taken from (0: never)
     int in_use = 0;                  // batches in flight that read d_idx
     bool free_deferred = false;
+    bool pinned = false;             // A / B carry this list's pin (list_pins)
 };
+
+static void pairlist_destroy(rhip_pairlist_t* L);
 
 static void ensure_dir(rhip_pool_t* P, uint32_t n_bitmaps, uint64_t n_cont) {
     P->bm_start.ensure(8 * ((size_t)n_bitmaps + 1));
@@ -762,7 +767,7 @@ extern "C" rhip_pool_t* rhip_pool_from_portable64(rhip_ctx_t* ctx, size_t n, con
 
 extern "C" void rhip_pool_free(rhip_pool_t* P) {
     if (!P) return;
-    if (P->in_use > 0) {  // an operand of batches in flight: released by the last of them (rhip_pairwise_end)
+    if (P->in_use > 0 || P->list_pins > 0) {  // an operand of batches in flight / of prepared pair lists: released by the last of them
         P->free_deferred = true;
         return;
     }
@@ -848,6 +853,7 @@ extern "C" rhip_pool_t* rhip_pool_synth_bitset(rhip_ctx_t* ctx, uint32_t n_bitma
             const uint64_t pay = P->n_cont * 8192ull;
             P->arena.pow2_large = ctx->arena_pow2;
             P->arena.ensure((ctx->arena_pow2 && pay >= (1ull << 30) && (pay & (pay - 1)) == 0) ? pay : P->arena_used);
+            if (P->arena_used > P->arena.cap) P->arena_used = P->arena.cap;  // (the exact allocation: nothing may copy arena_used bytes past it)
         }
         hipLaunchKernelGGL(k_synth_fill, dim3(256 * 16), dim3(256), 0, ctx->stream, P->arena.as<u64>(), n_bitmaps,
                            n_containers, (u64)seed);
@@ -2000,10 +2006,10 @@ extern "C" rhip_pool_t* rhip_pairwise_end(rhip_batch_t* b) {
     rhip_pairlist_t* bl = b->L;
     if (bl) --bl->in_use;
     auto drop_deferred = [](rhip_pool_t* X) {
-        if (X->free_deferred && X->in_use == 0) { X->release(); delete X; }
+        if (X->free_deferred && X->in_use == 0 && X->list_pins == 0) { X->release(); delete X; }
     };
     auto drop_list = [](rhip_pairlist_t* X) {  // (after the wait below: nothing reads its device copy any more)
-        if (X && X->free_deferred && X->in_use == 0) { X->d_idx.release(); delete X; }
+        if (X && X->free_deferred && X->in_use == 0) pairlist_destroy(X);
     };
     try {
         DeviceGuard dguard_(c->device);
@@ -2130,6 +2136,21 @@ extern "C" int rhip_pairwise_cardinality(rhip_ctx_t* c, rhip_op op, rhip_pool_t*
 }
 
 // ------------------------------------------------------------------ prepared pair lists (roaring_hip.h)
+// the end of a pair list: its operand pools are unpinned, and released if their rhip_pool_free was waiting for that
+static void pairlist_destroy(rhip_pairlist_t* L) {
+    if (L->pinned) {
+        rhip_pool_t *A = L->A, *B = L->B;
+        --A->list_pins;
+        --B->list_pins;
+        auto drop = [](rhip_pool_t* X) {
+            if (X->free_deferred && X->in_use == 0 && X->list_pins == 0) { X->free_deferred = false; rhip_pool_free(X); }
+        };
+        drop(A);
+        if (B != A) drop(B);
+    }
+    L->d_idx.release();
+    delete L;
+}
 static rhip_pairlist_t* pairlist_make(rhip_ctx_t* c, rhip_pool_t* A, rhip_pool_t* B, std::vector<uint32_t>&& lhs,
                                       std::vector<uint32_t>&& rhs) {
     rhip_pairlist_t* L = nullptr;
@@ -2146,6 +2167,9 @@ static rhip_pairlist_t* pairlist_make(rhip_ctx_t* c, rhip_pool_t* A, rhip_pool_t
         fetch_bounds(B);
         L->sums = pair_sums(A, B, L->npairs, L->lhs.data(), L->rhs.data());  // (range-checks every index)
         L->genA = A->bounds_gen; L->genB = B->bounds_gen;
+        ++A->list_pins;
+        ++B->list_pins;
+        L->pinned = true;
         L->d_idx.ensure(8 * L->npairs + 16);
         if (L->npairs) {
             HIPCHK(hipMemcpyAsync(L->d_idx.p, L->lhs.data(), 4 * L->npairs, hipMemcpyHostToDevice, c->stream));
@@ -2155,7 +2179,7 @@ static rhip_pairlist_t* pairlist_make(rhip_ctx_t* c, rhip_pool_t* A, rhip_pool_t
         return L;
     } catch (int e) {
         last_status() = e;
-        if (L) { L->d_idx.release(); delete L; }
+        if (L) { pairlist_destroy(L); }
         return nullptr;
     }
 }
@@ -2190,13 +2214,12 @@ extern "C" int rhip_pairlist_pairs(const rhip_pairlist_t* L, uint32_t* lhs, uint
 extern "C" void rhip_pairlist_free(rhip_pairlist_t* L) {
     if (!L) return;
     if (L->in_use > 0) { L->free_deferred = true; return; }  // released by the last batch that reads it (rhip_pairwise_end)
-    L->d_idx.release();
-    delete L;
+    pairlist_destroy(L);
 }
 extern "C" rhip_batch_t* rhip_pairwise_list_begin(rhip_ctx_t* c, size_t n_ops, const rhip_op* ops, rhip_pairlist_t* L,
                                                  rhip_pool_t* reuse) {
-    if (!L || L->free_deferred) {
-        set_err("null (or freed) pair list");
+    if (!L || L->free_deferred || (c && L->ctx != c)) {
+        set_err(!L || L->free_deferred ? "null (or freed) pair list" : "the pair list belongs to another context");
         last_status() = RHIP_ERR_ARG;
         if (reuse && !(reuse->pending || reuse->in_use)) { reuse->release(); delete reuse; }  // consumed, as everywhere
         return nullptr;
@@ -2210,6 +2233,7 @@ extern "C" rhip_pool_t* rhip_pairwise_list(rhip_ctx_t* c, size_t n_ops, const rh
 }
 extern "C" int rhip_pairwise_list_cardinality(rhip_ctx_t* c, rhip_op op, rhip_pairlist_t* L, uint64_t* out) {
     if (!L || L->free_deferred) { set_err("null (or freed) pair list"); return RHIP_ERR_ARG; }
+    if (c && L->ctx != c) { set_err("the pair list belongs to another context"); return RHIP_ERR_ARG; }
     return pairwise_cardinality_impl(c, op, L->A, L->B, L->npairs, L->lhs.data(), L->rhs.data(), out, L);
 }
 

@@ -199,8 +199,10 @@ rhip_batch_t *rhip_pairwise_multi_begin(rhip_ctx_t *ctx, size_t n_ops, const rhi
  * ONCE: validated, its indices resident on the device, the sums that size a batch (container counts, result-slot
  * bounds) taken.  Batches over it then skip the host's pass over the pairs and the staging copy -- 25-40 us of a
  * 20 000-pair call -- and are otherwise exactly rhip_pairwise / _multi / _cardinality: same kernels, same results.
- * The operand pools must outlive the list; if one of them is updated in place (or recycled) the list re-validates itself
- * at its next use.  rhip_pairlist_free while batches over the list are in flight is deferred to the last of them. */
+ * The list PINS its operand pools: rhip_pool_free of an operand is accepted and deferred until the last list over it
+ * (and the last batch in flight) is gone.  If an operand is updated in place (or recycled) the list re-validates itself
+ * at its next use.  A list is used with the context it was made on (anything else: RHIP_ERR_ARG).
+ * rhip_pairlist_free while batches over the list are in flight is deferred to the last of them. */
 typedef struct rhip_pairlist_s rhip_pairlist_t;
 rhip_pairlist_t *rhip_pairlist_create(rhip_ctx_t *ctx, rhip_pool_t *A, rhip_pool_t *B, size_t npairs,
                                       const uint32_t *lhs, const uint32_t *rhs);

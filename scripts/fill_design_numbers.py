@@ -1,9 +1,9 @@
-"""Regenerate the measured-numbers block of DESIGN.md (between the NUMBERS markers) from profiles/r04_* (the files
-scripts/collect_profiles.py r04 copies out of the round-4 measurement pass, scripts/gpu_final_r4.sh).  Fails loudly on a
+"""Regenerate the measured-numbers block of DESIGN.md (between the NUMBERS markers) from profiles/r05_* (the files
+scripts/collect_profiles.py r05 copies out of the round-5 measurement pass, scripts/gpu_final_r5.sh).  Fails loudly on a
 missing or empty input."""
 import json, os, re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "r04"
+TAG = "r05"
 
 
 def P(n):
@@ -32,15 +32,11 @@ def row(k, label):
     v = s[k]
     cpu = v.get("cpu1_ops_per_s")
     return (f"| {label} | {v['pairs']:,} | {v['ms_batch_median']:.3f} ({v['ms_batch_min']:.3f}) | {v['ms_adhoc_list']:.3f} | {v['ms_batch_pipelined2']:.3f} | "
-            f"{v['ops_per_s'] / 1e6:.1f} M | {v['alg_GBps'] / 1e3:.2f} | **{v['frac']:.3f}** | {cpu / 1e3:,.0f} k | {v['ops_per_s'] / cpu:,.0f}× | {'ok' if v['checksum_ok'] else 'FAIL'} |")
+            f"{v['ops_per_s'] / 1e6:.1f} M | {v['alg_GBps'] / 1e3:.2f} | **{v['frac']:.3f}** | {('%.2f' % v['hbm_traffic_frac']) if 'hbm_traffic_frac' in v else '--'} | {cpu / 1e3:,.0f} k | {v['ops_per_s'] / cpu:,.0f}× | {'ok' if v['checksum_ok'] else 'FAIL'} |")
 
 
 pl = d["config"]["result_arena_placement"]["probe_GBps_of_each_candidate"]
-_f = json.load(open(P(f"{TAG}_bench_final_code.json")))
-_r = _f["config"]["secondary_summary"]["rows"]
-FINAL = (f"weather `and` {_r['c3_and'][0]:.3f} / {_r['c3_and'][1]:.3f}, `or` {_r['c3_or'][0]:.3f} / {_r['c3_or'][1]:.3f}, `xor` {_r['c3_xor'][0]:.3f} / {_r['c3_xor'][1]:.3f}, "
-         f"`andnot` {_r['c3_andnot'][0]:.3f} / {_r['c3_andnot'][1]:.3f}; census1881 `and` {_r['c1_and'][0]:.3f}; C5 `and` {_r['c5_and'][0]:.3f}, `or` {_r['c5_or'][0]:.3f}; "
-         f"C4 {_r['c4_or_many'][0]:.3f}; C4 x 10 {_r['c4x10_or_many'][0]:.2f}; C2 `k_bb` {_f['roofline']['frac']:.3f} of peak.")
+FRESH = d['config'].get('c2_fresh_result_pool_ms', {})
 t = []
 t.append(f"""**Headline (`bench.py`, C2, N = 1, driver contract).** {d['value']:,.0f} set-ops/s = {d['config']['algorithmic_GBps'] / 1e3:.2f} TB/s algorithmic over a
 {d['config']['timed_region_s']:.2f} s timed region ({d['ms_per_step']:.1f} ms per step of 3 000 ops).  Dominant kernel `k_bb`: {r['achieved'] / 1e3:.2f} TB/s = **{r['frac']:.3f} of the 8 TB/s
@@ -64,21 +60,23 @@ for o in map(json.loads, open(P(f"{TAG}_c2_ops.jsonl"))):
 t.append(f"""
 (`and` / `andnot` write 8 GiB arenas, `or` / `xor` 16 GiB ones -- their slot bound is the sum of both operands -- and the
 cardinality forms write nothing: 16 384 B per pair.  Which physical pages an arena gets moves `k_bb` between 3.9 and 4.7 ms;
-§3 and `profiles/{TAG}_arena_distance.txt` say what was found out about it.)
-
-**On the final code** (`profiles/{TAG}_bench_final_code.json`: `bench.py --no-cpu --steps 10`, the realdata calls issued back
-to back; median ms / of the HBM peak): {FINAL}
+§3 and `profiles/r04_arena_distance.txt` say what was found out about it.  Round 5: the cardinality forms went from
+0.72 to 0.80 of peak -- a wave now adds its stretch of the queue in a register and issues one atomic per bitmap pair
+instead of one per container pair.  A call that has to ALLOCATE its result pool -- no `reuse` -- took
+{FRESH.get('and')} ms (`and`) / {FRESH.get('or')} ms (`or`) in this pass, placement search included: `c2_fresh_result_pool_ms` in the bench line.)
 
 **Realdata, ALL unordered pairs in one batched call per op** (`bench.py`, detail in `profiles/{TAG}_bench_detail.json`: wall time
 of the whole call incl. planning and the final wait over a PREPARED pair list (`rhip_pairlist_all_pairs`), median (min) of >= 10
 calls; "ad hoc" = the same call handed the two index arrays per call; "2 in flight" = per-call period of 40 calls issued with
 `rhip_pairwise_list_begin` / `_end`, two at a time; checksum = sum of result cardinalities against the reference fixture;
-CPU = real CRoaring, one core, same pairs).  In this pass `bench.py` still put a device barrier around every call, which idles
-the GPU between calls -- the medians below carry that; the same calls issued back to back (`scripts/quick_all.py`, min of 7):
+CPU = real CRoaring, one core, same pairs; "HBM traffic" = bytes that crossed the memory side per batch in the stored PMC
+pass (`profiles/{TAG}_realdata_traffic.md`) over the batch time, as a fraction of 8 TB/s: the operands of these sets live in
+the L2s, so the algorithmic fraction is NOT HBM utilisation -- the bound of every row is instruction issue + LDS + latency,
+with the results streaming out).  The same calls by `scripts/quick_all.py`, min of 7:
 weather {qa['prepared']['weather_sept_85']}, census1881 {qa['prepared']['census1881']}.
 
-| config | pairs | ms / batch, median (min) | ad hoc list | 2 in flight | set-ops/s | alg. TB/s | of HBM peak | CRoaring 1 core | ratio | checksum |
-|---|---|---|---|---|---|---|---|---|---|---|""")
+| config | pairs | ms / batch, median (min) | ad hoc list | 2 in flight | set-ops/s | alg. TB/s | of HBM peak (algorithmic) | HBM traffic / peak | CRoaring 1 core | ratio | checksum |
+|---|---|---|---|---|---|---|---|---|---|---|---|""")
 for k, l in (("c3_and", "C3 weather_sept_85 and"), ("c3_or", "C3 or"), ("c3_xor", "C3 xor"), ("c3_andnot", "C3 andnot"),
              ("c1_and", "C1 census1881 and"), ("c1_or", "C1 or"), ("c1_xor", "C1 xor"), ("c1_andnot", "C1 andnot"),
              ("c5_and", "C5 roaring64 wikileaks×10 and"), ("c5_or", "C5 or")):
@@ -92,12 +90,23 @@ for k, l in (("c3_multi4", "C3 and+or+xor+andnot, ONE batch"), ("c1_multi4", "C1
 t.append(f"| C4 `or_many`, 100 000 sparse bitmaps (3.2 M containers, 1.64 GB) | {c4['ms_median']:.3f} | {c4['alg_GBps'] / 1e3:.2f} | {c4['frac']:.3f} | CRoaring 1 core: {c4['cpu1_ms_first_10000']:.0f} ms for the first 10 000; sharded pipeline at world 1: {c4['sharded_w1']['vs_or_many']:.2f} x, with the collective on a 1-rank nccl group {c4['sharded_w1_nccl']['vs_or_many']:.2f} x; cardinality ok |")
 t.append(f"| C4 x 10 `or_many`, 10^6 sparse bitmaps (32 M containers, 16.4 GB) | {x10['ms_median']:.2f} | {x10['alg_GBps'] / 1e3:.2f} | {x10['frac']:.3f} | pool built in {x10['build_s_untimed']:.1f} s (untimed); cardinality equal to the reference's (`tests/golden/c4x10_or_many.npz`) |")
 t.append(f"| C5 union of 200 roaring64 bitmaps | {u['ms_median']:.3f} | -- | -- | CRoaring fold {u['cpu1_ms_fold']:.1f} ms; cardinality ok |")
+t.append("")
+t.append("**The reference benchmark's own loop shape** (`benchmarks/benchmark.cpp:2035-2091` successive_and / successive_or: the n - 1 "
+         "adjacent pairs, each result materialised + cardinality; here ONE batch over `rhip_pairlist_successive` + the cardinalities "
+         "read back -- almost pure fixed cost of a call) and the per-call drop-in:\n\n| row | pairs | ms / batch | us per op | CRoaring 1 core, us per op | GPU / CPU |\n|---|---|---|---|---|---|")
+for k in ("c1_successive_and", "c1_successive_or", "c3_successive_and", "c3_successive_or"):
+    if k in s:
+        v = s[k]
+        t.append(f"| {k} | {v['pairs']} | {v['ms_batch_median']:.3f} | {v['us_per_op']:.3f} | {v.get('cpu1_us_per_op', float('nan')):.3f} | {v.get('gpu_over_cpu1', float('nan')):.2f} x |")
+if "dropin_percall_us" in s and "and" in s["dropin_percall_us"]:
+    dp = s["dropin_percall_us"]
+    t.append(f"| per-call drop-in `roaring_bitmap_and` / `_or` on census1881 operands (host struct -> upload -> batch of one -> download) | 1 | -- | {dp['and']['dropin_us_per_call']:.0f} / {dp['or']['dropin_us_per_call']:.0f} | {dp['and']['croaring_us_per_call']:.2f} / {dp['or']['croaring_us_per_call']:.2f} | {1 / dp['and']['dropin_over_cpu']:.4f} x / {1 / dp['or']['dropin_over_cpu']:.4f} x |")
 t.append(f"""
 Cardinality-only batches: C3 `and` {s['c3_and_cardinality']['ms_batch_median']:.3f} ms, C1 {s['c1_and_cardinality']['ms_batch_median']:.3f} ms, C5 {s['c5_and_cardinality']['ms_batch_median']:.3f} ms.
 
 **One rank of N, measured on one GPU** (`bench.py` `c4_shard_stages`: rank 0's own pool -- bitmaps 0, N, 2N ... -- stage 1
 `rhip_many_partials_dense` into a world = N table and stage 3 `rhip_many_finalize_dense` over a world = N table, each timed to
-completion; beside them round 3's model `0.10 + 0.69 / N` and `0.03`):
+completion; beside them round 3's model `0.10 + 0.69 / N` and `0.03`, which the counting-sort grouping of round 5 now beats):
 
 | N | stage 1 ms | stage 3 ms | model stage 1 | model stage 3 |
 |---|---|---|---|---|""")
@@ -105,7 +114,7 @@ for n in ("1", "2", "4", "8"):
     v = st[n]
     t.append(f"| {n} | {v['stage1_ms']:.3f} | {v['stage3_ms']:.3f} | {v['model_stage1_ms']:.3f} | {v['model_stage3_ms']:.3f} |")
 t.append(f"""
-(§7a: the model's fixed part was too small -- stage 1 at N = 8 is {st['8']['stage1_ms']:.2f} ms, not 0.19.)
+(§7a: round 4 measured 0.759 / 0.470 / 0.440 / 0.319 ms for stage 1 -- a fixed part of ~0.25 ms; it is ~0.08 ms now.)
 
 **The corpus, back to back** (`profiles/{TAG}_quick_all.txt`: all pairs, min of 7 synchronous calls, ms; first the prepared pair
 list, then the ad hoc one):
@@ -142,10 +151,11 @@ for l in open(P(f"{TAG}_class_throughput.jsonl")):
 t.append(f"""
 SQ counters of the class kernels on weather: `profiles/{TAG}_pmc_weather_sq.md` (taken with kernels serialised by the
 profiler -- the context's self-test then joins with events, §2); L2 hit / miss and memory requests per class kernel:
-`profiles/{TAG}_pmc_l2.md` (reads to memory are 48 MB per `or` batch against 806 MB of writes: the operands live in L2,
-the results stream out).  Kernel timelines of one batch of every configuration: `profiles/{TAG}_timelines.txt` (C4 with
-the fill / copy commands of rocPRIM's radix sort between `k_many_gather` and `k_many_groups`: five fills and four sort
-kernels per call, no command of the engine's own); per-kernel `--stats` tables: `profiles/{TAG}_{{c1,c3,c5,c4}}_*_kernel_stats.csv`.""")
+`profiles/r04_pmc_l2.md`; HBM bytes per batch and issue shares of every realdata row: `profiles/{TAG}_realdata_traffic.md`.
+Kernel timelines of one batch of every configuration: `profiles/{TAG}_timelines.txt`, of the many-way calls (C4 and C4 x 10):
+`profiles/{TAG}_timelines_many.txt` -- six launches of the engine's own, no library kernel, no fill or copy command;
+SQ counters of the many-way kernels before / after the round: `profiles/{TAG}_pmc_c4_sq_before.md`, `profiles/{TAG}_pmc_c4_sq.md`;
+per-kernel `--stats` tables: `profiles/{TAG}_{{c1,c3,c5,c4,c4x10}}_*_kernel_stats.csv`.""")
 body = "\n".join(t)
 p = os.path.join(ROOT, "DESIGN.md")
 txt = open(p).read()

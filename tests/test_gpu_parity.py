@@ -757,6 +757,17 @@ def test_prepared_pair_lists(engine, oracle, synth):
     assert len(bb.end()) == 4          # (the last batch over it releases the list)
     import ctypes
     assert not engine.lib.rhip_pairwise_list(engine.h, 1, (ctypes.c_int * 1)(0), None, None)
+    # a pool freed while a list holds it as an operand stays alive until the list goes (the list pins its pools); the
+    # list of another context is refused
+    p4 = engine.pool_from_serialized(bufs[:40])
+    l4, r4 = np.arange(39, dtype=np.uint32), np.arange(1, 40, dtype=np.uint32)
+    want4 = engine.pairwise("xor", p4, l4, p4, r4).serialize_many()[0]
+    pl4 = engine.pairlist(p4, l4, p4, r4)
+    h4 = p4.h
+    engine.lib.rhip_pool_free(h4)      # deferred: pl4 pins the pool
+    p4.h = None
+    assert np.array_equal(engine.pairwise_list("xor", pl4).serialize_many()[0], want4)
+    pl4.free()                         # the list goes, and with it the pool
 
 
 def test_tiny_passthrough_containers(engine, oracle):
