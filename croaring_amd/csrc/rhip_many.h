@@ -38,7 +38,7 @@
 // every kernel takes its counts from device memory.
 #pragma once
 #include "rhip_kernels.h"
-#ifndef RHIP_ABL_SC   // ablation builds (scripts/r5/*.sh): 0 in the product
+#ifndef RHIP_ABL_SC   // ablation builds (scripts/gpu_exp.sh c4-variants; profiles/r05_many_l1_notes.md): 0 in the product
 #define RHIP_ABL_SC 0
 #endif
 #ifndef RHIP_ABL_L1
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_many_scatter(PoolView P, ManySel
             const uint32_t k = r.key - w0;
             if (k < MC_W3) {
                 const uint32_t pos = reverse ? atomicSub(&h[k], 1u) - 1u : atomicAdd(&h[k], 1u);
-#if RHIP_ABL_SC == 1   /* ablation builds only (scripts/r5): the kernel without its stores */
+#if RHIP_ABL_SC == 1   /* ablation builds only: the kernel without its stores */
                 if (pos == 0xFFFFFFFFu) { sdesc[0] = md_pack(r.off, r.ty, r.cd, r.nr); sord[0] = (uint32_t)t; }
 #elif RHIP_ABL_SC == 2  /* non-temporal stores */
                 __builtin_nontemporal_store(md_pack(r.off, r.ty, r.cd, r.nr), &sdesc[pos]);
