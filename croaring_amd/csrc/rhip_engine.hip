@@ -307,7 +307,6 @@ struct rhip_pool_s {
     std::vector<uint64_t> h_w;      // per-bitmap result-slot bound (k_bitmap_bounds), see fetch_bounds
     std::vector<uint64_t> h_wm;     // the same bound as the many-way path needs it (runs by rounded cardinality)
     uint64_t wm_total = 0;          // sum of h_wm
-    bool has_long_runs = false;     // some run container's payload exceeds 8192 bytes (a pass-through slot can then exceed a bitset's)
     uint64_t n_keys_distinct = 0;   // 32-bit pools: distinct container keys in the pool (fetch_bounds)
     uint64_t max_key = 0;           // largest container key in the pool
     std::vector<uint32_t> h_n;      // per-bitmap container count
@@ -1089,7 +1088,7 @@ static void fetch_bounds(rhip_pool_t* P) {
     rhip_ctx_t* c = P->ctx;
     P->h_w.assign((size_t)P->n_bitmaps, 0);
     P->h_wm.assign((size_t)P->n_bitmaps, 0);
-    uint32_t census[4] = {0, 0, 0, 0};
+    uint32_t census[3] = {0, 0, 0};
     uint64_t nkeys = P->n_cont;
     if (P->n_bitmaps && P->n_cont) {
         const size_t nb = (size_t)P->n_bitmaps;
@@ -1112,12 +1111,11 @@ static void fetch_bounds(rhip_pool_t* P) {
         }
         HIPCHK(hipMemcpyAsync(P->h_w.data(), dw, 8 * nb, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(P->h_wm.data(), dwm, 8 * nb, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(census, dcensus, 16, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(census, dcensus, 12, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(&P->max_key, dnk + 1, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     for (int t = 0; t < 3; ++t) P->census[t] = census[t] ? 1 : 0;
-    P->has_long_runs = census[3] != 0;
     P->n_keys_distinct = nkeys;
     P->wm_total = 0;
     for (uint64_t w : P->h_wm) P->wm_total += w;

@@ -90,8 +90,8 @@ struct ManyZero {   // scratch the first kernel of a call clears for the later o
     uint32_t* glast; u64 n_glast;
     u64* table; u64 n_table;   // dense stage-1 table of the sharded form (u64 words), may be null
 };
-// result-slot weight of a member, in 16-byte units: the slot of a group is its one member's weight, or the sum of its
-// members' weights capped at a bitset (512).  The same figure as the host's per-bitmap bound (k_bitmap_bounds' wmany:
+// result-slot weight of a member, in 16-byte units: the slot of a group is the sum of its members' weights capped at a
+// bitset (512: a run list longer than that never survives, many_pass_through).  The same figure as the host's per-bitmap bound (k_bitmap_bounds' wmany:
 // runs weighed by their cardinality rounded up to a multiple of 256) -- the arena is sized from the sum of those.
 __device__ __forceinline__ uint32_t many_weight16(uint32_t ty, uint32_t card, uint32_t nruns) {
     return slot_bound((uint8_t)ty, ty == T_RUN ? ((card + 255u) & ~255u) : card, nruns) >> 4;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(MC_KT * MC_SEG) void k_many_keyscan(const uint32_t*
         if (tc) {
             const u64 nu = many_group_pieces(gs, ge, per);
             np = nu > 1 ? (uint32_t)nu : 0u;
-            sl = (tc == 1 && !force_typed) ? tw : (tw > 512u ? 512u : tw);
+            sl = tw > 512u ? 512u : tw;  // (a single member's weight IS its slot; no result -- a pass-through run included -- exceeds a bitset)
         }
         const uint32_t ip = wave_incl_scan(np), is = wave_incl_scan(sl);
         const uint32_t tp = wave_lane<63>(ip), ts = wave_lane<63>(is);
@@ -511,6 +511,9 @@ __global__ __launch_bounds__(256) void k_many_units(const u64* __restrict__ sdes
             uint32_t sz;
             if (cnt == 1 && !force_typed) {
                 sz = align16(md_payload(sdesc[gs]));
+                const uint32_t cc = align16(2u * md_card_ub(sdesc[gs]));  // (an inefficient run is re-typed: many_pass_through)
+                sz = sz > (cc > 8192u ? 8192u : cc) ? sz : (cc > 8192u ? 8192u : cc);
+                sz = sz > 8192u ? 8192u : sz;
             } else {
                 const u64 c = gcs[g + 1] - gcs[g];
                 sz = c >= 4096ull ? 8192u : align16(2u * (uint32_t)c);
@@ -1023,27 +1026,34 @@ __device__ __forceinline__ bool many_image_full(const uint32_t* acc, BlockScratc
     return blk_sum(popc4(r0) + popc4(r1), sc->wsum) == 65536u;
 }
 
-// a single-member group keeps its container unchanged (type included): roaring.c:2660-2676.  The whole workgroup copies.
-__device__ __forceinline__ void many_pass_through(u64 d, const uint8_t* __restrict__ arena, const ManyOut& MO, uint32_t g,
+// A single-member group keeps its container (roaring.c:2660-2676) -- but container_repair_after_lazy still visits it
+// (containers.h:344-371): an array or a bitset stays as it is, a RUN container goes through
+// convert_run_to_efficient_container (convert.c:154-200) and only stays a run if that is its smallest form.  Every
+// container run_optimize produced is; a run list somebody serialized by hand (3 000 runs = 12 KB) is not, and comes out
+// as an array or a bitset: such a member is NOT handled here (returns false) and takes the accumulation path, whose
+// typing by cardinality is exactly that conversion.  The whole workgroup copies.
+__device__ __forceinline__ bool many_pass_through(u64 d, const uint8_t* __restrict__ arena, const ManyOut& MO, uint32_t g,
                                                   BlockScratch* sc) {
     const uint32_t ty = md_type(d), n = md_n(d);
     const uint32_t n16 = (md_payload(d) + 15u) >> 4;
     const uint4* __restrict__ ps = (const uint4*)(arena + md_off(d));
-    uint4* __restrict__ po = (uint4*)(MO.O.arena + MO.O.off[g]);
-    uint32_t card = 0;  // runs: the descriptor has no exact cardinality, the runs do (sum of length + 1)
-    for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) {
-        const uint4 x = ps[i];
-        po[i] = x;
-        if (ty == T_RUN) {
+    uint32_t card = ty == T_ARRAY ? n : n + 1u;
+    if (ty == T_RUN) {  // the descriptor has no exact cardinality, the runs do (sum of length + 1)
+        uint32_t c = 0;
+        for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) {
+            const uint4 x = ps[i];
             const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
             for (uint32_t k = 0; k < 4; ++k)
-                if (4u * i + k < n) card += (w[k] >> 16) + 1u;
+                if (4u * i + k < n) c += (w[k] >> 16) + 1u;
         }
+        card = blk_sum(c, sc->wsum);
+        if (type_eff(card, n) != T_RUN) return false;  // (block-uniform)
     }
-    if (ty == T_RUN) card = blk_sum(card, sc->wsum);  // (block-uniform branch: the descriptor is)
-    else card = ty == T_ARRAY ? n : n + 1u;
+    uint4* __restrict__ po = (uint4*)(MO.O.arena + MO.O.off[g]);
+    for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) po[i] = ps[i];
     if (threadIdx.x == 0) MO.O.meta[g] = pack_meta(ty, card, ty == T_RUN ? n : 0u);
+    return true;
 }
 
 // PF = 16-byte payload groups per lane loaded ahead of the LDS atomics (RHIP_MANY_PF selects 2 / 4 / 8; default 4)
@@ -1070,10 +1080,9 @@ __global__ __launch_bounds__(256, RHIP_MANY_WAVES) void k_many_l1(PoolView P, Ma
             const u64 gs = V.gstart[g], ge = V.gstart[g + 1];
             if (gs >= hi) break;
             const u64 q0 = gs / per, nu = (ge - 1) / per - q0 + 1;  // pieces the group is cut into
-            if (nu == 1 && (ge - gs) == 1 && !MO.force_typed && !MO.partial_mode) {
-                many_pass_through(V.sdesc[gs], P.arena, MO, g, &sc);  // a single member keeps its container (roaring.c:2660-2676)
+            if (nu == 1 && (ge - gs) == 1 && !MO.force_typed && !MO.partial_mode &&
+                many_pass_through(V.sdesc[gs], P.arena, MO, g, &sc))  // a single member keeps its container (unless it is an inefficient run)
                 continue;
-            }
             const u64* desc = V.sdesc;
             u64 a0 = gs > lo ? gs : lo, a1 = ge < hi ? ge : hi;
             // One accumulation site for the piece's members and -- rarely -- for the replay of a full union's prefix

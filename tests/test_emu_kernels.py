@@ -279,6 +279,10 @@ def test_emu_pairwise_placed(emu, oracle, synth):
     G.test_pairwise_placed(emu, oracle, synth)
 
 
+def test_emu_many_long_run_passthrough(emu, oracle):
+    G.test_many_long_run_passthrough(emu, oracle)
+
+
 def test_emu_join_fallback(oracle, synth, monkeypatch):
     """A forked batch whose flag gate reports a time-out (RHIP_JOIN_FAIL=1) is finished through the fallback of
     rhip_pairwise_end -- streams waited for, the tail's scratch cleared, the tail run again -- with the same bytes."""

@@ -1091,3 +1091,42 @@ def test_batches_in_flight(engine, oracle, synth):
     last = pb.end()
     blob, offs = last.serialize_many()
     assert np.array_equal(blob, want[k][0]) and np.array_equal(offs, want[k][1])
+
+
+def _long_run_bitmap(key: int, n_runs: int) -> bytes:
+    """A portable image with ONE run container of n_runs runs {20 k, length 1} -- valid (sorted, non-adjacent), never
+    produced by run_optimize once 4 n_runs + 2 exceeds a bitset: the only container whose payload is larger than 8 KiB."""
+    import struct
+    starts = 20 * np.arange(n_runs, dtype=np.uint32)
+    runs = np.empty(2 * n_runs, dtype=np.uint16)
+    runs[0::2] = starts.astype(np.uint16)
+    runs[1::2] = 1
+    card = 2 * n_runs
+    return (struct.pack("<I", 12347 | (0 << 16)) + bytes([1]) + struct.pack("<HH", key, card - 1) +
+            struct.pack("<H", n_runs) + runs.tobytes())
+
+
+def test_many_long_run_passthrough(engine, oracle):
+    """or_many / xor_many where a single-member group is a run container LONGER than a bitset (3 000 runs = 12 002
+    bytes): it passes through unchanged (roaring.c:2660-2676), so its result slot exceeds 8 192 bytes -- the arena bound
+    must not assume a bitset per group.  Also as a member of a two-member group (result typed by cardinality)."""
+    n_runs = 3000
+    img = _long_run_bitmap(7, n_runs)
+    h = oracle.deserialize(img)
+    assert oracle.validate(h) and oracle.cardinality(h) == 2 * n_runs
+    rng = np.random.default_rng(99)
+    others = [np.sort(rng.choice(1 << 22, 3000, replace=False)).astype(np.uint32) + np.uint32(16 << 16) for _ in range(5)]
+    hs = [oracle.from_sorted(v) for v in others]
+    bufs = [oracle.serialize(x) for x in hs] + [img]
+    pool = engine.pool_from_serialized(bufs)
+    allh = hs + [h]
+    got = engine.or_many(pool).serialize(0)
+    assert got == oracle.serialize(oracle.or_many(allh)), "or_many with a pass-through run container of 3 000 runs"
+    hx = oracle.deserialize(engine.xor_many(pool).serialize(0))
+    assert np.array_equal(oracle.to_array(hx), oracle.to_array(oracle.xor_many(allh)))
+    # the long run container meeting a partner with the same key
+    mate = oracle.from_sorted((np.arange(0, 60000, 7, dtype=np.uint32) + np.uint32(7 << 16)))
+    pool2 = engine.pool_from_serialized(bufs + [oracle.serialize(mate)])
+    assert engine.or_many(pool2).serialize(0) == oracle.serialize(oracle.or_many(allh + [mate]))
+    for x in allh + [mate]:
+        oracle.free(x)
