@@ -307,6 +307,7 @@ struct rhip_pool_s {
     std::vector<uint64_t> h_w;      // per-bitmap result-slot bound (k_bitmap_bounds), see fetch_bounds
     std::vector<uint64_t> h_wm;     // the same bound as the many-way path needs it (runs by rounded cardinality)
     uint64_t wm_total = 0;          // sum of h_wm
+    bool has_long_runs = false;     // some run container's payload exceeds a bitset's 8192 bytes (only a hand-made list can)
     uint64_t n_keys_distinct = 0;   // 32-bit pools: distinct container keys in the pool (fetch_bounds)
     uint64_t max_key = 0;           // largest container key in the pool
     std::vector<uint32_t> h_n;      // per-bitmap container count
@@ -1088,7 +1089,7 @@ static void fetch_bounds(rhip_pool_t* P) {
     rhip_ctx_t* c = P->ctx;
     P->h_w.assign((size_t)P->n_bitmaps, 0);
     P->h_wm.assign((size_t)P->n_bitmaps, 0);
-    uint32_t census[3] = {0, 0, 0};
+    uint32_t census[4] = {0, 0, 0, 0};
     uint64_t nkeys = P->n_cont;
     if (P->n_bitmaps && P->n_cont) {
         const size_t nb = (size_t)P->n_bitmaps;
@@ -1111,11 +1112,12 @@ static void fetch_bounds(rhip_pool_t* P) {
         }
         HIPCHK(hipMemcpyAsync(P->h_w.data(), dw, 8 * nb, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(P->h_wm.data(), dwm, 8 * nb, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(census, dcensus, 12, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(census, dcensus, 16, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(&P->max_key, dnk + 1, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
     }
     for (int t = 0; t < 3; ++t) P->census[t] = census[t] ? 1 : 0;
+    P->has_long_runs = census[3] != 0;
     P->n_keys_distinct = nkeys;
     P->wm_total = 0;
     for (uint64_t w : P->h_wm) P->wm_total += w;
@@ -1282,8 +1284,17 @@ Plan plan(rhip_ctx_t* c, const OpSet& ops, rhip_pool_t* A, rhip_pool_t* B, size_
         }
         NU = (size_t)(ops.n * (S.nu_a + (btiles ? S.nu_b : 0)));
         ub_match = (uint64_t)ops.n * S.s_mn;
-        ub = n_b0 * S.s_mn + n_b1 * S.s_na + n_b2 * (S.s_na + S.s_nb);
-        bound = n_b0 * S.s_wmin + n_b1 * S.s_wa + n_b2 * (S.s_wa + S.s_wb);
+        // or / xor: a result holds at most one container per key that occurs in the operand POOLS at all (counted once
+        // per pool, fetch_bounds) -- and none above a bitset's 8192 bytes unless a pool holds a longer run list.  Where
+        // every bitmap has every key (C2: 4 096 keys) that halves the bound: a 250-pair `or` arena is 8 GiB, not 16.
+        uint64_t cand2 = S.s_na + S.s_nb, bytes2 = S.s_wa + S.s_wb;
+        if (!A->is64) {
+            const uint64_t K = std::min<uint64_t>(65536, A->n_keys_distinct + (A == B ? 0 : B->n_keys_distinct));
+            cand2 = std::min<uint64_t>(cand2, (uint64_t)npairs * K);
+            if (!A->has_long_runs && !B->has_long_runs) bytes2 = std::min<uint64_t>(bytes2, (uint64_t)npairs * K * 8192ull);
+        }
+        ub = n_b0 * S.s_mn + n_b1 * S.s_na + n_b2 * cand2;
+        bound = n_b0 * S.s_wmin + n_b1 * S.s_wa + n_b2 * bytes2;
     }
     if (implicit) NU = nvirt * (btiles ? 2 : 1);
     if (NU >= 0x7FFFFFF0ull) { set_err("batch too large: %zu planning units", NU); throw (int)RHIP_ERR_ARG; }

@@ -1004,7 +1004,7 @@ __device__ __forceinline__ uint32_t slot_bound(uint8_t type, uint32_t card, uint
 // cardinality rounded up to a multiple of 256
 __global__ __launch_bounds__(256) void k_bitmap_bounds(PoolView P, uint32_t nbm, u64* __restrict__ wout,
                                                        u64* __restrict__ wmany,
-                                                       uint32_t* __restrict__ census /* [3] bitset, array, run */,
+                                                       uint32_t* __restrict__ census /* [4] bitset, array, run, some payload above 8192 bytes */,
                                                        u64* __restrict__ maxkey) {
     uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (b >= nbm) return;
@@ -1016,6 +1016,7 @@ __global__ __launch_bounds__(256) void k_bitmap_bounds(PoolView P, uint32_t nbm,
         s += slot_bound(t, cd, nr);
         sm += slot_bound(t, t == T_RUN ? ((cd + 255u) & ~255u) : cd, nr);
         seen |= 1u << (t - 1);
+        if (payload_bytes(t, cd, nr) > 8192u) seen |= 8u;  // a run list longer than a bitset (valid; run_optimize never leaves one)
     }
     s = wave_sum64(s);
     sm = wave_sum64(sm);
@@ -1028,7 +1029,7 @@ __global__ __launch_bounds__(256) void k_bitmap_bounds(PoolView P, uint32_t nbm,
             const u64 k = P.key[P.bm_start[b + 1] - 1];
             if (k > __atomic_load_n(maxkey, __ATOMIC_RELAXED)) atomicMax(maxkey, k);  // (100 000 same-address atomics cost 4 ms)
         }
-        for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < 4; ++t)
             if ((seen >> t) & 1u) census[t] = 1u;  // benign race: every writer stores the same value
     }
 }
