@@ -104,6 +104,7 @@ SYMBOLS = [
     ("rhip_debug_host_clock", _i, [_vp, C.POINTER(C.c_double), _i]),
     ("rhip_debug_last_placement", _i, [_vp, C.POINTER(C.c_float), _i]),
     ("rhip_debug_join_recovered", _u64, [_vp]),
+    ("rhip_ctx_trim", _u64, [_vp]),
 ]
 
 _lib = None

@@ -52,6 +52,7 @@ static int& last_status() {
     } while (0)
 
 // ------------------------------------------------------------------ device buffers
+static bool release_all_arena_spares();  // (the spare result arenas of every live context: called when an allocation fails)
 struct DBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -76,6 +77,11 @@ struct DBuf {
             want -= skew;
         }
         hipError_t e = hipMalloc(&base, want + skew);
+        if (e != hipSuccess && release_all_arena_spares()) {  // memory the library itself is sitting on (spare arenas)
+            (void)hipGetLastError();
+            base = nullptr;
+            e = hipMalloc(&base, want + skew);
+        }
         if (e != hipSuccess && want > n + 256) {
             // the rounded request (slack, round_to, next power of two: up to 2 x n) did not fit: what the caller
             // asked for may still.  hipMalloc's failure is sticky until read.
@@ -198,10 +204,16 @@ struct rhip_ctx_s {
     // caller does nothing; a recycled result pool (`reuse`) keeps its placement.  RHIP_ARENA_TRIES (0 / 1: off),
     // RHIP_ARENA_PLACE_MIN_MB.  The search goes on for up to arena_tries more candidates while the best so far is below
     // arena_fair_gbps.
+    int arena_keep_spares = 1;  // RHIP_ARENA_SPARES=0: the losers of a placement search are released, not kept
     int arena_tries = 10;
     uint64_t arena_place_min = 2ull << 30;
     double arena_good_gbps = 6250.0;
     double arena_fair_gbps = 5850.0;  // (probe scale: slow band 5.2-5.7 TB/s, mid 5.9-6.1, fast windows 6.2-6.4)
+    // Candidates that lost a placement search are KEPT (the next search probes them first): memory that is freed has to
+    // be scrubbed by the driver before it is handed out again, ~0.3 s per 8 GiB -- a second search right behind the first
+    // (bench.py's `or` arena behind its `and` arena) paid 3.2 s for ten allocations out of just-freed memory.  Released by
+    // rhip_ctx_trim, rhip_ctx_destroy, and by any allocation of the library that fails (DBuf::ensure retries after it).
+    std::vector<DBuf> arena_spares;
     std::vector<float> last_placement;  // probe GB/s of the candidates of the last placement (rhip_debug_last_placement)
     bool debug_plan = false;  // RHIP_DEBUG_PLAN=1: one line per batch on stderr (bounds, fork / merge decision)
     bool merge_classes = true;  // RHIP_MERGE_CLASSES=0: a small batch launches its class kernels one by one
@@ -368,6 +380,15 @@ static void ensure_dir(rhip_pool_t* P, uint32_t n_bitmaps, uint64_t n_cont) {
 static std::mutex g_ctx_mu;
 static std::set<rhip_ctx_t*> g_live_ctx;
 static uint64_t g_ctx_gen = 0;  // (under g_ctx_mu) every context gets the next generation number
+static bool release_all_arena_spares() {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    bool any = false;
+    for (rhip_ctx_t* c : g_live_ctx) {
+        for (DBuf& b : c->arena_spares) { any = any || b.base != nullptr; b.release(); }
+        c->arena_spares.clear();
+    }
+    return any;
+}
 static bool ctx_alive(rhip_ctx_t* c) {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     return g_live_ctx.count(c) != 0;
@@ -415,6 +436,7 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_ARENA_ROUND_MB")) c->arena_round = (size_t)strtoull(e, nullptr, 0) << 20;
         if (const char* e = getenv("RHIP_ARENA_POW2")) c->arena_pow2 = !(e[0] == '0');
         if (const char* e = getenv("RHIP_ARENA_TRIES")) c->arena_tries = atoi(e);
+        if (const char* e = getenv("RHIP_ARENA_SPARES")) c->arena_keep_spares = atoi(e);
         if (const char* e = getenv("RHIP_ARENA_PLACE_MIN_MB")) c->arena_place_min = (uint64_t)strtoull(e, nullptr, 0) << 20;
         if (const char* e = getenv("RHIP_ARENA_SKEW")) c->arena_skew = (size_t)strtoull(e, nullptr, 0) & ~(size_t)255;
         if (const char* e = getenv("RHIP_GROUP_X")) c->group_x = atoi(e);
@@ -468,6 +490,8 @@ extern "C" void rhip_ctx_destroy(rhip_ctx_t* c) {
     for (auto* b : all) b->release();
     for (auto& b : c->many) b.release();
     for (auto& b : c->shard) b.release();
+    for (auto& b : c->arena_spares) b.release();
+    c->arena_spares.clear();
     for (auto& b : c->sel) b.release();
     for (auto& b : c->partial_cache) { (void)hipFree(b.keys); (void)hipFree(b.words); }
     for (rhip_pool_t* R : c->many_free) { R->release(); delete R; }
@@ -1828,10 +1852,46 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
     c->last_placement.clear();
     hipEvent_t e0 = c->ev[0], e1 = c->ev[1];
     int best = -1;
+    auto probe = [&](Cand& cur) {
+        float ms_best = 1e30f;
+        for (int r = 0; r < 3; ++r) {  // (the first pass touches the pages)
+            HIPCHK(hipEventRecord(e0, s));
+            hipLaunchKernelGGL(k_place_probe, dim3(8192), dim3(256), 0, s, A->arena.as<uint8_t>(), a_items, cur.buf.as<uint8_t>(), n_slots, stride);
+            HIPCHK(hipEventRecord(e1, s));
+            HIPCHK(hipEventSynchronize(e1));
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            if (r && ms < ms_best) ms_best = ms;
+        }
+        cur.gbps = (float)((double)n_items * 24576.0 / (double)ms_best / 1e6);
+        c->last_placement.push_back(cur.gbps);
+    };
+    // the spares of earlier searches that fit (same exact-size allocation: within 1/8 above the need) are candidates again
+    // -- where they lie relative to THIS operand pool is a new question -- and cost no allocation
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        for (size_t k = 0; k < c->arena_spares.size();) {
+            DBuf& sp = c->arena_spares[k];
+            if (sp.base && sp.cap >= need && sp.cap <= need + need / 8 && sp.skew == arena.skew) {
+                Cand cd;
+                cd.buf = sp;
+                cands.push_back(cd);
+                c->arena_spares.erase(c->arena_spares.begin() + (long)k);
+            } else {
+                ++k;
+            }
+        }
+    }
+    for (size_t k = 0; k < cands.size(); ++k) {
+        probe(cands[k]);
+        if (best < 0 || cands[k].gbps > cands[best].gbps) best = (int)k;
+    }
+    const int n_spares_in = (int)cands.size();
     // arena_tries candidates -- and up to as many again while even the best of them is in the slow band: consecutive
     // allocations are neighbours (one process of round 4 drew ten slow candidates in a row), and with the losers still
     // alive the driver has to hand out pages further away
-    for (int t = 0; t < 2 * c->arena_tries; ++t) {
+    for (int t = n_spares_in; t < 2 * c->arena_tries; ++t) {
+        if (best >= 0 && cands[best].gbps >= c->arena_good_gbps) break;
         if (t >= c->arena_tries && best >= 0 && cands[best].gbps >= c->arena_fair_gbps) break;
         if (best >= 0) {  // never run the device out of memory for one more candidate
             size_t fr = 0, tot = 0;
@@ -1860,23 +1920,30 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
         }
         cands.push_back(cd);
         Cand& cur = cands.back();
-        float ms_best = 1e30f;
-        for (int r = 0; r < 3; ++r) {  // (the first pass touches the pages)
-            HIPCHK(hipEventRecord(e0, s));
-            hipLaunchKernelGGL(k_place_probe, dim3(8192), dim3(256), 0, s, A->arena.as<uint8_t>(), a_items, cur.buf.as<uint8_t>(), n_slots, stride);
-            HIPCHK(hipEventRecord(e1, s));
-            HIPCHK(hipEventSynchronize(e1));
-            float ms = 0;
-            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-            if (r && ms < ms_best) ms_best = ms;
-        }
-        cur.gbps = (float)((double)n_items * 24576.0 / (double)ms_best / 1e6);
-        c->last_placement.push_back(cur.gbps);
+        probe(cur);
         if (best < 0 || cur.gbps > cands[best].gbps) best = (int)cands.size() - 1;
         if (cur.gbps >= c->arena_good_gbps) break;
     }
-    cands.keep = best;  // (the others are released when `cands` goes out of scope)
-    arena.release();
+    if (best < 0) return;
+    // the losers become spares (RHIP_ARENA_SPARES=0: released instead), as long as the spares stay below half of the memory
+    // that was free when the search began
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        size_t held = 0;
+        for (const DBuf& b : c->arena_spares) held += b.cap;
+        for (int k = 0; k < (int)cands.size(); ++k) {
+            if (k == best || !cands[k].buf.base) continue;
+            if (c->arena_keep_spares && held + cands[k].buf.cap <= free_at_start / 2) {
+                held += cands[k].buf.cap;
+                c->arena_spares.push_back(cands[k].buf);
+                cands[k].buf.base = nullptr; cands[k].buf.p = nullptr; cands[k].buf.cap = 0;  // (ownership moved)
+            }
+        }
+    }
+    cands.keep = best;  // (what is left is released when `cands` goes out of scope)
+    if (arena.base) {  // the old, too small arena of a recycled pool
+        arena.release();
+    }
     const bool p2 = arena.pow2_large;
     const uint64_t g = arena.gen;
     arena = cands[best].buf;
@@ -2255,6 +2322,16 @@ extern "C" void rhip_debug_set_arena_round(rhip_ctx_t* c, unsigned long long byt
 extern "C" unsigned long long rhip_debug_pool_arena(rhip_pool_t* P) { return (unsigned long long)(uintptr_t)P->arena.p; }
 // probe rates (GB/s) of the candidates of the context's last measured arena placement, in allocation order; returns
 // how many there were (0: no placement has happened)
+// releases the spare result arenas a context keeps from its placement searches; returns the bytes released
+extern "C" unsigned long long rhip_ctx_trim(rhip_ctx_t* c) {
+    if (!c) return 0;
+    DeviceGuard guard(c->device);
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    unsigned long long n = 0;
+    for (DBuf& b : c->arena_spares) { n += b.cap; b.release(); }
+    c->arena_spares.clear();
+    return n;
+}
 // batches of this context that a flag join gave up on and that were finished through the fallback (rhip_pairwise_end)
 extern "C" unsigned long long rhip_debug_join_recovered(rhip_ctx_t* c) { return c ? (unsigned long long)c->join_recovered : 0ull; }
 extern "C" int rhip_debug_last_placement(rhip_ctx_t* c, float* out, int capacity) {

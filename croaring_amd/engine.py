@@ -83,6 +83,10 @@ class Engine:
         self.lib.rhip_debug_host_clock(self.h, out, 1 if reset else 0)
         return list(out)
 
+    def trim(self) -> int:
+        """Release the spare result arenas kept from placement searches (rhip_ctx_trim); bytes released."""
+        return int(self.lib.rhip_ctx_trim(self.h))
+
     def join_recovered(self) -> int:
         """Batches of this context whose flag join gave up and that were finished through the event fallback."""
         return int(self.lib.rhip_debug_join_recovered(self.h))

@@ -174,7 +174,11 @@ rhip_pool_t *rhip_pairwise(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *A, rhip_poo
  * pool and keeps the fastest (which physical pages an arena gets moves that kernel by up to 17 %).  This is
  * the one place where rhip_pairwise_begin WAITS for the device -- tens of milliseconds, once per new result pool -- and
  * its candidates stay allocated until the choice is made: the search stops when they reach half of the device memory
- * that was free when it began (so a crowded device gets fewer candidates, not an out-of-memory error).  A pool handed back through `reuse` keeps its arena and its placement:
+ * that was free when it began (so a crowded device gets fewer candidates, not an out-of-memory error).  The losers are
+ * KEPT by the context as spare arenas -- the next search probes them first, and memory that is never freed never has to
+ * be scrubbed by the driver (ten allocations out of just-freed memory cost 3 s) -- until rhip_ctx_trim or
+ * rhip_ctx_destroy, or until any allocation of this library fails (it then releases every spare and retries);
+ * RHIP_ARENA_SPARES=0 releases them at once instead.  A pool handed back through `reuse` keeps its arena and its placement:
  * steady-state callers never meet the search.  RHIP_ARENA_TRIES=0 (environment, read by rhip_ctx_create) turns it off. */
 #define RHIP_MAX_BATCHES_IN_FLIGHT 4
 typedef struct rhip_batch_s rhip_batch_t;
@@ -382,6 +386,9 @@ int rhip_debug_last_placement(rhip_ctx_t *ctx, float *out_gbps, int capacity);
  * fallback: the auxiliary streams waited for the ordinary way, the tail run again.  Such a batch returns the same result
  * as any other; the reference's functions cannot fail for scheduling reasons (roaring.h:102-113) and neither do these. */
 unsigned long long rhip_debug_join_recovered(rhip_ctx_t *ctx);
+/* Releases the spare result arenas the context keeps from its placement searches (see rhip_pairwise_begin); returns the
+ * bytes released.  Pools and batches are untouched. */
+unsigned long long rhip_ctx_trim(rhip_ctx_t *ctx);
 
 #ifdef __cplusplus
 }
