@@ -10,7 +10,7 @@ Headline workload (BASELINE.json configs[1], made concrete in SURVEY.md §8d "C2
 256 bitmaps x 4096 bitset containers (8 GiB, words = splitmix64 stream, density 0.5) and the pair schedule
 k -> (k mod 256, (97 k + 1) mod 256).  One STEP = `--rounds` x (one batched roaring_bitmap_and call + one batched
 roaring_bitmap_or call over `--pairs` bitmap pairs each): default 6 x (250 + 250) = 3000 set-ops, so the default
-20 steps time > 1 s.  A step runs the whole hot path: key merge / planning, the bitset x bitset kernel, result
+24 steps time > 1 s (49 ms per step).  A step runs the whole hot path: key merge / planning, the bitset x bitset kernel, result
 typing, directory compaction.  Inputs are resident in HBM before the timed region; results are materialised in HBM
 (result pools are recycled between calls: 60 000 x 32 MiB of distinct outputs cannot exist at once).
 N > 1: every rank runs the same schedule on its own pool (pairwise ops shard with no data-path collective,
@@ -64,7 +64,7 @@ CHECKSUMS = {
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--arena-tries", type=int, default=0,
                     help="diagnostic: caller-side start-up allocations of result pools, the two fastest kept (Engine.pairwise_placed). "
