@@ -416,7 +416,21 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIPCHK(hipHostMalloc(&c->h_pinned, 4096, hipHostMallocDefault));
         for (auto& es : c->evs) for (auto& e : es) HIPCHK(hipEventCreate(&e));
-        for (auto& a : c->aux) HIPCHK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+        {
+            // One auxiliary stream is created at the device's highest priority: aux2, which under andnot (and in multi-op
+            // batches) carries k_union_g beside the main stream's machine-filling k_filter_g -- launched a fork later, its
+            // workgroups otherwise only get what the filter leaves.  Measured round 5 (five alternating runs, one box):
+            // weather andnot 0.358-0.365 -> 0.333-0.335 ms, census-income or 0.264-0.270 -> 0.247-0.252, everything else
+            // within noise; aux1 instead (k_usmall under or / xor): weather or 0.55 -> 0.62 -- the main stream's k_union_g is
+            // that batch's critical kernel.  RHIP_AUX_PRIO=<index> picks another stream, -1 none.
+            int hi_aux = 2, least = 0, greatest = 0;
+            if (const char* e = getenv("RHIP_AUX_PRIO")) hi_aux = atoi(e);
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            for (int k = 0; k < rhip_ctx_s::N_AUX; ++k) {
+                if (k == hi_aux) HIPCHK(hipStreamCreateWithPriority(&c->aux[k], hipStreamNonBlocking, greatest));
+                else HIPCHK(hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
+            }
+        }
         HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_runs, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_ba, hipEventDisableTiming));
