@@ -33,16 +33,8 @@ struct IvlShape {
     static constexpr uint32_t NG = 64 / G;                        // pairs per wave
     static constexpr uint32_t NB = 2 * MAXIV + 2;                 // >= result runs: (boundaries of both lists) / 2
     static constexpr uint32_t LBYTES = (4 * MAXIV + 15) & ~15u;   // staged payload of one operand, 16-byte padded
-    // The groups of a wave walk their lists in lockstep: lane l of every group reads around the same list index at the
-    // same time.  With the natural strides (512 / 1 024 bytes = a multiple of the 32 banks x 4 bytes) those reads --
-    // and the lanes' run-table slices -- all fall into ONE bank: an 8-way (G = 8) / 4-way (G = 16) conflict on every
-    // step of the walk (profiles/r05_pmc_c5_sq.md: 55 % of k_ivl_all's LDS cycles were conflict cycles).  16 bytes
-    // between the groups' regions put them four banks apart.
-    static constexpr uint32_t GPAD = NG >= 4 ? 16u : 0u;
-    static constexpr uint32_t GLIST = 2 * LBYTES + GPAD;          // a group's two lists
-    static constexpr uint32_t GRSE = 2 * NB * 2 + GPAD;           // a group's run table (bytes)
-    static constexpr uint32_t LIST_BYTES = 4 * NG * GLIST;        // per block
-    static constexpr uint32_t RSE_BYTES = 4 * NG * GRSE;
+    static constexpr uint32_t LIST_BYTES = 4 * NG * 2 * LBYTES;   // per block
+    static constexpr uint32_t RSE_BYTES = 4 * NG * 2 * NB * 2;
     static constexpr uint32_t LDS_BYTES = LIST_BYTES + RSE_BYTES;
 };
 // One item of a group: both lists staged at lsA (list A, then list B HALF u16 slots later), run table at RSE.
@@ -255,11 +247,11 @@ __device__ __forceinline__ void ivl_body(uint8_t* lds, uint32_t bid, uint32_t nb
                                          const GenItem* __restrict__ q, const u64* __restrict__ qrange, int kop,
                                          int cardmode, u64* pair_acc, GenItem* retry_q, uint32_t* retry_count) {
     using SH = IvlShape<G, MAXIV>;
-    constexpr uint32_t NG = SH::NG, LBYTES = SH::LBYTES;
+    constexpr uint32_t NG = SH::NG, NB = SH::NB, LBYTES = SH::LBYTES;
     const Grp<G> gr;
     const uint32_t gslot = threadIdx.x / G;
-    uint8_t* lsA = lds + (size_t)gslot * SH::GLIST;   // this group's two lists, then (after all lists) its run table
-    uint16_t* RSE = (uint16_t*)(lds + SH::LIST_BYTES + (size_t)gslot * SH::GRSE);
+    uint8_t* lsA = lds + (size_t)gslot * 2 * LBYTES;   // this group's two lists, then (after all lists) its run table
+    uint16_t* RSE = (uint16_t*)(lds + SH::LIST_BYTES) + (size_t)gslot * 2 * NB;
     const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
     uint32_t wi = (bid * blockDim.x + threadIdx.x) >> 6;
