@@ -61,6 +61,8 @@ SYMBOLS = [
     ("rhip_pool_containers", _u64, [_vp]),
     ("rhip_pool_is64", _i, [_vp]),
     ("rhip_pool_payload_bytes", _u64, [_vp]),
+    ("rhip_pool_arena_bytes", _u64, [_vp]),
+    ("rhip_pool_payload_align", _u32, [_vp]),
     ("rhip_pool_type_counts", _i, [_vp, _vp]),
     ("rhip_pool_portable_size", _sz, [_vp, _u32]),
     ("rhip_pool_portable_serialize", _sz, [_vp, _u32, _vp]),

@@ -20,7 +20,8 @@ struct DesOut {   // directory under construction (fill pass only)
     uint32_t* card;
     uint32_t* nruns;
     u64* src;        // absolute blob offset of the payload (after the n_runs prefix of run containers)
-    uint32_t* slot;  // align16(payload bytes)
+    uint32_t* slot;  // payload bytes rounded up to the pool's slot granule (amask + 1 = 16 or 128)
+    uint32_t amask;
 };
 
 // Walk one 32-bit image at blob[p, end): returns its size in bytes, 0 if malformed.  Executed by a whole wave
@@ -132,7 +133,7 @@ __device__ u64 des_walk32(const uint8_t* __restrict__ blob, u64 p, u64 end, u64 
             D.card[c] = isrun ? 0u : card;  // run cardinalities come from the payload pass
             D.nruns[c] = nr;
             D.src[c] = isrun ? pos + 2 : pos;
-            D.slot[c] = align16(isrun ? 4u * nr : sz);
+            D.slot[c] = ((isrun ? 4u * nr : sz) + D.amask) & ~D.amask;
         }
         run_base += __shfl(inc, 63);
     }

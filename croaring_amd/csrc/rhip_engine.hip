@@ -238,6 +238,7 @@ struct rhip_ctx_s {
     uint64_t many_slots = 1024;  // RHIP_MANY_SLOTS: pieces of a large call = workgroups of k_many_l1 resident at once (4 per CU)
     uint64_t many_t = 0;         // RHIP_MANY_T: members per workgroup of k_many_hist / k_many_scatter; 0 = one workgroup per CU
     int many_reverse = 0;        // RHIP_MANY_REVERSE (tests): k_many_scatter fills its reservations backwards
+    uint32_t pool_align = 0;     // RHIP_POOL_ALIGN: slot granule of loaded pools, 16 / 128; 0 = by the images' average size (choose_pay_align)
     static constexpr size_t PINNED_MANY_FLAG_OFF = 2304, PINNED_MANY_TOT_OFF = 2560, PINNED_MANY_ERR_OFF = 2816;
     DBuf sel[5];  // pool_select / pool_convert scratch
     void* h_pinned = nullptr;  // small pinned readback area
@@ -301,6 +302,7 @@ struct rhip_pool_s {
     bool is64 = false;
     DBuf bm_start, key, type, card, nruns, off, arena;
     uint64_t arena_used = 0;
+    uint32_t pay_align = 16;    // slot granule the loader / rhip_pool_select used (16, or 128 = whole cache lines); spliced results keep 16
     bool pending = false;       // result of a batch that has begun and not ended: not usable yet
     int in_use = 0;             // batches in flight that read this pool as an operand: not recyclable yet
     bool free_deferred = false; // rhip_pool_free arrived while in_use / pinned: the last batch to end (or list to go) frees it
@@ -465,6 +467,7 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_MANY_SLOTS")) c->many_slots = (uint64_t)std::max(1, atoi(e));
         if (const char* e = getenv("RHIP_MANY_T")) c->many_t = (uint64_t)std::max(1024, atoi(e));
         if (const char* e = getenv("RHIP_MANY_REVERSE")) c->many_reverse = atoi(e);
+        if (const char* e = getenv("RHIP_POOL_ALIGN")) c->pool_align = atoi(e) == 128 ? 128 : (atoi(e) == 16 ? 16 : 0);
         memset(c->h_pinned, 0, 4096);
         if (c->spin_join && !spin_join_forced) {
             // do kernels of two streams overlap here?  (k_conc_probe: bounded wait on the main stream for a flag that a
@@ -864,6 +867,8 @@ extern "C" uint64_t rhip_pool_payload_bytes(rhip_pool_t* P) {
         return o[0];
     } catch (int) { return 0; }
 }
+extern "C" uint64_t rhip_pool_arena_bytes(const rhip_pool_t* P) { return P ? P->arena_used : 0; }
+extern "C" uint32_t rhip_pool_payload_align(const rhip_pool_t* P) { return P ? P->pay_align : 0; }
 extern "C" int rhip_pool_type_counts(rhip_pool_t* P, uint64_t out[3]) {
     try {
         DeviceGuard dguard_(P->ctx->device);

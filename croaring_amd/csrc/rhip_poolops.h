@@ -12,6 +12,7 @@
 // (align16(payload)) and records where the payload lives.
 struct SelSrc {
     const uint8_t* p;   // payload address in the source arena
+    u64 n16;            // 16-byte pieces to copy (the slot may be wider: line-aligned pools)
 };
 __global__ __launch_bounds__(256) void k_select_dir(const PoolView* __restrict__ srcs,
                                                     const uint32_t* __restrict__ src_pool,
@@ -19,7 +20,8 @@ __global__ __launch_bounds__(256) void k_select_dir(const PoolView* __restrict__
                                                     const u64* __restrict__ out_bm_start, uint32_t n_bitmaps, u64 n_out,
                                                     u64* __restrict__ okey, uint8_t* __restrict__ otype,
                                                     uint32_t* __restrict__ ocard, uint32_t* __restrict__ onruns,
-                                                    uint32_t* __restrict__ slot, SelSrc* __restrict__ from) {
+                                                    uint32_t* __restrict__ slot, SelSrc* __restrict__ from,
+                                                    uint32_t amask) {
     const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_out) return;
     // bitmap of output container j: last i with out_bm_start[i] <= j
@@ -37,8 +39,10 @@ __global__ __launch_bounds__(256) void k_select_dir(const PoolView* __restrict__
     otype[j] = t;
     ocard[j] = cd;
     onruns[j] = nr;
-    slot[j] = align16(payload_bytes(t, cd, nr));
+    const uint32_t pb = align16(payload_bytes(t, cd, nr));
+    slot[j] = (pb + amask) & ~amask;
     from[j].p = V.arena + V.off[c];
+    from[j].n16 = pb >> 4;
 }
 
 // Directory-only form for the in-place entry points: output container j takes its directory entry from its source
@@ -69,8 +73,8 @@ __global__ __launch_bounds__(256) void k_splice_dir(const PoolView* __restrict__
     ooff[j] = V.off[c] + off_add[sp];
 }
 
-// One wave per container: slot bytes (a multiple of 16) in 16-byte pieces, 64 lanes wide.
-__global__ __launch_bounds__(256) void k_select_copy(const SelSrc* __restrict__ from, const uint32_t* __restrict__ slot,
+// One wave per container: the payload in 16-byte pieces, 64 lanes wide.
+__global__ __launch_bounds__(256) void k_select_copy(const SelSrc* __restrict__ from,
                                                      const u64* __restrict__ off, uint8_t* __restrict__ arena,
                                                      u64 n_out) {
     const uint32_t lane = lane_id();
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256) void k_select_copy(const SelSrc* __restrict__ 
     for (u64 w = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n_out; w += nwaves) {
         const uint4* __restrict__ s = (const uint4*)from[w].p;
         uint4* __restrict__ d = (uint4*)(arena + off[w]);
-        const uint32_t n16 = slot[w] >> 4;
+        const uint32_t n16 = (uint32_t)from[w].n16;
         for (uint32_t i = lane; i < n16; i += 64) d[i] = s[i];
     }
 }

@@ -595,6 +595,15 @@ class Pool:
     def payload_bytes(self) -> int:
         return self.eng.lib.rhip_pool_payload_bytes(self.h)
 
+    def arena_bytes(self) -> int:
+        """HBM bytes of the payload arena, padding included (payload_bytes() is the algorithmic figure)."""
+        return self.eng.lib.rhip_pool_arena_bytes(self.h)
+
+    @property
+    def payload_align(self) -> int:
+        """Slot granule the loader chose: 16, or 128 (whole cache lines; RHIP_POOL_ALIGN pins it)."""
+        return self.eng.lib.rhip_pool_payload_align(self.h)
+
     def type_counts(self) -> tuple:
         out = (C.c_uint64 * 3)()
         if self.eng.lib.rhip_pool_type_counts(self.h, out) != 0:

@@ -122,6 +122,12 @@ int rhip_pool_is64(const rhip_pool_t *pool);
 int rhip_pool_max_key(rhip_pool_t *pool, uint64_t *out);
 /* payload bytes (bitset 8192, array 2*card, run 4*n_runs) of all containers */
 uint64_t rhip_pool_payload_bytes(rhip_pool_t *pool);
+/* bytes of HBM the pool's payload arena occupies (padding included), and the slot granule its loader chose: 16, or 128
+ * (whole cache lines) when the images average 256 bytes per container or more -- RHIP_POOL_ALIGN=16|128 pins it.  The
+ * many-way gather reads ~512-byte members at random offsets: line-aligned slots cost ~12 % more arena and save the
+ * 7/8 of a line an unaligned member straddles. */
+uint64_t rhip_pool_arena_bytes(const rhip_pool_t *pool);
+uint32_t rhip_pool_payload_align(const rhip_pool_t *pool);
 /* per-type container counts out[0]=bitset out[1]=array out[2]=run */
 int rhip_pool_type_counts(rhip_pool_t *pool, uint64_t out[3]);
 

@@ -144,6 +144,14 @@ def test_emu_device_deserialization(emu, oracle):
     GP.test_device_deserialization_fuzz_64bit(emu, oracle)
 
 
+def test_emu_payload_layout_16_vs_lines(oracle, monkeypatch):
+    from emu import build_emu, emu_engine
+    if not __import__("os").path.exists(build_emu.CXX):
+        pytest.skip("hipemu needs the ROCm clang++ to compile the kernels for the host")
+    import test_gpu_poolops as GP
+    GP.payload_layout_body(emu_engine, oracle, monkeypatch)
+
+
 def test_emu_flip(emu, oracle):
     import test_gpu_poolops as GP
     GP.test_flip(emu, oracle)

@@ -695,3 +695,67 @@ def test_device_deserialization_fuzz_64bit(engine, oracle):
         else:
             rejected += 1
     assert accepted > 10 and rejected > 50, (accepted, rejected)
+
+
+def payload_layout_body(make_engine, oracle, monkeypatch):
+    """The slot granule of a loaded pool is a layout choice, not a format: the same images loaded with 16-byte slots
+    and with whole 128-byte lines (RHIP_POOL_ALIGN; by default lines when the images average >= 256 bytes per
+    container) serialize back to the input, give the same pairwise / many-way / select / in-place results, and the
+    algorithmic payload figure does not count the padding."""
+    import croaring_amd
+    from util import load_bundle
+    n = 300
+    blob, offs = croaring_amd.synth_sparse_portable(0, 1, n)           # C4's ~512-byte arrays: lines by default
+    sparse = [bytes(blob[int(offs[i]):int(offs[i + 1])]) for i in range(n)]
+    fams = {"sparse": sparse, "wikileaks": load_bundle("wikileaks-noquotes")[:120], "weather": load_bundle("weather_sept_85")[:40]}
+    want_default = {"sparse": 128, "wikileaks": 16, "weather": 128}
+    out = {}
+    for align in ("16", "128", None):
+        if align is None:
+            monkeypatch.delenv("RHIP_POOL_ALIGN", raising=False)
+        else:
+            monkeypatch.setenv("RHIP_POOL_ALIGN", align)
+        eng = make_engine()
+        try:
+            for name, bufs in fams.items():
+                b, o = _pack(bufs)
+                P = eng.pool_from_blob(b, o)
+                assert P.payload_align == (int(align) if align else want_default[name]), (name, align)
+                assert P.serialize_all() == bufs, (name, align)
+                k = len(bufs) - 1
+                lhs, rhs = np.arange(k, dtype=np.uint32), np.arange(1, k + 1, dtype=np.uint32)
+                res = {op: eng.pairwise(op, P, lhs, P, rhs).serialize_all() for op in OPS}
+                res["or_many"] = eng.or_many(P).serialize(0)
+                res["xor_many"] = eng.xor_many(P).serialize(0)
+                sel = eng.pool_select([P], np.zeros(k // 2, np.uint32), np.arange(0, 2 * (k // 2), 2, dtype=np.uint32))
+                assert sel.payload_align == P.payload_align
+                res["select"] = sel.serialize_all()
+                res["or_many_sel"] = eng.or_many(sel).serialize(0)
+                eng.pairwise_inplace("or", sel, np.arange(4, dtype=np.uint32), P, np.arange(7, 11, dtype=np.uint32))
+                res["inplace"] = sel.serialize_all()
+                res["payload"] = P.payload_bytes()
+                res["arena"] = P.arena_bytes()
+                assert res["arena"] >= res["payload"]
+                out[(name, align)] = res
+        finally:
+            eng.close()
+    for name in fams:
+        a, b, d = out[(name, "16")], out[(name, "128")], out[(name, None)]
+        for k in a:
+            if k != "arena":
+                assert a[k] == b[k] == d[k], (name, k)
+        assert b["arena"] >= a["arena"]
+    # the price of the lines on C4-shaped members: an eighth more arena, not a quarter
+    assert out[("sparse", "128")]["arena"] <= 1.2 * out[("sparse", "16")]["arena"]
+    hs = [oracle.deserialize(x) for x in sparse]
+    want = oracle.or_many(hs)
+    assert out[("sparse", None)]["or_many"] == oracle.serialize(want)
+    oracle.free(want)
+    for h in hs:
+        oracle.free(h)
+
+
+def test_payload_layout_16_vs_lines(oracle, monkeypatch):
+    import torch  # noqa: F401
+    import croaring_amd
+    payload_layout_body(lambda: croaring_amd.Engine(), oracle, monkeypatch)
