@@ -69,6 +69,9 @@ SYMBOLS = [
     ("rhip_pool_cardinalities", _i, [_vp, _vp]),
     ("rhip_pool_portable_sizes", _i, [_vp, _sz, _vp, _vp]),
     ("rhip_pool_portable_serialize_many", _sz, [_vp, _sz, _vp, _vp, _sz, _vp]),
+    ("rhip_pool_from_frozen", _vp, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    ("rhip_pool_frozen_sizes", _i, [_vp, _sz, _vp, _vp, _vp]),
+    ("rhip_pool_frozen_serialize_many", _sz, [_vp, _sz, _vp, _vp, _sz, _vp, _vp]),
     ("rhip_pairwise", _vp, [_vp, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     ("rhip_pairwise_begin", _vp, [_vp, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     ("rhip_pairwise_end", _vp, [_vp]),

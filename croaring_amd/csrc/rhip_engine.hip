@@ -23,6 +23,7 @@
 #include "rhip_poolops.h"
 #include "rhip_serial.h"
 #include "rhip_deser.h"
+#include "rhip_frozen.h"
 #include "rhip_values.h"
 #include "rhip_flip.h"
 #include "rhip_prims.h"

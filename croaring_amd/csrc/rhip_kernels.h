@@ -3,7 +3,8 @@
 // Data layout in HBM: a pool is a structure-of-arrays container DIRECTORY
 // (key, type, card, nruns, byte offset; containers sorted by (bitmap, key)) plus one payload
 // ARENA.  Every payload starts 16-byte aligned and is padded to a multiple of 16 bytes, so
-// every kernel moves payload as 16 B/lane (1 KiB per wave instruction, fully coalesced).
+// every kernel moves payload as 16 B/lane (1 KiB per wave instruction, fully coalesced); a loaded
+// pool of larger containers pads to whole 128-byte lines instead (rhip_pool_payload_align).
 // A bitset container is 1024 contiguous u64 words = 8 wave-wide 16-byte loads.
 //
 // Kernel inventory (one per SURVEY §2.2 row it replaces; DESIGN.md §2 / §4 have the pipeline and the table):
@@ -35,6 +36,7 @@
 //                      (measured placement of large result arenas)
 //   k_many_*           group-by-key OR/XOR accumulation for or_many / xor_many
 //   k_compact          directory compaction of the flip / many-way paths
+//   k_des_* / k_ser_* / k_frz_*   portable and frozen images parsed / assembled on the device (rhip_deser.h, rhip_serial.h, rhip_frozen.h)
 #pragma once
 #include "rhip_common.h"
 #include "rhip_plan.h"

@@ -161,6 +161,20 @@ class Engine:
             raise RoaringHipError("deserialize failed: " + self._err())
         return Pool(self, h)
 
+    def pool_from_frozen(self, blob, offsets, lens) -> "Pool":
+        """n FROZEN images (roaring_bitmap_frozen_serialize) in one uint8 array, image i = blob[offsets[i] : offsets[i] +
+        lens[i]] -- e.g. the output of Pool.frozen_serialize_many: ONE upload, parsed and validated on the device."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        lens = np.ascontiguousarray(lens, dtype=np.uint64)
+        offsets = np.ascontiguousarray(np.asarray(offsets, dtype=np.uint64)[:lens.size])
+        if offsets.shape != lens.shape:
+            raise ValueError("offsets/lens length mismatch")
+        h = self.lib.rhip_pool_from_frozen(self.h, blob.ctypes.data, blob.size, offsets.size, offsets.ctypes.data,
+                                           lens.ctypes.data)
+        if not h:
+            raise RoaringHipError("frozen load failed: " + self._err())
+        return Pool(self, h)
+
     def pool_from_values(self, lists: Sequence, is64: bool = False) -> "Pool":
         """roaring_bitmap_of_ptr for every list, on the device; each list sorted and free of duplicates."""
         dt = np.uint64 if is64 else np.uint32
@@ -663,6 +677,29 @@ class Pool:
             if w != blob.size:
                 raise RoaringHipError(f"serialize_many wrote {w} of {blob.size} bytes: " + self.eng._err())
         return blob, offs
+
+    def frozen_serialize_many(self, ids=None):
+        """Frozen images of bitmaps `ids` (None: all), packed at 32-byte aligned offsets: (uint8 blob, uint64
+        offsets[n+1], uint64 lens[n]); image k = blob[offsets[k] : offsets[k] + lens[k]], byte-identical to
+        roaring_bitmap_frozen_serialize.  32-bit pools only."""
+        ids_a = None if ids is None else _u32(ids)
+        n = len(self) if ids_a is None else ids_a.size
+        ip = None if ids_a is None else ids_a.ctypes.data
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        lens = np.zeros(max(n, 1), dtype=np.uint64)
+        if self.eng.lib.rhip_pool_frozen_sizes(self.h, n, ip, offs.ctypes.data, lens.ctypes.data) != 0:
+            raise RoaringHipError("frozen_sizes failed: " + self.eng._err())
+        blob = np.empty(int(offs[n]), dtype=np.uint8)
+        if n and int(offs[n]):
+            w = self.eng.lib.rhip_pool_frozen_serialize_many(self.h, n, ip, blob.ctypes.data, blob.size, None, None)
+            if w != blob.size:
+                raise RoaringHipError(f"frozen_serialize_many wrote {w} of {blob.size} bytes: " + self.eng._err())
+        return blob, offs, lens[:n]
+
+    def frozen_serialize_all(self) -> list:
+        blob, offs, lens = self.frozen_serialize_many()
+        raw = blob.tobytes()
+        return [raw[int(offs[i]):int(offs[i]) + int(lens[i])] for i in range(len(self))]
 
     def serialize_all(self) -> list:
         blob, offs = self.serialize_many()

@@ -91,6 +91,15 @@ rhip_pool_t *rhip_pool_from_portable64(rhip_ctx_t *ctx, size_t n, const char *co
  * do.  is64 != 0: the images are roaring64 portable images. */
 rhip_pool_t *rhip_pool_from_blob(rhip_ctx_t *ctx, const char *blob, size_t blob_bytes, size_t n,
                                  const uint64_t *offsets, const uint64_t *lens, int is64);
+/* The FROZEN format (include/roaring/roaring.h:815-860, layout src/roaring.c:3176-3205): n images in one host blob,
+ * parsed and moved into place by kernels like the loader above.  roaring_bitmap_frozen_view (src/roaring.c:3330-3457)
+ * points INTO a 32-byte aligned buffer; a device pool is a copy, so neither the blob nor the offsets need any alignment.
+ * Accepted: what frozen_view accepts (cookie 13766, typecodes 1..3, length exactly zones + 5 n + 4) and
+ * roaring_bitmap_internal_validate passes -- the view does not validate its input, a pool must hold valid containers:
+ * unsorted keys, an array above 4096 values, a bitset of 4096 or fewer, zero runs, or a bad payload give
+ * RHIP_ERR_FORMAT.  32-bit pools only. */
+rhip_pool_t *rhip_pool_from_frozen(rhip_ctx_t *ctx, const char *blob, size_t blob_bytes, size_t n,
+                                   const uint64_t *offsets, const uint64_t *lens);
 /* roaring_bitmap_of_ptr (roaring.h:88, src/roaring.c:195-199) / roaring64_bitmap_of_ptr (roaring64.h:92) for n
  * bitmaps at once, built on the device: bitmap i = values[offsets[i] .. offsets[i+1]) (offsets[0] = 0), STRICTLY
  * INCREASING inside a bitmap (anything else is rejected -- sort and deduplicate first).  Containers come out as the
@@ -147,6 +156,15 @@ int rhip_pool_cardinalities(rhip_pool_t *pool, uint64_t *out /* [rhip_pool_size]
 int rhip_pool_portable_sizes(rhip_pool_t *pool, size_t n, const uint32_t *ids, uint64_t *offsets);
 size_t rhip_pool_portable_serialize_many(rhip_pool_t *pool, size_t n, const uint32_t *ids, char *buf, size_t cap,
                                          uint64_t *offsets);
+/* roaring_bitmap_frozen_size_in_bytes / roaring_bitmap_frozen_serialize (roaring.h:829-846, src/roaring.c:3207-3328) for
+ * pool[ids[0..n)] (ids == NULL: every bitmap; 32-bit pools only), assembled on the device and downloaded in one copy.
+ * The images are packed at 32-BYTE ALIGNED offsets -- what roaring_bitmap_frozen_view requires of its buffer, so a host
+ * that places the blob at a 32-byte aligned address can view every image in place; the gaps are zero.
+ * offsets[k] = start of image k, offsets[n_sel] = bytes of the packed blob; lens[k] (may be NULL) = exact length of
+ * image k = roaring_bitmap_frozen_size_in_bytes.  Each image is byte-identical to the reference's. */
+int rhip_pool_frozen_sizes(rhip_pool_t *pool, size_t n, const uint32_t *ids, uint64_t *offsets, uint64_t *lens);
+size_t rhip_pool_frozen_serialize_many(rhip_pool_t *pool, size_t n, const uint32_t *ids, char *buf, size_t cap,
+                                       uint64_t *offsets, uint64_t *lens);
 /* roaring_bitmap_to_uint32_array (roaring.h:571, src/roaring.c:1510-1512) / roaring64_bitmap_to_uint64_array
  * (roaring64.h:768) for the whole pool: the sorted values of bitmap 0, then bitmap 1, ...; offsets (n+1 entries,
  * may be NULL) receives where each bitmap starts.  out == NULL: offsets only.  capacity is in values. */

@@ -19,6 +19,9 @@ Outputs (committed; the GPU box cannot see /root/reference):
   tests/golden/c4x10_or_many.npz    the C4 generator at 10^6 bitmaps (opt-in: `gen_golden.py c4x10`): cardinality / size / crc32
   tests/golden/c4_or_many.npz       BASELINE config C4: roaring_bitmap_or_many over the 100 000 seeded sparse bitmaps
                                     (cardinality, size, crc32 of the reference's result; crc32 of the inputs).
+  tests/golden/frozen.npz           (`gen_golden.py frozen`) size and crc32 of roaring_bitmap_frozen_serialize's image of every
+                                    bitmap of the four realdata bundles and of the seeded synthetic inputs
+  tests/golden/frozen_withruns.bin  the reference's frozen image of bitmapwithruns.bin (a verbatim reader fixture)
   tests/golden/synth_mixed.npz      crc32/size/cardinality of the reference's results on seeded synthetic
                                     bitmaps hitting every container-type pair and result-typing branch
                                     (inputs are regenerated from the seed; their crc32 is pinned too).
@@ -245,6 +248,46 @@ def c4x10_golden(R, n_bitmaps=1000000, chunk=50000):
     R.free(acc)
 
 
+def read_bundle(path):
+    raw = lzma.open(path, "rb").read()
+    n = struct.unpack_from("<I", raw, 4)[0]
+    out, p = [], 8
+    for _ in range(n):
+        ln = struct.unpack_from("<I", raw, p)[0]
+        out.append(raw[p + 4:p + 4 + ln])
+        p += 4 + ln
+    return out
+
+
+def frozen_golden(R):
+    """roaring_bitmap_frozen_serialize (src/roaring.c:3242-3328) of every realdata bitmap (inputs: the committed portable
+    bundles) and of the seeded synthetic inputs: size + crc32; one image verbatim."""
+    out = {}
+    for name in ("census1881", "weather_sept_85", "wikileaks-noquotes", "census-income"):
+        bufs = read_bundle(os.path.join(GOLD, f"{name}.rbnd.xz"))
+        crc, size = [], []
+        for b in bufs:
+            h = R.deserialize(b)
+            f = R.frozen_serialize(h)
+            crc.append(zlib.crc32(f)); size.append(len(f))
+            R.free(h)
+        out[f"{name}_crc"], out[f"{name}_size"] = crc, size
+    singles, _ = synth_inputs()
+    crc, size = [], []
+    for a, b in singles:
+        for v in (a, b):
+            h = R.from_sorted(v)
+            f = R.frozen_serialize(h)
+            crc.append(zlib.crc32(f)); size.append(len(f))
+            R.free(h)
+    out["synth_crc"], out["synth_size"] = crc, size
+    np.savez_compressed(os.path.join(GOLD, "frozen.npz"), **{k: np.array(v, dtype=np.uint32) for k, v in out.items()})
+    h = R.deserialize(open(os.path.join(GOLD, "bitmapwithruns.bin"), "rb").read())
+    open(os.path.join(GOLD, "frozen_withruns.bin"), "wb").write(R.frozen_serialize(h))
+    R.free(h)
+    print("  frozen:", {k: len(v) for k, v in out.items() if k.endswith("_crc")})
+
+
 def main():
     R = Ref()
     os.makedirs(GOLD, exist_ok=True)
@@ -259,9 +302,11 @@ def main():
         c5_golden(R)
     if "c4" in names:
         c4_golden(R)
+    if "frozen" in names:  # (reads the committed bundles: run after the datasets)
+        frozen_golden(R)
     if "c4x10" in names:  # (not in the default list: 10^6 bitmaps, a few minutes)
         c4x10_golden(R)
-    for name in [n for n in names if n not in ("synth", "c4", "c5", "c4x10")]:
+    for name in [n for n in names if n not in ("synth", "c4", "c5", "c4x10", "frozen")]:
         print(name)
         hs = load_text_dataset(R, name)
         write_bundle(os.path.join(GOLD, f"{name}.rbnd.xz"), [R.serialize(h) for h in hs])

@@ -41,6 +41,9 @@ class Oracle:
         L.oc_deserialize.restype = vp; L.oc_deserialize.argtypes = [C.c_char_p, sz]
         L.oc_size_in_bytes.restype = sz; L.oc_size_in_bytes.argtypes = [vp]
         L.oc_serialize.restype = sz; L.oc_serialize.argtypes = [vp, C.c_char_p]
+        L.oc_frozen_size_in_bytes.restype = sz; L.oc_frozen_size_in_bytes.argtypes = [vp]
+        L.oc_frozen_serialize.restype = sz; L.oc_frozen_serialize.argtypes = [vp, C.c_char_p]
+        L.oc_frozen_deserialize.restype = vp; L.oc_frozen_deserialize.argtypes = [C.c_char_p, sz]
         L.oc_op.restype = vp; L.oc_op.argtypes = [C.c_int, vp, vp]
         L.oc_get_cardinality.restype = u64; L.oc_get_cardinality.argtypes = [vp]
         L.oc_and_cardinality.restype = u64; L.oc_and_cardinality.argtypes = [vp, vp]
@@ -82,6 +85,16 @@ class Oracle:
         w = self.L.oc_serialize(h, out)
         assert w == n
         return out.raw
+
+    def frozen_serialize(self, h) -> bytes:
+        n = self.L.oc_frozen_size_in_bytes(h)
+        out = C.create_string_buffer(n)
+        assert self.L.oc_frozen_serialize(h, out) == n
+        return out.raw
+
+    def frozen_deserialize(self, buf: bytes):
+        """roaring_bitmap_frozen_view's acceptance, as a copy (None when the view would be NULL)."""
+        return self.L.oc_frozen_deserialize(buf, len(buf)) or None
 
     def from_sorted(self, vals, run_optimize=True):
         v = np.ascontiguousarray(vals, dtype=np.uint32)
@@ -197,6 +210,10 @@ class Ref:
         L.roaring_bitmap_portable_size_in_bytes.argtypes = [vp]
         L.roaring_bitmap_portable_serialize.restype = sz
         L.roaring_bitmap_portable_serialize.argtypes = [vp, C.c_char_p]
+        L.roaring_bitmap_frozen_size_in_bytes.restype = sz; L.roaring_bitmap_frozen_size_in_bytes.argtypes = [vp]
+        L.roaring_bitmap_frozen_serialize.restype = None; L.roaring_bitmap_frozen_serialize.argtypes = [vp, vp]
+        L.roaring_bitmap_frozen_view.restype = vp; L.roaring_bitmap_frozen_view.argtypes = [vp, sz]
+        L.roaring_bitmap_copy.restype = vp; L.roaring_bitmap_copy.argtypes = [vp]
         L.roaring_bitmap_get_cardinality.restype = u64; L.roaring_bitmap_get_cardinality.argtypes = [vp]
         L.roaring_bitmap_or_many.restype = vp; L.roaring_bitmap_or_many.argtypes = [sz, C.POINTER(vp)]
         L.roaring_bitmap_xor_many.restype = vp; L.roaring_bitmap_xor_many.argtypes = [sz, C.POINTER(vp)]
@@ -240,6 +257,25 @@ class Ref:
         out = C.create_string_buffer(n)
         assert self.L.roaring_bitmap_portable_serialize(h, out) == n
         return out.raw
+
+    def frozen_serialize(self, h) -> bytes:
+        n = self.L.roaring_bitmap_frozen_size_in_bytes(h)
+        out = C.create_string_buffer(n)
+        self.L.roaring_bitmap_frozen_serialize(h, C.addressof(out))
+        return out.raw
+
+    def frozen_deserialize(self, buf: bytes):
+        """roaring_bitmap_frozen_view on a 32-byte aligned copy of buf, then roaring_bitmap_copy (the view borrows the
+        buffer); None when the view is NULL."""
+        raw = np.zeros(len(buf) + 64, dtype=np.uint8)
+        o = (-raw.ctypes.data) % 32
+        raw[o:o + len(buf)] = np.frombuffer(buf, dtype=np.uint8)
+        v = self.L.roaring_bitmap_frozen_view(raw.ctypes.data + o, len(buf))
+        if not v:
+            return None
+        h = self.L.roaring_bitmap_copy(v)
+        self.L.roaring_bitmap_free(v)
+        return h
 
     def from_sorted(self, vals, run_optimize=True):
         # benchmarks/benchmark.cpp:1938-1942: of_ptr + run_optimize + shrink_to_fit

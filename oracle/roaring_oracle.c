@@ -944,6 +944,102 @@ oc_bitmap_t *oc_deserialize(const char *buf, size_t maxbytes) { /* ra_portable_d
     return b;
 }
 
+/* ----------------------------------------------------------- frozen format */
+/* The "frozen" serialization (roaring.c:3176-3205 describes the layout):
+ *   <bitset zone><run zone><array zone><keys u16 x n><counts u16 x n><typecodes u8 x n><header u32>
+ * zones = the payloads of all containers of one type, in container order; counts[i] = cardinality - 1 for
+ * bitset / array containers and n_runs for run containers; header = (n << 15) | FROZEN_COOKIE (13766,
+ * roaring.h / roaring.c FROZEN_COOKIE).  The image is read from its END (the header is the last word). */
+#define OC_FROZEN_COOKIE 13766u
+
+size_t oc_frozen_size_in_bytes(const oc_bitmap_t *b) { /* roaring_bitmap_frozen_size_in_bytes, roaring.c:3207-3234 */
+    size_t s = 0;
+    for (int i = 0; i < b->n; i++) s += c_payload(&b->c[i]);
+    return s + 5 * (size_t)b->n + 4;
+}
+
+size_t oc_frozen_serialize(const oc_bitmap_t *b, char *buf) { /* roaring_bitmap_frozen_serialize, roaring.c:3242-3328 */
+    size_t zone[4] = {0, 0, 0, 0}; /* bytes per typecode */
+    for (int i = 0; i < b->n; i++) zone[b->c[i].type] += c_payload(&b->c[i]);
+    char *at[4];
+    at[OC_BITSET] = buf;
+    at[OC_RUN] = buf + zone[OC_BITSET];
+    at[OC_ARRAY] = at[OC_RUN] + zone[OC_RUN];
+    char *keys = at[OC_ARRAY] + zone[OC_ARRAY];
+    char *counts = keys + 2 * (size_t)b->n;
+    char *types = counts + 2 * (size_t)b->n;
+    char *header = types + (size_t)b->n;
+    for (int i = 0; i < b->n; i++) {
+        const oc_container_t *c = &b->c[i];
+        size_t nb = c_payload(c);
+        memcpy(at[c->type], c->data, nb);
+        at[c->type] += nb;
+        uint16_t count;
+        if (c->type == OC_RUN) count = (uint16_t)c->nruns;
+        else if (c->type == OC_BITSET && c->card < 0) count = (uint16_t)(popcnt_words((const uint64_t *)c->data) - 1);
+        else count = (uint16_t)(c->card - 1);
+        memcpy(keys + 2 * (size_t)i, &b->keys[i], 2);
+        memcpy(counts + 2 * (size_t)i, &count, 2);
+        types[i] = (char)c->type;
+    }
+    uint32_t h = ((uint32_t)b->n << 15) | OC_FROZEN_COOKIE;
+    memcpy(header, &h, 4);
+    return (size_t)(header + 4 - buf);
+}
+
+/* roaring_bitmap_frozen_view, roaring.c:3330-3457, as a COPY: same acceptance -- cookie, typecodes in {1, 2, 3}, and
+ * length EXACTLY the sum of the zones, the three per-container arrays and the header -- except the 32-byte alignment
+ * of the buffer, which only the zero-copy view needs.  Like the view it does not look inside the payloads. */
+oc_bitmap_t *oc_frozen_deserialize(const char *buf, size_t length) {
+    if (length < 4) return NULL;
+    uint32_t h;
+    memcpy(&h, buf + length - 4, 4);
+    if ((h & 0x7FFF) != OC_FROZEN_COOKIE) return NULL;
+    size_t n = h >> 15;
+    if (length < 4 + 5 * n) return NULL;
+    const char *keys = buf + length - 4 - 5 * n, *counts = buf + length - 4 - 3 * n, *types = buf + length - 4 - n;
+    size_t zone[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < n; i++) {
+        uint16_t cnt;
+        memcpy(&cnt, counts + 2 * i, 2);
+        switch ((uint8_t)types[i]) {
+            case OC_BITSET: zone[OC_BITSET] += 8192; break;
+            case OC_RUN: zone[OC_RUN] += 4 * (size_t)cnt; break;
+            case OC_ARRAY: zone[OC_ARRAY] += 2 * ((size_t)cnt + 1); break;
+            default: return NULL;
+        }
+    }
+    if (length != zone[OC_BITSET] + zone[OC_RUN] + zone[OC_ARRAY] + 5 * n + 4) return NULL;
+    const char *at[4];
+    at[OC_BITSET] = buf;
+    at[OC_RUN] = buf + zone[OC_BITSET];
+    at[OC_ARRAY] = at[OC_RUN] + zone[OC_RUN];
+    oc_bitmap_t *b = oc_create();
+    for (size_t i = 0; i < n; i++) {
+        uint16_t cnt, key;
+        memcpy(&cnt, counts + 2 * i, 2);
+        memcpy(&key, keys + 2 * i, 2);
+        uint8_t t = (uint8_t)types[i];
+        if (t == OC_BITSET) {
+            uint64_t *w = words_new();
+            memcpy(w, at[t], 8192);
+            at[t] += 8192;
+            bm_push(b, key, mk_bitset(w, (int)cnt + 1));
+        } else if (t == OC_RUN) {
+            uint16_t *r = (uint16_t *)malloc(4 * ((size_t)cnt + 1));
+            memcpy(r, at[t], 4 * (size_t)cnt);
+            at[t] += 4 * (size_t)cnt;
+            bm_push(b, key, mk_run(r, cnt));
+        } else {
+            uint16_t *a = (uint16_t *)malloc(2 * ((size_t)cnt + 1));
+            memcpy(a, at[t], 2 * ((size_t)cnt + 1));
+            at[t] += 2 * ((size_t)cnt + 1);
+            bm_push(b, key, mk_array(a, (int)cnt + 1));
+        }
+    }
+    return b;
+}
+
 /* ----------------------------------------------------------- pairwise */
 /* roaring_bitmap_and (roaring.c:731-770), _or (:877-953), _xor (:1121-1196),
  * _andnot (:1275-1338): two-pointer merge over the key arrays; matched keys go

@@ -77,6 +77,11 @@ oc_bitmap_t *oc_deserialize(const char *buf, size_t maxbytes);
 size_t oc_size_in_bytes(const oc_bitmap_t *b);
 size_t oc_serialize(const oc_bitmap_t *b, char *buf);
 
+/* ---- frozen format, roaring.c:3176-3457 (frozen_view restated as a copy: no alignment requirement) ---- */
+size_t oc_frozen_size_in_bytes(const oc_bitmap_t *b);
+size_t oc_frozen_serialize(const oc_bitmap_t *b, char *buf);
+oc_bitmap_t *oc_frozen_deserialize(const char *buf, size_t length);
+
 /* ---- hot path ---- */
 oc_bitmap_t *oc_op(int op, const oc_bitmap_t *a, const oc_bitmap_t *b);
 oc_bitmap_t *oc_and(const oc_bitmap_t *a, const oc_bitmap_t *b);

@@ -152,6 +152,11 @@ def test_emu_payload_layout_16_vs_lines(oracle, monkeypatch):
     GP.payload_layout_body(emu_engine, oracle, monkeypatch)
 
 
+def test_emu_frozen_format(emu, oracle):
+    import test_gpu_poolops as GP
+    GP.frozen_body(emu, oracle)
+
+
 def test_emu_flip(emu, oracle):
     import test_gpu_poolops as GP
     GP.test_flip(emu, oracle)

@@ -759,3 +759,85 @@ def test_payload_layout_16_vs_lines(oracle, monkeypatch):
     import torch  # noqa: F401
     import croaring_amd
     payload_layout_body(lambda: croaring_amd.Engine(), oracle, monkeypatch)
+
+
+def frozen_body(eng, oracle):
+    """The frozen format through the C ABI (rhip_pool_frozen_sizes / _serialize_many / rhip_pool_from_frozen): every image
+    has the size and crc32 of roaring_bitmap_frozen_serialize's (tests/golden/frozen.npz, made by the reference), images
+    sit at 32-byte aligned offsets, the packed blob loads back into a pool that serializes to the inputs, the
+    reference's own image (frozen_withruns.bin) loads, results of a batch go out frozen and match the oracle, and the
+    loader rejects what roaring_bitmap_frozen_view rejects plus what internal_validate would."""
+    import os
+    import croaring_amd
+    from util import DATASETS, GOLD, crc, load_bundle
+    gold = np.load(os.path.join(GOLD, "frozen.npz"))
+    for name in DATASETS:
+        bufs = load_bundle(name)
+        P = eng.pool_from_serialized(bufs)
+        blob, offs, lens = P.frozen_serialize_many()
+        assert np.all(offs % 32 == 0) and np.array_equal(lens, gold[f"{name}_size"].astype(np.uint64)), name
+        raw = blob.tobytes()
+        got = [crc(raw[int(offs[k]):int(offs[k]) + int(lens[k])]) for k in range(len(bufs))]
+        assert got == [int(x) for x in gold[f"{name}_crc"]], name
+        for k in range(len(bufs)):  # the gaps are zero
+            assert not any(raw[int(offs[k]) + int(lens[k]):int(offs[k + 1])]), (name, k)
+        Q = eng.pool_from_frozen(blob, offs, lens)
+        assert Q.serialize_all() == bufs, name
+        assert Q.type_counts() == P.type_counts() and np.array_equal(Q.cardinalities(), P.cardinalities()), name
+        sub = np.arange(len(bufs) - 1, -1, -3, dtype=np.uint32)  # a selection, any order
+        b2, o2, l2 = P.frozen_serialize_many(sub)
+        r2 = b2.tobytes()
+        assert [r2[int(o2[k]):int(o2[k]) + int(l2[k])] for k in range(len(sub))] == \
+               [raw[int(offs[i]):int(offs[i]) + int(lens[i])] for i in sub], name
+        # a frozen-loaded pool is an ordinary operand, and results leave frozen
+        k = min(len(bufs) - 1, 24)
+        lhs, rhs = np.arange(k, dtype=np.uint32), np.arange(1, k + 1, dtype=np.uint32)
+        res = eng.pairwise("xor", Q, lhs, Q, rhs)
+        fr = res.frozen_serialize_all()
+        hs = [oracle.deserialize(b) for b in bufs[:k + 1]]
+        for i in range(k):
+            w = oracle.op("xor", hs[i], hs[i + 1])
+            assert fr[i] == oracle.frozen_serialize(w), (name, i)
+            oracle.free(w)
+        for h in hs:
+            oracle.free(h)
+    # the reference's own image, at an unaligned position of the blob (a copy needs no alignment)
+    ref_img = open(os.path.join(GOLD, "frozen_withruns.bin"), "rb").read()
+    blob = np.frombuffer(b"\x55\x55\x55" + ref_img + b"\x55", dtype=np.uint8)
+    Q = eng.pool_from_frozen(blob, [3], [len(ref_img)])
+    assert Q.serialize(0) == open(os.path.join(GOLD, "bitmapwithruns.bin"), "rb").read()
+    assert Q.frozen_serialize_all() == [ref_img]
+    # empty bitmaps and an empty selection
+    E = eng.pool_from_serialized([oracle.serialize(oracle.from_sorted(np.zeros(0, np.uint32)))] * 3)
+    assert E.frozen_serialize_all() == [(13766).to_bytes(4, "little")] * 3
+    b, o, l = E.frozen_serialize_many()
+    assert len(eng.pool_from_frozen(b, o, l)) == 3
+    # rejected: frozen_view's NULL cases ...
+    n = int.from_bytes(ref_img[-4:], "little") >> 15
+    def load(img):
+        return eng.pool_from_frozen(np.frombuffer(img, dtype=np.uint8), [0], [len(img)])
+    bad_cookie = bytearray(ref_img); bad_cookie[-4] ^= 1
+    bad_type = bytearray(ref_img); bad_type[len(ref_img) - 4 - n] = 4
+    for img in (ref_img[:3], ref_img[:-1], b"\x00" + ref_img, bytes(bad_cookie), bytes(bad_type)):
+        with pytest.raises(croaring_amd.RoaringHipError):
+            load(img)
+    # ... and what roaring_bitmap_internal_validate rejects (the view would hand these to the caller unchecked)
+    keys_at = len(ref_img) - 4 - 5 * n
+    swapped = bytearray(ref_img)
+    swapped[keys_at:keys_at + 2], swapped[keys_at + 2:keys_at + 4] = ref_img[keys_at + 2:keys_at + 4], ref_img[keys_at:keys_at + 2]
+    h = oracle.from_sorted(np.array([5, 9, 700, 70000], np.uint32), run_optimize=False)
+    small = bytearray(oracle.frozen_serialize(h))
+    oracle.free(h)
+    unsorted = bytearray(small); unsorted[0:2], unsorted[2:4] = small[2:4], small[0:2]   # array values 9, 5, 700
+    for img in (bytes(swapped), bytes(unsorted)):
+        with pytest.raises(croaring_amd.RoaringHipError):
+            load(img)
+    assert load(bytes(small)).cardinalities()[0] == 4
+    # 64-bit pools have no frozen form
+    P64 = eng.pool_from_values([np.array([1, 1 << 40], np.uint64)], is64=True)
+    with pytest.raises(croaring_amd.RoaringHipError):
+        P64.frozen_serialize_many()
+
+
+def test_frozen_format(engine, oracle):
+    frozen_body(engine, oracle)

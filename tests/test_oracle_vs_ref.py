@@ -171,3 +171,31 @@ def test_flip_64bit_oracle_vs_ref(oracle, ref):
             oracle.free64(h)
         for h in (hr, fr):
             ref.free64(h)
+
+
+def test_frozen_format(oracle, ref):
+    """roaring_bitmap_frozen_size_in_bytes / _serialize / _view (src/roaring.c:3207-3457) against the restatement on
+    random bitmaps: identical images, each side reads the other's, same acceptance of damaged images."""
+    from gen_inputs import random_bitmap
+    rng = np.random.default_rng(77)
+    for t in range(150):
+        v = random_bitmap(rng)
+        ho, hr = oracle.from_sorted(v), ref.from_sorted(v)
+        fo, fr = oracle.frozen_serialize(ho), ref.frozen_serialize(hr)
+        assert fo == fr, t
+        h2 = oracle.frozen_deserialize(fr)
+        h3 = ref.frozen_deserialize(fo)
+        assert h2 and h3 and oracle.serialize(h2) == ref.serialize(h3) == ref.serialize(hr), t
+        for cut in (1, 2, 4, 7):
+            d = fr[:-cut] if len(fr) > cut else b""
+            assert (oracle.frozen_deserialize(d) is None) == (ref.frozen_deserialize(d) is None), (t, cut)
+        if len(fr) > 8:
+            d = bytearray(fr)
+            d[int(rng.integers(max(0, len(d) - 64), len(d)))] ^= 1 << int(rng.integers(0, 8))
+            a, b = oracle.frozen_deserialize(bytes(d)), ref.frozen_deserialize(bytes(d))
+            assert (a is None) == (b is None), t
+            if a:
+                oracle.free(a)
+            if b:
+                ref.free(b)
+        oracle.free(ho); oracle.free(h2); ref.free(hr); ref.free(h3)
