@@ -236,7 +236,7 @@ struct rhip_ctx_s {
     bool copy_wide = true;       // RHIP_COPY_WIDE=0: k_copy always takes four items per wave
     int many_pf = 2;  // RHIP_MANY_PF: payload groups per lane k_many_l1 loads ahead (2 / 4 / 8; round 5: 2 beats 4 by 4 % on C4 -- the memory system queues, more requests in flight only wait longer)
     int many_ch = 0;  // RHIP_MANY_CH: members per piece (tests of the multi-chunk / cut-group paths on small inputs); 0 = by size
-    uint64_t many_slots = 1024;  // RHIP_MANY_SLOTS: pieces of a large call = workgroups of k_many_l1 resident at once (4 per CU)
+    uint64_t many_slots = MANY_RESIDENT;  // RHIP_MANY_SLOTS: pieces of a large call = workgroups of k_many_l1 resident at once (RHIP_MANY_WAVES per CU)
     uint64_t many_t = 0;         // RHIP_MANY_T: members per workgroup of k_many_hist / k_many_scatter; 0 = one workgroup per CU
     int many_reverse = 0;        // RHIP_MANY_REVERSE (tests): k_many_scatter fills its reservations backwards
     uint32_t pool_align = 0;     // RHIP_POOL_ALIGN: slot granule of loaded pools, 16 / 128; 0 = by the images' average size (choose_pay_align)

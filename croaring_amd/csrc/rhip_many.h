@@ -737,8 +737,8 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
             m = lo;
             enter();
         }
-        uint4 cur[PF], nxt[PF];
-        uint32_t cn[PF], nn[PF];
+        uint4 cur[PF];
+        uint32_t cn[PF];
         auto fetch = [&](uint4& x, uint32_t& nv) {  // this lane's next slot
             nv = 0;
             x = make_uint4(0, 0, 0, 0);
@@ -762,21 +762,23 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
         const uint32_t nsteps = S >> 3;
 #pragma unroll
         for (int p = 0; p < PF; ++p) fetch(cur[p], cn[p]);
+        // A ring of PF buffers: a buffer's next load goes out as soon as its values are in registers of their own, ahead
+        // of their atomics -- PF loads in flight at any time with PF buffers (a second set of PF "next" buffers cost 10
+        // VGPRs, the difference between spilling and not at five waves per SIMD).
         for (uint32_t c = 0; c < nsteps; c += PF) {
 #pragma unroll
-            for (int p = 0; p < PF; ++p) fetch(nxt[p], nn[p]);
-#pragma unroll
             for (int p = 0; p < PF; ++p) {
-                const bool all_full = __ballot(cn[p] != 0u && cn[p] != 8u) == 0ull;  // (no ragged group in this step)
-                if (cn[p]) many_scatter8<OP>(acc, cur[p], cn[p], all_full);  // (lead / padding slots and lanes past the range sit out)
+                const uint4 x = cur[p];
+                const uint32_t nv = cn[p];
+                fetch(cur[p], cn[p]);
+                const bool all_full = __ballot(nv != 0u && nv != 8u) == 0ull;  // (no ragged group in this step)
+                if (nv) many_scatter8<OP>(acc, x, nv, all_full);  // (lead / padding slots and lanes past the range sit out)
             }
-#pragma unroll
-            for (int p = 0; p < PF; ++p) { cur[p] = nxt[p]; cn[p] = nn[p]; }
         }
     }
     __syncthreads();
     // ---- phase B: bitset members, thread-owned words (through the swizzle: the image stays swizzled until the whole
-    // group is in), four members' loads in flight.  XOR / OR are commutative, so the arbitrary list order is fine.
+    // group is in), two members' loads in flight.  XOR / OR are commutative, so the arbitrary list order is fine.
     {
         const uint32_t nb = ml->n_bitset;
         if (nb) {
@@ -784,10 +786,10 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
 #pragma unroll
             for (int k = 0; k < 8; ++k) r[k] = acc[mswz(8u * tid + k)];
             uint4 r0 = make_uint4(r[0], r[1], r[2], r[3]), r1 = make_uint4(r[4], r[5], r[6], r[7]);
-            for (uint32_t k = 0; k < nb; k += 4) {
-                uint4 a[4], b[4];
+            for (uint32_t k = 0; k < nb; k += 2) {  // (two members' loads in flight: four put the kernel's register peak here)
+                uint4 a[2], b[2];
 #pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) {
+                for (uint32_t u = 0; u < 2; ++u) {
                     a[u] = make_uint4(0, 0, 0, 0); b[u] = a[u];
                     if (k + u < nb) {
                         const uint4* __restrict__ g = (const uint4*)(arena + md_off(mdl[ml->bitset[k + u]]));
@@ -796,7 +798,7 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
                     }
                 }
 #pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) { r0 = op4(op, r0, a[u]); r1 = op4(op, r1, b[u]); }  // (x op 0 = x for or / xor)
+                for (uint32_t u = 0; u < 2; ++u) { r0 = op4(op, r0, a[u]); r1 = op4(op, r1, b[u]); }  // (x op 0 = x for or / xor)
             }
             const uint32_t w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
@@ -1056,17 +1058,26 @@ __device__ __forceinline__ bool many_pass_through(u64 d, const uint8_t* __restri
     return true;
 }
 
-// PF = 16-byte payload groups per lane loaded ahead of the LDS atomics (RHIP_MANY_PF selects 2 / 4 / 8; default 4)
-// (-DRHIP_MANY_WAVES=5, a variant build for A/B runs -- croaring_amd/build.py RHIP_BUILD_VARIANT: five waves per SIMD at 96
-// VGPRs and 24 bytes of scratch per lane; compiled in round 4, not yet measured)
+// PF = 16-byte payload groups per lane loaded ahead of the LDS atomics (RHIP_MANY_PF selects 2 / 4 / 8; default 2)
+// RHIP_MANY_WAVES = waves per SIMD the kernel is compiled for = workgroups per CU: five (96 VGPRs; the few spills -- 32
+// bytes per lane -- are outside the member stream's loop).  Five only pays when five workgroups really are resident:
+// 24.7 KB of LDS each (the array window shares the staging tables) and MANY_RESIDENT pieces per call, one per resident
+// workgroup (round 5 measured "five waves: no change" with 32.9 KB of LDS and 1 024 pieces -- neither let a fifth
+// workgroup in; with both fixed C4 goes 0.573 -> 0.549 ms on one box, profiles/r05_many_l1_notes.md).
 #ifndef RHIP_MANY_WAVES
-#define RHIP_MANY_WAVES 1
+#define RHIP_MANY_WAVES 5
 #endif
+constexpr unsigned long long MANY_RESIDENT = 256ull * RHIP_MANY_WAVES;  // gfx950: 256 CUs
 template <int PF, int OP>
 __global__ __launch_bounds__(256, RHIP_MANY_WAVES) void k_many_l1(PoolView P, ManyView V, ManyOut MO) {
     __shared__ __attribute__((aligned(16))) uint32_t acc[2048];
     __shared__ __attribute__((aligned(16))) uint32_t tmp[MANY_TMP_WORDS];
-    __shared__ __attribute__((aligned(16))) uint16_t stage[4096 + 8];
+    // The array-extraction window of many_emit lives in tmp: the staging tables are dead once a group's image is complete.
+    // (As an array of its own it put the workgroup at 32 936 bytes of LDS -- 168 bytes more than a fifth of the CU's 160 KiB,
+    // so a fifth workgroup per CU could never be resident whatever the register count: the "five waves per SIMD, no
+    // change" of profiles/r05_many_l1_notes.md was this.)
+    static_assert(MANY_TMP_WORDS * 4 >= (4096 + 8) * 2, "many_emit's window fits the staging tables");
+    uint16_t* stage = (uint16_t*)tmp;
     __shared__ BlockScratch sc;
     __shared__ ManyLists ml;
     __shared__ u64 red[4];

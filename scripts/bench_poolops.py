@@ -46,6 +46,13 @@ def main():
         print(json.dumps({"what": "download", "dataset": name, "results": int(len(lhs)), "bytes": int(rb.size),
                           "per_bitmap_ms_extrapolated": t_one * 10 * 1e3, "bulk_ms": t_bulk * 1e3,
                           "bulk_GBps": rb.size / t_bulk / 1e9}), flush=True)
+        t_fz, (fb, fo, fl) = best(lambda: R.frozen_serialize_many(), reps=3)
+        t_fl, F = best(lambda: eng.pool_from_frozen(fb, fo, fl), reps=3)
+        assert np.array_equal(F.cardinalities(), R.cardinalities())
+        print(json.dumps({"what": "frozen", "dataset": name, "results": int(len(lhs)), "bytes": int(fb.size),
+                          "serialize_ms": t_fz * 1e3, "serialize_GBps": fb.size / t_fz / 1e9, "load_ms": t_fl * 1e3,
+                          "load_GBps": fb.size / t_fl / 1e9, "portable_bulk_ms": t_bulk * 1e3}), flush=True)
+        F.free()
         t_opt, Q = best(lambda: eng.run_optimize(R), reps=3)
         print(json.dumps({"what": "run_optimize", "dataset": name, "containers": int(R.n_containers),
                           "payload_in": int(R.payload_bytes()), "payload_out": int(Q.payload_bytes()),
