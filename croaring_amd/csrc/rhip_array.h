@@ -186,8 +186,21 @@ __device__ __forceinline__ uint32_t probe_rank(const uint16_t* __restrict__ x16,
     *present = pos != 0u && last == v;
     return pos == 0u ? 0u : (last == v ? idx : idx + 1u);
 }
-constexpr uint32_t D_WORDS = 1032, DEL_WORDS = 136, GP_WORDS = 264, ST_WORDS = 392;  // k_usmall's LDS per wave, words
-constexpr uint32_t USMALL_LDS_WORDS = 4 * (D_WORDS + DEL_WORDS + GP_WORDS + ST_WORDS);
+// k_usmall's LDS per wave, words.  GP holds a count of at most USMALL_MAX = 255 per 8-index group.  As 16-bit counts
+// (GP8 = false, the default) the workgroup takes 29 184 bytes, five per CU; as BYTES (GP8 = true, RHIP_USMALL_GP8=1) 27 136
+// and a sixth fits.  Measured (round 5, same box, alternating, three passes): C5 `or` / `xor` the same either way, weather
+// `or` 0.555 -> 0.57-0.60 ms with bytes -- more resident k_usmall workgroups take LDS and issue slots from k_union_g, that
+// batch's critical kernel (the stream-priority experiment said the same).  Kept as a switch, not as the default.
+static_assert(USMALL_MAX <= 255u, "k_usmall: deleted-before counts fit a byte");
+constexpr uint32_t D_WORDS = 1032, DEL_WORDS = 136, ST_WORDS = 392;
+template <bool GP8> struct UsmallLds {
+    typedef typename std::conditional<GP8, uint8_t, uint16_t>::type gp_t;
+    static constexpr uint32_t GP_WORDS = GP8 ? 136u : 264u;
+    static constexpr uint32_t WAVE_WORDS = D_WORDS + DEL_WORDS + GP_WORDS + ST_WORDS;
+    static constexpr uint32_t WORDS = 4 * WAVE_WORDS;
+};
+constexpr uint32_t USMALL_LDS_WORDS = UsmallLds<false>::WORDS;
+template <bool GP8>
 __device__ __forceinline__ void usmall_body(uint32_t* __restrict__ lds, uint32_t bid, uint32_t nblk, const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                                 OutView O, const FatItem* __restrict__ q,
                                                 const u64* __restrict__ qrange, int kop) {
@@ -195,9 +208,11 @@ __device__ __forceinline__ void usmall_body(uint32_t* __restrict__ lds, uint32_t
     // in both), GP = deleted-before count of every 8-index group
     // ST = output window of one step: <= 7 carried + 512 of X + 255 new values
     const uint32_t lane = lane_id();
-    uint32_t* D32 = lds + (threadIdx.x >> 6) * (D_WORDS + DEL_WORDS + GP_WORDS + ST_WORDS);
+    typedef typename UsmallLds<GP8>::gp_t usmall_gp_t;
+    constexpr uint32_t GP_WORDS = UsmallLds<GP8>::GP_WORDS;
+    uint32_t* D32 = lds + (threadIdx.x >> 6) * UsmallLds<GP8>::WAVE_WORDS;
     uint32_t* DEL = D32 + D_WORDS;
-    uint16_t* GP = (uint16_t*)(DEL + DEL_WORDS);
+    usmall_gp_t* GP = (usmall_gp_t*)(DEL + DEL_WORDS);
     uint16_t* ST = (uint16_t*)(DEL + DEL_WORDS + GP_WORDS);
     const uint32_t nwaves = (nblk * blockDim.x) >> 6;
     const uint32_t n = (uint32_t)(qrange[1] - qrange[0]);
@@ -283,7 +298,7 @@ __device__ __forceinline__ void usmall_body(uint32_t* __restrict__ lds, uint32_t
             const uint32_t inc = wave_incl_scan(packed);
             const uint32_t excl = inc - packed;
             uint32_t newc = run_new + (excl & 0xFFFFu), delc = run_del + (excl >> 16);
-            if (op == OP_XOR && act) GP[g] = (uint16_t)delc;
+            if (op == OP_XOR && act) GP[g] = (usmall_gp_t)delc;
             const uint32_t tot = wave_lane<63>(inc);
             run_new += tot & 0xFFFFu;
             run_del += tot >> 16;
@@ -329,11 +344,12 @@ __device__ __forceinline__ void usmall_body(uint32_t* __restrict__ lds, uint32_t
     }
     PH_FLUSH(16);
 }
+template <bool GP8>
 __global__ __launch_bounds__(256) void k_usmall(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                                 OutView O, const FatItem* __restrict__ q,
                                                 const u64* __restrict__ qrange, int kop) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[USMALL_LDS_WORDS];
-    usmall_body(lds, blockIdx.x, gridDim.x, arenaA, arenaB, O, q, qrange, kop);
+    __shared__ __attribute__((aligned(16))) uint32_t lds[UsmallLds<GP8>::WORDS];
+    usmall_body<GP8>(lds, blockIdx.x, gridDim.x, arenaA, arenaB, O, q, qrange, kop);
 }
 
 

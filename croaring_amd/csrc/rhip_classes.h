@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_classes(ClassLaunch L) {
             probe_body(lds, b, nblk, L.arenaA, L.arenaB, L.O, L.q_probe, R + 2 * SEC_PROBE, L.kop, L.cardmode, L.pair_acc);
             break;
         case CSEG_USMALL:
-            usmall_body(lds, b, nblk, L.arenaA, L.arenaB, L.O, L.q_usmall, R + 2 * SEC_USMALL, L.kop);
+            usmall_body<false>(lds, b, nblk, L.arenaA, L.arenaB, L.O, L.q_usmall, R + 2 * SEC_USMALL, L.kop);
             break;
         case CSEG_WAVE:
             wave_body(lds, b, nblk, L.arenaA, L.arenaB, L.O, L.q_wave, R + 2 * SEC_WAVE, L.kop);

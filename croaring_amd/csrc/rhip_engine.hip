@@ -239,6 +239,7 @@ struct rhip_ctx_s {
     uint64_t many_slots = MANY_RESIDENT;  // RHIP_MANY_SLOTS: pieces of a large call = workgroups of k_many_l1 resident at once (RHIP_MANY_WAVES per CU)
     uint64_t many_t = 0;         // RHIP_MANY_T: members per workgroup of k_many_hist / k_many_scatter; 0 = one workgroup per CU
     int many_reverse = 0;        // RHIP_MANY_REVERSE (tests): k_many_scatter fills its reservations backwards
+    int usmall_gp8 = 0;          // RHIP_USMALL_GP8=1: k_usmall's six-per-CU instantiation (measured: no gain on C5, weather or / xor 3-7 % slower; rhip_array.h)
     uint32_t pool_align = 0;     // RHIP_POOL_ALIGN: slot granule of loaded pools, 16 / 128; 0 = by the images' average size (choose_pay_align)
     static constexpr size_t PINNED_MANY_FLAG_OFF = 2304, PINNED_MANY_TOT_OFF = 2560, PINNED_MANY_ERR_OFF = 2816;
     DBuf sel[5];  // pool_select / pool_convert scratch
@@ -468,6 +469,7 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_MANY_SLOTS")) c->many_slots = (uint64_t)std::max(1, atoi(e));
         if (const char* e = getenv("RHIP_MANY_T")) c->many_t = (uint64_t)std::max(1024, atoi(e));
         if (const char* e = getenv("RHIP_MANY_REVERSE")) c->many_reverse = atoi(e);
+        if (const char* e = getenv("RHIP_USMALL_GP8")) c->usmall_gp8 = atoi(e) ? 1 : 0;
         if (const char* e = getenv("RHIP_POOL_ALIGN")) c->pool_align = atoi(e) == 128 ? 128 : (atoi(e) == 16 ? 16 : 0);
         memset(c->h_pinned, 0, 4096);
         if (c->spin_join && !spin_join_forced) {
@@ -1688,7 +1690,8 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
     }
     if (has_wave && any_union)  // or / xor of a short array with a long one, by rank: 170 us alone on weather -- a stream of
                                 // its own when the filter's is free (or / xor), else the light chain
-        hipLaunchKernelGGL(k_usmall, dim3(bounded_grid(nm)), dim3(256), 0, (fork && crit == 2) ? on_aux(1) : lst, VA.arena, VB.arena, O,
+        hipLaunchKernelGGL(c->usmall_gp8 ? k_usmall<true> : k_usmall<false>, dim3(bounded_grid(nm)),
+                           dim3(256), 0, (fork && crit == 2) ? on_aux(1) : lst, VA.arena, VB.arena, O,
                            c->ss[P.slot].q[CLS_USMALL].as<FatItem>(), ranges + 2 * SEC_USMALL, op);
     if (has_filt)  // short streamed arrays: no LDS, 8 waves per SIMD -- co-resides with the LDS-bound kernels
         hipLaunchKernelGGL(k_probe, dim3(bounded_grid(nm)), dim3(256), 0, lst, VA.arena, VB.arena, O,

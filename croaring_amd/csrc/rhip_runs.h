@@ -292,7 +292,13 @@ struct IvlQueues {
     const GenItem* q[3];   // CLS_RUNS16, CLS_RUNS16W, CLS_RUNS
     const u64* range[3];
 };
-__global__ __launch_bounds__(256) void k_ivl_all(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
+// Five waves per SIMD: the kernel fits 96 VGPRs without a spill (105 left to itself = four waves) and five workgroups'
+// 32 KiB are exactly a CU's LDS.  Round 5, same box, alternating: C5 `or` 0.716-0.734 -> 0.659-0.680 ms, `xor` 0.709-0.724 ->
+// 0.683-0.687, everything else within noise (C5 `and`: unchanged -- its 847 000 short pairs are issue-bound).
+#ifndef RHIP_IVL_WAVES
+#define RHIP_IVL_WAVES 5
+#endif
+__global__ __launch_bounds__(256, RHIP_IVL_WAVES) void k_ivl_all(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                                  OutView O, IvlQueues Q, uint32_t g1, uint32_t g2, int op, int cardmode,
                                                  u64* pair_acc, GenItem* retry_q, uint32_t* retry_count) {
     constexpr uint32_t LDS_A = IvlShape<R16_G, R16_MAX_IV>::LDS_BYTES, LDS_B = IvlShape<16, R16W_MAX_IV>::LDS_BYTES,

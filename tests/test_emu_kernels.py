@@ -362,6 +362,20 @@ def test_emu_arena_placement_forced(oracle, synth, monkeypatch):
         eng.close()
 
 
+@pytest.mark.parametrize("gp8", ["0", "1"])
+def test_emu_usmall_lds_variants(oracle, synth, monkeypatch, gp8):
+    from emu import build_emu, emu_engine
+    if not __import__("os").path.exists(build_emu.CXX):
+        pytest.skip("hipemu needs the ROCm clang++ to compile the kernels for the host")
+    monkeypatch.setenv("RHIP_USMALL_GP8", gp8)
+    monkeypatch.setenv("RHIP_MERGE_CLASSES", "0")
+    eng = emu_engine()
+    try:
+        G.usmall_variants_body(eng, oracle, synth)
+    finally:
+        eng.close()
+
+
 def test_emu_batches_in_flight(emu, oracle, synth):
     G.test_batches_in_flight(emu, oracle, synth)
 

@@ -1012,6 +1012,28 @@ def test_grouped_queues(oracle, synth, monkeypatch, mode):
         eng.close()
 
 
+def usmall_variants_body(eng, oracle, synth):
+    for op in ("or", "xor"):
+        test_synth_every_type_pair(eng, oracle, synth, op)
+    test_array_array_union_boundaries(eng, oracle)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gp8", ["0", "1"])
+def test_usmall_lds_variants(oracle, synth, monkeypatch, gp8):
+    """k_usmall is built twice (deleted-before counts as 16-bit words: five workgroups per CU; as bytes: six) and the host
+    picks per batch; RHIP_USMALL_GP8 pins either, RHIP_MERGE_CLASSES=0 keeps the small test batches out of the merged
+    launch (which always runs the 16-bit body)."""
+    import croaring_amd
+    monkeypatch.setenv("RHIP_USMALL_GP8", gp8)
+    monkeypatch.setenv("RHIP_MERGE_CLASSES", "0")
+    eng = croaring_amd.Engine()
+    try:
+        usmall_variants_body(eng, oracle, synth)
+    finally:
+        eng.close()
+
+
 @pytest.mark.gpu
 def test_batches_in_flight(engine, oracle, synth):
     """rhip_pairwise_begin / _end: four batches of different ops and pair lists in flight at once, ended out of order,
