@@ -554,7 +554,10 @@ __device__ __forceinline__ uint32_t many_group_of(const u64* __restrict__ gstart
 
 // ------------------------------------------------------------------ accumulation of one unit into an LDS image
 constexpr uint32_t MANY_CHUNK = 1024;  // members staged at a time (four per thread)
-constexpr uint32_t MANY_TMP_WORDS = 3 * MANY_CHUNK + 8;  // g16[MANY_CHUNK + 1] | descriptors; later one rasterised run member (2048 words)
+// One ARRAY member of the staged chunk as the stream of phase A sees it: its slots [start, next) of the chunk's stream and
+// its descriptor -- 16 bytes, one ds_read_b128 when a lane enters the member.
+struct __attribute__((aligned(16))) ManyArr { uint32_t start, next; u64 d; };
+constexpr uint32_t MANY_TMP_WORDS = 4 * MANY_CHUNK + 8;  // ManyArr[MANY_CHUNK]; later one rasterised run member (2048 words) or many_emit's window
 struct ManyLists {  // bitset / run members of the chunk (relative member indices), listed by the staging pass
     uint32_t n_bitset, n_run, n_g16, pad;
     uint16_t bitset[MANY_CHUNK], run[MANY_CHUNK];
@@ -613,8 +616,8 @@ __device__ void many_raster_runs(uint32_t* dst, const uint8_t* __restrict__ aren
 }
 
 // Accumulate the members [m0, m1) (at most MANY_CHUNK of them) into the LDS image acc.
-// `tmp` (8 KiB) first holds the staging tables of the array stream -- g16[j] = number of 16-byte payload groups of the
-// chunk's array members in front of member j, and the members' descriptors -- and later the rasterised run members.
+// `tmp` (16 KiB) first holds the records of the chunk's array members (ManyArr: slot range of the stream + descriptor),
+// later the rasterised run members.
 // One 16-byte payload group (eight sorted values, the first nv of them valid) into the swizzled image.  No branch per
 // value: an invalid value contributes the mask 0 (x | 0 = x ^ 0 = x), and a wave none of whose groups is ragged (only a
 // member's last group can be) skips the validity selects altogether.  The swizzle of both halves
@@ -628,8 +631,8 @@ __device__ void many_raster_runs(uint32_t* dst, const uint8_t* __restrict__ aren
 __device__ __forceinline__ uint32_t many_lead(u64 d) { return (uint32_t)(d & 7ull); }  // (offset / 16) mod 8
 __device__ __forceinline__ uint32_t many_slots(u64 d) { return (many_lead(d) + ((md_n(d) + 7u) >> 3) + 7u) & ~7u; }
 
-template <int OP>
-__device__ __forceinline__ void many_scatter8(uint32_t* acc, const uint4& x, uint32_t nv, bool all_full) {
+template <int OP, bool FULL>
+__device__ __forceinline__ void many_scatter8(uint32_t* acc, const uint4& x, uint32_t nv) {
 #if RHIP_ABL_L1 == 1 || RHIP_ABL_L1 == 7  /* ablation builds only: the member stream without its LDS atomics */
     if ((x.x ^ x.y ^ x.z ^ x.w) == 0x12345678u && nv == 77u) atomicOr(&acc[0], 1u);
     return;
@@ -640,7 +643,7 @@ __device__ __forceinline__ void many_scatter8(uint32_t* acc, const uint4& x, uin
         const uint32_t d = dd[q] ^ ((dd[q] >> 5) & 0x03E003E0u);
         const uint32_t w0 = (d >> 5) & 2047u, w1 = d >> 21;
         uint32_t b0 = 1u << (d & 31u), b1 = 1u << ((d >> 16) & 31u);
-        if (!all_full) {
+        if (!FULL) {
             b0 = (uint32_t)(2 * q) < nv ? b0 : 0u;
             b1 = (uint32_t)(2 * q + 1) < nv ? b1 : 0u;
         }
@@ -662,13 +665,13 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
     constexpr int op = OP;
     const uint32_t tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const uint32_t nm = (uint32_t)(m1 - m0);
-    uint32_t* g16 = tmp;                          // [MANY_CHUNK + 1]
-    u64* mdl = (u64*)(tmp + MANY_CHUNK + 2);      // [MANY_CHUNK] (8-byte aligned: MANY_CHUNK + 2 is even)
+    ManyArr* rec = (ManyArr*)tmp;                 // [MANY_CHUNK]: the chunk's ARRAY members, compacted, in member order
     __syncthreads();
     if (tid == 0) { ml->n_bitset = 0; ml->n_run = 0; }
     __syncthreads();
-    // ---- staging: descriptors, lists of the bitset / run members, prefix of the array members' 16-byte groups.
-    // A thread takes four CONSECUTIVE members: their loads go out together and ONE block scan serves the chunk.
+    // ---- staging: the array members' records (slot prefix + descriptor), lists of the bitset / run members.
+    // A thread takes four CONSECUTIVE members: their loads go out together and ONE block scan -- slots in the low 20
+    // bits (a member is at most 66 lines = 528 slots), array members counted above them -- serves the chunk.
     uint32_t carry;
     {
         u64 d[4];
@@ -683,9 +686,8 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
             const uint32_t j = 4u * tid + r;
             ng[r] = 0;
             if (j < nm) {
-                mdl[j] = d[r];
                 const uint32_t ty = md_type(d[r]);
-                if (ty == T_ARRAY) ng[r] = many_slots(d[r]);
+                if (ty == T_ARRAY) ng[r] = many_slots(d[r]) | (1u << 20);
                 else if (ty == T_BITSET) ml->bitset[atomicAdd(&ml->n_bitset, 1u)] = (uint16_t)j;
                 else ml->run[atomicAdd(&ml->n_run, 1u)] = (uint16_t)j;
             }
@@ -694,85 +696,84 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
         uint32_t ex = blk_exscan(mine, sc->wsum, &carry);
 #pragma unroll
         for (uint32_t r = 0; r < 4; ++r) {
-            const uint32_t j = 4u * tid + r;
-            if (j < nm) g16[j] = ex;
+            if (ng[r]) {
+                const uint32_t st = ex & 0xFFFFFu;
+                rec[ex >> 20] = ManyArr{st, st + (ng[r] & 0xFFFFFu), d[r]};
+            }
             ex += ng[r];
         }
     }
-    if (tid == 0) { g16[nm] = carry; ml->n_g16 = carry; }
+    const uint32_t T = carry & 0xFFFFFu, na = carry >> 20;  // slots of the stream, array members (block-uniform)
+    if (tid == 0) ml->n_g16 = T;
     __syncthreads();
     // ---- phase A: the array members as one flattened stream of 16-byte groups, LDS atomics (commutative: no ordering
-    // needed).  The stream is cut into 32 equal ranges, one per OCTET of lanes (8 per wave): an octet walks its range
-    // eight groups = one 128-byte line per step, every lane eight values whatever the members' cardinalities.  A lane's
-    // groups are 8 apart, a member is ~32 groups long: a lane stays inside its member for several steps and keeps the
-    // member's base, end and cardinality in registers -- the LDS tables are read only when it crosses into the next
-    // member.  (Until round 5 a wave walked 64 consecutive groups per step: every lane crossed a member or two at every
-    // step, a chain of three to five dependent LDS reads in front of every load -- the kernel took 370 us with its loads
-    // or its atomics removed, neither being the bound.)  PF steps are loaded ahead while the previous PF feed the atomics.
-    {
-        const uint32_t T = carry;
-        const uint32_t S = (((T + 31u) >> 5) + 7u) & ~7u;  // groups per octet range
-        const uint32_t oct = wave * 8u + (lane >> 3);
-        uint32_t q = oct * S + (lane & 7u);
-        const uint32_t qend = (oct + 1u) * S < T ? (oct + 1u) * S : T;
-        uint32_t m = 0, mnext = 0, mcard = 0;
-        int mfirst = 0;  // stream index of the member's first GROUP (its first slot + lead)
-        const uint4* __restrict__ mbase = (const uint4*)arena;
-        auto enter = [&]() {  // registers of member m
-            const u64 d = mdl[m];
-            mfirst = (int)(g16[m] + many_lead(d)); mnext = g16[m + 1u]; mcard = md_n(d);
-#if RHIP_ABL_L1 == 8  /* ablation: every member inside one MiB (cache-resident payloads) */
-            mbase = (const uint4*)(arena + (md_off(d) & 0xFFC00ull));
-#else
-            mbase = (const uint4*)(arena + md_off(d));
-#endif
-        };
-        if (q < qend) {  // cursor: largest member index with g16[m] <= first slot of this lane
-            uint32_t lo = 0, hi = nm;
+    // needed).  The stream is cut into 32 equal ranges of whole lines, one per OCTET of lanes (8 per wave): an octet walks
+    // its range one 128-byte line per step, every lane eight values whatever the members' cardinalities.
+    // The walk is BRANCH-FREE: every lane loads at every step -- a lane with nothing to fetch (lead / padding slot, past
+    // its range) re-reads its member's first group and contributes no value -- and enters the next member with a select
+    // plus one 16-byte LDS read.  Until round 5 the fetch was nested conditionals around the load; with loads inside
+    // divergent branches the compiler cannot count the loads in flight and waited for ALL of them (s_waitcnt vmcnt(0))
+    // before every scatter -- including the one it had just issued: no prefetch depth ever overlapped anything, each
+    // step paid a full memory latency, and only occupancy hid it (profiles/r05_many_l1_notes.md: payloads forced into
+    // the L2 were no faster, PF 2 / 4 / 8 made no difference).  Straight-line, the PF loads of the ring stay in flight
+    // behind the scatter of the oldest.
+    if (na) {
+        const uint32_t S = (((T + 31u) >> 5) + 7u) & ~7u;  // slots per octet range
+        const uint32_t oct = wave * 8u + (lane >> 3), sub = lane & 7u;
+        uint32_t qb = oct * S;                               // first slot of the octet's current line
+        const uint32_t qe = (oct + 1u) * S < T ? (oct + 1u) * S : T;
+        uint32_t m = 0;
+        if (qb < qe) {  // largest member with start <= qb
+            uint32_t lo = 0, hi = na;
             while (lo + 1u < hi) {
                 const uint32_t mid = (lo + hi) >> 1;
-                if (g16[mid] <= q) lo = mid;
+                if (rec[mid].start <= qb) lo = mid;
                 else hi = mid;
             }
             m = lo;
-            enter();
         }
-        uint4 cur[PF];
-        uint32_t cn[PF];
-        auto fetch = [&](uint4& x, uint32_t& nv) {  // this lane's next slot
-            nv = 0;
-            x = make_uint4(0, 0, 0, 0);
-            if (q < qend) {
-                if (q >= mnext) {  // (octet-uniform: members start and end on line boundaries of the stream)
-                    do { ++m; } while (g16[m + 1u] <= q);  // (members without array payload span no slots and are stepped over)
-                    enter();
-                }
-                const int j = (int)q - mfirst;  // group of the member (negative: lead slot)
-                if (j >= 0 && 8u * (uint32_t)j < mcard) {
-                    nv = mcard - 8u * (uint32_t)j < 8u ? mcard - 8u * (uint32_t)j : 8u;
+        ManyArr R = rec[m];
+        constexpr int NB = PF + 1;  // buffers of the ring
+        uint4 buf[NB];
+        uint32_t bn[NB];
+        auto fetch = [&](uint4& x, uint32_t& nv) {  // this lane's slot of the octet's next line
+            const bool active = qb < qe;
+            const bool adv = active && qb >= R.next;  // (a line belongs to one member and every member has a line: one step)
+            m += adv ? 1u : 0u;
+            const ManyArr Rn = rec[m];
+            R.start = adv ? Rn.start : R.start; R.next = adv ? Rn.next : R.next; R.d = adv ? Rn.d : R.d;
+            const uint32_t card = md_n(R.d);
+            const int j = (int)(qb + sub) - (int)(R.start + many_lead(R.d));  // group of the member (negative: lead slot)
+            const bool valid = active && j >= 0 && 8u * (uint32_t)j < card;
+            const uint32_t jj = valid ? (uint32_t)j : 0u;
+            nv = valid ? (card - 8u * jj < 8u ? card - 8u * jj : 8u) : 0u;
 #if RHIP_ABL_L1 == 2 || RHIP_ABL_L1 == 4 || RHIP_ABL_L1 == 6 || RHIP_ABL_L1 == 7 /* ablation builds only: the LDS atomics without the member loads */
-                    x = make_uint4(q * 2654435761u, q * 40503u + lane, (q + lane) * 2246822519u, q ^ (lane * 3266489917u));
+            x = make_uint4(qb * 2654435761u, qb * 40503u + lane, (qb + lane) * 2246822519u, qb ^ (lane * 3266489917u));
+#elif RHIP_ABL_L1 == 8  /* ablation: every member inside one MiB (cache-resident payloads) */
+            x = ((const uint4*)(arena + (md_off(R.d) & 0xFFC00ull)))[jj];
 #else
-                    x = mbase[j];
+            x = ((const uint4*)(arena + md_off(R.d)))[jj];
 #endif
-                }
-            }
-            q += 8u;
+            qb += 8u;
         };
         const uint32_t nsteps = S >> 3;
 #pragma unroll
-        for (int p = 0; p < PF; ++p) fetch(cur[p], cn[p]);
-        // A ring of PF buffers: a buffer's next load goes out as soon as its values are in registers of their own, ahead
-        // of their atomics -- PF loads in flight at any time with PF buffers (a second set of PF "next" buffers cost 10
-        // VGPRs, the difference between spilling and not at five waves per SIMD).
-        for (uint32_t c = 0; c < nsteps; c += PF) {
+        for (int p = 0; p < PF; ++p) fetch(buf[p], bn[p]);
+        // A ring of PF + 1 buffers, unrolled over one turn: step i issues the load of step i + PF into the buffer step i - 1
+        // emptied, then scatters its own -- PF loads in flight behind every scatter, and no buffer is ever copied (a
+        // rotation through "current" / "next" variables costs a register move per loaded dword at the loop's back edge,
+        // and a move needs its load to have LANDED: the compiler put s_waitcnt vmcnt(0) there).
+        for (uint32_t c = 0; c < nsteps; c += NB) {
 #pragma unroll
-            for (int p = 0; p < PF; ++p) {
-                const uint4 x = cur[p];
-                const uint32_t nv = cn[p];
-                fetch(cur[p], cn[p]);
-                const bool all_full = __ballot(nv != 0u && nv != 8u) == 0ull;  // (no ragged group in this step)
-                if (nv) many_scatter8<OP>(acc, x, nv, all_full);  // (lead / padding slots and lanes past the range sit out)
+            for (int i = 0; i < NB; ++i) {
+                fetch(buf[(i + PF) % NB], bn[(i + PF) % NB]);
+                const uint32_t nv = bn[i];
+                // (wave-uniform: only a member's last group can be ragged; lead / padding slots and lanes past the range sit out)
+                if (__ballot(nv != 0u && nv != 8u) == 0ull) {
+                    if (nv) many_scatter8<OP, true>(acc, buf[i], nv);
+                } else if (nv) {
+                    many_scatter8<OP, false>(acc, buf[i], nv);
+                }
             }
         }
     }
@@ -792,7 +793,7 @@ __device__ __forceinline__ void many_accumulate_chunk(uint32_t* acc, uint32_t* t
                 for (uint32_t u = 0; u < 2; ++u) {
                     a[u] = make_uint4(0, 0, 0, 0); b[u] = a[u];
                     if (k + u < nb) {
-                        const uint4* __restrict__ g = (const uint4*)(arena + md_off(mdl[ml->bitset[k + u]]));
+                        const uint4* __restrict__ g = (const uint4*)(arena + md_off(sdesc[m0 + ml->bitset[k + u]]));  // (the records hold array members only)
                         a[u] = g[2 * tid];
                         b[u] = g[2 * tid + 1];
                     }
