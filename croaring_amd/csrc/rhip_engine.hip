@@ -234,7 +234,7 @@ struct rhip_ctx_s {
     uint64_t join_recovered = 0;  // batches finished through the fallback (rhip_debug_join_recovered)
     u64* join_timeout_word() const { return (u64*)((char*)h_pinned + PINNED_JOIN_TIMEOUT_OFF); }
     bool copy_wide = true;       // RHIP_COPY_WIDE=0: k_copy always takes four items per wave
-    int many_pf = 2;  // RHIP_MANY_PF: payload groups per lane k_many_l1 loads ahead (2 / 4 / 8; round 5: 2 beats 4 by 4 % on C4 -- the memory system queues, more requests in flight only wait longer)
+    int many_pf = 1;  // RHIP_MANY_PF: loads of k_many_l1's ring in flight behind every scatter (1 / 2 / 3 / 4; round 5, after the stream became branch-free: 0.50 / 0.51 / 0.52 / 0.54 ms on C4 -- the kernel is bound by its LDS atomics and instruction issue, five waves per SIMD hide the latency, every further buffer costs spills)
     int many_ch = 0;  // RHIP_MANY_CH: members per piece (tests of the multi-chunk / cut-group paths on small inputs); 0 = by size
     uint64_t many_slots = MANY_RESIDENT;  // RHIP_MANY_SLOTS: pieces of a large call = workgroups of k_many_l1 resident at once (RHIP_MANY_WAVES per CU)
     uint64_t many_t = 0;         // RHIP_MANY_T: members per workgroup of k_many_hist / k_many_scatter; 0 = one workgroup per CU

@@ -1059,7 +1059,7 @@ __device__ __forceinline__ bool many_pass_through(u64 d, const uint8_t* __restri
     return true;
 }
 
-// PF = 16-byte payload groups per lane loaded ahead of the LDS atomics (RHIP_MANY_PF selects 2 / 4 / 8; default 2)
+// PF = loads of the ring in flight behind every scatter (RHIP_MANY_PF selects 1 / 2 / 3 / 4; default 1)
 // RHIP_MANY_WAVES = waves per SIMD the kernel is compiled for = workgroups per CU: five (96 VGPRs; the few spills -- 32
 // bytes per lane -- are outside the member stream's loop).  Five only pays when five workgroups really are resident:
 // 24.7 KB of LDS each (the array window shares the staging tables) and MANY_RESIDENT pieces per call, one per resident
