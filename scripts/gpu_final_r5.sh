@@ -10,6 +10,7 @@ timeout 200 python scripts/bench_c2_ops.py 2>/dev/null > $O/c2_ops.jsonl
 TAG="prepared" LIST=1 MULTI=1 timeout 200 python scripts/quick_all.py > $O/quick_all.txt 2>/dev/null
 TAG="adhoc" LIST=0 MULTI=0 timeout 200 python scripts/quick_all.py >> $O/quick_all.txt 2>/dev/null
 timeout 200 python scripts/quick_classes.py > $O/class_throughput.jsonl 2>/dev/null
+timeout 300 python scripts/bench_poolops.py > $O/poolops.jsonl 2>/dev/null
 # kernel-trace stats + timelines
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -- python bench.py --steps 6 --warmup 2 --no-cpu --no-secondary > $O/prof_bench.log 2>&1
 for spec in w_and:and:weather_sept_85 w_or:or:weather_sept_85 w_xor:xor:weather_sept_85 w_andnot:andnot:weather_sept_85 c1_and:and:census1881 c1_or:or:census1881 c5_and:and:c5 c5_or:or:c5; do
