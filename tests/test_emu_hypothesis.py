@@ -119,6 +119,10 @@ def test_flip_convert_and_value_lists_match_the_oracle(emu, oracle, a, s, n):
     assert np.array_equal(vals, va)
     blob, boffs = pool.serialize_many()
     assert emu.pool_from_blob(blob, boffs).serialize(0) == pool.serialize(0)
+    # the frozen format both ways (roaring_bitmap_frozen_serialize / _view): the oracle's bytes, and back
+    fblob, foffs, flens = pool.frozen_serialize_many()
+    assert fblob[int(foffs[0]):int(foffs[0]) + int(flens[0])].tobytes() == oracle.frozen_serialize(h)
+    assert emu.pool_from_frozen(fblob, foffs, flens).serialize(0) == pool.serialize(0)
     oracle.free(plain)
     oracle.free(h)
 
