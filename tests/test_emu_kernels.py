@@ -264,6 +264,22 @@ def test_emu_many_unit_shapes(oracle, synth, monkeypatch, ch):
         eng.close()
 
 
+@pytest.mark.parametrize("pf", ["2", "4"])
+def test_emu_many_ring_depths(oracle, synth, monkeypatch, pf):
+    """RHIP_MANY_PF: k_many_l1's ring of load buffers at other depths than the default (1) -- PF + 1 buffers unrolled over
+    one turn, the tail of every octet's range running past its end."""
+    from emu import build_emu, emu_engine
+    if not __import__("os").path.exists(build_emu.CXX):
+        pytest.skip("hipemu needs the ROCm clang++ to compile the kernels for the host")
+    monkeypatch.setenv("RHIP_MANY_PF", pf)
+    eng = emu_engine()
+    try:
+        G.sparse_many_body(eng, oracle, n=200, worlds=(2,))
+        G.test_synth_many(eng, oracle, synth)
+    finally:
+        eng.close()
+
+
 def test_emu_array_filter_probe_boundaries(emu, oracle):
     G.test_array_filter_probe_boundaries(emu, oracle)
 
