@@ -551,6 +551,7 @@ def run_ormany(args, eng, D: Dist, steps: int, warmup: int, chk=None):
     row = {"bitmaps": args.bitmaps, "containers": 32 * args.bitmaps, "ms_median": tmed * 1e3, "ms_min": tmin * 1e3,
            "ops_per_s": 1 / tmed, "alg_GBps": (tot_payload + bytes_out) / tmed / 1e9,
            "result_cardinality": int(card), "scaling": "strong",
+           "pool_layout": {"payload_align": int(pool.payload_align), "arena_over_payload": round(pool.arena_bytes() / max(1, payload), 4)},
            "parallelism": f"bitmaps b mod {D.world}; dense key-owner all-to-all over RCCL, one host wait" if D.world > 1 else "single GPU"}
     row["frac"] = row["alg_GBps"] / HBM_PEAK_GBS
     gp = os.path.join(ROOT, "tests", "golden", "c4_or_many.npz")
