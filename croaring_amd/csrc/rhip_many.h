@@ -638,15 +638,15 @@ __device__ __forceinline__ void many_scatter8(uint32_t* acc, const uint4& x, uin
     return;
 #endif
     const uint32_t dd[4] = {x.x, x.y, x.z, x.w};
+    const uint32_t keep = FULL ? 0xFFu : (1u << nv) - 1u;  // bit h: value h of the group is there
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint32_t d = dd[q] ^ ((dd[q] >> 5) & 0x03E003E0u);
         const uint32_t w0 = (d >> 5) & 2047u, w1 = d >> 21;
-        uint32_t b0 = 1u << (d & 31u), b1 = 1u << ((d >> 16) & 31u);
-        if (!FULL) {
-            b0 = (uint32_t)(2 * q) < nv ? b0 : 0u;
-            b1 = (uint32_t)(2 * q + 1) < nv ? b1 : 0u;
-        }
+        // (a value that is not there shifts a ZERO into place: one bit-field extract per value where a compare and a select
+        // were two)
+        const uint32_t b0 = (FULL ? 1u : (keep >> (2 * q)) & 1u) << (d & 31u);
+        const uint32_t b1 = (FULL ? 1u : (keep >> (2 * q + 1)) & 1u) << ((d >> 16) & 31u);
 #if RHIP_ABL_L1 == 3 || RHIP_ABL_L1 == 4  /* ablation builds only (wrong results): plain stores instead of atomics */
         ((volatile uint32_t*)acc)[w0] = b0; ((volatile uint32_t*)acc)[w1] = b1;
 #elif RHIP_ABL_L1 == 5 || RHIP_ABL_L1 == 6  /* ablation: byte stores */
