@@ -329,13 +329,14 @@ __global__ __launch_bounds__(MC_KT * MC_SEG) void k_many_keyscan(const uint32_t*
 
 // every member's descriptor (and tag) into its group: position = kstart[key] + rel[workgroup][key] (members of the key in
 // earlier workgroups) + rank inside the workgroup (an LDS cursor) -- no global atomics.  glast[2g], glast[2g+1] = tag + 1
-// of the group's LAST (in gathered order) full-run member and LAST bitset member (0 = none), for the replay of
-// roaring_bitmap_or_many's full-union typing.  reverse != 0 (tests): a workgroup fills its ranges from the top -- the
+// of the group's LAST (in gathered order) full-run member (all_runs: run member of any length) and LAST bitset member
+// (0 = none), for the replay of roaring_bitmap_or_many's full-union typing / roaring_bitmap_xor_many's fold.  reverse != 0 (tests): a workgroup fills its ranges from the top -- the
 // order inside a group must not matter.
 __global__ __launch_bounds__(MC_THREADS) void k_many_scatter(PoolView P, ManySel S, uint32_t KS, const uint32_t* __restrict__ rel,
                                                             const uint32_t* __restrict__ kstart, const uint32_t* __restrict__ kgrp,
                                                             u64* __restrict__ sdesc, uint32_t* __restrict__ sord,
-                                                            uint32_t* __restrict__ glast, ManyTotals* __restrict__ tot, int reverse) {
+                                                            uint32_t* __restrict__ glast, ManyTotals* __restrict__ tot, int reverse,
+                                                            int all_runs) {
     __shared__ uint32_t h[MC_W3];
     __shared__ u64 s_bytes[MC_THREADS / 64];
     u64 bytes = 0;
@@ -364,7 +365,8 @@ __global__ __launch_bounds__(MC_THREADS) void k_many_scatter(PoolView P, ManySel
                 if (sord) sord[pos] = (uint32_t)t;
 #endif
                 bytes += payload_bytes((uint8_t)r.ty, r.cd, r.nr);
-                if (r.ty == T_BITSET || (r.ty == T_RUN && r.cd == 65536u))
+                // (all_runs -- xor_many: ANY run member makes the group replay the reference's fold, many_xor_replay)
+                if (r.ty == T_BITSET || (r.ty == T_RUN && (all_runs || r.cd == 65536u)))
                     atomicMax(&glast[2 * (u64)kgrp[r.key] + (r.ty == T_BITSET ? 1u : 0u)], (uint32_t)t + 1u);
             }
         });
@@ -412,7 +414,7 @@ __device__ __forceinline__ void many_two_scans(uint32_t* sa, uint32_t* sb, const
 __global__ __launch_bounds__(256) void k_many_groups(const u64* __restrict__ skey, const u64* __restrict__ sdesc, u64 M,
                                                      ManyLb lb, u64* __restrict__ gstart, u64* __restrict__ gcs,
                                                      u64* __restrict__ gkey, uint32_t* __restrict__ glast,
-                                                     ManyTotals* __restrict__ tot) {
+                                                     ManyTotals* __restrict__ tot, int all_runs) {
     __shared__ uint32_t s_h[32], s_c[32];
     __shared__ uint32_t s_tile;
     __shared__ u64 s_ph, s_pc, s_th, s_tc;
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(256) void k_many_groups(const u64* __restrict__ ske
         // last full-run / last bitset member of the group.  At a fixed k the wave's members are consecutive, so when
         // the flagged ones share a group only the highest lane needs to publish.
         const uint32_t ty = md_type(d[k]);
-        const bool frf = in && ty == T_RUN && md_full(d[k]), fb = in && ty == T_BITSET;
+        const bool frf = in && ty == T_RUN && (all_runs || md_full(d[k])), fb = in && ty == T_BITSET;
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
             const bool f = x ? fb : frf;
@@ -843,6 +845,8 @@ struct ManyOut {
     int force_typed;    // 1: single-member groups are typed by cardinality too
     int exact_or_many;  // 1: reproduce roaring_bitmap_or_many's run-vs-bitset choice for FULL containers
     int arrays_only;    // 1: the pool holds array containers only (type census): a full union is a bitset, member tags are not kept
+    int exact_xor_many; // 1: reproduce roaring_bitmap_xor_many's container types: a group with a run member replays the fold (many_xor_replay)
+    int single_copy;    // 1: ONE bitmap selected -- the reference returns roaring_bitmap_copy (roaring.c:779-781, 799-801): no repair pass
     uint32_t world, dense_b;
     u64 key_space;
     const uint32_t* glast;  // [2 G] tag + 1 of the last full-run / last bitset member of every group (0 = none)
@@ -1051,12 +1055,177 @@ __device__ __forceinline__ bool many_pass_through(u64 d, const uint8_t* __restri
                 if (4u * i + k < n) c += (w[k] >> 16) + 1u;
         }
         card = blk_sum(c, sc->wsum);
-        if (type_eff(card, n) != T_RUN) return false;  // (block-uniform)
+        if (!MO.single_copy && type_eff(card, n) != T_RUN) return false;  // (block-uniform)
     }
     uint4* __restrict__ po = (uint4*)(MO.O.arena + MO.O.off[g]);
     for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) po[i] = ps[i];
     if (threadIdx.x == 0) MO.O.meta[g] = pack_meta(ty, card, ty == T_RUN ? n : 0u);
     return true;
+}
+
+// ------------------------------------------------------------------ roaring_bitmap_xor_many: the fold, replayed
+// roaring_bitmap_xor_many (roaring.c:795-809) is a FIXED left fold -- lazy_xor(x0, x1), lazy_xor_inplace(.., x2) ...,
+// repair_after_lazy -- so the container TYPES of its result are reproducible, and they are not always the canonical
+// ones: a RUN accumulator survives R ^ R (run_run_container_xor, mixed_xor.c:179-186: typed by size) and R ^ A with
+// fewer than 32 array values (array_run_container_xor, mixed_xor.c:104-138), the first step keeps A ^ R as a raw run
+// (containers.h:1636-1651), and whatever is a run at the end goes through convert_run_to_efficient_container
+// (containers.h:344-371) -- the result can be a run container.  Without run members every path ends typed by
+// cardinality (many_finalize).  A group WITH a run member takes this replay: its members one by one in gathered order
+// (their tags), the accumulator's type tracked by the reference's rules from the accumulator's cardinality and run
+// count after every step.  State: T = 0 (no accumulator: none yet, or REMOVED when it became empty, roaring.c:2812-2820),
+// T_BITSET (lazy or not: the two behave alike), T_ARRAY, T_RUN.
+constexpr uint32_t XR_CAP = 1024;  // members sorted at a time (tmp: 2048 words of run raster + XR_CAP u64 sort entries)
+static_assert(MANY_TMP_WORDS >= 2048 + 2 * XR_CAP, "the replay's raster buffer and sort window share tmp");
+
+__device__ __forceinline__ void blk_sum2(uint32_t a, uint32_t b, BlockScratch* sc, uint32_t* sa, uint32_t* sb) {
+    a = wave_sum(a); b = wave_sum(b);
+    __syncthreads();
+    if (lane_id() == 0) { sc->wsum[threadIdx.x >> 6] = a; sc->wsum2[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    *sa = sc->wsum[0] + sc->wsum[1] + sc->wsum[2] + sc->wsum[3];
+    *sb = sc->wsum2[0] + sc->wsum2[1] + sc->wsum2[2] + sc->wsum2[3];
+}
+// cardinality and canonical run count of the (linear) LDS image
+__device__ __forceinline__ void many_image_stats(const uint32_t* acc, BlockScratch* sc, uint32_t* card, uint32_t* nruns) {
+    const uint32_t tid = threadIdx.x;
+    const uint4 r0 = ((const uint4*)acc)[2 * tid], r1 = ((const uint4*)acc)[2 * tid + 1];
+    const uint32_t r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    uint32_t pm = tid ? (acc[8 * tid - 1] >> 31) : 0u, c = 0, ns = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        c += __popc(r[k]);
+        ns += __popc(r[k] & ~((r[k] << 1) | pm));  // run starts: set bits whose predecessor is clear
+        pm = r[k] >> 31;
+    }
+    blk_sum2(c, ns, sc, card, nruns);
+}
+// one member XORed into the linear image (tmp[0, 2048): raster scratch of a run member)
+__device__ __forceinline__ void many_xor_member(uint32_t* acc, uint32_t* tmp, const uint8_t* __restrict__ arena, u64 d,
+                                                BlockScratch* sc) {
+    const uint32_t tid = threadIdx.x, ty = md_type(d);
+    if (ty == T_ARRAY) {
+        const uint32_t n = md_n(d);
+        const uint16_t* __restrict__ a = (const uint16_t*)(arena + md_off(d));
+        for (uint32_t i = tid; i < n; i += 256) {
+            const uint32_t v = a[i];
+            atomicXor(&acc[v >> 5], 1u << (v & 31u));
+        }
+    } else if (ty == T_BITSET) {
+        const uint4* __restrict__ g = (const uint4*)(arena + md_off(d));
+        const uint4 a = g[2 * tid], b = g[2 * tid + 1];
+        uint4 r0 = ((uint4*)acc)[2 * tid], r1 = ((uint4*)acc)[2 * tid + 1];
+        r0 = op4(OP_XOR, r0, a); r1 = op4(OP_XOR, r1, b);
+        ((uint4*)acc)[2 * tid] = r0; ((uint4*)acc)[2 * tid + 1] = r1;
+    } else {
+        many_raster_runs(tmp, arena, d, sc);  // (ends with a barrier)
+        uint4 r0 = ((uint4*)acc)[2 * tid], r1 = ((uint4*)acc)[2 * tid + 1];
+        r0 = op4(OP_XOR, r0, ((const uint4*)tmp)[2 * tid]); r1 = op4(OP_XOR, r1, ((const uint4*)tmp)[2 * tid + 1]);
+        ((uint4*)acc)[2 * tid] = r0; ((uint4*)acc)[2 * tid + 1] = r1;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void xr_sort(u64* L, uint32_t n) {  // bitonic, ascending; n <= XR_CAP
+    uint32_t n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    for (uint32_t i = n + threadIdx.x; i < n2; i += 256) L[i] = ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= n2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < n2; i += 256) {
+                const uint32_t x = i ^ j;
+                if (x > i) {
+                    const u64 a = L[i], b = L[x];
+                    if ((a > b) == ((i & k) == 0u)) { L[i] = b; L[x] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+// The whole workgroup; acc / tmp are the caller's LDS image and scratch, s_cnt one LDS word.  Writes the group's result
+// (payload + meta) like many_finalize does.
+__device__ void many_xor_replay(uint32_t* acc, uint32_t* tmp, const PoolView& P, const ManyView& V, const ManyOut& MO,
+                                uint32_t g, u64 gs, u64 ge, BlockScratch* sc, uint32_t* s_cnt) {
+    const uint32_t tid = threadIdx.x;
+    const u64 key = MO.O.key[g];
+    // the first step is container_lazy_xor iff ids[0] AND ids[1] hold the key (their members have the two smallest tags)
+    const bool first = many_key_in(P, MO.first_lo, MO.first_hi, key) && many_key_in(P, MO.second_lo, MO.second_hi, key);
+    u64* L = (u64*)(tmp + 2048);
+    __syncthreads();
+    lds_zero(acc);
+    __syncthreads();
+    uint32_t T = 0, card = 0, nruns = 0, step = 0;
+    const u64 m = ge - gs, Mtot = V.gstart[V.tot->n_groups];
+    u64 done = 0, lo = 0, width = Mtot + 1;  // tags in [lo, lo + width) next
+    while (done < m) {
+        uint32_t cnt;
+        if (!V.sord) {  // sorted path: positions ARE the tags
+            cnt = (uint32_t)(m - done < XR_CAP ? m - done : XR_CAP);
+            for (uint32_t j = tid; j < cnt; j += 256) L[j] = done + j;
+            __syncthreads();
+        } else {
+            // the members with lo <= tag < lo + width into the window; too many: halve the width (tags are unique, so
+            // a width of XR_CAP always fits); none: move on
+            for (;;) {
+                __syncthreads();
+                if (tid == 0) *s_cnt = 0;
+                __syncthreads();
+                const u64 hi = lo + width;
+                for (u64 i = gs + tid; i < ge; i += 256) {
+                    const u64 t = V.sord[i];
+                    if (t >= lo && t < hi) {
+                        const uint32_t p = atomicAdd(s_cnt, 1u);
+                        if (p < XR_CAP) L[p] = (t << 32) | (i - gs);
+                    }
+                }
+                __syncthreads();
+                cnt = *s_cnt;
+                if (cnt > XR_CAP) { width = width / 2 > XR_CAP ? width / 2 : XR_CAP; continue; }
+                lo = hi;
+                if (cnt) break;
+            }
+            xr_sort(L, cnt);
+        }
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const u64 d = V.sdesc[gs + (L[j] & 0xFFFFFFFFull)];
+            const uint32_t ty = md_type(d), mc = md_n(d);  // (mc: an array member's cardinality)
+            const uint32_t pc = card;                      // the accumulator's cardinality before this step
+            many_xor_member(acc, tmp, P.arena, d, sc);
+            many_image_stats(acc, sc, &card, &nruns);
+            ++step;
+            const uint32_t by_card = (uint32_t)type_ba(card), by_size = (uint32_t)type_eff(card, nruns);
+            if (T == 0u) T = ty;                                   // cloned (roaring.c:2718-2731, 2829-2841)
+            else if (T == T_BITSET && ty == T_BITSET) T = T_BITSET;  // bitset_container_xor_nocard
+            else if (first && step == 2u) {                        // container_lazy_xor, containers.h:1570-1653
+                if (T == T_ARRAY && ty == T_ARRAY) T = pc + mc <= 1024u ? T_ARRAY : T_BITSET;  // mixed_xor.c:221-253
+                else if (T == T_RUN && ty == T_RUN) T = by_size;
+                else if (T == T_BITSET || ty == T_BITSET) T = T_BITSET;
+                else T = T_RUN;                                    // array_run_container_lazy_xor: a raw run
+            } else {                                               // container_lazy_ixor -> container_ixor
+                if (T == T_RUN && ty == T_RUN) T = by_size;
+                else if (T == T_ARRAY && ty == T_RUN) T = pc < 32u ? by_size : by_card;
+                else if (T == T_RUN && ty == T_ARRAY) T = mc < 32u ? by_size : by_card;
+                else T = by_card;
+            }
+            if (card == 0u) T = 0u;                                // container_nonzero_cardinality fails: key removed
+        }
+        done += cnt;
+    }
+    // repair_after_lazy: a run goes through convert_run_to_efficient_container, a bitset is typed by cardinality
+    int ty = T_ARRAY;
+    if (card) {
+        ty = T == T_RUN ? type_eff(card, nruns) : type_ba(card);
+        const uint4 r0 = ((const uint4*)acc)[2 * tid], r1 = ((const uint4*)acc)[2 * tid + 1];
+        const uint32_t r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        __syncthreads();
+        if (ty == T_RUN) lds_emit(acc, r, T_RUN, card, nruns, (uint16_t*)tmp, MO.O.arena + MO.O.off[g], sc);
+        else many_emit(r, ty, card, (uint16_t*)tmp, MO.O.arena + MO.O.off[g], sc);
+    }
+    if (tid == 0) MO.O.meta[g] = pack_meta(ty, card, ty == T_RUN ? nruns : 0u);
+    __syncthreads();
+}
+// does group g (members [gs, ge)) take the replay?
+__device__ __forceinline__ bool many_xor_replays(const ManyOut& MO, uint32_t g, u64 gs, u64 ge) {
+    return MO.exact_xor_many && ge - gs >= 2 && MO.glast[2 * (u64)g] != 0u;
 }
 
 // PF = loads of the ring in flight behind every scatter (RHIP_MANY_PF selects 1 / 2 / 3 / 4; default 1)
@@ -1095,6 +1264,10 @@ __global__ __launch_bounds__(256, RHIP_MANY_WAVES) void k_many_l1(PoolView P, Ma
             if (nu == 1 && (ge - gs) == 1 && !MO.force_typed && !MO.partial_mode &&
                 many_pass_through(V.sdesc[gs], P.arena, MO, g, &sc))  // a single member keeps its container (unless it is an inefficient run)
                 continue;
+            if (many_xor_replays(MO, g, gs, ge)) {  // xor_many, a run member: the reference's fold decides the type
+                if (nu == 1) many_xor_replay(acc, tmp, P, V, MO, g, gs, ge, &sc, &s_cnt);
+                continue;                           // (a cut group: k_many_l2 replays it)
+            }
             const u64* desc = V.sdesc;
             u64 a0 = gs > lo ? gs : lo, a1 = ge < hi ? ge : hi;
             // One accumulation site for the piece's members and -- rarely -- for the replay of a full union's prefix
@@ -1137,6 +1310,10 @@ __global__ __launch_bounds__(256) void k_many_l2(PoolView P, ManyView V, ManyOut
     for (uint32_t g = blockIdx.x; g < G; g += gridDim.x) {
         const u64 p0 = V.pstart[g], np = V.pstart[g + 1] - p0;
         if (np < 2) continue;
+        if (many_xor_replays(MO, g, V.gstart[g], V.gstart[g + 1])) {
+            many_xor_replay(acc, tmp, P, V, MO, g, V.gstart[g], V.gstart[g + 1], &sc, &s_cnt);
+            continue;
+        }
         uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
         for (u64 u = 0; u < np; u += 8) {  // eight chunks' loads in flight (one at a time: 15 GB/s for the one block)
             uint4 a[8], b[8];

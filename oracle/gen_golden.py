@@ -288,6 +288,72 @@ def frozen_golden(R):
     print("  frozen:", {k: len(v) for k, v in out.items() if k.endswith("_crc")})
 
 
+def robust_corpus():
+    """The malformed / borderline portable images the reference's own tests hold
+    (tests/robust_deserialization_unit.c:98-124 crashproneinput1-7.bin, :168-388 the hand-made vectors;
+    tests/cpp_roaring64_unit.cpp:427-439 the four bad 64map*.bin) as (name, bytes, is64)."""
+    td = os.path.join(REF, "tests", "testdata")
+    out = [(f"crashproneinput{i}", open(os.path.join(td, f"crashproneinput{i}.bin"), "rb").read(), 0) for i in range(1, 8)]
+    b = bytes
+    out.append(("negative_container_count", b([0x3A, 0x30, 0, 0, 0, 0, 0, 0x80]), 0))
+    n = (1 << 16)
+    out.append(("max_container_count_valid", b([0x3A, 0x30, 0, 0, 0, 0, 0x01, 0]) + b(n * 10), 0))
+    out.append(("huge_container_count", b([0x3A, 0x30, 0, 0, 1, 0, 0x01, 0]) + b((n + 1) * 10), 0))
+    hdr = [0x3B, 0x30, 0, 0]
+    out.append(("run_container_empty", b(hdr + [1, 0, 0, 0, 0, 0, 0]), 0))
+    out.append(("run_should_combine", b(hdr + [1, 0, 0, 1, 0, 2, 0, 0, 0, 0, 0, 1, 0, 0, 0]), 0))
+    out.append(("run_overlap", b(hdr + [1, 0, 0, 4, 0, 2, 0, 0, 0, 4, 0, 1, 0, 0, 0]), 0))
+    out.append(("run_overflow", b(hdr + [1, 0, 0, 4, 0, 1, 0, 0xFE, 0xFF, 4, 0]), 0))
+    out.append(("run_incorrect_cardinality_still_allowed", b(hdr + [1, 0, 0, 0, 0, 1, 0, 0, 0, 8, 0]), 0))
+    two = [0x3B, 0x30, 1, 0, 0]
+    out.append(("duplicate_keys", b(two + [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]), 0))
+    out.append(("unsorted_keys", b(two + [1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]), 0))
+    out.append(("unsorted_array", b(hdr + [0, 0, 0, 1, 0, 1, 0, 0, 0]), 0))
+    out.append(("duplicate_array", b(hdr + [0, 0, 0, 1, 0, 0, 0, 0, 0]), 0))
+    full = b(hdr + [0, 0, 0, 0xFF, 0xFF]) + b([0xFF]) * 8192
+    out.append(("bitset_full_valid", full, 0))
+    out.append(("bitset_incorrect_cardinality", full[:-1] + b([0xFE]), 0))
+    for i in range(len(out)):  # truncated by one byte: never a bitmap (robust_deserialization_unit.c:147-149)
+        nm, d, _ = out[i]
+        if not nm.startswith("crash") and len(d) < 100000:
+            out.append((nm + "_truncated", d[:-1], 0))
+    for f in ("64mapemptyinput", "64mapsizetoosmall", "64mapinvalidsize", "64mapkeytoosmall",
+              "64map32bitvals", "64mapspreadvals", "64maphighvals", "64mapempty"):
+        out.append((f, open(os.path.join(td, f + ".bin"), "rb").read(), 1))
+    return out
+
+
+def robust_golden(R):
+    """For every vector: does the reference hand back a VALID bitmap (deserialize_safe non-NULL AND
+    roaring_bitmap_internal_validate -- what robust_deserialization_unit.c:131-166 asserts), and its re-serialization."""
+    import ctypes as C
+    R.L.roaring64_bitmap_internal_validate.restype = C.c_bool
+    R.L.roaring64_bitmap_internal_validate.argtypes = [C.c_void_p, C.POINTER(C.c_char_p)]
+    names, blobs, is64, accept, nonnull, reser = [], [], [], [], [], []
+    for nm, d, w in robust_corpus():
+        reason = C.c_char_p()
+        if w:
+            h = R.L.roaring64_bitmap_portable_deserialize_safe(d, len(d))
+            ok = bool(h) and bool(R.L.roaring64_bitmap_internal_validate(h, C.byref(reason)))
+            ser = R.serialize64(h) if ok else b""
+            if h:
+                R.free64(h)
+        else:
+            h = R.L.roaring_bitmap_portable_deserialize_safe(d, len(d))
+            ok = bool(h) and R.validate(h)
+            ser = R.serialize(h) if ok else b""
+            if h:
+                R.free(h)
+        names.append(nm); blobs.append(d); is64.append(w); accept.append(int(ok)); nonnull.append(int(bool(h))); reser.append(ser)
+        print(f"  robust {nm}: {len(d)} bytes, reference {'accepts' if ok else ('returns an INVALID bitmap' if h else 'rejects')}")
+    lens = np.array([len(d) for d in blobs], np.uint64)
+    rlens = np.array([len(d) for d in reser], np.uint64)
+    np.savez_compressed(os.path.join(GOLD, "robust_corpus.npz"), names=np.array(names), is64=np.array(is64, np.uint8),
+                        accept=np.array(accept, np.uint8), nonnull=np.array(nonnull, np.uint8), lens=lens,
+                        blob=np.frombuffer(b"".join(blobs), np.uint8), rlens=rlens,
+                        reser=np.frombuffer(b"".join(reser), np.uint8))
+
+
 def main():
     R = Ref()
     os.makedirs(GOLD, exist_ok=True)
@@ -304,9 +370,11 @@ def main():
         c4_golden(R)
     if "frozen" in names:  # (reads the committed bundles: run after the datasets)
         frozen_golden(R)
+    if "robust" in names:
+        robust_golden(R)
     if "c4x10" in names:  # (not in the default list: 10^6 bitmaps, a few minutes)
         c4x10_golden(R)
-    for name in [n for n in names if n not in ("synth", "c4", "c5", "c4x10", "frozen")]:
+    for name in [n for n in names if n not in ("synth", "c4", "c5", "c4x10", "frozen", "robust")]:
         print(name)
         hs = load_text_dataset(R, name)
         write_bundle(os.path.join(GOLD, f"{name}.rbnd.xz"), [R.serialize(h) for h in hs])

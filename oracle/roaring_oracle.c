@@ -1224,18 +1224,88 @@ oc_bitmap_t *oc_or_many(size_t n, const oc_bitmap_t **x) {
     return ans;
 }
 
-/* roaring_bitmap_xor_many, roaring.c:795-809.  Set-level restatement: the
- * reference folds with lazy_xor; the fold below uses the eager pairwise xor,
- * which yields the same SET (container types of *_many results are not stable
- * inside the reference either), so parity for xor_many is L1. */
+/* One matched-key step of roaring_bitmap_xor_many's fold.  first_step: container_lazy_xor
+ * (containers.h:1570-1653, called by roaring_bitmap_lazy_xor, roaring.c:2684-2770, for a key both x[0] and x[1]
+ * hold); otherwise container_lazy_ixor (containers.h:1747-1773, called by roaring_bitmap_lazy_xor_inplace,
+ * roaring.c:2772-2843): only B,B stays lazy, every other pair is the EAGER container_ixor -- whose typing is
+ * container_xor's (mixed_xor.c:221-380: the _ixor forms forward to the _xor forms). */
+static void lazy_xor_step(oc_container_t *acc, const oc_container_t *c2, int first_step) {
+    int t1 = acc->type, t2 = c2->type;
+    oc_container_t out;
+    if (t1 == OC_BITSET && t2 == OC_BITSET) { /* bitset_container_xor_nocard: cardinality unknown */
+        uint64_t *w = words_from(acc);
+        const uint64_t *w2 = (const uint64_t *)c2->data;
+        for (int i = 0; i < WORDS; i++) w[i] ^= w2[i];
+        out = mk_bitset(w, -1);
+    } else if (first_step && t1 == OC_ARRAY && t2 == OC_ARRAY) {
+        /* array_array_container_lazy_xor, mixed_xor.c:221-253: an array up to ARRAY_LAZY_LOWERBOUND = 1024
+         * values in total, a lazy bitset (never converted back here) beyond */
+        if (acc->card + c2->card <= 1024) {
+            uint16_t *o = (uint16_t *)malloc(2 * (size_t)(acc->card + c2->card + 1));
+            int k = merge_xor((const uint16_t *)acc->data, acc->card, (const uint16_t *)c2->data, c2->card, o);
+            out = mk_array(o, k);
+        } else {
+            uint64_t *w = words_from(acc), *w2 = words_from(c2);
+            for (int i = 0; i < WORDS; i++) w[i] ^= w2[i];
+            free(w2);
+            out = mk_bitset(w, -1);
+        }
+    } else if (first_step && (t1 == OC_BITSET || t2 == OC_BITSET)) {
+        /* array_bitset_container_lazy_xor / run_bitset_container_lazy_xor, mixed_xor.c:41-59, 83-98 */
+        uint64_t *w = words_from(acc), *w2 = words_from(c2);
+        for (int i = 0; i < WORDS; i++) w[i] ^= w2[i];
+        free(w2);
+        out = mk_bitset(w, -1);
+    } else if (first_step && t1 != t2) { /* A,R / R,A: array_run_container_lazy_xor keeps the raw run list */
+        out = t1 == OC_ARRAY ? ar_xor_raw(acc, c2) : ar_xor_raw(c2, acc);
+    } else {
+        /* first step R,R (run_run_container_xor: converted at once), and every eager step.  A lazy bitset gets its
+         * cardinality first (containers.h:1763-1769); c_xor never reads a bitset's card field, so nothing to do */
+        out = c_xor(acc, c2);
+    }
+    c_free(acc);
+    *acc = out;
+}
+/* container_nonzero_cardinality, containers.h:436-451 (a lazy bitset is scanned: bitset.h bitset_container_empty) */
+static int c_nonzero(const oc_container_t *c) {
+    if (c->type == OC_ARRAY) return c->card > 0;
+    if (c->type == OC_RUN) return c->nruns > 0;
+    if (c->card >= 0) return c->card > 0;
+    const uint64_t *w = (const uint64_t *)c->data;
+    for (int i = 0; i < WORDS; i++)
+        if (w[i]) return 1;
+    return 0;
+}
+static void bm_remove(oc_bitmap_t *b, int pos) { /* ra_remove_at_index, roaring_array.c:381-389 */
+    c_free(&b->c[pos]);
+    for (int i = pos; i + 1 < b->n; i++) {
+        b->keys[i] = b->keys[i + 1];
+        b->c[i] = b->c[i + 1];
+    }
+    b->n--;
+}
+
+/* roaring_bitmap_xor_many, roaring.c:795-809: lazy_xor(x0, x1), then lazy_xor_inplace with x2 ..., then
+ * repair_after_lazy.  A FIXED left fold, so the container types of the result are reproducible (unlike the heap's):
+ * the answer's container under a key is a clone of the first member, an accumulator that becomes empty is REMOVED
+ * (roaring.c:2713-2717, 2812-2820) -- the next member under that key is cloned afresh. */
 oc_bitmap_t *oc_xor_many(size_t n, const oc_bitmap_t **x) {
     if (n == 0) return oc_create();
+    if (n == 1) return oc_copy(x[0]);
     oc_bitmap_t *ans = oc_copy(x[0]);
     for (size_t k = 1; k < n; k++) {
-        oc_bitmap_t *t = oc_xor(ans, x[k]);
-        oc_free(ans);
-        ans = t;
+        for (int j = 0; j < x[k]->n; j++) {
+            int pos = bm_find(ans, x[k]->keys[j]);
+            if (pos < 0) {
+                bm_insert(ans, -pos - 1, x[k]->keys[j], c_clone(&x[k]->c[j]));
+                continue;
+            }
+            /* the first step's matched keys are exactly the keys x[0] and x[1] share: ans == copy of x[0] at k == 1 */
+            lazy_xor_step(&ans->c[pos], &x[k]->c[j], k == 1);
+            if (!c_nonzero(&ans->c[pos])) bm_remove(ans, pos);
+        }
     }
+    for (int i = 0; i < ans->n; i++) repair(&ans->c[i]);
     return ans;
 }
 

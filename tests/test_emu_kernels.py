@@ -312,6 +312,20 @@ def test_emu_many_long_run_passthrough(emu, oracle):
     G.test_many_long_run_passthrough(emu, oracle)
 
 
+def test_emu_xor_many_fold_typing(emu, oracle):
+    G.xor_many_typing_body(emu, oracle, iters=36)
+
+
+def test_emu_many_selection_with_a_wide_bitmap(emu, oracle):
+    G.test_many_selection_with_a_wide_bitmap(emu, oracle)
+
+
+def test_emu_robust_deserialization_corpus(emu):
+    import test_gpu_poolops as GP
+    from oracle.pyoracle import Ref
+    GP.robust_corpus_body(emu, Ref() if Ref.available() else None)
+
+
 def test_emu_join_fallback(oracle, synth, monkeypatch):
     """A forked batch whose flag gate reports a time-out (RHIP_JOIN_FAIL=1) is finished through the fallback of
     rhip_pairwise_end -- streams waited for, the tail's scratch cleared, the tail run again -- with the same bytes."""

@@ -414,6 +414,67 @@ def test_device_deserialization_64bit(engine, oracle):
         H.serialize_many([0, 1])            # 64-bit pools are serialized whole
 
 
+def robust_corpus_body(eng, ref=None):
+    """The reference's OWN malformed / borderline images (tests/robust_deserialization_unit.c:98-388: crashproneinput1-7.bin,
+    negative / huge container counts, empty / adjacent / overlapping / overflowing runs, duplicate and unsorted keys and
+    values, a bitset whose cardinality field lies, every vector truncated by a byte; tests/cpp_roaring64_unit.cpp:
+    427-439: the four bad 64map*.bin) through EVERY loader of the engine -- host-parsed (rhip_pool_from_portable /
+    _portable64), device-parsed (rhip_pool_from_blob, 32- and 64-bit), and as a frozen image (rhip_pool_from_frozen must
+    never take a portable image for a frozen one unless the reference's view + validate does).  A loader accepts a
+    vector exactly when the reference hands back a bitmap that passes roaring_bitmap_internal_validate
+    (tests/golden/robust_corpus.npz, written by oracle/gen_golden.py robust from the reference itself; re-checked live
+    against oracle/_ref where it is present), and then re-serializes to the reference's bytes."""
+    import os
+    from util import GOLD
+    g = np.load(os.path.join(GOLD, "robust_corpus.npz"))
+    names, is64, accept = [str(x) for x in g["names"]], g["is64"], g["accept"]
+    lens, rlens = g["lens"].astype(np.int64), g["rlens"].astype(np.int64)
+    blob, reser = g["blob"].tobytes(), g["reser"].tobytes()
+    o = np.concatenate([[0], np.cumsum(lens)]); ro = np.concatenate([[0], np.cumsum(rlens)])
+    assert len(names) >= 40 and int(accept.sum()) >= 5
+    for k, nm in enumerate(names):
+        d, want = blob[o[k]:o[k + 1]], reser[ro[k]:ro[k + 1]]
+        ok = bool(accept[k])
+        if ref is not None and not is64[k]:  # the fixture against the live reference
+            h = ref.L.roaring_bitmap_portable_deserialize_safe(d, len(d))
+            live = bool(h) and ref.validate(h)
+            if h:
+                ref.free(h)
+            assert live == ok, nm
+        arr = np.frombuffer(d, dtype=np.uint8) if len(d) else np.zeros(0, np.uint8)
+        loaders = [("host", lambda: (eng.pool_from_serialized64 if is64[k] else eng.pool_from_serialized)([d])),
+                   ("device", lambda: eng.pool_from_blob(arr, [0], [len(d)], is64=bool(is64[k])))]
+        for which, load in loaders:
+            try:
+                P = load()
+            except Exception:
+                P = None
+            assert (P is not None) == ok, f"{nm}: the {which} loader {'accepts' if P is not None else 'rejects'}, the reference {'accepts' if ok else 'does not'}"
+            if P is not None:
+                assert P.serialize(0) == want, f"{nm}: {which} loader re-serializes differently from the reference"
+        if not is64[k]:  # a portable image is not a frozen image
+            fz = ref.frozen_deserialize(d) if ref is not None and len(d) else None
+            fz_ok = fz is not None and ref.validate(fz)
+            try:
+                F = eng.pool_from_frozen(arr, [0], [len(d)])
+            except Exception:
+                F = None
+            if ref is not None:
+                # (the reference's view of an EMPTY bitmap image: cookie only -- accepted by both)
+                assert (F is not None) == fz_ok or (F is None and not fz_ok), f"{nm}: frozen loader disagrees with frozen_view + validate"
+                if F is not None and fz_ok:
+                    assert F.serialize(0) == ref.serialize(fz), nm
+            else:
+                assert F is None or len(F) == 1
+            if fz:
+                ref.free(fz)
+
+
+def test_robust_deserialization_corpus(engine):
+    from oracle.pyoracle import Ref
+    robust_corpus_body(engine, Ref() if Ref.available() else None)
+
+
 def _mutations(rng, buf, count):
     out = []
     b = bytearray(buf)
@@ -812,6 +873,9 @@ def frozen_body(eng, oracle):
     assert E.frozen_serialize_all() == [(13766).to_bytes(4, "little")] * 3
     b, o, l = E.frozen_serialize_many()
     assert len(eng.pool_from_frozen(b, o, l)) == 3
+    # a repeated id is refused, as the portable form refuses it (the destination table is indexed by pool container)
+    with pytest.raises(croaring_amd.RoaringHipError):
+        E.frozen_serialize_many(np.array([1, 1], np.uint32))
     # rejected: frozen_view's NULL cases ...
     n = int.from_bytes(ref_img[-4:], "little") >> 15
     def load(img):
