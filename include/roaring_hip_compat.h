@@ -30,10 +30,16 @@
  * *_cardinality functions return UINT64_MAX.  The void in-place / repair functions have no error channel: a
  * device or allocation failure inside them prints rhip_last_error() to stderr and abort()s rather than
  * silently leaving x1 unchanged.
- * Parity: pairwise, in-place, cardinality and or_many(_heap = or_many) results are byte-identical to the
- * reference's (container types included); roaring_bitmap_xor_many is SET-EQUAL and canonical (array iff
- * cardinality <= 4096, else bitset), not type-identical -- the reference's lazy_xor fold leaves order-dependent
- * container types.
+ * Parity: pairwise, in-place, cardinality, roaring_bitmap_or_many and roaring_bitmap_xor_many results are
+ * byte-identical to the reference's (container types included: both *_many functions are fixed left folds, whose
+ * order-dependent typing -- full unions, run accumulators -- is replayed on the device).
+ * roaring_bitmap_or_many_heap is the ONE exception: its result is SET-EQUAL to the reference's, valid
+ * (roaring_bitmap_internal_validate) and carries the container types of roaring_bitmap_or_many -- not the heap's.
+ * The reference's tournament (src/roaring_priority_queue.c:200-247) orders its merges by the serialized size of every
+ * intermediate and never converts to bitsets early (bitsetconversion = false), so the type of a container depends on
+ * which partial unions met in which order: n - 1 sequentially dependent steps, each needing the previous one's size.
+ * The reference's own two many-way unions already disagree byte-wise (wikileaks-noquotes, census-income: SURVEY G11);
+ * a caller that needs the heap's exact bytes keeps the reference's symbol.
  *
  * How a program uses it: keep including <roaring/roaring.h>, link libroaring_hip.so BEFORE libroaring
  * (or build libroaring with these symbols renamed): these symbols then resolve here,

@@ -87,6 +87,10 @@ def test_realdata_many(engine, oracle, name):
         assert oracle.validate(hg)
         assert np.array_equal(oracle.to_array(hg), oracle.to_array(hw)), f"{name} {nm}: set mismatch"
         assert got == want, f"{name} {nm}: container types differ from roaring_bitmap_{nm}"
+        if nm == "or_many":  # the heap variant's contract is L1 (roaring_hip_compat.h): the same SET as the reference's tournament
+            hh = oracle.deserialize(bytes(gold["or_many_heap"]))
+            assert np.array_equal(oracle.to_array(hg), oracle.to_array(hh)), f"{name}: or_many vs the reference's or_many_heap"
+            oracle.free(hh)
         oracle.free(hg)
         oracle.free(hw)
 
