@@ -335,8 +335,15 @@ def run_realdata(eng, D: Dist, name: str, tag: str, chk, is64=False, ops=("and",
 
         def call_adhoc():
             res[0] = eng.pairwise(op, pool, lhs, pool, rhs, reuse=res[0])
+        def call_first():  # a batch that has to PLAN: the list's cached plans dropped in front of it (untimed)
+            plist.drop_plans()
+            t0 = time.perf_counter()
+            call()
+            return time.perf_counter() - t0
         amin, amed = timed_calls(D, call_adhoc)
-        tmin, tmed = timed_calls(D, call)
+        call_first()
+        fmed = float(np.median([D.max(call_first()) for _ in range(max(5, min(D.reps, 15)))]))
+        tmin, tmed = timed_calls(D, call)  # (every call after the first takes its plan from the list: rhip_pairlist, round 6)
         st = eng.last_stats()
         alg = D.sum(float(st["bytes_in"] + st["bytes_out"]))
         csum = D.sum(float(res[0].cardinalities().sum()))
@@ -344,7 +351,9 @@ def run_realdata(eng, D: Dist, name: str, tag: str, chk, is64=False, ops=("and",
         if want is not None and D.rank == 0:
             assert int(csum) == want, f"{name} {op}: checksum {int(csum)} != SURVEY §8d {want}"
         row = {"pairs": int(L.size), "ops_per_s": L.size / tmed, "ops_per_s_best": L.size / tmin,
-               "ms_batch_median": tmed * 1e3, "ms_batch_min": tmin * 1e3, "ms_adhoc_list": amed * 1e3, "alg_GBps": alg / tmed / 1e9,
+               "ms_batch_median": tmed * 1e3, "ms_batch_min": tmin * 1e3, "ms_first_call": fmed * 1e3,
+               "plan_cached": bool(eng.plan_cached()), "ms_adhoc_list": amed * 1e3, "alg_GBps": alg / tmed / 1e9,
+               "frac_first_call": alg / fmed / 1e9 / HBM_PEAK_GBS,
                "frac": alg / tmed / 1e9 / HBM_PEAK_GBS, "checksum": int(csum), "checksum_ok": want is None or int(csum) == want,
                "matched_pairs_rank0": int(st["matched_pairs"]), "passthrough_rank0": int(st["passthrough"])}
         # `frac` is ALGORITHMIC bytes over time -- on a 7.6 MB data set the operands live in the L2s, so it is
@@ -914,7 +923,8 @@ def main():
             row = [None if ms is None else round(ms, 4), None if r.get("frac") is None else round(r["frac"], 4), ok]
             if "ms_adhoc_list" in r:
                 row += [round(r["ms_adhoc_list"], 4), round(r.get("ms_batch_pipelined2", 0.0), 4),
-                        None if "hbm_traffic_frac" not in r else round(r["hbm_traffic_frac"], 3)]
+                        None if "hbm_traffic_frac" not in r else round(r["hbm_traffic_frac"], 3),
+                        None if "ms_first_call" not in r else round(r["ms_first_call"], 4)]
             if "sharded_w1" in r:
                 row += [round(r["sharded_w1"]["vs_or_many"], 3)]
             if "us_per_op" in r:
@@ -922,10 +932,12 @@ def main():
             summ[k] = row
         out["config"]["secondary_summary"] = {
             "rows": summ,
-            "columns": "ms per batch (median, whole call: planning + kernels + wait) | fraction of the 8 TB/s HBM peak | checksum / "
+            "columns": "ms per batch (median, whole call incl. the wait; realdata: a REPEATED batch over a prepared pair list, whose plan "
+                       "is kept with the list -- ms_planned) | fraction of the 8 TB/s HBM peak | checksum / "
                        "cardinality equal to the reference's | realdata only: ms with the pair list handed over per call instead of "
-                       "prepared once, ms per call with two calls in flight, HBM TRAFFIC (stored PMC pass) / time / 8 TB/s -- the "
-                       "second column counts algorithmic bytes, which on these cache-resident sets is not HBM utilisation | c4: sharded pipeline at world 1 / or_many | "
+                       "prepared once (plans every time), ms per call with two calls in flight, HBM TRAFFIC (stored PMC pass) / time / 8 TB/s -- the "
+                       "second column counts algorithmic bytes, which on these cache-resident sets is not HBM utilisation --, ms of the "
+                       "FIRST call over the prepared list (planning kernels included: ms_first_call) | c4: sharded pipeline at world 1 / or_many | "
                        "c4_shard_stages: N -> [stage 1 ms, stage 3 ms, DESIGN 7a model ms] for one rank of N on this GPU | "
                        "*_successive_*: the n - 1 adjacent pairs as one batch + cardinalities read back (the reference benchmark's "
                        "successive_and / _or loop), then us per op here, us per op of CRoaring on one core | dropin_percall_us: op -> "

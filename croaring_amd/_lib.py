@@ -109,6 +109,8 @@ SYMBOLS = [
     ("rhip_debug_host_clock", _i, [_vp, C.POINTER(C.c_double), _i]),
     ("rhip_debug_last_placement", _i, [_vp, C.POINTER(C.c_float), _i]),
     ("rhip_debug_join_recovered", _u64, [_vp]),
+    ("rhip_debug_plan_cached", _i, [_vp]),
+    ("rhip_pairlist_drop_plans", _i, [_vp]),
     ("rhip_ctx_trim", _u64, [_vp]),
 ]
 

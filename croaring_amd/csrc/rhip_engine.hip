@@ -172,6 +172,11 @@ struct rhip_ctx_s {
         }
     } ss[N_SLOTS + 1];
     hipEvent_t ev_plan[N_SLOTS] = {};
+    // A batch over a PREPARED pair list keeps its plan on the list (PlanCache below): the matched container pairs, the class
+    // queues and the candidate directory are a pure function of the two pools' directories and the ops, so a repeated batch
+    // starts at its class kernels.  RHIP_PLAN_CACHE=0: every batch plans afresh.
+    bool plan_cache = true;
+    bool last_plan_cached = false;  // the last batch begun on this context took its plan from a pair list's cache (rhip_debug_plan_cached)
     bool plan_overlap = true;  // RHIP_PLAN_OVERLAP=0: the planning kernels of a batch always run on the main stream
     uint64_t plan_overlap_max_bytes = 2ull << 30;
     int in_flight() const { int n = 0; for (bool b : slot_busy) n += b ? 1 : 0; return n; }
@@ -349,6 +354,8 @@ struct rhip_pool_s {
 };
 
 // sums over a pair list that size a batch (plan()): planning units, matched / candidate containers, result-slot bytes
+struct PlanCache;       // (defined behind Plan, further down)
+struct PlanCacheEntry;
 struct PairSums {
     uint64_t nu_a = 0, nu_b = 0, s_mn = 0, s_na = 0, s_nb = 0, s_wmin = 0, s_wa = 0, s_wb = 0;
 };
@@ -366,6 +373,7 @@ struct rhip_pairlist_s {
     int in_use = 0;                  // batches in flight that read d_idx
     bool free_deferred = false;
     bool pinned = false;             // A / B carry this list's pin (list_pins)
+    PlanCache* cache = nullptr;  // the list's cached plans (below): what k_count / k_scan / k_emit leave behind
 };
 
 static void pairlist_destroy(rhip_pairlist_t* L);
@@ -447,6 +455,7 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_STAGE_KERNEL")) c->stage_kernel = !(e[0] == '0');
         if (const char* e = getenv("RHIP_FORK_MIN_MB")) c->fork_min_bytes = c->fork_light_bytes = (uint64_t)atoll(e) << 20;
         if (const char* e = getenv("RHIP_PLAN_OVERLAP")) c->plan_overlap = !(e[0] == '0');
+        if (const char* e = getenv("RHIP_PLAN_CACHE")) c->plan_cache = atoi(e) != 0;
         if (const char* e = getenv("RHIP_MANY_PF")) c->many_pf = atoi(e);
         if (const char* e = getenv("RHIP_MERGE_CLASSES")) c->merge_classes = !(e[0] == '0');
         if (const char* e = getenv("RHIP_DEBUG_PLAN")) c->debug_plan = e[0] == '1';
@@ -1211,6 +1220,12 @@ struct Plan {
     bool grouped = false;  // the filter / union items are queued by X container (k_filter_g / k_union_g)
     uint32_t copy_per_wave = 4;  // pass-through items a wave of k_copy takes at a time: 16 when the pools hold tiny containers
     const u64* xranges() const { return words + sc.w_ranges + 2 * N_SEC; }
+    // where the planning kernels left what the class kernels and the tail only READ -- the class queues (all but the
+    // retry queue), the candidate directory: the slot's scratch, or the entry of the pair list's plan cache
+    rhip_ctx_s::SlotScratch* Q = nullptr;
+    ::PlanCacheEntry* ce = nullptr;  // the cache entry this plan was taken from / saved to (its buffers are Q)
+    bool cache_hit = false;
+    DBuf& q(rhip_ctx_t* c, int cls) const { return (cls == CLS_RETRY || !Q) ? c->ss[slot].q[cls] : Q->q[cls]; }
     // device pointers
     uint32_t *d_lhs = nullptr, *d_rhs = nullptr, *d_upair = nullptr, *d_utile = nullptr;
     u64* d_pair0 = nullptr;
@@ -1223,6 +1238,32 @@ struct Plan {
     u64* tail_part() const { return words + sc.w_tail_part; }
     u64* join_flags() const { return words + sc.w_join; }
 };
+
+}  // namespace
+// One cached plan of a prepared pair list: key = (ops, cardinality mode, the operand pools' bounds_gen -- an in-place
+// update or a reload of a pool gives it a new one).  `ss` holds the buffers the class kernels only read (queues, candidate
+// directory), `ranges` the section ranges k_scan computed (they live in the slot's scratch words, which every call
+// clears: k_plan_restore writes them back).  An entry is re-planned only while no batch in flight reads it.
+struct PlanCacheEntry {
+    bool valid = false;
+    uint32_t ops_packed = 0;
+    int n_ops = 0, cardmode = 0;
+    uint64_t genA = 0, genB = 0, stamp = 0;
+    int in_use = 0;
+    Plan P;
+    rhip_ctx_s::SlotScratch ss;
+    DBuf ranges;
+};
+struct PlanCache {
+    static constexpr int N = 6;  // and / or / xor / andnot, a multi-op batch, a cardinality form
+    PlanCacheEntry e[N];
+    uint64_t clock = 0;
+    void release() {
+        for (auto& x : e) { x.ss.release(); x.ranges.release(); x.valid = false; }
+    }
+};
+namespace {
+constexpr uint32_t N_RANGE_WORDS = 2 * N_SEC + 3;
 
 void check_pair_args(rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32_t* lhs, const uint32_t* rhs) {
     if (!A || !B) { set_err("null pool"); throw (int)RHIP_ERR_ARG; }
@@ -1237,8 +1278,8 @@ void check_pair_args(rhip_pool_t* A, rhip_pool_t* B, size_t npairs, const uint32
 template <int OP>
 void launch_bb(rhip_ctx_t* c, hipStream_t st, unsigned grid, const PoolView& A, const PoolView& B, const OutView& O, const Plan& P,
                int cardmode) {
-    hipLaunchKernelGGL(k_bb<OP>, dim3(grid), dim3(256), 0, st, A.arena, B.arena, O, c->ss[P.slot].q[CLS_BB].as<BBItem>(),
-                       P.ranges() + 2 * SEC_BB, cardmode, c->pair_acc.as<u64>(), c->ss[P.slot].q[CLS_RETRY].as<GenItem>(),
+    hipLaunchKernelGGL(k_bb<OP>, dim3(grid), dim3(256), 0, st, A.arena, B.arena, O, P.q(c, CLS_BB).as<BBItem>(),
+                       P.ranges() + 2 * SEC_BB, cardmode, c->pair_acc.as<u64>(), P.q(c, CLS_RETRY).as<GenItem>(),
                        P.retry_count());
 }
 
@@ -1302,6 +1343,43 @@ Plan plan(rhip_ctx_t* c, const OpSet& ops, rhip_pool_t* A, rhip_pool_t* B, size_
     P.slot = slot;
     fetch_bounds(A);
     fetch_bounds(B);
+    // ---- the pair list's plan cache: a hit starts the batch at its class kernels
+    ::PlanCacheEntry* ce = nullptr;
+    if (L && c->plan_cache) {
+        if (!L->cache) L->cache = new PlanCache();
+        PlanCache& PC = *L->cache;
+        const uint32_t opk = ops.packed();
+        for (auto& e : PC.e) {
+            if (!(e.valid && e.ops_packed == opk && e.n_ops == ops.n && e.cardmode == cardmode && e.genA == A->bounds_gen &&
+                  e.genB == B->bounds_gen))
+                continue;
+            Plan H = e.P;
+            H.slot = slot;
+            H.cache_hit = true;
+            SS.misc.ensure(8 * H.sc.n_words + 64);
+            H.words = SS.misc.as<u64>();
+            SS.q[CLS_RETRY].ensure(sizeof(GenItem) * (H.ub_match + 1));
+            if (cardmode) c->pair_acc.ensure(8 * (npairs + 1));
+            else SS.o_meta.ensure(8 * (H.ub_cand + 1));
+            if (H.work_bound >= c->plan_overlap_max_bytes) s = c->stream;
+            H.plan_stream = s;
+            const size_t zt = std::max<size_t>(H.sc.n_words, cardmode ? npairs : 0);
+            hipLaunchKernelGGL(k_plan_restore, dim3((unsigned)std::min<size_t>(256, (zt + 255) / 256 + 1)), dim3(256), 0, s, H.words,
+                               (uint32_t)H.sc.n_words, (uint32_t)H.sc.w_ranges, (const u64*)e.ranges.as<u64>(), N_RANGE_WORDS,
+                               cardmode ? c->pair_acc.as<u64>() : (u64*)nullptr, (uint32_t)npairs);
+            e.stamp = ++PC.clock;
+            if (clk) { clk->lap(0); clk->lap(2); }
+            return H;
+        }
+        // a miss: the plan made below is left with an entry no batch in flight reads -- a free one, else the least recently used
+        for (auto& e : PC.e) {
+            if (e.in_use) continue;
+            if (!e.valid) { ce = &e; break; }
+            if (!ce || e.stamp < ce->stamp) ce = &e;
+        }
+        if (ce) ce->valid = false;
+    }
+    rhip_ctx_s::SlotScratch& SQ = ce ? ce->ss : SS;  // where the queues and the candidate directory go
     const size_t nvirt = npairs * (size_t)ops.n;  // virtual pairs = result bitmaps
     if (nvirt >= 0x3FFFFFF0ull) { set_err("too many result bitmaps"); throw (int)RHIP_ERR_ARG; }
     // per op: does the result carry B's unmatched containers (B-side tiles), and which bound formula applies
@@ -1440,25 +1518,29 @@ Plan plan(rhip_ctx_t* c, const OpSet& ops, rhip_pool_t* A, rhip_pool_t* B, size_
     SS.hist_at = nullptr;  // until this batch's k_emit is enqueued the area is not known to come back to zero
     SS.misc.ensure(8 * P.sc.n_words + 64);
     P.words = SS.misc.as<u64>();
-    SS.q[CLS_BB].ensure(sizeof(BBItem) * (ub_match + 1));
-    SS.q[CLS_GEN].ensure(sizeof(GenItem) * (ub_match + 1));
-    SS.q[CLS_FILT].ensure(sizeof(FatItem) * (ub_match + 1));
-    SS.q[CLS_WAVE].ensure(sizeof(FatItem) * (ub_match + 1));
-    SS.q[CLS_BA].ensure(sizeof(FatItem) * (ub_match + 1));
-    SS.q[CLS_RUNS].ensure(sizeof(GenItem) * (ub_match + 1));
+    // (a cache entry keeps what it holds for the life of the pair list: only the queues the operand pools can fill at all)
+    const bool all_q = ce == nullptr;
+    auto qsz = [&](bool may, size_t item, uint64_t n) { return (all_q || may) ? item * (n + 1) : (size_t)64; };
+    SQ.q[CLS_BB].ensure(qsz(P.may_bb, sizeof(BBItem), ub_match));
+    SQ.q[CLS_GEN].ensure(qsz(P.may_runs, sizeof(GenItem), ub_match));
+    SQ.q[CLS_FILT].ensure(qsz(P.may_filt || P.grouped, sizeof(FatItem), ub_match));
+    SQ.q[CLS_WAVE].ensure(qsz(P.may_wave, sizeof(FatItem), ub_match));
+    SQ.q[CLS_BA].ensure(qsz(P.may_ba, sizeof(FatItem), ub_match));
+    SQ.q[CLS_RUNS].ensure(qsz(P.may_runs, sizeof(GenItem), ub_match));
     SS.q[CLS_RETRY].ensure(sizeof(GenItem) * (ub_match + 1));
-    SS.q[CLS_PROBE].ensure(sizeof(FatItem) * (ub_match + 1));
-    SS.q[CLS_BBA].ensure(sizeof(BBItem) * (ub_match + 1));
-    SS.q[CLS_USMALL].ensure(sizeof(FatItem) * (ub_match + 1));
-    SS.q[CLS_RUNS16].ensure(sizeof(GenItem) * (ub_match + 1));
-    SS.q[CLS_RUNS16W].ensure(sizeof(GenItem) * (ub_match + 1));
-    SS.q[CLS_COPY].ensure(sizeof(CopyItem) * (P.ub_cand + 1));
+    SQ.q[CLS_PROBE].ensure(qsz(P.may_filt, sizeof(FatItem), ub_match));
+    SQ.q[CLS_BBA].ensure(qsz(P.may_bb, sizeof(BBItem), ub_match));
+    SQ.q[CLS_USMALL].ensure(qsz(P.may_wave, sizeof(FatItem), ub_match));
+    SQ.q[CLS_RUNS16].ensure(qsz(P.may_runs, sizeof(GenItem), ub_match));
+    SQ.q[CLS_RUNS16W].ensure(qsz(P.may_runs, sizeof(GenItem), ub_match));
+    SQ.q[CLS_COPY].ensure(qsz(P.may_copy, sizeof(CopyItem), P.ub_cand));
     if (cardmode) c->pair_acc.ensure(8 * (npairs + 1));
     if (!cardmode) {
-        SS.o_key.ensure(8 * (ub + 1)); SS.o_meta.ensure(8 * (ub + 1)); SS.o_off.ensure(8 * (ub + 2));
-        SS.o_pair.ensure(4 * (ub + 2));
-        P.CO = CandOut{SS.o_key.as<u64>(), SS.o_off.as<u64>(), SS.o_pair.as<uint32_t>()};
+        SQ.o_key.ensure(8 * (ub + 1)); SS.o_meta.ensure(8 * (ub + 1)); SQ.o_off.ensure(8 * (ub + 2));
+        SQ.o_pair.ensure(4 * (ub + 2));
+        P.CO = CandOut{SQ.o_key.as<u64>(), SQ.o_off.as<u64>(), SQ.o_pair.as<uint32_t>()};
     }
+    P.Q = &SQ;
     // (Letting the planning kernels read two short index lists in place from the pinned staging area was measured:
     // the PCIe round trips inside k_count / k_emit cost 25 us more per batch than the copy command they replace.)
     if (clk) clk->lap(6);  // ([6]: sizing + scratch; [1]: the staging of the batch description alone)
@@ -1493,10 +1575,10 @@ Plan plan(rhip_ctx_t* c, const OpSet& ops, rhip_pool_t* A, rhip_pool_t* B, size_
     const size_t plan_waves = G == 64 ? NU : (NU + 64 / G - 1) / (64 / G) + 1;
     unsigned gp = (unsigned)std::max<size_t>(1, (std::max<size_t>(plan_waves * 64, std::min<size_t>(zero_threads, 1 << 16)) + 255) / 256);
     const u64 n_scan = (u64)N_SEC * S + n_hist;
-    EmitQueues Q{SS.q[CLS_BB].as<BBItem>(), SS.q[CLS_GEN].as<GenItem>(), SS.q[CLS_COPY].as<CopyItem>(),
-                 SS.q[CLS_FILT].as<FatItem>(), SS.q[CLS_WAVE].as<FatItem>(), SS.q[CLS_RUNS].as<GenItem>(),
-                 SS.q[CLS_PROBE].as<FatItem>(), SS.q[CLS_BBA].as<BBItem>(), SS.q[CLS_USMALL].as<FatItem>(),
-                 SS.q[CLS_RUNS16].as<GenItem>(), SS.q[CLS_RUNS16W].as<GenItem>(), SS.q[CLS_BA].as<FatItem>()};
+    EmitQueues Q{SQ.q[CLS_BB].as<BBItem>(), SQ.q[CLS_GEN].as<GenItem>(), SQ.q[CLS_COPY].as<CopyItem>(),
+                 SQ.q[CLS_FILT].as<FatItem>(), SQ.q[CLS_WAVE].as<FatItem>(), SQ.q[CLS_RUNS].as<GenItem>(),
+                 SQ.q[CLS_PROBE].as<FatItem>(), SQ.q[CLS_BBA].as<BBItem>(), SQ.q[CLS_USMALL].as<FatItem>(),
+                 SQ.q[CLS_RUNS16].as<GenItem>(), SQ.q[CLS_RUNS16W].as<GenItem>(), SQ.q[CLS_BA].as<FatItem>()};
     const unsigned ge = (unsigned)((plan_waves * 64 + 255) / 256);
     auto count = G == 16 ? k_count<16> : G == 32 ? k_count<32> : k_count<64>;
     auto emit = G == 16 ? k_emit<16> : G == 32 ? k_emit<32> : k_emit<64>;
@@ -1509,6 +1591,16 @@ Plan plan(rhip_ctx_t* c, const OpSet& ops, rhip_pool_t* A, rhip_pool_t* B, size_
         hipLaunchKernelGGL(emit, dim3(ge), dim3(256), 0, s, VA, VB, P.d_lhs, P.d_rhs, UV, cardmode,
                            SS.cand_start.as<u64>(), SS.match.as<uint32_t>(), P.CO, Q, XG);
     if (P.grouped) { SS.hist_at = XG.hist; SS.hist_n = n_hist; SS.hist_gen = SS.cand.gen; }
+    if (ce) {  // leave the plan with the pair list
+        ce->ranges.ensure(8 * N_RANGE_WORDS + 64);
+        hipLaunchKernelGGL(k_ranges_save, dim3(1), dim3(64), 0, s, (const u64*)P.ranges(), ce->ranges.as<u64>(), N_RANGE_WORDS);
+        P.ce = ce;
+        ce->P = P;
+        ce->ops_packed = ops.packed(); ce->n_ops = ops.n; ce->cardmode = cardmode;
+        ce->genA = A->bounds_gen; ce->genB = B->bounds_gen;
+        ce->stamp = ++L->cache->clock;
+        ce->valid = true;
+    }
     if (clk) clk->lap(2);
     return P;
 }
@@ -1569,15 +1661,14 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
     // -- which cost the 847 000 interval pairs of a C5 `and` batch 0.35 -> 0.41 ms, while census1881 `and` went 0.152 ->
     // 0.144 ms.)
     if (c->merge_classes && c->overlap && !fork && !P.grouped && (P.work_bound < c->fork_min_bytes || light) && nm <= c->merge_max_items) {
-        rhip_ctx_s::SlotScratch& SS = c->ss[P.slot];
         ClassLaunch L{};
         L.arenaA = VA.arena; L.arenaB = VB.arena; L.O = O; L.ranges = ranges;
-        L.q_bb = SS.q[CLS_BB].as<BBItem>(); L.q_bba = SS.q[CLS_BBA].as<BBItem>();
-        L.q_filt = SS.q[CLS_FILT].as<FatItem>(); L.q_probe = SS.q[CLS_PROBE].as<FatItem>();
-        L.q_usmall = SS.q[CLS_USMALL].as<FatItem>(); L.q_wave = SS.q[CLS_WAVE].as<FatItem>(); L.q_ba = SS.q[CLS_BA].as<FatItem>();
-        L.q_copy = SS.q[CLS_COPY].as<CopyItem>();
-        L.q_r16 = SS.q[CLS_RUNS16].as<GenItem>(); L.q_r16w = SS.q[CLS_RUNS16W].as<GenItem>(); L.q_r64 = SS.q[CLS_RUNS].as<GenItem>();
-        L.retry_q = SS.q[CLS_RETRY].as<GenItem>(); L.retry_count = retry_count; L.pair_acc = c->pair_acc.as<u64>();
+        L.q_bb = P.q(c, CLS_BB).as<BBItem>(); L.q_bba = P.q(c, CLS_BBA).as<BBItem>();
+        L.q_filt = P.q(c, CLS_FILT).as<FatItem>(); L.q_probe = P.q(c, CLS_PROBE).as<FatItem>();
+        L.q_usmall = P.q(c, CLS_USMALL).as<FatItem>(); L.q_wave = P.q(c, CLS_WAVE).as<FatItem>(); L.q_ba = P.q(c, CLS_BA).as<FatItem>();
+        L.q_copy = P.q(c, CLS_COPY).as<CopyItem>();
+        L.q_r16 = P.q(c, CLS_RUNS16).as<GenItem>(); L.q_r16w = P.q(c, CLS_RUNS16W).as<GenItem>(); L.q_r64 = P.q(c, CLS_RUNS).as<GenItem>();
+        L.retry_q = P.q(c, CLS_RETRY).as<GenItem>(); L.retry_count = retry_count; L.pair_acc = c->pair_acc.as<u64>();
         L.kop = op; L.cardmode = cardmode; L.copy_per_wave = P.copy_per_wave;
         const unsigned cap = 512;  // blocks per class: its waves loop over the queue (the real queues are short)
         auto seg = [&](bool present, uint64_t ub) { return present ? ::bounded_grid(ub, cap) : 0u; };
@@ -1593,15 +1684,15 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
             const bool gen = has_runs, ret = has_retry;
             if (gen && ret)
                 hipLaunchKernelGGL(k_genw<true>, dim3(4 * ::bounded_grid(nm, 512)), dim3(64), 0, s, VA.arena, VB.arena, O,
-                                   SS.q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, cardmode,
-                                   c->pair_acc.as<u64>(), (const GenItem*)SS.q[CLS_RETRY].as<GenItem>(), (const uint32_t*)retry_count);
+                                   P.q(c, CLS_GEN).as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, cardmode,
+                                   c->pair_acc.as<u64>(), (const GenItem*)P.q(c, CLS_RETRY).as<GenItem>(), (const uint32_t*)retry_count);
             else if (gen)
                 hipLaunchKernelGGL(k_genw<true>, dim3(4 * ::bounded_grid(nm, 512)), dim3(64), 0, s, VA.arena, VB.arena, O,
-                                   SS.q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, cardmode,
+                                   P.q(c, CLS_GEN).as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, cardmode,
                                    c->pair_acc.as<u64>(), (const GenItem*)nullptr, (const uint32_t*)nullptr);
             else
                 hipLaunchKernelGGL(k_genw<false>, dim3(4 * ::bounded_grid(nm, 512)), dim3(64), 0, s, VA.arena, VB.arena, O,
-                                   SS.q[CLS_RETRY].as<GenItem>(), (const u64*)nullptr, retry_count, op, 0,
+                                   P.q(c, CLS_RETRY).as<GenItem>(), (const u64*)nullptr, retry_count, op, 0,
                                    c->pair_acc.as<u64>(), (const GenItem*)nullptr, (const uint32_t*)nullptr);
         }
         return;
@@ -1631,16 +1722,15 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
         // interval algebra, three size classes in one launch: short lists four pairs per wave (most of a sparse
         // run-compressed batch), long lists one pair per wave.  Few items as a rule, so few blocks (an empty block of an
         // LDS-heavy kernel still queues for a slot); many items simply loop.
-        rhip_ctx_s::SlotScratch& SS = c->ss[P.slot];
         // (forked: at most 2 048 blocks in all -- the queues are short as a rule and every block of this LDS-heavy kernel,
         // empty or not, has to find a slot beside the image kernels: with 8 192 the kernel's last blocks ran 400 us after
         // its first on weather `or`, and the retry pass waits for them; 1 024 + 512 + 512 blocks still fill the machine
         // when the interval pairs ARE the batch -- C5)
         const unsigned g1 = bounded_grid(nm, fork ? 1024 : 4096), g2 = bounded_grid(nm, fork ? 512 : 2048), g3 = bounded_grid(nm, fork ? 512 : 2048);
-        IvlQueues IQ{{SS.q[CLS_RUNS16].as<GenItem>(), SS.q[CLS_RUNS16W].as<GenItem>(), SS.q[CLS_RUNS].as<GenItem>()},
+        IvlQueues IQ{{P.q(c, CLS_RUNS16).as<GenItem>(), P.q(c, CLS_RUNS16W).as<GenItem>(), P.q(c, CLS_RUNS).as<GenItem>()},
                      {ranges + 2 * SEC_RUNS16, ranges + 2 * SEC_RUNS16W, ranges + 2 * SEC_RUNS}};
         hipLaunchKernelGGL(k_ivl_all, dim3(g1 + g2 + g3), dim3(256), 0, on(0), VA.arena, VB.arena, O, IQ, g1, g2, op,
-                           cardmode, c->pair_acc.as<u64>(), SS.q[CLS_RETRY].as<GenItem>(), retry_count);
+                           cardmode, c->pair_acc.as<u64>(), P.q(c, CLS_RETRY).as<GenItem>(), retry_count);
     }
     // the general image class: forked, beside the interval chain on the auxiliary stream this op leaves idle (a multi-op
     // batch leaves none idle: ahead of k_filter -- its one-wave blocks slip in wherever two slots are free); on one
@@ -1648,21 +1738,21 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
     const bool genw_merged = !fork && has_runs && has_retry;
     auto launch_genw_general = [&](hipStream_t sg) {
         hipLaunchKernelGGL(k_genw<true>, dim3(4 * bounded_grid(nm, 512)), dim3(64), 0, sg, VA.arena, VB.arena, O,
-                           c->ss[P.slot].q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op,
+                           P.q(c, CLS_GEN).as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op,
                            cardmode, c->pair_acc.as<u64>(), (const GenItem*)nullptr, (const uint32_t*)nullptr);
     };
     if (multi && has_runs && !genw_merged) launch_genw_general(on(1));
     // grouped batch: the filter and the union items sit in ONE queue (the filter class's buffer), sorted by X container;
     // a wave walks >= 8 items in a row, so the grids are an eighth of the wave-per-item ones (and at most two rounds of
     // the machine's 5 120 resident image waves)
-    const FatItem* xq = c->ss[P.slot].q[CLS_FILT].as<FatItem>();
+    const FatItem* xq = P.q(c, CLS_FILT).as<FatItem>();
     const unsigned gx = (unsigned)std::min<uint64_t>(std::max<uint64_t>((nm + 4 * c->group_chunk - 1) / (4 * c->group_chunk), 1), 2560u * 8u / c->group_chunk);
     if (has_filt && P.grouped)
         hipLaunchKernelGGL((op == OP_AND || cardmode) ? k_filter_g<false> : k_filter_g<true>, dim3(gx), dim3(256), 0, on(1), VA.arena,
                            VB.arena, O, xq, P.xranges(), op, cardmode, c->pair_acc.as<u64>(), c->group_chunk);
     else if (has_filt)
         hipLaunchKernelGGL((op == OP_AND || cardmode) ? k_filter<false> : k_filter<true>, dim3(bounded_grid(nm)), dim3(256), 0, on(1), VA.arena, VB.arena, O,
-                           c->ss[P.slot].q[CLS_FILT].as<FatItem>(), ranges + 2 * SEC_FILT, op, cardmode, c->pair_acc.as<u64>());
+                           P.q(c, CLS_FILT).as<FatItem>(), ranges + 2 * SEC_FILT, op, cardmode, c->pair_acc.as<u64>());
     if ((has_wave || has_ba) && P.grouped) {
         hipStream_t su = on(2);
         if (multi) hipLaunchKernelGGL(k_union_g<OP_ITEM>, dim3(gx), dim3(256), 0, su, VA.arena, VB.arena, O, xq, P.xranges(), c->group_chunk);
@@ -1671,7 +1761,7 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
         else hipLaunchKernelGGL(k_union_g<OP_ANDNOT>, dim3(gx), dim3(256), 0, su, VA.arena, VB.arena, O, xq, P.xranges(), c->group_chunk);
     } else if (has_wave)
         hipLaunchKernelGGL(k_wave, dim3(bounded_grid(nm)), dim3(256), 0, on(2), VA.arena, VB.arena, O,
-                           c->ss[P.slot].q[CLS_WAVE].as<FatItem>(), ranges + 2 * SEC_WAVE, op);
+                           P.q(c, CLS_WAVE).as<FatItem>(), ranges + 2 * SEC_WAVE, op);
     // The main stream's own kernels are issued right after the big image kernels: the host's launches are what the device
     // waits for in a forked batch (~25 API calls), and k_probe / k_usmall are on its critical path, the few general items are not.
     const bool need_bb_event = fork && has_retry && has_bb;  // the retry pass (another stream) consumes what k_bb re-queues
@@ -1692,32 +1782,32 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
                                 // its own when the filter's is free (or / xor), else the light chain
         hipLaunchKernelGGL(c->usmall_gp8 ? k_usmall<true> : k_usmall<false>, dim3(bounded_grid(nm)),
                            dim3(256), 0, (fork && crit == 2) ? on_aux(1) : lst, VA.arena, VB.arena, O,
-                           c->ss[P.slot].q[CLS_USMALL].as<FatItem>(), ranges + 2 * SEC_USMALL, op);
+                           P.q(c, CLS_USMALL).as<FatItem>(), ranges + 2 * SEC_USMALL, op);
     if (has_filt)  // short streamed arrays: no LDS, 8 waves per SIMD -- co-resides with the LDS-bound kernels
         hipLaunchKernelGGL(k_probe, dim3(bounded_grid(nm)), dim3(256), 0, lst, VA.arena, VB.arena, O,
-                           c->ss[P.slot].q[CLS_PROBE].as<FatItem>(), ranges + 2 * SEC_PROBE, op, cardmode, c->pair_acc.as<u64>());
+                           P.q(c, CLS_PROBE).as<FatItem>(), ranges + 2 * SEC_PROBE, op, cardmode, c->pair_acc.as<u64>());
     if (has_bba) {  // bitset pairs expected to give arrays
         if (multi)
             hipLaunchKernelGGL(k_bba<OP_ITEM>, dim3(bounded_grid(nm)), dim3(256), 0, lst, VA.arena, VB.arena, O,
-                               c->ss[P.slot].q[CLS_BBA].as<BBItem>(), ranges + 2 * SEC_BBA);
+                               P.q(c, CLS_BBA).as<BBItem>(), ranges + 2 * SEC_BBA);
         else if (op == OP_AND)
             hipLaunchKernelGGL(k_bba<OP_AND>, dim3(bounded_grid(nm)), dim3(256), 0, lst, VA.arena, VB.arena, O,
-                               c->ss[P.slot].q[CLS_BBA].as<BBItem>(), ranges + 2 * SEC_BBA);
+                               P.q(c, CLS_BBA).as<BBItem>(), ranges + 2 * SEC_BBA);
         else
             hipLaunchKernelGGL(k_bba<OP_ANDNOT>, dim3(bounded_grid(nm)), dim3(256), 0, lst, VA.arena, VB.arena, O,
-                               c->ss[P.slot].q[CLS_BBA].as<BBItem>(), ranges + 2 * SEC_BBA);
+                               P.q(c, CLS_BBA).as<BBItem>(), ranges + 2 * SEC_BBA);
     }
     if (has_copy)
         hipLaunchKernelGGL(k_copy, dim3(bounded_grid(P.copy_per_wave == 16 ? (P.ub_cand + 3) / 4 : P.ub_cand)), dim3(256), 0, lst, VA.arena, VB.arena, O,
-                           c->ss[P.slot].q[CLS_COPY].as<CopyItem>(), ranges + 2 * SEC_COPY, P.copy_per_wave);
+                           P.q(c, CLS_COPY).as<CopyItem>(), ranges + 2 * SEC_COPY, P.copy_per_wave);
     // (or / xor: at the end of the light chain, whose stream is idle by then; and / cardinality: the union stream, idle)
     if (!multi && has_runs && !genw_merged) launch_genw_general(!has_filt ? lst : on(!has_wave ? 2 : 1));
     if (has_ba && !P.grouped) {  // bitset (op) array, behind the few general items of its stream: andnot has no k_wave items, so that
                    // stream is free; or / xor: the filter's stream
         hipStream_t sb = multi ? on(0) : op == OP_ANDNOT ? on(2) : lst;  // (multi-op: behind the interval kernel; or / xor: the light chain -- k_usmall has the filter's stream)
-        const FatItem* qb = c->ss[P.slot].q[CLS_BA].as<FatItem>();
+        const FatItem* qb = P.q(c, CLS_BA).as<FatItem>();
         const unsigned gb = bounded_grid(nm);
-        GenItem* rq = c->ss[P.slot].q[CLS_RETRY].as<GenItem>();
+        GenItem* rq = P.q(c, CLS_RETRY).as<GenItem>();
         if (multi) hipLaunchKernelGGL(k_ba<OP_ITEM>, dim3(gb), dim3(256), 0, sb, VA.arena, VB.arena, O, qb, ranges + 2 * SEC_BA, rq, retry_count);
         else if (op == OP_OR) hipLaunchKernelGGL(k_ba<OP_OR>, dim3(gb), dim3(256), 0, sb, VA.arena, VB.arena, O, qb, ranges + 2 * SEC_BA, rq, retry_count);
         else if (op == OP_XOR) hipLaunchKernelGGL(k_ba<OP_XOR>, dim3(gb), dim3(256), 0, sb, VA.arena, VB.arena, O, qb, ranges + 2 * SEC_BA, rq, retry_count);
@@ -1730,14 +1820,13 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
         hipStream_t sr = fork ? on_aux(0) : s;  // (behind the interval kernel, which re-queues too; never the image kernel's stream)
         if (need_bb_event) HIPCHK(hipStreamWaitEvent(sr, c->ev_runs, 0));
         if (fork && has_ba && !P.grouped && op != OP_OR) HIPCHK(hipStreamWaitEvent(sr, c->ev_ba, 0));  // k_ba re-queues its rare array results
-        rhip_ctx_s::SlotScratch& SS = c->ss[P.slot];
         if (genw_merged)  // one stream: the general class and the re-queued results in one launch, after their producers
             hipLaunchKernelGGL(k_genw<true>, dim3(4 * bounded_grid(nm, 512)), dim3(64), 0, sr, VA.arena, VB.arena, O,
-                               SS.q[CLS_GEN].as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, 0,
-                               c->pair_acc.as<u64>(), (const GenItem*)SS.q[CLS_RETRY].as<GenItem>(), (const uint32_t*)retry_count);
+                               P.q(c, CLS_GEN).as<GenItem>(), ranges + 2 * SEC_GEN, (const uint32_t*)nullptr, op, 0,
+                               c->pair_acc.as<u64>(), (const GenItem*)P.q(c, CLS_RETRY).as<GenItem>(), (const uint32_t*)retry_count);
         else
             hipLaunchKernelGGL(k_genw<false>, dim3(4 * bounded_grid(nm, 512)), dim3(64), 0, sr, VA.arena, VB.arena, O,
-                               SS.q[CLS_RETRY].as<GenItem>(), (const u64*)nullptr, retry_count, op, 0,
+                               P.q(c, CLS_RETRY).as<GenItem>(), (const u64*)nullptr, retry_count, op, 0,
                                c->pair_acc.as<u64>(), (const GenItem*)nullptr, (const uint32_t*)nullptr);
     }
     if (fork)
@@ -1842,6 +1931,8 @@ struct rhip_batch_s {
     bool grouped;       // its filter / union items are in the X-grouped queue
     rhip_pairlist_t* L; // the prepared pair list the batch reads (its device copy), or NULL
     TailRedo redo;
+    ::PlanCacheEntry* ce = nullptr;  // the cached plan the batch's kernels read (pinned by in_use until the batch ends)
+    rhip_ctx_s::SlotScratch* Q = nullptr;  // where its class queues are (class statistics)
 };
 
 // Measured placement of a large result arena (rhip_ctx_s::arena_tries).  The physical address of device memory is not
@@ -2070,6 +2161,10 @@ static rhip_batch_t* pairwise_begin_ops(rhip_ctx_t* c, size_t n_ops, const rhip_
         ++A->in_use;
         ++B->in_use;
         if (L) ++L->in_use;
+        b->ce = P.ce;
+        b->Q = P.Q;
+        if (P.ce) ++P.ce->in_use;
+        c->last_plan_cached = P.cache_hit;
         return b;
     } catch (int e) {
         last_status() = e;
@@ -2104,6 +2199,7 @@ extern "C" rhip_pool_t* rhip_pairwise_end(rhip_batch_t* b) {
     --b->B->in_use;
     rhip_pairlist_t* bl = b->L;
     if (bl) --bl->in_use;
+    if (b->ce) --b->ce->in_use;
     auto drop_deferred = [](rhip_pool_t* X) {
         if (X->free_deferred && X->in_use == 0 && X->list_pins == 0) { X->release(); delete X; }
     };
@@ -2145,12 +2241,13 @@ extern "C" rhip_pool_t* rhip_pairwise_end(rhip_batch_t* b) {
         c->slot_flagjoin[slot] = false;
         if (c->class_stats) {  // (diagnostics: the slot's queues and meta words are intact until its next batch)
             rhip_ctx_s::SlotScratch& SS = c->ss[slot];
-            ClassQueues CQ{SS.q[CLS_BB].as<BBItem>(), SS.q[CLS_BBA].as<BBItem>(),
-                           {SS.q[CLS_FILT].as<FatItem>(), SS.q[CLS_WAVE].as<FatItem>(), SS.q[CLS_PROBE].as<FatItem>(),
-                            SS.q[CLS_USMALL].as<FatItem>(), SS.q[CLS_BA].as<FatItem>()},
-                           {SS.q[CLS_GEN].as<GenItem>(), SS.q[CLS_RUNS].as<GenItem>(), SS.q[CLS_RUNS16].as<GenItem>(),
-                            SS.q[CLS_RUNS16W].as<GenItem>()},
-                           SS.q[CLS_COPY].as<CopyItem>()};
+            rhip_ctx_s::SlotScratch& SQ = b->Q ? *b->Q : SS;  // (a cached plan's queues live with the pair list)
+            ClassQueues CQ{SQ.q[CLS_BB].as<BBItem>(), SQ.q[CLS_BBA].as<BBItem>(),
+                           {SQ.q[CLS_FILT].as<FatItem>(), SQ.q[CLS_WAVE].as<FatItem>(), SQ.q[CLS_PROBE].as<FatItem>(),
+                            SQ.q[CLS_USMALL].as<FatItem>(), SQ.q[CLS_BA].as<FatItem>()},
+                           {SQ.q[CLS_GEN].as<GenItem>(), SQ.q[CLS_RUNS].as<GenItem>(), SQ.q[CLS_RUNS16].as<GenItem>(),
+                            SQ.q[CLS_RUNS16W].as<GenItem>()},
+                           SQ.q[CLS_COPY].as<CopyItem>()};
             c->misc.ensure(8 * 3 * N_CLS + 64);
             hipLaunchKernelGGL(k_class_stats, dim3(N_CLS), dim3(256), 0, c->stream, (const u64*)b->ranges, CQ,
                                (const u64*)SS.o_meta.as<u64>(), c->misc.as<u64>(), b->grouped ? 1 : 0);
@@ -2248,6 +2345,7 @@ static void pairlist_destroy(rhip_pairlist_t* L) {
         if (B != A) drop(B);
     }
     L->d_idx.release();
+    if (L->cache) { L->cache->release(); delete L->cache; }
     delete L;
 }
 static rhip_pairlist_t* pairlist_make(rhip_ctx_t* c, rhip_pool_t* A, rhip_pool_t* B, std::vector<uint32_t>&& lhs,
@@ -2310,6 +2408,22 @@ extern "C" int rhip_pairlist_pairs(const rhip_pairlist_t* L, uint32_t* lhs, uint
     if (rhs && L->npairs) memcpy(rhs, L->rhs.data(), 4 * L->npairs);
     return RHIP_OK;
 }
+// forget the list's cached plans (those no batch in flight reads) and release their device memory; the next batch of
+// each (ops, form) plans afresh.  Returns how many were dropped.
+extern "C" int rhip_pairlist_drop_plans(rhip_pairlist_t* L) {
+    if (!L || !L->cache) return 0;
+    DeviceGuard dguard_(L->ctx->device);
+    int n = 0;
+    for (auto& e : L->cache->e) {
+        if (e.in_use || !e.valid) continue;
+        (void)hipStreamSynchronize(L->ctx->stream);  // (a synchronous call may still be reading it on the stream)
+        e.valid = false;
+        e.ss.release();
+        e.ranges.release();
+        ++n;
+    }
+    return n;
+}
 extern "C" void rhip_pairlist_free(rhip_pairlist_t* L) {
     if (!L) return;
     if (L->in_use > 0) { L->free_deferred = true; return; }  // released by the last batch that reads it (rhip_pairwise_end)
@@ -2356,6 +2470,7 @@ extern "C" unsigned long long rhip_ctx_trim(rhip_ctx_t* c) {
     return n;
 }
 // batches of this context that a flag join gave up on and that were finished through the fallback (rhip_pairwise_end)
+extern "C" int rhip_debug_plan_cached(rhip_ctx_t* c) { return c && c->last_plan_cached ? 1 : 0; }
 extern "C" unsigned long long rhip_debug_join_recovered(rhip_ctx_t* c) { return c ? (unsigned long long)c->join_recovered : 0ull; }
 extern "C" int rhip_debug_last_placement(rhip_ctx_t* c, float* out, int capacity) {
     if (!c) return 0;

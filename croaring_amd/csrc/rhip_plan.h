@@ -139,6 +139,24 @@ __global__ __launch_bounds__(256) void k_scan(const uint32_t* __restrict__ in, u
 __global__ __launch_bounds__(256) void k_stage_in(const uint4* __restrict__ host_src, uint4* __restrict__ dst, uint32_t n16) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) dst[i] = host_src[i];
 }
+// A batch over a prepared pair list whose plan is cached (rhip_engine.hip, PlanCache) starts here instead of at k_count:
+// the call's scratch words are cleared as k_count clears them -- except the section ranges, which come back from the
+// cache entry -- and, in cardinality mode, the per-pair accumulators.
+__global__ __launch_bounds__(256) void k_plan_restore(u64* __restrict__ words, uint32_t n_words, uint32_t w_ranges,
+                                                      const u64* __restrict__ saved, uint32_t n_ranges,
+                                                      u64* __restrict__ pair_acc, uint32_t n_pairs) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    for (uint32_t i = gid; i < n_words; i += nth) {
+        const uint32_t r = i - w_ranges;  // (unsigned: below the ranges it wraps around)
+        words[i] = r < n_ranges ? saved[r] : 0ull;
+    }
+    if (pair_acc)
+        for (uint32_t i = gid; i < n_pairs; i += nth) pair_acc[i] = 0ull;
+}
+// ... and the first batch of that plan leaves its section ranges with the cache entry (behind k_emit on the plan's stream)
+__global__ void k_ranges_save(const u64* __restrict__ ranges, u64* __restrict__ saved, uint32_t n) {
+    if (threadIdx.x < n) saved[threadIdx.x] = ranges[threadIdx.x];
+}
 
 // ------------------------------------------------------------------ planning
 // Planning works on UNITS: one unit = one tile of up to 256 consecutive directory entries of the

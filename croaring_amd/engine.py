@@ -91,6 +91,10 @@ class Engine:
         """Batches of this context whose flag join gave up and that were finished through the event fallback."""
         return int(self.lib.rhip_debug_join_recovered(self.h))
 
+    def plan_cached(self) -> bool:
+        """Did the last batch begun on this engine take its plan from its pair list's cache?"""
+        return bool(self.lib.rhip_debug_plan_cached(self.h))
+
     def last_placement(self) -> list:
         """Probe rates (GB/s) of the candidate result arenas of the last measured placement (rhip_debug_last_placement)."""
         out = (C.c_float * 32)()
@@ -538,6 +542,10 @@ class PairList:
         if self.engine.lib.rhip_pairlist_pairs(self.h, lhs.ctypes.data, rhs.ctypes.data) != 0:
             raise RoaringHipError(self.engine._err())
         return lhs, rhs
+
+    def drop_plans(self) -> int:
+        """Forget the plans cached with the list (rhip_pairlist_drop_plans); the next batch of each op plans afresh."""
+        return int(self.engine.lib.rhip_pairlist_drop_plans(self.h)) if self.h else 0
 
     def free(self):
         if getattr(self, "h", None) and self.engine is not None and self.engine.h:

@@ -230,7 +230,15 @@ rhip_batch_t *rhip_pairwise_multi_begin(rhip_ctx_t *ctx, size_t n_ops, const rhi
  * The list PINS its operand pools: rhip_pool_free of an operand is accepted and deferred until the last list over it
  * (and the last batch in flight) is gone.  If an operand is updated in place (or recycled) the list re-validates itself
  * at its next use.  A list is used with the context it was made on (anything else: RHIP_ERR_ARG).
- * rhip_pairlist_free while batches over the list are in flight is deferred to the last of them. */
+ * rhip_pairlist_free while batches over the list are in flight is deferred to the last of them.
+ * THE PLAN IS KEPT WITH THE LIST (round 6).  Which containers of a pair meet, the class every matched container pair
+ * goes to, its result slot -- the output of the key merge (src/roaring.c:742-768), here the three planning kernels -- is a
+ * pure function of the operand pools' directories, the pairs and the ops.  The first batch of a given (ops, form) over
+ * a list leaves its class queues, candidate directory and section ranges with the list; every later one starts at its
+ * class kernels (one small kernel restores the call's scratch).  Up to six plans per list, least recently used
+ * replaced, never one a batch in flight reads; a pool that is updated in place or reloaded invalidates them (they are
+ * keyed by the pools' generation).  Cost: device memory for the queues, sized by the same upper bounds as a batch's own
+ * scratch, for the life of the list.  RHIP_PLAN_CACHE=0 in the environment switches it off. */
 typedef struct rhip_pairlist_s rhip_pairlist_t;
 rhip_pairlist_t *rhip_pairlist_create(rhip_ctx_t *ctx, rhip_pool_t *A, rhip_pool_t *B, size_t npairs,
                                       const uint32_t *lhs, const uint32_t *rhs);
@@ -242,6 +250,9 @@ size_t rhip_pairlist_size(const rhip_pairlist_t *list);
 /* the pairs themselves (lhs / rhs: rhip_pairlist_size entries each; either may be NULL) */
 int rhip_pairlist_pairs(const rhip_pairlist_t *list, uint32_t *lhs, uint32_t *rhs);
 void rhip_pairlist_free(rhip_pairlist_t *list);
+/* Forgets the plans kept with the list (those no batch in flight reads) and releases their device memory; returns how
+ * many.  The next batch of each (ops, form) plans afresh -- what bench.py's `ms_first_call` measures. */
+int rhip_pairlist_drop_plans(rhip_pairlist_t *list);
 /* rhip_pairwise_multi_begin / rhip_pairwise_multi / rhip_pairwise_cardinality over a prepared list (n_ops = 1: rhip_pairwise) */
 rhip_batch_t *rhip_pairwise_list_begin(rhip_ctx_t *ctx, size_t n_ops, const rhip_op *ops, rhip_pairlist_t *list,
                                        rhip_pool_t *reuse);
@@ -410,6 +421,8 @@ int rhip_debug_last_placement(rhip_ctx_t *ctx, float *out_gbps, int capacity);
  * fallback: the auxiliary streams waited for the ordinary way, the tail run again.  Such a batch returns the same result
  * as any other; the reference's functions cannot fail for scheduling reasons (roaring.h:102-113) and neither do these. */
 unsigned long long rhip_debug_join_recovered(rhip_ctx_t *ctx);
+/* 1 if the last batch begun on the context took its plan from its pair list's cache (no planning kernels ran), else 0 */
+int rhip_debug_plan_cached(rhip_ctx_t *ctx);
 /* Releases the spare result arenas the context keeps from its placement searches (see rhip_pairwise_begin); returns the
  * bytes released.  Pools and batches are untouched. */
 unsigned long long rhip_ctx_trim(rhip_ctx_t *ctx);

@@ -1,7 +1,8 @@
 """Print the kernel timeline of the last batch of each rocprofv3 kernel trace under gpurun_out/prof_r2/<name>."""
 import csv, glob, sys
 for name in sys.argv[1:]:
-    f = glob.glob(f'gpurun_out/prof_r2/{name}/*kernel_trace.csv')[0]
+    # (a name under gpurun_out/prof_r2, or any directory that holds a rocprofv3 kernel trace)
+    f = (glob.glob(f'{name}/**/*kernel_trace.csv', recursive=True) if '/' in name else glob.glob(f'gpurun_out/prof_r2/{name}/*kernel_trace.csv'))[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
     idx = [i for i, r in enumerate(rows) if "k_count" in r["Kernel_Name"] or "k_plan" in r["Kernel_Name"]]
     i0, i1 = idx[-2], idx[-1]

@@ -1,5 +1,7 @@
 """GPU parity tests: the HIP engine (through the C ABI) vs the reference's golden results
 (tests/golden/*, produced by the real CRoaring) and vs the CPU oracle, bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -700,6 +702,25 @@ def test_prepared_pair_lists(engine, oracle, synth):
     wm = engine.pairwise_multi(["xor", "and", "or"], pool, lhs, pool, rhs)
     gm = engine.pairwise_list(["xor", "and", "or"], pl)
     assert np.array_equal(gm.serialize_many()[0], wm.serialize_many()[0])
+    # the plan is kept with the list (round 6): a repeated (ops, form) starts at its class kernels, same bytes; more
+    # distinct plans than the list keeps (six) evict the least recently used; two batches in flight share one plan
+    cached = os.environ.get("RHIP_PLAN_CACHE", "1") != "0"
+    wants = {op: engine.pairwise(op, pool, lhs, pool, rhs).serialize_many()[0] for op in OPS}
+    for rnd in range(2):
+        for op in OPS:
+            got = engine.pairwise_list(op, pl)
+            if rnd == 1:  # (round 0: some of the four were evicted by the nine plans made above)
+                assert engine.plan_cached() == cached, op
+            assert np.array_equal(got.serialize_many()[0], wants[op]), (rnd, op)
+    gm2 = engine.pairwise_list(["xor", "and", "or"], pl)
+    assert np.array_equal(gm2.serialize_many()[0], wm.serialize_many()[0])
+    for op in OPS:
+        c1 = engine.pairwise_list_cardinality(op, pl)
+        c2 = engine.pairwise_list_cardinality(op, pl)
+        assert np.array_equal(c1, c2) and np.array_equal(c1, engine.pairwise_cardinality(op, pool, lhs, pool, rhs)), op
+    ba, bb, bc = (engine.pairwise_list_begin("xor", pl) for _ in range(3))
+    for b in (bb, bc, ba):
+        assert np.array_equal(b.end().serialize_many()[0], wants["xor"])
     b1 = engine.pairwise_list_begin("or", pl)
     b2 = engine.pairwise_list_begin(["andnot"], pl)
     pl_small = engine.pairlist(pool, lhs[:5], pool, rhs[:5])
@@ -726,11 +747,16 @@ def test_prepared_pair_lists(engine, oracle, synth):
     p2 = engine.pool_from_serialized(bufs)
     pl2 = engine.pairlist(p2, lhs, p2, rhs)
     engine.pairwise_list("or", pl2)
+    engine.pairwise_list("or", pl2)
+    assert engine.plan_cached() == cached
     upd = np.arange(0, n, 3, dtype=np.uint32)
     engine.pairwise_inplace("or", p2, upd, p2, (upd + 1) % n)
     got = engine.pairwise_list("or", pl2)
+    assert not engine.plan_cached(), "a plan cached before an in-place update of an operand pool must not be used after it"
     want = engine.pairwise("or", p2, lhs, p2, rhs)
     assert np.array_equal(got.serialize_many()[0], want.serialize_many()[0])
+    got = engine.pairwise_list("or", pl2)
+    assert engine.plan_cached() == cached and np.array_equal(got.serialize_many()[0], want.serialize_many()[0])
     hs = [oracle.deserialize(b) for b in bufs]
     for i in upd[:20]:
         o = oracle.op("or", hs[i], hs[(i + 1) % n])
