@@ -818,6 +818,19 @@ def main():
     assert results["or"].type_counts() == (args.pairs * args.containers, 0, 0)
     results["and"].free()
     results["or"].free()
+    # What a caller WITHOUT `reuse` pays per call in steady state -- allocate, compute, free, again: the arena of a freed
+    # result pool is parked with the context (round 6) and taken back, as placed, by the next result pool for the same
+    # operand: no allocation, no probe.  (untimed region of the bench: after the clock stopped)
+    if fresh_ms:
+        lhs, rhs = schedule(0, args.pairs, args.pool)
+        for op in ("and", "or"):
+            ts = []
+            for _ in range(3):
+                t_ = time.perf_counter()
+                r_ = eng.pairwise(op, pool, lhs, pool, rhs)
+                ts.append((time.perf_counter() - t_) * 1e3)
+                r_.free()
+            fresh_ms["steady_" + op] = float(np.median(ts))
 
     ops_per_step = 2 * args.pairs * args.rounds
     total_ops = ops_per_step * args.steps * world
@@ -856,9 +869,10 @@ def main():
                    "timed_region_s": dt,
                    "algorithmic_GBps": total_ops * args.containers * BB_BYTES_PER_PAIR / dt / 1e9,
                    "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective",
-                   "c2_fresh_result_pool_ms": {"note": "one 250-pair call that has to allocate (and, >= 2 GiB, place) its result pool: what a "
-                                                       "caller that does not pass `reuse` pays per call; a steady-state call is ms_per_step / "
-                                                       f"{2 * args.rounds}", **{k: round(v, 2) for k, v in fresh_ms.items()}},
+                   "c2_fresh_result_pool_ms": {"note": "and / or: the FIRST 250-pair call, which has to allocate (and, >= 2 GiB, place by measurement) its "
+                                                       "result pool; steady_and / steady_or: a caller that never passes `reuse` -- call, free, call "
+                                                       "again -- in steady state (the freed pool's placed arena is parked with the context and taken back); "
+                                                       f"a call with `reuse` is ms_per_step / {2 * args.rounds}", **{k: round(v, 2) for k, v in fresh_ms.items()}},
                    "result_arena_placement": {"by": "library (rhip place_arena, untimed warm-up)" if args.arena_tries == 0 else "caller (Engine.pairwise_placed)",
                                               "probe_GBps_of_each_candidate": placement if args.arena_tries == 0 else None,
                                               "k_bb_ms_of_each_try": arena_probe or None,

@@ -110,6 +110,7 @@ SYMBOLS = [
     ("rhip_debug_last_placement", _i, [_vp, C.POINTER(C.c_float), _i]),
     ("rhip_debug_join_recovered", _u64, [_vp]),
     ("rhip_debug_plan_cached", _i, [_vp]),
+    ("rhip_debug_fail_allocs", None, [_i, _i]),
     ("rhip_pairlist_drop_plans", _i, [_vp]),
     ("rhip_ctx_trim", _u64, [_vp]),
 ]

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <set>
 #include <string>
@@ -54,6 +55,16 @@ static int& last_status() {
 
 // ------------------------------------------------------------------ device buffers
 static bool release_all_arena_spares();  // (the spare result arenas of every live context: called when an allocation fails)
+// tests (rhip_debug_fail_allocs): the next g_fail_allocs device allocations of the library fail as if the device were out
+// of memory, after g_fail_skip have been let through
+static std::atomic<int> g_fail_skip{0}, g_fail_allocs{0};
+static hipError_t dev_malloc(void** p, size_t n) {
+    if (g_fail_allocs.load(std::memory_order_relaxed) > 0) {
+        if (g_fail_skip.load() > 0) --g_fail_skip;
+        else { --g_fail_allocs; *p = nullptr; return hipErrorOutOfMemory; }
+    }
+    return hipMalloc(p, n);
+}
 struct DBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -63,12 +74,18 @@ struct DBuf {
     bool pow2_large = false;  // allocations of 1 GiB and more take the next power of two, no slack (see rhip_ctx_s::arena_pow2)
     bool exact = false;       // no slack at all (place_arena: the candidates' sizes decide how the driver composes them)
     uint64_t gen = 0;      // bumped by every (re)allocation: "is this still the memory I initialised?"
+    // a result arena the placement search chose or probed (place_arena): against which operand arena (address + generation)
+    // and at what probe rate -- so that a parked arena can be taken back for the same operand without probing again
+    const void* placed_for = nullptr;
+    uint64_t placed_for_gen = 0;
+    float placed_gbps = 0.f;
     void ensure(size_t n) {
         if (n <= cap) return;
         ++gen;
         if (base) (void)hipFree(base);
         p = base = nullptr;
         cap = 0;
+        placed_for = nullptr; placed_gbps = 0.f;  // (a new allocation: whatever was measured was measured on the old one)
         size_t want = n + n / 8 + 256;
         if (round_to && want + skew >= round_to) want = (want + skew + round_to - 1) / round_to * round_to - skew;
         if (exact) want = (n + 4095) & ~(size_t)4095;
@@ -77,11 +94,11 @@ struct DBuf {
             while (want < n + skew) want <<= 1;
             want -= skew;
         }
-        hipError_t e = hipMalloc(&base, want + skew);
+        hipError_t e = dev_malloc(&base, want + skew);
         if (e != hipSuccess && release_all_arena_spares()) {  // memory the library itself is sitting on (spare arenas)
             (void)hipGetLastError();
             base = nullptr;
-            e = hipMalloc(&base, want + skew);
+            e = dev_malloc(&base, want + skew);
         }
         if (e != hipSuccess && want > n + 256) {
             // the rounded request (slack, round_to, next power of two: up to 2 x n) did not fit: what the caller
@@ -89,7 +106,7 @@ struct DBuf {
             (void)hipGetLastError();
             base = nullptr;
             want = (n + 255) & ~(size_t)255;
-            e = hipMalloc(&base, want + skew);
+            e = dev_malloc(&base, want + skew);
         }
         if (e != hipSuccess) {
             (void)hipGetLastError();
@@ -277,6 +294,10 @@ struct rhip_ctx_s {
     // ... unless the batch is LIGHT: at most 128 k matched container pairs and a slot bound below this (RHIP_FORK_MIN_MB
     // sets both: 0 = always fork)
     uint64_t fork_light_bytes = 320ull << 20;
+    // A batch of run-dominated pools (C5: 847 000 interval pairs) is forked whatever its bytes once it has this many matched
+    // container pairs (upper bound): its interval kernel keeps the MAIN stream and the few filter / probe / image items
+    // run beside it instead of behind it (RHIP_FORK_RUNS_MIN; 0 = never)
+    uint64_t fork_runs_min_items = 512u << 10;
 };
 
 void rhip_ctx_s::ensure_stage(int slot, size_t n) {
@@ -333,6 +354,7 @@ struct rhip_pool_s {
     uint64_t max_key = 0;           // largest container key in the pool
     std::vector<uint32_t> h_n;      // per-bitmap container count
     uint32_t max_n = 0;             // largest of them
+    uint64_t n_run_cont = 0;        // run containers of the pool (fetch_bounds)
     bool host_w = false;
     uint64_t bounds_gen = 0;        // which fetch_bounds() filled the mirrors above (a prepared pair list remembers it)
     int8_t census[3] = {1, 1, 1};   // does the pool hold bitset / array / run containers (1 until known otherwise)
@@ -410,6 +432,7 @@ static bool ctx_alive(rhip_ctx_t* c) {
 // (another device, other buffers), which the generation number tells apart.
 static bool many_recycle_push(rhip_pool_t* P);
 static rhip_pool_t* many_recycle_pop(rhip_ctx_t* c);
+static void arena_park(rhip_pool_t* P);
 extern "C" const char* rhip_last_error(void) { return g_err.c_str(); }
 extern "C" const char* rhip_version(void) { return "roaring-hip 0.1 (gfx950)"; }
 
@@ -456,6 +479,7 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_FORK_MIN_MB")) c->fork_min_bytes = c->fork_light_bytes = (uint64_t)atoll(e) << 20;
         if (const char* e = getenv("RHIP_PLAN_OVERLAP")) c->plan_overlap = !(e[0] == '0');
         if (const char* e = getenv("RHIP_PLAN_CACHE")) c->plan_cache = atoi(e) != 0;
+        if (const char* e = getenv("RHIP_FORK_RUNS_MIN")) c->fork_runs_min_items = (uint64_t)atoll(e);
         if (const char* e = getenv("RHIP_MANY_PF")) c->many_pf = atoi(e);
         if (const char* e = getenv("RHIP_MERGE_CLASSES")) c->merge_classes = !(e[0] == '0');
         if (const char* e = getenv("RHIP_DEBUG_PLAN")) c->debug_plan = e[0] == '1';
@@ -827,8 +851,22 @@ extern "C" void rhip_pool_free(rhip_pool_t* P) {
     // A many-way result goes back to its context, buffers and all: hipFree synchronises with the device and hipMalloc of
     // the next result costs as much again -- together more than the aggregation of a small bitmap set itself.
     if (P->from_many && many_recycle_push(P)) return;
+    arena_park(P);  // (a measured placement is worth keeping: the next result pool for the same operand takes it back)
     P->release();  // hipFree synchronises with the device; the context may already be gone
     delete P;
+}
+// A result arena that place_arena chose goes to its context's spares instead of back to the driver (at most two parked
+// winners per context; rhip_ctx_trim, rhip_ctx_destroy and a failing allocation release them like every spare)
+static void arena_park(rhip_pool_t* P) {
+    if (!P->arena.base || !P->arena.placed_for || P->pending) return;
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    rhip_ctx_t* c = P->ctx;
+    if (!g_live_ctx.count(c) || !c->arena_keep_spares) return;
+    int parked = 0;
+    for (const DBuf& b : c->arena_spares) parked += b.placed_gbps >= (float)c->arena_fair_gbps ? 1 : 0;
+    if (parked >= 2) return;
+    c->arena_spares.push_back(P->arena);
+    P->arena.base = nullptr; P->arena.p = nullptr; P->arena.cap = 0;  // (ownership moved)
 }
 static bool many_recycle_push(rhip_pool_t* P) {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
@@ -1175,7 +1213,12 @@ static void fetch_bounds(rhip_pool_t* P) {
     P->has_long_runs = census[3] != 0;
     P->n_keys_distinct = nkeys;
     P->wm_total = 0;
-    for (uint64_t w : P->h_wm) P->wm_total += w;
+    P->n_run_cont = 0;
+    for (uint64_t& w : P->h_wm) {  // (k_bitmap_bounds packs the bitmap's run-container count above the bound)
+        P->n_run_cont += w >> WM_RUNS_SHIFT;
+        w &= (1ull << WM_RUNS_SHIFT) - 1ull;
+        P->wm_total += w;
+    }
     P->h_n.resize((size_t)P->n_bitmaps);
     P->max_n = 0;
     for (uint32_t b = 0; b < P->n_bitmaps; ++b) {
@@ -1218,6 +1261,7 @@ struct Plan {
     hipStream_t plan_stream = nullptr;
     bool may_bb = true, may_filt = true, may_wave = true, may_runs = true, may_copy = true, may_ba = true;
     bool grouped = false;  // the filter / union items are queued by X container (k_filter_g / k_union_g)
+    bool runs_dominant = false;  // at least half of the operand pools' containers are run containers (C5, wikileaks): the interval kernel is the batch's longest
     uint32_t copy_per_wave = 4;  // pass-through items a wave of k_copy takes at a time: 16 when the pools hold tiny containers
     const u64* xranges() const { return words + sc.w_ranges + 2 * N_SEC; }
     // where the planning kernels left what the class kernels and the tail only READ -- the class queues (all but the
@@ -1474,6 +1518,7 @@ Plan plan(rhip_ctx_t* c, const OpSet& ops, rhip_pool_t* A, rhip_pool_t* B, size_
     const bool aB = has(A, 0), aA = has(A, 1), aR = has(A, 2), bB = has(B, 0), bA = has(B, 1), bR = has(B, 2);
     P.may_bb = aB && bB;
     P.may_runs = aR || bR;  // interval class and the general image class
+    P.runs_dominant = 2 * (A->n_run_cont + B->n_run_cont) >= A->n_cont + B->n_cont;
     P.may_filt = P.may_wave = P.may_ba = P.may_copy = false;
     for (int o = 0; o < ops.n; ++o) {
         const int op = ops.op[o];
@@ -1651,7 +1696,12 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
     // (few items AND a moderate slot bound: the class kernels are short whatever the bytes say -- one merged launch beats
     // the fork / join: census-income andnot, 73 k container pairs / 223 MB: 0.30 -> 0.27 ms)
     const bool light = nm <= (128u << 10) && P.work_bound < c->fork_light_bytes;
-    const bool fork = c->overlap && (has_runs || has_filt || has_wave || has_ba) && P.work_bound >= c->fork_min_bytes && !light;
+    // (round 6) interval-dominated batch: forked for its item count, the interval kernel on the main stream
+    // (and / andnot / cardinality only: C5 `and` 0.268 -> 0.246 ms, `andnot` 0.424 -> 0.412; under or / xor the pass-through copies
+    // and the array unions are as long as the interval kernel and the fork costs more than it hides: C5 `or` 0.515 -> 0.533)
+    const bool ivl_main = c->overlap && has_runs && P.runs_dominant && c->fork_runs_min_items && nm >= c->fork_runs_min_items &&
+                          !any_union && (has_filt || has_ba || has_bb);
+    const bool fork = ivl_main || (c->overlap && (has_runs || has_filt || has_wave || has_ba) && P.work_bound >= c->fork_min_bytes && !light);
     if (c->debug_plan)
         fprintf(stderr, "[rhip plan] ops %d nm %llu work_bound %.1f MB fork %d merge_eligible %d grouped %d copy_per_wave %u\n", ops.n, (unsigned long long)nm,
                 P.work_bound / 1048576.0, (int)fork, (int)(nm <= c->merge_max_items), (int)P.grouped, P.copy_per_wave);
@@ -1704,7 +1754,7 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
     // light chain k_bb -> k_usmall / k_probe -> k_bba -> k_copy, which used to own the main stream, takes the auxiliary
     // stream the image kernel vacated.
     bool used[rhip_ctx_s::N_AUX] = {false, false, false};
-    const int crit = !fork ? -1 : has_filt ? 1 : (has_wave || has_ba) ? 2 : -1;
+    const int crit = !fork ? -1 : ivl_main ? 0 : has_filt ? 1 : (has_wave || has_ba) ? 2 : -1;
     auto on_aux = [&](int a) -> hipStream_t {
         if (!used[a]) {
             HIPCHK(hipStreamWaitEvent(c->aux[a], c->ev_fork, 0));
@@ -1726,7 +1776,8 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
         // empty or not, has to find a slot beside the image kernels: with 8 192 the kernel's last blocks ran 400 us after
         // its first on weather `or`, and the retry pass waits for them; 1 024 + 512 + 512 blocks still fill the machine
         // when the interval pairs ARE the batch -- C5)
-        const unsigned g1 = bounded_grid(nm, fork ? 1024 : 4096), g2 = bounded_grid(nm, fork ? 512 : 2048), g3 = bounded_grid(nm, fork ? 512 : 2048);
+        const bool capg = fork && !ivl_main;  // (where the interval pairs ARE the batch the kernel keeps its full grid)
+        const unsigned g1 = bounded_grid(nm, capg ? 1024 : 4096), g2 = bounded_grid(nm, capg ? 512 : 2048), g3 = bounded_grid(nm, capg ? 512 : 2048);
         IvlQueues IQ{{P.q(c, CLS_RUNS16).as<GenItem>(), P.q(c, CLS_RUNS16W).as<GenItem>(), P.q(c, CLS_RUNS).as<GenItem>()},
                      {ranges + 2 * SEC_RUNS16, ranges + 2 * SEC_RUNS16W, ranges + 2 * SEC_RUNS}};
         hipLaunchKernelGGL(k_ivl_all, dim3(g1 + g2 + g3), dim3(256), 0, on(0), VA.arena, VB.arena, O, IQ, g1, g2, op,
@@ -1817,7 +1868,8 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
     if (has_retry) {
         // results that need the LDS image path after all: bitset x bitset results that must become
         // arrays (card <= 4096), interval results that must become bitsets
-        hipStream_t sr = fork ? on_aux(0) : s;  // (behind the interval kernel, which re-queues too; never the image kernel's stream)
+        // (behind the interval kernel, which re-queues too -- wherever that one runs; never the image kernel's stream)
+        hipStream_t sr = !fork || crit == 0 ? s : on_aux(0);
         if (need_bb_event) HIPCHK(hipStreamWaitEvent(sr, c->ev_runs, 0));
         if (fork && has_ba && !P.grouped && op != OP_OR) HIPCHK(hipStreamWaitEvent(sr, c->ev_ba, 0));  // k_ba re-queues its rare array results
         if (genw_merged)  // one stream: the general class and the re-queued results in one launch, after their producers
@@ -1960,6 +2012,34 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
         size_t live() const { size_t n = 0; for (const Cand& x : *this) n += x.buf.base ? 1 : 0; return n; }
         ~Cands() { for (int k = 0; k < (int)size(); ++k) if (k != keep) (*this)[k].buf.release(); }
     } cands;
+    // A spare that was already probed against THIS operand arena and streamed well -- the arena of a result pool the caller
+    // freed (rhip_pool_free parks a placed arena with its context), or a good loser of an earlier search -- is taken as it
+    // is: no allocation, no probe.  A caller without `reuse` pays the search once, not per call.
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        int pick = -1;
+        for (size_t k = 0; k < c->arena_spares.size(); ++k) {
+            const DBuf& sp = c->arena_spares[k];
+            if (sp.base && sp.cap >= need && sp.cap <= need + need / 8 && sp.skew == arena.skew && sp.placed_for == A->arena.base &&
+                sp.placed_for_gen == A->arena.gen && sp.placed_gbps >= (float)c->arena_fair_gbps &&
+                (pick < 0 || sp.placed_gbps > c->arena_spares[(size_t)pick].placed_gbps))
+                pick = (int)k;
+        }
+        if (pick >= 0) {
+            DBuf take = c->arena_spares[(size_t)pick];
+            c->arena_spares.erase(c->arena_spares.begin() + pick);
+            if (arena.base) arena.release();
+            const bool p2 = arena.pow2_large;
+            const uint64_t g = arena.gen;
+            arena = take;
+            arena.pow2_large = p2;
+            arena.exact = false;
+            arena.gen = g + 1;
+            c->last_placement.clear();
+            c->last_placement.push_back(take.placed_gbps);
+            return;
+        }
+    }
     size_t free_at_start = 0, tot_mem = 0;
     if (hipMemGetInfo(&free_at_start, &tot_mem) != hipSuccess) { (void)hipGetLastError(); free_at_start = 0; }
     if (free_at_start < 2 * need) return;  // (no room to choose: the caller's ordinary allocation follows)
@@ -1978,6 +2058,7 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
             if (r && ms < ms_best) ms_best = ms;
         }
         cur.gbps = (float)((double)n_items * 24576.0 / (double)ms_best / 1e6);
+        cur.buf.placed_for = A->arena.base; cur.buf.placed_for_gen = A->arena.gen; cur.buf.placed_gbps = cur.gbps;
         c->last_placement.push_back(cur.gbps);
     };
     // the spares of earlier searches that fit (same exact-size allocation: within 1/8 above the need) are candidates again
@@ -2470,6 +2551,56 @@ extern "C" unsigned long long rhip_ctx_trim(rhip_ctx_t* c) {
     return n;
 }
 // batches of this context that a flag join gave up on and that were finished through the fallback (rhip_pairwise_end)
+// diagnostics (scripts/slab_offsets.py): ONE allocation of slab_bytes, then the placement probe of a `need`-byte result
+// arena at offsets 0, step, 2 step ... inside it against pool A: out[k] = GB/s at offset k * step.  Says whether a slab
+// holds a fast window at all, how wide it is and whether its position repeats from process to process.
+extern "C" int rhip_debug_probe_offsets(rhip_ctx_t* c, rhip_pool_t* A, unsigned long long slab_bytes, unsigned long long need,
+                                        unsigned long long step, float* out, int capacity) {
+    if (!c || !A || !out || need > slab_bytes || !step) return 0;
+    DeviceGuard guard(c->device);
+    void* slab = nullptr;
+    if (hipMalloc(&slab, slab_bytes) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    hipStream_t s = c->stream;
+    const u64 a_items = A->arena.cap / 8192ull, n_slots = need / 8192ull;
+    const u64 stride = std::max<u64>(1, n_slots / ((2ull << 30) / 8192ull)), n_items = (n_slots + stride - 1) / stride;
+    int n = 0;
+    for (unsigned long long off = 0; off + need <= slab_bytes && n < capacity; off += step, ++n) {
+        float best = 1e30f;
+        for (int r = 0; r < 3; ++r) {
+            (void)hipEventRecord(c->ev[0], s);
+            hipLaunchKernelGGL(k_place_probe, dim3(8192), dim3(256), 0, s, A->arena.as<uint8_t>(), a_items, (uint8_t*)slab + off, n_slots, stride);
+            (void)hipEventRecord(c->ev[1], s);
+            (void)hipEventSynchronize(c->ev[1]);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+            if (r && ms < best) best = ms;
+        }
+        out[n] = (float)((double)n_items * 24576.0 / (double)best / 1e6);
+    }
+    (void)hipFree(slab);
+    return n;
+}
+// ... and the same probe on memory the caller owns (scripts/seq_candidates.py)
+extern "C" float rhip_debug_probe_at(rhip_ctx_t* c, rhip_pool_t* A, void* mem, unsigned long long need) {
+    if (!c || !A || !mem) return 0.f;
+    DeviceGuard guard(c->device);
+    hipStream_t s = c->stream;
+    const u64 a_items = A->arena.cap / 8192ull, n_slots = need / 8192ull;
+    const u64 stride = std::max<u64>(1, n_slots / ((2ull << 30) / 8192ull)), n_items = (n_slots + stride - 1) / stride;
+    float best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+        (void)hipEventRecord(c->ev[0], s);
+        hipLaunchKernelGGL(k_place_probe, dim3(8192), dim3(256), 0, s, A->arena.as<uint8_t>(), a_items, (uint8_t*)mem, n_slots, stride);
+        (void)hipEventRecord(c->ev[1], s);
+        (void)hipEventSynchronize(c->ev[1]);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+        if (r && ms < best) best = ms;
+    }
+    return (float)((double)n_items * 24576.0 / (double)best / 1e6);
+}
+// tests: after `skip` more device allocations of the library, the next `count` fail (hipErrorOutOfMemory, no driver call)
+extern "C" void rhip_debug_fail_allocs(int skip, int count) { g_fail_skip = skip; g_fail_allocs = count; }
 extern "C" int rhip_debug_plan_cached(rhip_ctx_t* c) { return c && c->last_plan_cached ? 1 : 0; }
 extern "C" unsigned long long rhip_debug_join_recovered(rhip_ctx_t* c) { return c ? (unsigned long long)c->join_recovered : 0ull; }
 extern "C" int rhip_debug_last_placement(rhip_ctx_t* c, float* out, int capacity) {

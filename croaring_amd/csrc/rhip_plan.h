@@ -1019,7 +1019,9 @@ __device__ __forceinline__ uint32_t slot_bound(uint8_t type, uint32_t card, uint
     return w < 16u ? 16u : w;
 }
 // wmany: the same bound for the many-way path, whose member descriptors (rhip_many.h) carry a run container's
-// cardinality rounded up to a multiple of 256
+// cardinality rounded up to a multiple of 256 -- in bits 0 .. WM_RUNS_SHIFT - 1 (a bitmap's bound is below 2^34); the
+// bits above count the bitmap's RUN containers (the host's "interval work dominates this pool" census)
+constexpr int WM_RUNS_SHIFT = 44;
 __global__ __launch_bounds__(256) void k_bitmap_bounds(PoolView P, uint32_t nbm, u64* __restrict__ wout,
                                                        u64* __restrict__ wmany,
                                                        uint32_t* __restrict__ census /* [4] bitset, array, run, some payload above 8192 bytes */,
@@ -1033,6 +1035,7 @@ __global__ __launch_bounds__(256) void k_bitmap_bounds(PoolView P, uint32_t nbm,
         const uint32_t cd = P.card[i], nr = P.nruns[i];
         s += slot_bound(t, cd, nr);
         sm += slot_bound(t, t == T_RUN ? ((cd + 255u) & ~255u) : cd, nr);
+        sm += t == T_RUN ? (1ull << WM_RUNS_SHIFT) : 0ull;  // (the bitmap's run containers, counted above the bound's bits)
         seen |= 1u << (t - 1);
         if (payload_bytes(t, cd, nr) > 8192u) seen |= 8u;  // a run list longer than a bitset (valid; run_optimize never leaves one)
     }

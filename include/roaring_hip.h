@@ -421,6 +421,8 @@ int rhip_debug_last_placement(rhip_ctx_t *ctx, float *out_gbps, int capacity);
  * fallback: the auxiliary streams waited for the ordinary way, the tail run again.  Such a batch returns the same result
  * as any other; the reference's functions cannot fail for scheduling reasons (roaring.h:102-113) and neither do these. */
 unsigned long long rhip_debug_join_recovered(rhip_ctx_t *ctx);
+/* Tests: after `skip` more device allocations of the library, the next `count` fail as if the device were out of memory. */
+void rhip_debug_fail_allocs(int skip, int count);
 /* 1 if the last batch begun on the context took its plan from its pair list's cache (no planning kernels ran), else 0 */
 int rhip_debug_plan_cached(rhip_ctx_t *ctx);
 /* Releases the spare result arenas the context keeps from its placement searches (see rhip_pairwise_begin); returns the

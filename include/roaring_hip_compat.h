@@ -27,9 +27,10 @@
  * downloads the result: correct, but latency-bound.  Throughput users bind the batched
  * API in roaring_hip.h instead.  A process-wide context on the current HIP device is created on
  * first use; without a device pointer-returning functions return NULL (roaring.h:216-226), the
- * *_cardinality functions return UINT64_MAX.  The void in-place / repair functions have no error channel: a
- * device or allocation failure inside them prints rhip_last_error() to stderr and abort()s rather than
- * silently leaving x1 unchanged.
+ * *_cardinality functions return UINT64_MAX.  The void in-place / repair functions have no error channel: when a
+ * device allocation fails inside one, the drop-ins give back what they hold themselves (the recycled operand / result
+ * pools of every idle lane, the spare result arenas of their contexts) and the call is made ONCE MORE; only a failure
+ * that persists prints rhip_last_error() to stderr and abort()s -- rather than silently leaving x1 unchanged.
  * Parity: pairwise, in-place, cardinality, roaring_bitmap_or_many and roaring_bitmap_xor_many results are
  * byte-identical to the reference's (container types included: both *_many functions are fixed left folds, whose
  * order-dependent typing -- full unions, run accumulators -- is replayed on the device).

@@ -6,6 +6,7 @@ print("value", round(d["value"]), "ms/step", round(d["ms_per_step"], 2), "k_bb m
       "frac", round(d["roofline"]["frac"], 4), "transport", d.get("transport"))
 c = d["config"]
 print("fresh pool ms", c.get("c2_fresh_result_pool_ms", {}).get("and"), c.get("c2_fresh_result_pool_ms", {}).get("or"),
+      "steady", c.get("c2_fresh_result_pool_ms", {}).get("steady_and"), c.get("c2_fresh_result_pool_ms", {}).get("steady_or"),
       "probes", c.get("result_arena_placement", {}).get("probe_GBps_of_each_candidate"))
 for k, r in c.get("secondary_summary", {}).get("rows", {}).items():
     print(" ", k, r)

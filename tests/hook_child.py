@@ -28,6 +28,21 @@ vp = C.c_void_p
 for op in ("and", "or", "xor", "andnot"):
     f = getattr(lib, f"roaring_bitmap_{op}"); f.restype = vp; f.argtypes = [vp, vp]
     f = getattr(lib, f"roaring_bitmap_{op}_inplace"); f.restype = None; f.argtypes = [vp, vp]
+if len(sys.argv) > 2 and sys.argv[2] == "allocfail":
+    # test_inplace_dropins_survive_transient_alloc_failure: a device allocation failure that PERSISTS inside a void
+    # in-place drop-in ends the process (abort) with the reason on stderr
+    lib.rhip_debug_fail_allocs.restype = None
+    lib.rhip_debug_fail_allocs.argtypes = [C.c_int, C.c_int]
+    rng = np.random.default_rng(5)
+    a, b = ref.from_sorted(random_bitmap(rng)), ref.from_sorted(random_bitmap(rng))
+    getattr(lib, "roaring_bitmap_or_inplace")(a, b)  # (a working call first: the lane exists)
+    keys = np.sort(rng.choice(4000, 900, replace=False)).astype(np.uint32)  # (larger than what the lane has recycled: it must allocate)
+    big = np.concatenate([(k << np.uint32(16)) | np.unique(rng.integers(0, 65536, 500)).astype(np.uint32) for k in keys])
+    a, b = ref.from_sorted(big), ref.from_sorted(big[::2].copy())
+    lib.rhip_debug_fail_allocs(0, 1 << 30)
+    getattr(lib, "roaring_bitmap_xor_inplace")(a, b)
+    print("not reached: the call above must abort")
+    sys.exit(0)
 lib.rhip_install_pinned_allocator.restype = C.c_int
 lib.rhip_install_pinned_allocator.argtypes = [C.c_size_t]
 lib.rhip_pinned_allocator_stats.restype = C.c_int

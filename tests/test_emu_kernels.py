@@ -326,6 +326,14 @@ def test_emu_robust_deserialization_corpus(emu):
     GP.robust_corpus_body(emu, Ref() if Ref.available() else None)
 
 
+def test_emu_inplace_dropins_survive_transient_alloc_failure(emu, ref):
+    import os, sys
+    import test_gpu_compat as GC
+    lib = GC.bind(emu.lib)
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hook_child.py")
+    GC.alloc_failure_body(lib, ref, [sys.executable, child, "emu", "allocfail"])
+
+
 def test_emu_join_fallback(oracle, synth, monkeypatch):
     """A forked batch whose flag gate reports a time-out (RHIP_JOIN_FAIL=1) is finished through the fallback of
     rhip_pairwise_end -- streams waited for, the tail's scratch cleared, the tail run again -- with the same bytes."""

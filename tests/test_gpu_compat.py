@@ -171,6 +171,50 @@ def test_dropin_many(hip, ref):
     dropin_many_body(hip, ref)
 
 
+def alloc_failure_body(hip, ref, child_cmd):
+    """The void in-place drop-ins under a device allocation that fails (rhip_debug_fail_allocs): a TRANSIENT failure is
+    survived -- the drop-ins release what they hold and the call is made once more, the result is the reference's --
+    and only a failure that persists ends the process, loudly (the reference's in-place functions have no error channel,
+    roaring.h:280-348; leaving x1 unchanged would be a silently wrong result)."""
+    import subprocess, sys
+    hip.rhip_debug_fail_allocs.restype = None
+    hip.rhip_debug_fail_allocs.argtypes = [C.c_int, C.c_int]
+    rng = np.random.default_rng(12)
+
+    def grown(k):  # operands larger than anything the lanes have recycled so far: the call HAS to allocate
+        n = 60 * (k + 1)
+        keys = np.sort(rng.choice(4000, n, replace=False)).astype(np.uint32)
+        return np.concatenate([(kk << np.uint32(16)) | np.unique(rng.integers(0, 65536, 300 + 50 * k)).astype(np.uint32) for kk in keys])
+    for it in range(6):
+        a, b = ref.from_sorted(grown(it)), ref.from_sorted(grown(it))
+        want = ref.op("or", a, b)
+        hip.rhip_debug_fail_allocs(it % 3, 1)  # the first / second / third allocation of the call fails, once
+        hip.roaring_bitmap_or_inplace(a, b)
+        hip.rhip_debug_fail_allocs(0, 0)
+        assert ref.validate(a) and ref.serialize(a) == ref.serialize(want), it
+        for h in (a, b, want):
+            ref.free(h)
+    # a pointer-returning drop-in reports the same failure as NULL (roaring.h:216-226) and the next call works again
+    a, b = ref.from_sorted(grown(8)), ref.from_sorted(grown(8))
+    hip.rhip_debug_fail_allocs(0, 1000)
+    assert not hip.roaring_bitmap_or(a, b)
+    hip.rhip_debug_fail_allocs(0, 0)
+    r = hip.roaring_bitmap_or(a, b)
+    w = ref.op("or", a, b)
+    assert r and ref.serialize(r) == ref.serialize(w)
+    for h in (a, b, r, w):
+        ref.free(h)
+    # persistent failure inside a void function: abort, with the reason on stderr (a process of its own)
+    p = subprocess.run(child_cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "has no way to report it" in p.stderr, (p.returncode, p.stderr[-2000:])
+
+
+def test_inplace_dropins_survive_transient_alloc_failure(hip, ref):
+    import os, sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hook_child.py")
+    alloc_failure_body(hip, ref, [sys.executable, child, "hip", "allocfail"])
+
+
 def test_dropin_lazy_family(hip, ref):
     """lazy_or / lazy_xor are eager on the device; repair_after_lazy must also canonicalise a bitmap that
     the REFERENCE's lazy functions left unrepaired (unknown bitset cardinalities, non-efficient runs)."""
