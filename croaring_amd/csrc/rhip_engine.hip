@@ -237,6 +237,7 @@ struct rhip_ctx_s {
     // (bench.py's `or` arena behind its `and` arena) paid 3.2 s for ten allocations out of just-freed memory.  Released by
     // rhip_ctx_trim, rhip_ctx_destroy, and by any allocation of the library that fails (DBuf::ensure retries after it).
     std::vector<DBuf> arena_spares;
+    int batches_since_place = 0;  // (trim_spares_when_steady)
     std::vector<float> last_placement;  // probe GB/s of the candidates of the last placement (rhip_debug_last_placement)
     bool debug_plan = false;  // RHIP_DEBUG_PLAN=1: one line per batch on stderr (bounds, fork / merge decision)
     bool merge_classes = true;  // RHIP_MERGE_CLASSES=0: a small batch launches its class kernels one by one
@@ -418,10 +419,25 @@ static bool release_all_arena_spares() {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     bool any = false;
     for (rhip_ctx_t* c : g_live_ctx) {
+        if (c->arena_spares.empty()) continue;
+        DeviceGuard guard(c->device);  // (the spares of a context live on ITS device)
         for (DBuf& b : c->arena_spares) { any = any || b.base != nullptr; b.release(); }
         c->arena_spares.clear();
     }
     return any;
+}
+// Spares are for the searches that follow each other at start-up (a second search right behind the first would otherwise
+// be served just-freed memory the driver has to scrub: seconds).  Once a context has run `after` batches without placing
+// anything, all but its two best spares go back to the driver: other allocators on the device (a caching allocator,
+// another rank) cannot ask this library to let go.
+static void trim_spares_when_steady(rhip_ctx_t* c, int after = 16) {
+    if (c->arena_spares.size() <= 2 || ++c->batches_since_place != after) return;
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    std::sort(c->arena_spares.begin(), c->arena_spares.end(), [](const DBuf& a, const DBuf& b) { return a.placed_gbps > b.placed_gbps; });
+    while (c->arena_spares.size() > 2) {
+        c->arena_spares.back().release();
+        c->arena_spares.pop_back();
+    }
 }
 static bool ctx_alive(rhip_ctx_t* c) {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
@@ -1904,11 +1920,12 @@ void wait_word(rhip_ctx_t* c, volatile uint64_t* flag, uint64_t seq) {
         return;
     }
     for (uint32_t spins = 0;; ++spins) {
-        if (__atomic_load_n((const uint64_t*)flag, __ATOMIC_ACQUIRE) == seq) break;
+        // (seq | TAIL_EARLY: the tail behind a flag join that gave up -- rhip_pairwise_end takes it from there)
+        if ((__atomic_load_n((const uint64_t*)flag, __ATOMIC_ACQUIRE) & ~TAIL_EARLY) == seq) break;
         if ((spins & 0x3FFFu) == 0x3FFFu) {
             const hipError_t q = hipStreamQuery(s);
             if (q == hipSuccess) {  // stream drained: the word is there now, or the kernel never ran
-                if (__atomic_load_n((const uint64_t*)flag, __ATOMIC_ACQUIRE) == seq) break;
+                if ((__atomic_load_n((const uint64_t*)flag, __ATOMIC_ACQUIRE) & ~TAIL_EARLY) == seq) break;
                 set_err("the last kernel of the call finished without publishing its completion word");
                 throw (int)RHIP_ERR_DEVICE;
             }
@@ -2044,6 +2061,7 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
     if (hipMemGetInfo(&free_at_start, &tot_mem) != hipSuccess) { (void)hipGetLastError(); free_at_start = 0; }
     if (free_at_start < 2 * need) return;  // (no room to choose: the caller's ordinary allocation follows)
     c->last_placement.clear();
+    c->batches_since_place = 0;
     hipEvent_t e0 = c->ev[0], e1 = c->ev[1];
     int best = -1;
     auto probe = [&](Cand& cur) {
@@ -2225,7 +2243,8 @@ static rhip_batch_t* pairwise_begin_ops(rhip_ctx_t* c, size_t n_ops, const rhip_
         const uint64_t seq = ++c->seq;
         hipLaunchKernelGGL(k_tail, dim3(tail_blocks), dim3(256), 0,
                            s, P.ranges(), CO, O.meta, D, (uint32_t)(npairs * n_ops), P.tail_lb(), P.tail_part(),
-                           (Stats*)c->slot_stats(slot), (u64*)c->done_flag(slot), (u64)seq);
+                           (Stats*)c->slot_stats(slot), (u64*)c->done_flag(slot), (u64)seq,
+                           join_mask ? (const u64*)c->join_timeout_word() : (const u64*)nullptr);
         if (c->timing) HIPCHK(hipEventRecord(c->evs[slot][1], s));
         HIPCHK(hipGetLastError());  // a refused launch anywhere above must not pass silently
         clk.lap(3);
@@ -2299,6 +2318,13 @@ extern "C" rhip_pool_t* rhip_pairwise_end(rhip_batch_t* b) {
             // tail only reads them.  Wait the ordinary way, clear the tail's scratch, run it again.  The word is per
             // context, so every flag-joined batch that ends while it is set takes this path (its tail may be the early
             // one); it is cleared when no flag-joined batch is left in flight.  Later batches join with events.
+            if (c->spin_join) {
+                static std::atomic<bool> warned{false};
+                if (!warned.exchange(true))
+                    fprintf(stderr, "libroaring_hip: kernels of different streams did not run side by side within %.2f s (a tool that "
+                                    "serialises kernels, a busy device): batches join their streams with events from here on\n",
+                            (double)c->join_spins * 3.4e-6);
+            }
             c->spin_join = false;
             for (int a = 0; a < rhip_ctx_s::N_AUX; ++a) HIPCHK(hipStreamSynchronize(c->aux[a]));
             HIPCHK(hipStreamSynchronize(c->stream));
@@ -2341,6 +2367,7 @@ extern "C" rhip_pool_t* rhip_pairwise_end(rhip_batch_t* b) {
         for (int t = 0; t < 3; ++t) R->census[t] = st.n_type[t] ? 1 : 0;
         R->pending = false;
         c->slot_busy[slot] = false;
+        if (c->in_flight() == 0) trim_spares_when_steady(c);
         rhip_pool_t *A = b->A, *B = b->B;
         delete b;
         drop_deferred(A);  // (the batch has completed: nothing reads the operands any more)

@@ -322,6 +322,7 @@ __device__ __forceinline__ uint32_t unit_of_group(const UnitView& U, uint32_t w,
 // per wave when no bitmap of the batch has more than 64 containers -- the realdata sets with 10-50 containers per
 // bitmap otherwise leave three quarters of every planning wave idle): contributions of the unit to every section; the
 // match positions are kept for k_emit.
+constexpr u64 TAIL_EARLY = 1ull << 63;  // bit of a batch's completion word: "published by a tail that may have run too early"
 template <uint32_t G>
 __global__ __launch_bounds__(256) void k_count(PoolView A, PoolView B, const uint32_t* __restrict__ lhs,
                                                const uint32_t* __restrict__ rhs, UnitView U, int cardmode,
@@ -724,7 +725,8 @@ __global__ void k_conc_probe(const u64* flag, u64* out) {
 }
 __global__ __launch_bounds__(256) void k_tail(const u64* __restrict__ ranges, CandOut C, const u64* __restrict__ meta,
                                               DirOut R, uint32_t n_pairs, LbState lb, u64* __restrict__ part,
-                                              Stats* __restrict__ host_stats, u64* host_flag, u64 seq) {
+                                              Stats* __restrict__ host_stats, u64* host_flag, u64 seq,
+                                              const u64* join_timed_out = nullptr) {
     __shared__ u64 sm[4];
     __shared__ uint32_t s_tile;
     __shared__ u64 s_prefix;
@@ -860,7 +862,10 @@ __global__ __launch_bounds__(256) void k_tail(const u64* __restrict__ ranges, Ca
         for (uint32_t k = 0; k < sizeof(Stats) / 8; ++k) hv[k] = lv[k];
         // "the totals are there": the host polls this word instead of waiting for the stream's completion signal
         __threadfence_system();
-        __atomic_store_n(host_flag, seq, __ATOMIC_RELEASE);
+        // (a flag join in front of this tail that gave up: the class kernels may still be writing -- the completion word
+        // says so, TAIL_EARLY, and rhip_pairwise_end runs the tail again; nobody who polls the word takes this for "done")
+        const u64 early = (join_timed_out && lb_load(join_timed_out) != 0ull) ? TAIL_EARLY : 0ull;
+        __atomic_store_n(host_flag, seq | early, __ATOMIC_RELEASE);
     }
 }
 // cardinality mode has no tail: the same statistics from the section totals

@@ -372,7 +372,11 @@ rhip_pool_t *rhip_many_finalize_dense(rhip_ctx_t *ctx, rhip_op op, int is64, uin
  *               key % world == rank (the shares are disjoint: their serialized forms concatenate by key).
  * Everything is enqueued on the context's stream (rhip_ctx_stream); the call returns when the share is complete.
  * RCCL has no OR / XOR reduction and a ring all-reduce of 8 KiB chunks would be bound by one xGMI link: the
- * personalised all-to-all keeps all point-to-point links busy.  Returns RHIP_OK or an error code. */
+ * personalised all-to-all keeps all point-to-point links busy.  Returns RHIP_OK or an error code.
+ * Failure of ONE rank: a rank whose local stage fails (a bad id, a key >= key_space ...) still takes part in every
+ * collective of the call -- contributing an empty share -- and returns its error afterwards; its peers complete with
+ * what they received and are not left waiting.  Null arguments, a missing librccl and a failure to allocate the exchange
+ * buffers are reported BEFORE the first collective: the group then has to be resolved by the caller, as in any RCCL program. */
 int rhip_many_sharded(rhip_ctx_t *ctx, void *nccl_comm, rhip_op op, rhip_pool_t *local, size_t n, const uint32_t *ids,
                       uint64_t key_space, rhip_pool_t **owned);
 
