@@ -200,6 +200,8 @@ struct rhip_ctx_s {
     void ensure_stage(int slot, size_t n);
     int acquire_slot();
     DBuf many[20];
+    DBuf many_kid, many_dict_buf;  // key dictionary of a chunk table (rhip_many_finalize over 48-bit keys): per call
+    bool many_dict = true;         // RHIP_MANY_DICT=0: roaring64 pools group by a radix sort of (key, descriptor) pairs, as until round 5
     DBuf shard[9];  // rhip_many_sharded: send / receive tables and the sparse exchange's staging, kept between calls
     int shard_force_collective = 0;  // RHIP_SHARD_FORCE_COLLECTIVE=1: issue the all-to-all on a one-rank communicator too (tests, timing)
     // many-way path: pinned staging of the selection (ids + member prefix), the event that says the device has read
@@ -356,6 +358,10 @@ struct rhip_pool_s {
     std::vector<uint32_t> h_n;      // per-bitmap container count
     uint32_t max_n = 0;             // largest of them
     uint64_t n_run_cont = 0;        // run containers of the pool (fetch_bounds)
+    // roaring64 pools: the key dictionary of the many-way path (rhip_many.h: the pool's distinct 48-bit keys, sorted, and
+    // every container's dense key id), built once per state of the pool (kd_gen = the bounds_gen it was built for)
+    DBuf kd_kid, kd_dict;
+    uint64_t kd_K = 0, kd_gen = 0;
     bool host_w = false;
     uint64_t bounds_gen = 0;        // which fetch_bounds() filled the mirrors above (a prepared pair list remembers it)
     int8_t census[3] = {1, 1, 1};   // does the pool hold bitset / array / run containers (1 until known otherwise)
@@ -373,6 +379,8 @@ struct rhip_pool_s {
     void release() {
         bm_start.release(); key.release(); type.release(); card.release(); nruns.release(); off.release();
         arena.release();
+        kd_kid.release(); kd_dict.release();
+        kd_gen = 0;
     }
 };
 
@@ -497,6 +505,7 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_PLAN_CACHE")) c->plan_cache = atoi(e) != 0;
         if (const char* e = getenv("RHIP_FORK_RUNS_MIN")) c->fork_runs_min_items = (uint64_t)atoll(e);
         if (const char* e = getenv("RHIP_MANY_PF")) c->many_pf = atoi(e);
+        if (const char* e = getenv("RHIP_MANY_DICT")) c->many_dict = atoi(e) != 0;
         if (const char* e = getenv("RHIP_MERGE_CLASSES")) c->merge_classes = !(e[0] == '0');
         if (const char* e = getenv("RHIP_DEBUG_PLAN")) c->debug_plan = e[0] == '1';
         if (const char* e = getenv("RHIP_MERGE_MAX_K")) c->merge_max_items = strtoull(e, nullptr, 0) << 10;
@@ -2333,7 +2342,7 @@ extern "C" rhip_pool_t* rhip_pairwise_end(rhip_batch_t* b) {
             HIPCHK(hipMemsetAsync(T.lb.ticket, 0, 8, c->stream));
             const uint64_t seq2 = ++c->seq;
             hipLaunchKernelGGL(k_tail, dim3(T.blocks), dim3(256), 0, c->stream, b->ranges, T.CO, T.meta, T.D, T.n_virt, T.lb, T.part,
-                               (Stats*)c->slot_stats(slot), (u64*)c->done_flag(slot), (u64)seq2);
+                               (Stats*)c->slot_stats(slot), (u64*)c->done_flag(slot), (u64)seq2, (const u64*)nullptr);
             HIPCHK(hipGetLastError());
             wait_word(c, c->done_flag(slot), seq2);
             memcpy(&st, c->slot_stats(slot), sizeof(Stats));

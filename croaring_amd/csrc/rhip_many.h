@@ -125,6 +125,71 @@ __global__ __launch_bounds__(256) void k_many_gather(PoolView P, const uint32_t*
     }
 }
 
+// ------------------------------------------------------------------ the key dictionary of a roaring64 pool
+// The counting sort below works over a dense key space.  A 32-bit pool has one: its 16-bit container keys.  A roaring64
+// pool's 48-bit keys (high 32 bits << 16 | key16: no ART on the device) get one -- ONCE per pool, like the other host
+// mirrors: the distinct keys are collected in an open-addressing table (k_kd_insert), compacted (k_kd_compact), sorted by
+// one workgroup (k_kd_sort: a pool holds a few thousand distinct keys, 65 536 at most here) and every container's key is
+// replaced by its rank (k_kd_rank).  Until round 6 every many-way call over a roaring64 pool gathered (key, descriptor)
+// pairs and ran a library radix sort over them (rocPRIM: four kernels + five fills) -- BASELINE configs[4]'s aggregation.
+constexpr u64 KD_EMPTY = ~0ull;
+__device__ __forceinline__ u64 kd_hash(u64 k) {
+    k ^= k >> 33; k *= 0xFF51AFD7ED558CCDull; k ^= k >> 33; k *= 0xC4CEB9FE1A85EC53ull; k ^= k >> 33;
+    return k;
+}
+__global__ __launch_bounds__(256) void k_kd_insert(const u64* __restrict__ key, u64 n, u64* __restrict__ tab, u64 mask,
+                                                   u64* __restrict__ n_distinct) {
+    uint32_t mine = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 k = key[i];
+        for (u64 h = kd_hash(k) & mask;; h = (h + 1) & mask) {
+            const u64 cur = __atomic_load_n(&tab[h], __ATOMIC_RELAXED);
+            if (cur == k) break;
+            if (cur == KD_EMPTY) {
+                const u64 old = atomicCAS((unsigned long long*)&tab[h], (unsigned long long)KD_EMPTY, (unsigned long long)k);
+                if (old == KD_EMPTY) { ++mine; break; }
+                if (old == k) break;
+            }
+        }
+    }
+    mine = wave_sum(mine);
+    if (lane_id() == 0 && mine) atomicAdd((unsigned long long*)n_distinct, (unsigned long long)mine);
+}
+__global__ __launch_bounds__(256) void k_kd_compact(const u64* __restrict__ tab, u64 slots, u64* __restrict__ out, u64 cap,
+                                                    u64* __restrict__ cursor) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (u64)gridDim.x * blockDim.x) {
+        const u64 k = tab[i];
+        if (k != KD_EMPTY) {
+            const u64 p = atomicAdd((unsigned long long*)cursor, 1ull);
+            if (p < cap) out[p] = k;
+        }
+    }
+}
+// ascending bitonic sort of v[0, n) in place, ONE workgroup; v holds n2 >= n slots (n2 = next power of two), the slots
+// behind n are filled with ~0
+__global__ __launch_bounds__(1024) void k_kd_sort(u64* __restrict__ v, const u64* __restrict__ n_ptr, uint32_t n2) {
+    const uint32_t n = *n_ptr < (u64)n2 ? (uint32_t)*n_ptr : n2;  // (the number of distinct keys lives on the device)
+    for (uint32_t i = n + threadIdx.x; i < n2; i += 1024) v[i] = ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= n2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < n2; i += 1024) {
+                const uint32_t x = i ^ j;
+                if (x > i) {
+                    const u64 a = v[i], b = v[x];
+                    if ((a > b) == ((i & k) == 0u)) { v[i] = b; v[x] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+__global__ __launch_bounds__(256) void k_kd_rank(const u64* __restrict__ key, u64 n, const u64* __restrict__ dict,
+                                                 const u64* __restrict__ n_ptr, uint32_t n2, uint32_t* __restrict__ kid) {
+    const u64 K = *n_ptr < (u64)n2 ? *n_ptr : (u64)n2;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
+        kid[i] = (uint32_t)lower_bound(dict, 0, K, key[i]);
+}
+
 // ------------------------------------------------------------------ grouping by counting sort (16-bit keys)
 // The members of a call in GATHERED order: member t (its tag) is container `t` of the pool (ids == null), or container
 // bm_start[ids[s]] + (t - sel_start[s]) of the s-th selected bitmap.  A workgroup's share: `per_block` consecutive members
@@ -137,6 +202,9 @@ struct ManySel {
     u64 M;
     u64 per_block;
     uint32_t n_blocks;     // workgroups that hold members = rows of the count matrix
+    const uint32_t* kid;   // 48-bit keys (roaring64 pools): the dense id of every container's key -- its rank among the pool's
+                           // distinct keys (rhip_key_dict, computed once per pool) -- which the counting sort takes for the key;
+                           // null: the 16-bit key itself
 };
 constexpr uint32_t MC_THREADS = 1024;
 constexpr uint32_t MC_W1 = 8192;    // keys per LDS window of k_many_hist (u64 bins: 64 KiB)
@@ -157,7 +225,7 @@ __device__ __forceinline__ uint32_t many_row(uint32_t b, uint32_t n) {
 // many of them in flight (k_many_scatter: 99 -> us on C4 with eight members' loads issued before the first is used).
 struct ManyRec { uint32_t key, ty, cd, nr; u64 off; };
 template <bool WITH_OFF>
-__device__ __forceinline__ ManyRec many_load(const PoolView& P, u64 c) {
+__device__ __forceinline__ ManyRec many_load(const PoolView& P, const uint32_t* __restrict__ kid, u64 c) {
     // (non-temporal: the directory streams through once; what should stay in the L2 are the partly written lines of
     // k_many_scatter's output, which only leave as whole lines if they survive until their neighbours arrive)
     ManyRec r;
@@ -165,7 +233,7 @@ __device__ __forceinline__ ManyRec many_load(const PoolView& P, u64 c) {
     r.key = (uint32_t)P.key[c] & 0xFFFFu; r.ty = P.type[c]; r.cd = P.card[c]; r.nr = P.nruns[c];
     r.off = WITH_OFF ? P.off[c] : 0ull;
 #else
-    r.key = (uint32_t)__builtin_nontemporal_load(&P.key[c]) & 0xFFFFu;
+    r.key = kid ? __builtin_nontemporal_load(&kid[c]) : (uint32_t)__builtin_nontemporal_load(&P.key[c]) & 0xFFFFu;
     r.ty = __builtin_nontemporal_load(&P.type[c]);
     r.cd = __builtin_nontemporal_load(&P.card[c]);
     r.nr = __builtin_nontemporal_load(&P.nruns[c]);
@@ -183,7 +251,7 @@ __device__ __forceinline__ void many_for_members(const PoolView& P, const ManySe
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const u64 t = base + (u64)j * MC_THREADS;
-                r[j] = many_load<WITH_OFF>(P, t < hi ? t : hi - 1);
+                r[j] = many_load<WITH_OFF>(P, S.kid, t < hi ? t : hi - 1);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -197,7 +265,7 @@ __device__ __forceinline__ void many_for_members(const PoolView& P, const ManySe
     for (u64 s = s0 + (threadIdx.x >> 6); s < s1; s += MC_THREADS / 64) {
         const uint32_t b = S.ids[s];
         const u64 c0 = P.bm_start[b], c1 = P.bm_start[b + 1], d0 = S.sel_start[s];
-        for (u64 i = c0 + lane_id(); i < c1; i += 64) f(many_load<WITH_OFF>(P, i), d0 + (i - c0));
+        for (u64 i = c0 + lane_id(); i < c1; i += 64) f(many_load<WITH_OFF>(P, S.kid, i), d0 + (i - c0));
     }
 }
 
@@ -244,7 +312,8 @@ __global__ __launch_bounds__(MC_KT * MC_SEG) void k_many_keyscan(const uint32_t*
                                                                 ManyKeyLb lb, u64* __restrict__ gstart, u64* __restrict__ gkey,
                                                                 u64* __restrict__ pstart, u64* __restrict__ off,
                                                                 uint32_t* __restrict__ kstart, uint32_t* __restrict__ kgrp,
-                                                                ManyTotals* __restrict__ tot) {
+                                                                ManyTotals* __restrict__ tot, const u64* __restrict__ dict) {
+    // (dict != null: the key space is the dense ids of a roaring64 pool's distinct keys; dict[id] = the 48-bit key)
     __shared__ uint32_t s_cnt[MC_SEG][MC_KT], s_w[MC_SEG][MC_KT];
     __shared__ uint32_t s_tile;
     if (threadIdx.x == 0) s_tile = atomicAdd(lb.ticket, 1u);
@@ -301,8 +370,9 @@ __global__ __launch_bounds__(MC_KT * MC_SEG) void k_many_keyscan(const uint32_t*
         const u64 pp = (pb >> 32) + ip - np, ss = (pb & 0xFFFFFFFFull) + is - sl;
         if (kin) { kstart[k] = (uint32_t)gs; kgrp[k] = (uint32_t)g; }
         if (tc) {
-            gstart[g] = gs; gkey[g] = k; pstart[g] = pp; off[g] = 16ull * ss;
-            if (g + 1 == Gt) atomicMax(&tot->max_key, (u64)k);  // (one per non-empty tile: the last group so far)
+            const u64 kk = dict ? dict[k] : (u64)k;
+            gstart[g] = gs; gkey[g] = kk; pstart[g] = pp; off[g] = 16ull * ss;
+            if (g + 1 == Gt) atomicMax(&tot->max_key, kk);  // (one per non-empty tile: the last group so far)
         }
         if (tile == n_tiles - 1 && lane == 0) {  // the last tile closes the lists
             const u64 NP = (pb >> 32) + tp, NS = (pb & 0xFFFFFFFFull) + ts;

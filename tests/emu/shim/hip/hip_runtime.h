@@ -258,6 +258,8 @@ template <class T, class U>
 static inline T atomicAnd(T* p, U v) { T o = *p; *p = (T)(o & (T)v); return o; }
 template <class T, class U>
 static inline T atomicMax(T* p, U v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
+template <class T, class U, class V>
+static inline T atomicCAS(T* p, U cmp, V v) { T o = *p; if (o == (T)cmp) *p = (T)v; return o; }
 template <class T, class U>
 static inline T atomicMin(T* p, U v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
 

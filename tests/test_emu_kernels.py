@@ -334,6 +334,13 @@ def test_emu_inplace_dropins_survive_transient_alloc_failure(emu, ref):
     GC.alloc_failure_body(lib, ref, [sys.executable, child, "emu", "allocfail"])
 
 
+def test_emu_64bit_many_grouping_paths(oracle, monkeypatch):
+    from emu import build_emu, emu_engine
+    if not __import__("os").path.exists(build_emu.CXX):
+        pytest.skip("hipemu needs the ROCm clang++ to compile the kernels for the host")
+    G64.many64_grouping_body(emu_engine, oracle, monkeypatch)
+
+
 def test_emu_join_fallback(oracle, synth, monkeypatch):
     """A forked batch whose flag gate reports a time-out (RHIP_JOIN_FAIL=1) is finished through the fallback of
     rhip_pairwise_end -- streams waited for, the tail's scratch cleared, the tail run again -- with the same bytes."""
