@@ -536,6 +536,42 @@ def _time_steps(D: Dist, step, steps: int, warmup: int):
     return float(np.median(ts)), float(np.min(ts))
 
 
+def gather_floats(D: Dist, x: float):
+    """x of every rank, in rank order (world 1: [x])."""
+    if D.world == 1:
+        return [float(x)]
+    t = D.torch.tensor([x], dtype=D.torch.float64, device=D.rdev)
+    out = [D.torch.zeros_like(t) for _ in range(D.world)]
+    D.dist.all_gather(out, t)
+    return [float(v.item()) for v in out]
+
+
+def measure_dense_a2a(eng, D: Dist, key_space: int = 4096, reps: int = 7):
+    """The exchange step of the dense sharded or_many ALONE: one fixed-shape all_to_all_single of the [world x ceil(K /
+    world), 1024] u64 table (32 MiB at K = 4096) on the engine's stream, max over ranks, median of `reps` -- the t_a2a of
+    DESIGN 7a's model, which a single GPU cannot show.  None at world 1."""
+    if D.world == 1:
+        return None
+    import torch
+    from croaring_amd.distributed import dense_block
+    B = dense_block(key_space, D.world)
+    dev = eng.torch_device() if D.rdev == "cuda" else "cpu"
+    with eng.torch_stream():
+        src = torch.zeros((D.world * B, 1024), dtype=torch.int64, device=dev)
+        dst = torch.empty_like(src)
+        ts = []
+        for it in range(reps + 2):
+            D.barrier()
+            t0 = time.perf_counter()
+            D.dist.all_to_all_single(dst, src)
+            torch.cuda.synchronize()
+            dt = D.max(time.perf_counter() - t0)
+            if it >= 2:
+                ts.append(dt)
+    return {"ms_median": float(np.median(ts)) * 1e3, "ms_min": float(np.min(ts)) * 1e3, "bytes_per_rank": int(src.numel() * 8),
+            "bytes_to_peers": int(src.numel() * 8 * (D.world - 1) // D.world)}
+
+
 def run_ormany(args, eng, D: Dist, steps: int, warmup: int, chk=None):
     """C4, strong scaling: --bitmaps sparse bitmaps in total, rank r holds bitmaps b with b mod world == r; one step
     = one or_many over ALL of them.  world > 1: per-rank partial chunks written into the dense send table -> ONE
@@ -563,6 +599,13 @@ def run_ormany(args, eng, D: Dist, steps: int, warmup: int, chk=None):
            "pool_layout": {"payload_align": int(pool.payload_align), "arena_over_payload": round(pool.arena_bytes() / max(1, payload), 4)},
            "parallelism": f"bitmaps b mod {D.world}; dense key-owner all-to-all over RCCL, one host wait" if D.world > 1 else "single GPU"}
     row["frac"] = row["alg_GBps"] / HBM_PEAK_GBS
+    if D.world > 1:
+        # DESIGN 7a beside the measurement: T(N) = 0.08 + 0.52 / N + t_a2a(N) + 0.03 ms (fixed part of stage 1, the rank's share
+        # of the reduction, the exchange, stage 3) with t_a2a MEASURED here on its own
+        a2a = measure_dense_a2a(eng, D)
+        row["t_a2a"] = a2a
+        row["model_ms"] = {"N": D.world, "stage1_fixed": 0.08, "stage1_share": 0.52 / D.world, "t_a2a_measured": a2a["ms_median"],
+                           "stage3": 0.03, "predicted": 0.08 + 0.52 / D.world + a2a["ms_median"] + 0.03, "measured": tmed * 1e3}
     gp = os.path.join(ROOT, "tests", "golden", "c4_or_many.npz")
     if os.path.exists(gp) and args.bitmaps == 100000:
         row["cardinality_ok"] = bool(int(np.load(gp)["or_many_100000"][0]) == int(card))
@@ -837,6 +880,8 @@ def main():
     ms_kernel = float(np.mean(bb_ms)) if bb_ms else 0.0
     pairs_per_launch = float(np.mean(bb_pairs)) if bb_pairs else 0.0
     achieved = (pairs_per_launch * BB_BYTES_PER_PAIR) / (ms_kernel * 1e-3) / 1e9 if ms_kernel > 0 else 0.0
+    per_rank_frac = gather_floats(D, achieved / HBM_PEAK_GBS)
+    per_rank_ms = gather_floats(D, ms_kernel)
     traffic, traffic_source = None, None
     tp = os.path.join(ROOT, "profiles", "bb_traffic.json")
     if os.path.exists(tp):
@@ -861,6 +906,13 @@ def main():
         "dtype": "u64",
         "data": "synthetic",
         "transport": transport,
+        "collective": None if world == 1 else {
+            "backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
+            "note": "torch.distributed's nccl backend IS RCCL on ROCm; rccl_ranks = the size of the communicator the many-way rows exchange over "
+                    "(0: the gloo dry run on one GPU)"},
+        "per_rank": None if world == 1 else {
+            "k_bb_frac": [round(v, 4) for v in per_rank_frac], "k_bb_avg_launch_ms": [round(v, 4) for v in per_rank_ms],
+            "note": "every rank's own HIP-event average of k_bb over the timed region (roofline.* is rank 0's)"},
         "config": {"workload": f"C2 synthetic bitset-only: pool {args.pool} bitmaps x {args.containers} bitset "
                                f"containers (density 0.5), batched pairwise AND+OR, {args.pairs} pairs per call, "
                                f"{args.rounds} x (AND call + OR call) per step, two calls in flight "
@@ -941,6 +993,8 @@ def main():
                         None if "ms_first_call" not in r else round(r["ms_first_call"], 4)]
             if "sharded_w1" in r:
                 row += [round(r["sharded_w1"]["vs_or_many"], 3)]
+            if r.get("t_a2a"):  # N > 1: the exchange measured alone, and DESIGN 7a's model with it
+                row += [round(r["t_a2a"]["ms_median"], 4), round(r["model_ms"]["predicted"], 4)]
             if "us_per_op" in r:
                 row += [round(r["us_per_op"], 3), None if "cpu1_us_per_op" not in r else round(r["cpu1_us_per_op"], 3)]
             summ[k] = row
@@ -951,7 +1005,8 @@ def main():
                        "cardinality equal to the reference's | realdata only: ms with the pair list handed over per call instead of "
                        "prepared once (plans every time), ms per call with two calls in flight, HBM TRAFFIC (stored PMC pass) / time / 8 TB/s -- the "
                        "second column counts algorithmic bytes, which on these cache-resident sets is not HBM utilisation --, ms of the "
-                       "FIRST call over the prepared list (planning kernels included: ms_first_call) | c4: sharded pipeline at world 1 / or_many | "
+                       "FIRST call over the prepared list (planning kernels included: ms_first_call) | c4: sharded pipeline at world 1 / or_many; "
+                       "N > 1: ms of the dense all-to-all measured alone (t_a2a), ms DESIGN 7a's model predicts with it | "
                        "c4_shard_stages: N -> [stage 1 ms, stage 3 ms, DESIGN 7a model ms] for one rank of N on this GPU | "
                        "*_successive_*: the n - 1 adjacent pairs as one batch + cardinalities read back (the reference benchmark's "
                        "successive_and / _or loop), then us per op here, us per op of CRoaring on one core | dropin_percall_us: op -> "

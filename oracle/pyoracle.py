@@ -49,6 +49,7 @@ class Oracle:
         L.oc_and_cardinality.restype = u64; L.oc_and_cardinality.argtypes = [vp, vp]
         L.oc_op_cardinality.restype = u64; L.oc_op_cardinality.argtypes = [C.c_int, vp, vp]
         L.oc_or_many.restype = vp; L.oc_or_many.argtypes = [sz, C.POINTER(vp)]
+        L.oc_or_many_heap.restype = vp; L.oc_or_many_heap.argtypes = [sz, C.POINTER(vp)]
         L.oc_xor_many.restype = vp; L.oc_xor_many.argtypes = [sz, C.POINTER(vp)]
         L.oc_free.restype = None; L.oc_free.argtypes = [vp]
         L.oc_from_sorted.restype = vp; L.oc_from_sorted.argtypes = [vp, sz]
@@ -134,6 +135,9 @@ class Oracle:
 
     def xor_many(self, hs):
         return self._many(self.L.oc_xor_many, hs)
+
+    def or_many_heap(self, hs):
+        return self._many(self.L.oc_or_many_heap, hs)
 
     def validate(self, h) -> bool:
         return bool(self.L.oc_validate(h))

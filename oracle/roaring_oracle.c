@@ -1309,6 +1309,151 @@ oc_bitmap_t *oc_xor_many(size_t n, const oc_bitmap_t **x) {
     return ans;
 }
 
+/* ------------------------------------------------------- or_many_heap */
+/* container_lazy_or (containers.h:1113-1215) and container_lazy_ior (:1333-1442) WITHOUT the early bitset conversion
+ * (bitsetconversion = false, as roaring_priority_queue.c calls them).  Functional restatement: a new container is
+ * returned whatever the reference does in place; `inplace` selects the one typing difference between the two --
+ * B,B: lazy_or leaves the cardinality unknown, lazy_ior counts (LAZY_OR_BITSET_CONVERSION_TO_FULL, perfparameters.h:45)
+ * and turns a full result into a full run. */
+static oc_container_t lazy_or_nc(const oc_container_t *c1, const oc_container_t *c2, int inplace) {
+    int t1 = c1->type, t2 = c2->type;
+    if (t1 == OC_BITSET && t2 == OC_BITSET) {
+        uint64_t *w = words_from(c1);
+        const uint64_t *w2 = (const uint64_t *)c2->data;
+        for (int i = 0; i < WORDS; i++) w[i] |= w2[i];
+        if (!inplace) return mk_bitset(w, -1);
+        int card = popcnt_words(w);
+        if (card == 65536) {
+            free(w);
+            uint16_t *r = (uint16_t *)malloc(4);
+            r[0] = 0; r[1] = 0xFFFF;
+            return mk_run(r, 1);
+        }
+        return mk_bitset(w, card);
+    }
+    if (t1 == OC_ARRAY && t2 == OC_ARRAY) { /* array_array_container_lazy(_inplace)_union, mixed_union.c:247-365 */
+        if (c1->card + c2->card <= 1024) {
+            uint16_t *o = (uint16_t *)malloc(2 * (size_t)(c1->card + c2->card + 1));
+            int k = merge_or((const uint16_t *)c1->data, c1->card, (const uint16_t *)c2->data, c2->card, o);
+            return mk_array(o, k);
+        }
+        uint64_t *w = words_from(c1), *w2 = words_from(c2);
+        for (int i = 0; i < WORDS; i++) w[i] |= w2[i];
+        free(w2);
+        return mk_bitset(w, -1);
+    }
+    if (t1 == OC_RUN && t2 == OC_RUN) return run_to_efficient(rr_union_raw(c1, c2)); /* converted at once in both forms */
+    if (t1 == OC_BITSET || t2 == OC_BITSET) {
+        const oc_container_t *other = t1 == OC_BITSET ? c2 : c1;
+        if (other->type == OC_RUN && run_is_full(other)) return c_clone(other); /* containers.h:1169-1196, 1395-1416 */
+        uint64_t *w = words_from(c1), *w2 = words_from(c2);
+        for (int i = 0; i < WORDS; i++) w[i] |= w2[i];
+        free(w2);
+        return mk_bitset(w, -1);
+    }
+    /* A,R / R,A: array_run_container_union -- the raw run list, no conversion ("we are lazy") */
+    return t1 == OC_ARRAY ? ar_union_raw(c1, c2) : ar_union_raw(c2, c1);
+}
+static int c_is_full(const oc_container_t *c) { /* container_is_full, containers.h:262-277 */
+    return c->type == OC_RUN ? run_is_full(c) : c->card == 65536;
+}
+/* what one step of the tournament builds out of two elements.  mode 0: roaring_bitmap_lazy_or(x1, x2, false)
+ * (roaring.c:2509-2598); 1: roaring_bitmap_lazy_or_inplace(acc = x1, x2, false) (roaring.c:2600-2682: a full accumulator
+ * container is skipped); 3: lazy_or_from_lazy_inputs (roaring_priority_queue.c:98-192: a bitset second operand goes first). */
+static oc_bitmap_t *heap_merge(const oc_bitmap_t *x1, const oc_bitmap_t *x2, int mode) {
+    oc_bitmap_t *ans = oc_create();
+    int i = 0, j = 0;
+    while (i < x1->n || j < x2->n) {
+        if (j >= x2->n || (i < x1->n && x1->keys[i] < x2->keys[j])) { bm_push(ans, x1->keys[i], c_clone(&x1->c[i])); i++; }
+        else if (i >= x1->n || x2->keys[j] < x1->keys[i]) { bm_push(ans, x2->keys[j], c_clone(&x2->c[j])); j++; }
+        else {
+            const oc_container_t *a = &x1->c[i], *b = &x2->c[j];
+            oc_container_t r;
+            if (mode == 0) r = lazy_or_nc(a, b, 0);
+            else if (mode == 1) r = c_is_full(a) ? c_clone(a) : lazy_or_nc(a, b, 1);
+            else r = (b->type == OC_BITSET && a->type != OC_BITSET) ? lazy_or_nc(b, a, 1) : lazy_or_nc(a, b, 1);
+            bm_push(ans, x1->keys[i], r);
+            i++; j++;
+        }
+    }
+    return ans;
+}
+/* roaring_bitmap_portable_size_in_bytes of a (possibly lazy) bitmap: a lazy bitset is 8192 bytes like any other */
+static uint64_t heap_size(const oc_bitmap_t *b) { return (uint64_t)oc_size_in_bytes(b); }
+
+typedef struct { uint64_t size; int temp; oc_bitmap_t *bm; } pq_el;
+typedef struct { pq_el *e; uint64_t n; } pq_t;
+/* the reference's binary heap, move for move (roaring_priority_queue.c:27-96): ties are broken by position */
+static void pq_down(pq_t *pq, uint32_t i) {
+    uint32_t size = (uint32_t)pq->n, hsize = size >> 1;
+    pq_el ai = pq->e[i];
+    while (i < hsize) {
+        uint32_t l = (i << 1) + 1, r = l + 1;
+        pq_el best = pq->e[l];
+        if (r < size && pq->e[r].size < best.size) { l = r; best = pq->e[r]; }
+        if (!(best.size < ai.size)) break;
+        pq->e[i] = best;
+        i = l;
+    }
+    pq->e[i] = ai;
+}
+static void pq_push(pq_t *pq, pq_el t) {
+    uint64_t i = pq->n;
+    pq->e[pq->n++] = t;
+    while (i > 0) {
+        uint64_t p = (i - 1) >> 1;
+        pq_el ap = pq->e[p];
+        if (!(t.size < ap.size)) break;
+        pq->e[i] = ap;
+        i = p;
+    }
+    pq->e[i] = t;
+}
+static pq_el pq_pop(pq_t *pq) {
+    pq_el ans = pq->e[0];
+    if (pq->n > 1) {
+        pq->e[0] = pq->e[--pq->n];
+        pq_down(pq, 0);
+    } else
+        --pq->n;
+    return ans;
+}
+/* roaring_bitmap_or_many_heap, roaring_priority_queue.c:200-247: a tournament ordered by serialized size, lazy unions
+ * without early bitset conversion, one repair pass at the end. */
+oc_bitmap_t *oc_or_many_heap(size_t n, const oc_bitmap_t **x) {
+    if (n == 0) return oc_create();
+    if (n == 1) return oc_copy(x[0]);
+    pq_t pq;
+    pq.e = (pq_el *)malloc(sizeof(pq_el) * n);
+    pq.n = n;
+    for (size_t i = 0; i < n; i++) { pq.e[i].bm = (oc_bitmap_t *)x[i]; pq.e[i].temp = 0; pq.e[i].size = heap_size(x[i]); }
+    for (int32_t i = (int32_t)(n >> 1); i >= 0; i--) pq_down(&pq, (uint32_t)i);
+    while (pq.n > 1) {
+        pq_el x1 = pq_pop(&pq), x2 = pq_pop(&pq);
+        pq_el ne;
+        ne.temp = 1;
+        if (x1.temp && x2.temp) {
+            /* (an empty operand: the other one is handed back as it is -- the same containers) */
+            ne.bm = heap_merge(x1.bm, x2.bm, 3);
+        } else if (x2.temp) {
+            ne.bm = heap_merge(x2.bm, x1.bm, 1);
+        } else if (x1.temp) {
+            ne.bm = heap_merge(x1.bm, x2.bm, 1);
+        } else {
+            ne.bm = heap_merge(x1.bm, x2.bm, 0);
+        }
+        if (x1.temp) oc_free(x1.bm);
+        if (x2.temp) oc_free(x2.bm);
+        ne.size = heap_size(ne.bm);
+        pq_push(&pq, ne);
+    }
+    pq_el X = pq_pop(&pq);
+    free(pq.e);
+    oc_bitmap_t *ans = X.bm;
+    for (int i = 0; i < ans->n; i++) repair(&ans->c[i]);
+    return ans;
+}
+
 /* -------------------------------------------------------------- checks */
 int oc_validate(const oc_bitmap_t *b) { /* roaring.c:454-523 + bitset.c:1023-1044, array.c:456-493, run.c:669-716 */
     for (int i = 0; i < b->n; i++) {

@@ -92,6 +92,8 @@ uint64_t oc_get_cardinality(const oc_bitmap_t *b);
 uint64_t oc_and_cardinality(const oc_bitmap_t *a, const oc_bitmap_t *b);
 uint64_t oc_op_cardinality(int op, const oc_bitmap_t *a, const oc_bitmap_t *b);
 oc_bitmap_t *oc_or_many(size_t n, const oc_bitmap_t **x);
+/* roaring_bitmap_or_many_heap (roaring_priority_queue.c:200-247): byte-identical container types */
+oc_bitmap_t *oc_or_many_heap(size_t n, const oc_bitmap_t **x);
 oc_bitmap_t *oc_xor_many(size_t n, const oc_bitmap_t **x);
 
 /* ---- checks / decoding ---- */

@@ -38,5 +38,9 @@ def test_bench_multi_rank_dry_run(n):
             assert r[2] is not False, (k, r)  # checksum / cardinality equal to the reference's wherever one is asserted
     for k in ("c3_and", "c3_or", "c3_xor", "c3_andnot", "c1_and", "c1_or"):
         assert rows[k][2] is True, (k, rows[k])  # the SURVEY 8d checksums over ALL pairs, summed over the ranks' shares
+    # the line proves what it ran on: the collective's backend and size, every rank's own k_bb figure, the exchange timed alone
+    assert out["collective"]["world_size"] == n and out["collective"]["backend"] == "gloo" and out["collective"]["rccl_ranks"] == 0
+    assert len(out["per_rank"]["k_bb_frac"]) == n and all(v > 0 for v in out["per_rank"]["k_bb_avg_launch_ms"])
+    assert len(rows["c4_or_many"]) >= 5 and rows["c4_or_many"][-2] > 0 and rows["c4_or_many"][-1] > rows["c4_or_many"][-2]
     assert out["cpu_baseline"] is not None and "error" not in out["cpu_baseline"], out["cpu_baseline"]
     assert out["cpu_baseline"]["value"] > 0

@@ -40,11 +40,11 @@ def test_many_way(oracle, ref):
         assert ref.serialize(rr) == oracle.serialize(oo), f"or_many {it}"
         rx, ox = ref.xor_many(rs), oracle.xor_many(os_)
         assert ref.serialize(rx) == oracle.serialize(ox), f"xor_many {it}"
-        rh = ref.or_many_heap(rs)
-        assert np.array_equal(ref.to_array(rh), oracle.to_array(oo))
+        rh, oh = ref.or_many_heap(rs), oracle.or_many_heap(os_)
+        assert ref.serialize(rh) == oracle.serialize(oh), f"or_many_heap {it}"
         for h in rs + [rr, rx, rh]:
             ref.free(h)
-        for h in os_ + [oo, ox]:
+        for h in os_ + [oo, ox, oh]:
             oracle.free(h)
 
 
@@ -74,6 +74,36 @@ def test_xor_many_fold_typing(oracle, ref):
         for h in rs + [rx]:
             ref.free(h)
         for h in os_ + [ox]:
+            oracle.free(h)
+
+
+def test_or_many_heap_tournament_typing(oracle, ref):
+    """roaring_bitmap_or_many_heap (roaring_priority_queue.c:200-247): the tournament ordered by serialized size, lazy
+    unions without early bitset conversion (arrays stay arrays up to 1024 values, run | array stays a raw run, run | run is
+    typed by size at every step, a bitset absorbs, full runs short-circuit), one repair pass -- BYTES, on few keys with many
+    members, equal-sized inputs (ties are broken by heap position), empty bitmaps, with and without run compression."""
+    rng = np.random.default_rng(5151)
+    mixes = (("runs", "shortruns", "tiny", "single", "edge"), ("runs", "tiny"), ("runs", "shortruns", "dense", "sparse"),
+             ("sparse", "tiny", "mid", "boundary4096"), ("full", "nearfull", "runs", "blocks", "verydense"), None)
+    for it in range(300):
+        profs = mixes[it % len(mixes)]
+        n = int(rng.integers(2, 24))
+        kw = dict(max_keys=4, key_space=4) if profs is None else dict(max_keys=4, key_space=4, profiles=profs)
+        vs = [random_bitmap(rng, **kw) for _ in range(n)]
+        if it % 7 == 0:
+            vs[int(rng.integers(0, n))] = np.zeros(0, np.uint32)
+        if it % 5 == 0 and n > 3:  # equal sizes: the same bitmap several times
+            vs[2] = vs[0]; vs[3] = vs[0]
+        rs = [ref.from_sorted(v) for v in vs]
+        if it % 3 == 1:
+            for r in rs[::2]:
+                ref.remove_run_compression(r)
+        os_ = [oracle.deserialize(ref.serialize(r)) for r in rs]
+        rh, oh = ref.or_many_heap(rs), oracle.or_many_heap(os_)
+        assert ref.serialize(rh) == oracle.serialize(oh), f"or_many_heap {it}"
+        for h in rs + [rh]:
+            ref.free(h)
+        for h in os_ + [oh]:
             oracle.free(h)
 
 
