@@ -96,6 +96,7 @@ SYMBOLS = [
     ("rhip_pool_max_key", _i, [_vp, _vp]),
     ("rhip_or_many", _vp, [_vp, _vp, _sz, _vp]),
     ("rhip_xor_many", _vp, [_vp, _vp, _sz, _vp]),
+    ("rhip_or_many_heap", _vp, [_vp, _vp, _sz, _vp]),
     ("rhip_many_partials", _i, [_vp, _i, _vp, _sz, _vp, C.POINTER(Partials)]),
     ("rhip_partials_free", None, [_vp, C.POINTER(Partials)]),
     ("rhip_many_finalize", _vp, [_vp, _i, _i, _u64, _vp, _vp]),

@@ -12,7 +12,7 @@ OUT = os.path.join(PKG, "libroaring_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-pthread", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 SOURCES = ["rhip_prims.hip", "rhip_engine.hip"]
-DEPS = ["rhip_kernels.h", "rhip_common.h", "rhip_plan.h", "rhip_bitset.h", "rhip_array.h", "rhip_grouped.h", "rhip_runs.h", "rhip_classes.h", "rhip_block.h", "rhip_many.h", "rhip_many_host.inc", "rhip_sharded.inc", "rhip_synth.inc", "rhip_prims.h", "roaring_compat.inc", "rhip_poolops.h", "rhip_pool_ops.inc", "rhip_wemit.inc", "rhip_serial.h", "rhip_deser.h", "rhip_frozen.h", "rhip_values.h", "rhip_flip.h",
+DEPS = ["rhip_kernels.h", "rhip_common.h", "rhip_plan.h", "rhip_bitset.h", "rhip_array.h", "rhip_grouped.h", "rhip_runs.h", "rhip_classes.h", "rhip_block.h", "rhip_many.h", "rhip_many_host.inc", "rhip_heap.h", "rhip_heap_host.inc", "rhip_sharded.inc", "rhip_synth.inc", "rhip_prims.h", "roaring_compat.inc", "rhip_poolops.h", "rhip_pool_ops.inc", "rhip_wemit.inc", "rhip_serial.h", "rhip_deser.h", "rhip_frozen.h", "rhip_values.h", "rhip_flip.h",
         os.path.join("..", "..", "include", "roaring_hip.h"), os.path.join("..", "..", "include", "roaring_hip_compat.h")]
 
 

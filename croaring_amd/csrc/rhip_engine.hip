@@ -21,6 +21,7 @@
 #include "../../include/roaring_hip.h"
 #include "rhip_kernels.h"
 #include "rhip_many.h"
+#include "rhip_heap.h"
 #include "rhip_poolops.h"
 #include "rhip_serial.h"
 #include "rhip_deser.h"
@@ -2666,6 +2667,7 @@ extern "C" int rhip_debug_phases(rhip_ctx_t* c, unsigned long long out[32], int 
 #endif
 
 #include "rhip_many_host.inc"
+#include "rhip_heap_host.inc"
 #include "rhip_sharded.inc"
 #include "rhip_synth.inc"
 #include "rhip_pool_ops.inc"

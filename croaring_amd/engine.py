@@ -431,6 +431,11 @@ class Engine:
     def xor_many(self, P: "Pool", ids=None) -> "Pool":
         return self._many(self.lib.rhip_xor_many, P, ids)
 
+    def or_many_heap(self, P: "Pool", ids=None) -> "Pool":
+        """roaring_bitmap_or_many_heap with the reference's container types: the size-ordered tournament itself (exact, n - 1
+        dependent steps; or_many is the fast path for the same set)."""
+        return self._many(self.lib.rhip_or_many_heap, P, ids)
+
     def many_partials(self, op: str, P: "Pool", ids=None) -> "PartialChunks":
         """Stage 1 of the sharded or_many/xor_many: one uncompressed 1024-word chunk per key."""
         out = Partials()

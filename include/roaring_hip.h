@@ -306,13 +306,23 @@ rhip_pool_t *rhip_pool_flip(rhip_ctx_t *ctx, rhip_pool_t *pool, const uint64_t *
  * roaring_bitmap_xor_many (roaring.h:334, src/roaring.c:795-809) over
  * pool[ids[0..n)] (ids == NULL: the whole pool, in order).  Returns a pool
  * holding ONE bitmap.  n == 0 gives an empty bitmap, n == 1 a copy.
- * Parity level: rhip_or_many is byte-identical to roaring_bitmap_or_many (container types included, the
- * fold-order dependent full-run / full-bitset choice replayed).  rhip_xor_many guarantees SET EQUALITY and a
- * valid, canonical bitmap (array iff cardinality <= 4096, else bitset; single-member keys keep their container)
- * -- not the reference's container types: roaring_bitmap_xor_many's lazy_xor -> repair path leaves types that
- * depend on the fold order, and the reference's own or_many / or_many_heap disagree the same way. */
+ * Parity level: BYTE-IDENTICAL to the reference, container types included.  Both functions are fixed left folds whose
+ * order-dependent typing is replayed on the device: the run-vs-bitset choice of a FULL union under or_many; under
+ * xor_many the whole fold of every key that has a run member (a run accumulator survives R ^ R and R ^ small array, an
+ * accumulator that empties is removed and re-cloned: src/roaring.c:2684-2843, containers/mixed_xor.c).  Keys without run
+ * members -- and the partial / sharded forms below -- are typed by cardinality, which is what the fold gives there. */
 rhip_pool_t *rhip_or_many(rhip_ctx_t *ctx, rhip_pool_t *pool, size_t n, const uint32_t *ids);
 rhip_pool_t *rhip_xor_many(rhip_ctx_t *ctx, rhip_pool_t *pool, size_t n, const uint32_t *ids);
+/* roaring_bitmap_or_many_heap (roaring.h:312, src/roaring_priority_queue.c:200-247) over pool[ids[0..n)], BYTE-IDENTICAL to the
+ * reference: the same set as rhip_or_many, with the container types the reference's size-ordered tournament leaves (lazy
+ * unions without early bitset conversion: arrays stay arrays to 1024 values, run | array stays a run, run | run is typed
+ * by size at every step; ties between equal sizes are broken by heap position, as the reference's heap breaks them).
+ * The tournament is n - 1 sequentially dependent merges, each needing the serialized size of the previous result: the
+ * heap runs on the host (restated move for move), every merge is three small launches and one wait -- ~40 us per step
+ * plus the unions.  EXACT, NOT FAST: rhip_or_many is the throughput path (one wait in all); use this one where the heap's
+ * bytes matter.  32-bit pools (roaring64 has no heap union).  Scratch: one 8-byte record per key of the key space and live
+ * temporary, one 8 KiB image per merged container (RHIP_ERR_ALLOC above half of the free device memory). */
+rhip_pool_t *rhip_or_many_heap(rhip_ctx_t *ctx, rhip_pool_t *pool, size_t n, const uint32_t *ids);
 
 /* Multi-GPU or_many / xor_many building blocks.  Stage 1 on each
  * rank: reduce the local shard to one UNCOMPRESSED 1024-word chunk per distinct

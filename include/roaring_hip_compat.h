@@ -31,16 +31,12 @@
  * device allocation fails inside one, the drop-ins give back what they hold themselves (the recycled operand / result
  * pools of every idle lane, the spare result arenas of their contexts) and the call is made ONCE MORE; only a failure
  * that persists prints rhip_last_error() to stderr and abort()s -- rather than silently leaving x1 unchanged.
- * Parity: pairwise, in-place, cardinality, roaring_bitmap_or_many and roaring_bitmap_xor_many results are
- * byte-identical to the reference's (container types included: both *_many functions are fixed left folds, whose
- * order-dependent typing -- full unions, run accumulators -- is replayed on the device).
- * roaring_bitmap_or_many_heap is the ONE exception: its result is SET-EQUAL to the reference's, valid
- * (roaring_bitmap_internal_validate) and carries the container types of roaring_bitmap_or_many -- not the heap's.
- * The reference's tournament (src/roaring_priority_queue.c:200-247) orders its merges by the serialized size of every
- * intermediate and never converts to bitsets early (bitsetconversion = false), so the type of a container depends on
- * which partial unions met in which order: n - 1 sequentially dependent steps, each needing the previous one's size.
- * The reference's own two many-way unions already disagree byte-wise (wikileaks-noquotes, census-income: SURVEY G11);
- * a caller that needs the heap's exact bytes keeps the reference's symbol.
+ * Parity: EVERY symbol below returns the reference's bytes (container types included).  The three many-way functions
+ * have order-dependent typing, which is replayed: roaring_bitmap_or_many's full-union choice and roaring_bitmap_xor_many's
+ * fold on the device, roaring_bitmap_or_many_heap's size-ordered tournament (src/roaring_priority_queue.c:200-247) step by
+ * step -- its heap on the host, every merge on the device (rhip_or_many_heap: exact, n - 1 dependent steps of ~40 us; should
+ * its scratch exceed half of the free device memory the drop-in says so on stderr, once, and returns the same SET with
+ * roaring_bitmap_or_many's types).
  *
  * How a program uses it: keep including <roaring/roaring.h>, link libroaring_hip.so BEFORE libroaring
  * (or build libroaring with these symbols renamed): these symbols then resolve here,

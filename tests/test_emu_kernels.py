@@ -341,6 +341,10 @@ def test_emu_64bit_many_grouping_paths(oracle, monkeypatch):
     G64.many64_grouping_body(emu_engine, oracle, monkeypatch)
 
 
+def test_emu_or_many_heap_tournament(emu, oracle):
+    G.or_many_heap_body(emu, oracle, iters=30)
+
+
 def test_emu_join_fallback(oracle, synth, monkeypatch):
     """A forked batch whose flag gate reports a time-out (RHIP_JOIN_FAIL=1) is finished through the fallback of
     rhip_pairwise_end -- streams waited for, the tail's scratch cleared, the tail run again -- with the same bytes."""

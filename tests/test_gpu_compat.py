@@ -140,10 +140,9 @@ def test_pinned_allocator_hook(ref):
 
 
 def dropin_many_body(hip, ref, iters=24):
-    """The many-way drop-ins against the functions they replace.  roaring_bitmap_or_many and roaring_bitmap_xor_many:
-    BYTES (both are fixed folds, replayed on the device).  roaring_bitmap_or_many_heap: set-equal to the reference's
-    heap result and valid, byte-identical to the reference's roaring_bitmap_or_many -- the documented L1 contract of
-    that one symbol (roaring_hip_compat.h), asserted against BOTH reference functions so that neither half can drift."""
+    """The many-way drop-ins against the functions they replace, BYTES: roaring_bitmap_or_many and roaring_bitmap_xor_many
+    (fixed folds, replayed on the device) and roaring_bitmap_or_many_heap (the size-ordered tournament, replayed step by
+    step: rhip_or_many_heap)."""
     from gen_inputs import random_bitmap
     rng = np.random.default_rng(6)
     mixes = (None, ("runs", "shortruns", "tiny"), ("runs", "sparse", "dense"), ("full", "nearfull", "runs", "verydense"))
@@ -155,7 +154,7 @@ def dropin_many_body(hip, ref, iters=24):
         arr = (C.c_void_p * max(n, 1))(*hs)
         want_or, want_heap, want_xor = ref.or_many(hs), ref.or_many_heap(hs), ref.xor_many(hs)
         for nm, fn, want_bytes, want_set in (("or_many", hip.roaring_bitmap_or_many, want_or, want_or),
-                                             ("or_many_heap", hip.roaring_bitmap_or_many_heap, want_or, want_heap),
+                                             ("or_many_heap", hip.roaring_bitmap_or_many_heap, want_heap, want_heap),
                                              ("xor_many", hip.roaring_bitmap_xor_many, want_xor, want_xor)):
             got = fn(n, arr)
             assert got, "drop-in many-way aggregation returned NULL (no device?)"
