@@ -80,10 +80,29 @@ struct DBuf {
     const void* placed_for = nullptr;
     uint64_t placed_for_gen = 0;
     float placed_gbps = 0.f;
+    // A result arena placed by ADDRESS (place_arena_va): physical memory of its own (hipMemCreate) mapped at `base`, somewhere
+    // inside an address range reserved for it -- the memory is released by unmapping, not by hipFree
+    bool vmm = false;
+    hipMemGenericAllocationHandle_t* vmm_handles = nullptr;  // chunks of vmm_chunk bytes (the last one may be shorter), owned with `base`
+    uint32_t vmm_n = 0;
+    size_t vmm_chunk = 0;
+    void* va_base = nullptr;  // the reserved range
+    size_t va_len = 0, map_len = 0;
+    void free_mem() {
+        if (base && vmm) {
+            for (uint32_t k = 0; k < vmm_n; ++k) (void)hipMemUnmap((char*)base + (size_t)k * vmm_chunk, std::min(vmm_chunk, map_len - (size_t)k * vmm_chunk));
+            for (uint32_t k = 0; k < vmm_n; ++k) (void)hipMemRelease(vmm_handles[k]);
+            delete[] vmm_handles;
+            (void)hipMemAddressFree(va_base, va_len);
+        } else if (base) {
+            (void)hipFree(base);
+        }
+        vmm = false; vmm_handles = nullptr; vmm_n = 0; vmm_chunk = 0; va_base = nullptr; va_len = map_len = 0;
+    }
     void ensure(size_t n) {
         if (n <= cap) return;
         ++gen;
-        if (base) (void)hipFree(base);
+        free_mem();
         p = base = nullptr;
         cap = 0;
         placed_for = nullptr; placed_gbps = 0.f;  // (a new allocation: whatever was measured was measured on the old one)
@@ -119,7 +138,7 @@ struct DBuf {
         cap = want;
     }
     void release() {
-        if (base) (void)hipFree(base);
+        free_mem();
         p = base = nullptr;
         cap = 0;
     }
@@ -230,6 +249,12 @@ struct rhip_ctx_s {
     // caller does nothing; a recycled result pool (`reuse`) keeps its placement.  RHIP_ARENA_TRIES (0 / 1: off),
     // RHIP_ARENA_PLACE_MIN_MB.  The search goes on for up to arena_tries more candidates while the best so far is below
     // arena_fair_gbps.
+    // Round 6: the mode is a function of the arena's VIRTUAL address (scripts/vmm_place2.hip: the same physical chunks stream
+    // at 6.4 or 5.9 TB/s depending on where they are mapped; other chunks at the same address give the same rate), so the
+    // search moves ONE physical allocation through an address window instead of allocating candidates: place_arena_va.
+    // RHIP_ARENA_VMM=0: the candidate search of round 4; RHIP_ARENA_VA_WINDOW_MB, RHIP_ARENA_VA_STEP_MB: the window walked.
+    bool arena_vmm = true;
+    uint64_t arena_va_window = 512ull << 30, arena_va_step = 1ull << 30;  // (address space only: 512 GiB = 56 positions of an 8 GiB arena)
     int arena_keep_spares = 1;  // RHIP_ARENA_SPARES=0: the losers of a placement search are released, not kept
     int arena_tries = 10;
     uint64_t arena_place_min = 2ull << 30;
@@ -514,6 +539,9 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_ARENA_POW2")) c->arena_pow2 = !(e[0] == '0');
         if (const char* e = getenv("RHIP_ARENA_TRIES")) c->arena_tries = atoi(e);
         if (const char* e = getenv("RHIP_ARENA_SPARES")) c->arena_keep_spares = atoi(e);
+        if (const char* e = getenv("RHIP_ARENA_VMM")) c->arena_vmm = !(e[0] == '0');
+        if (const char* e = getenv("RHIP_ARENA_VA_WINDOW_MB")) c->arena_va_window = (uint64_t)strtoull(e, nullptr, 0) << 20;
+        if (const char* e = getenv("RHIP_ARENA_VA_STEP_MB")) c->arena_va_step = std::max<uint64_t>(2, strtoull(e, nullptr, 0)) << 20;
         if (const char* e = getenv("RHIP_ARENA_PLACE_MIN_MB")) c->arena_place_min = (uint64_t)strtoull(e, nullptr, 0) << 20;
         if (const char* e = getenv("RHIP_ARENA_SKEW")) c->arena_skew = (size_t)strtoull(e, nullptr, 0) & ~(size_t)255;
         if (const char* e = getenv("RHIP_GROUP_X")) c->group_x = atoi(e);
@@ -2014,6 +2042,131 @@ struct rhip_batch_s {
     rhip_ctx_s::SlotScratch* Q = nullptr;  // where its class queues are (class statistics)
 };
 
+// Placement of a large result arena by ADDRESS (round 6).  What decides the bitset kernel's rate on C2 beside a given
+// operand pool is where the arena sits in the VIRTUAL address space, not which physical pages it got: the same eight 1 GiB
+// chunks mapped at 89 addresses one GiB apart streamed at 6.40 TB/s at three of them and 5.89 at the others, and 17 other
+// chunk sets mapped at one address all gave that address's rate to +-0.2 % (scripts/vmm_place2.hip, gpurun_out/r6g) --
+// the translation path, not the HBM channels.  So the candidates are ADDRESSES: the arena's memory is created once
+// (hipMemCreate, chunks of <= 1 GiB), one range of address space is reserved (hipMemAddressReserve: 512 GiB by default --
+// addresses, not memory), and the memory is mapped at one position of the range after the other -- hipMemMap,
+// k_place_probe against the operand pool, hipMemUnmap: ~2 ms each -- until a position streams at arena_good_gbps.  When
+// the first half of the positions holds no such address, the search goes on through the second half for the first
+// position within 1.5 % of the best rate seen (the rates come in a few discrete levels) and stays there.  No candidate
+// allocations, nothing released and created again (that stalled 250 ms per 8 GiB: the driver clears released memory),
+// no footprint beyond the arena itself.
+// What the driver does NOT tolerate, and this function never does (scripts/vmm_place4.hip, gpurun_out/r6j):
+//   * mapping at an ADDRESS that was mapped before (while the handle that was mapped there is alive): the address keeps
+//     translating to the old memory and the new mapping is silently ignored -- moving eight chunks one GiB at a time left
+//     two addresses aliasing one chunk, and the pattern test lost 1 GiB per move; a full-size C2 batch returned zeros in
+//     its results.  Every position here is address space of its own (`pitch` apart, longer than the arena) and is visited
+//     ONCE: the search never goes back to an earlier position, which is why it continues forward for an equal of the best;
+//   * one handle of 8 GiB mapped, unmapped and mapped one position on: memory access fault at the second position, four
+//     of four processes.  Chunks of 1 GiB each went through 40 positions in every variant;
+//   * a range changing between a 1 GiB page and a table of smaller pages (both addresses and physical chunks GiB-aligned,
+//     then not): faulted twice in scripts/vmm_place3.hip.  Positions are 2 MiB past a GiB boundary, never on one.
+// Returns false (nothing changed) when the virtual-memory calls are missing or fail; the caller falls back to
+// place_arena's candidate allocations.
+static bool place_arena_va(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool_t* A) {
+    if (!c->arena_vmm) return false;
+    const size_t MB2 = 2ull << 20, G1 = 1ull << 30;
+    const size_t len = (need + arena.skew + MB2 - 1) / MB2 * MB2;
+    size_t free_b = 0, tot_b = 0;
+    if (hipMemGetInfo(&free_b, &tot_b) != hipSuccess || free_b < len + (256ull << 20)) { (void)hipGetLastError(); return false; }
+    if (g_fail_allocs.load(std::memory_order_relaxed) > 0) return false;  // (tests of the allocation-failure paths: through DBuf::ensure)
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = c->device;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    // positions: `pitch` apart -- the arena's length rounded up to the step, plus one step, so that consecutive positions
+    // differ in every address bit from the step upwards (the fast zones are 3-9 GiB wide and have no period we could find)
+    const size_t step = std::max<size_t>(MB2, c->arena_va_step / MB2 * MB2);
+    const size_t pitch = (len + step - 1) / step * step + step;
+    const size_t n_pos = (size_t)std::min<uint64_t>(64, std::max<uint64_t>(2, c->arena_va_window / pitch));
+    const size_t chunk = std::min<size_t>(G1, step);
+    const uint32_t n_chunks = (uint32_t)((len + chunk - 1) / chunk);
+    auto chunk_len = [&](uint32_t k) { return std::min<size_t>(chunk, len - (size_t)k * chunk); };
+    hipMemGenericAllocationHandle_t* hs = new hipMemGenericAllocationHandle_t[n_chunks];
+    uint32_t n_made = 0;
+    for (; n_made < n_chunks; ++n_made)
+        if (hipMemCreate(&hs[n_made], chunk_len(n_made), &prop, 0) != hipSuccess) break;
+    auto drop_chunks = [&]() { for (uint32_t k = 0; k < n_made; ++k) (void)hipMemRelease(hs[k]); delete[] hs; };
+    if (n_made < n_chunks) { (void)hipGetLastError(); drop_chunks(); return false; }
+    const size_t va_len = n_pos * pitch + G1 + MB2;
+    void* R = nullptr;
+    if (hipMemAddressReserve(&R, va_len, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); drop_chunks(); return false; }
+    uint8_t* base0 = (uint8_t*)(((uintptr_t)R + G1 - 1) / G1 * G1) + MB2;  // = 2 MiB past a GiB boundary
+    if (step % G1) base0 = (uint8_t*)(((uintptr_t)R + MB2 - 1) / MB2 * MB2);  // (sub-GiB steps: tests on small arenas)
+    const u64 a_items = A->arena.cap / 8192ull;
+    const u64 n_slots = need / 8192ull;
+    const u64 stride = std::max<u64>(1, n_slots / ((1ull << 30) / 8192ull));  // ~1 GiB of the arena is written, spread over all of it
+    const u64 n_items = (n_slots + stride - 1) / stride;
+    hipStream_t s = c->stream;
+    hipEvent_t e0 = c->ev[0], e1 = c->ev[1];
+    uint8_t* at = nullptr;  // where the memory is mapped now
+    uint32_t n_mapped = 0;
+    auto unmap = [&]() {
+        bool ok = true;
+        for (uint32_t k = 0; k < n_mapped; ++k) ok = hipMemUnmap(at + (size_t)k * chunk, chunk_len(k)) == hipSuccess && ok;
+        at = nullptr; n_mapped = 0;
+        return ok;
+    };
+    auto bail = [&]() {
+        (void)hipGetLastError();
+        (void)unmap();
+        drop_chunks();
+        (void)hipMemAddressFree(R, va_len);
+        return false;
+    };
+    auto map_at = [&](uint8_t* where) {  // (`where`: never mapped before)
+        if (!unmap()) return false;
+        at = where;
+        for (; n_mapped < n_chunks; ++n_mapped)
+            if (hipMemMap(where + (size_t)n_mapped * chunk, chunk_len(n_mapped), 0, hs[n_mapped], 0) != hipSuccess) return false;
+        return hipMemSetAccess(where, len, &acc, 1) == hipSuccess;
+    };
+    auto probe = [&](float& gbps) {
+        float ms_best = 1e30f;
+        for (int r = 0; r < 3; ++r) {  // (the first pass warms the translations)
+            if (hipEventRecord(e0, s) != hipSuccess) return false;
+            hipLaunchKernelGGL(k_place_probe, dim3(8192), dim3(256), 0, s, A->arena.as<uint8_t>(), a_items, at + arena.skew, n_slots, stride);
+            if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return false;
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return false;
+            if (r && ms < ms_best) ms_best = ms;
+        }
+        gbps = (float)((double)n_items * 24576.0 / (double)std::max(ms_best, 1e-6f) / 1e6);
+        return true;
+    };
+    c->last_placement.clear();
+    c->batches_since_place = 0;
+    float best = 0.f, here = 0.f;
+    for (size_t pos = 0; pos < n_pos; ++pos) {
+        if (!map_at(base0 + pos * pitch) || !probe(here)) return bail();
+        c->last_placement.push_back(here);
+        if (here >= (float)c->arena_good_gbps) break;                     // a fast address
+        if (pos >= n_pos / 2 && here >= 0.985f * best) break;             // second half: as good as the best of the first
+        best = std::max(best, here);
+    }
+    if (arena.base) arena.release();  // the old, too small arena of a recycled pool
+    arena.base = at;
+    arena.p = at + arena.skew;
+    arena.cap = len - arena.skew;
+    arena.vmm = true;
+    arena.vmm_handles = hs;
+    arena.vmm_n = n_chunks;
+    arena.vmm_chunk = chunk;
+    arena.va_base = R;
+    arena.va_len = va_len;
+    arena.map_len = len;
+    arena.exact = false;
+    ++arena.gen;
+    arena.placed_for = A->arena.base; arena.placed_for_gen = A->arena.gen; arena.placed_gbps = here;
+    return true;
+}
+
 // Measured placement of a large result arena (rhip_ctx_s::arena_tries).  The physical address of device memory is not
 // visible to a process, and it is what decides: with the operand pool and the result arena in ONE 128 GiB allocation the
 // bitset kernel of C2 takes 4.62-4.66 ms while the arena starts within ~24 GiB behind the pool, 3.91-3.98 ms in 5-6 GiB
@@ -2067,6 +2220,7 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
             return;
         }
     }
+    if (place_arena_va(c, arena, need, A)) return;  // (round 6: one allocation moved through an address window)
     size_t free_at_start = 0, tot_mem = 0;
     if (hipMemGetInfo(&free_at_start, &tot_mem) != hipSuccess) { (void)hipGetLastError(); free_at_start = 0; }
     if (free_at_start < 2 * need) return;  // (no room to choose: the caller's ordinary allocation follows)

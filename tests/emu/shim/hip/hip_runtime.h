@@ -16,6 +16,8 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cstdio>
@@ -77,6 +79,40 @@ static inline hipError_t hipMalloc(void** p, size_t n) {
 template <class T>
 static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+// virtual-memory API (place_arena_va): an address range is a PROT_NONE mapping, physical memory a memfd, hipMemMap a shared
+// MAP_FIXED mapping of it inside the range -- the same bytes at whatever address they are mapped, as on the device
+enum hipMemAllocationType { hipMemAllocationTypePinned = 1 };
+enum hipMemLocationType { hipMemLocationTypeDevice = 1 };
+enum hipMemAccessFlags { hipMemAccessFlagsProtReadWrite = 3 };
+struct hipMemLocation { hipMemLocationType type; int id; };
+struct hipMemAllocationProp { hipMemAllocationType type; int requestedHandleType; hipMemLocation location; void* win32HandleMetaData; };
+struct hipMemAccessDesc { hipMemLocation location; hipMemAccessFlags flags; };
+struct hipemu_vmm_handle { int fd; size_t len; };
+typedef hipemu_vmm_handle* hipMemGenericAllocationHandle_t;
+static inline hipError_t hipMemCreate(hipMemGenericAllocationHandle_t* h, size_t n, const hipMemAllocationProp*, unsigned long long) {
+    if (getenv("HIPEMU_NO_VMM")) return hipErrorInvalidValue;
+    const int fd = memfd_create("hipemu_vmm", 0);
+    if (fd < 0) return hipErrorOutOfMemory;
+    if (ftruncate(fd, (off_t)n) != 0) { close(fd); return hipErrorOutOfMemory; }
+    *h = new hipemu_vmm_handle{fd, n};
+    return hipSuccess;
+}
+static inline hipError_t hipMemRelease(hipMemGenericAllocationHandle_t h) { close(h->fd); delete h; return hipSuccess; }
+static inline hipError_t hipMemAddressReserve(void** p, size_t n, size_t, void*, unsigned long long) {
+    void* q = mmap(nullptr, n, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (q == MAP_FAILED) return hipErrorOutOfMemory;
+    *p = q;
+    return hipSuccess;
+}
+static inline hipError_t hipMemAddressFree(void* p, size_t n) { return munmap(p, n) == 0 ? hipSuccess : hipErrorInvalidValue; }
+static inline hipError_t hipMemMap(void* at, size_t n, size_t off, hipMemGenericAllocationHandle_t h, unsigned long long) {
+    if (n > h->len) return hipErrorInvalidValue;
+    return mmap(at, n, PROT_NONE, MAP_SHARED | MAP_FIXED, h->fd, (off_t)off) == at ? hipSuccess : hipErrorInvalidValue;
+}
+static inline hipError_t hipMemSetAccess(void* at, size_t n, const hipMemAccessDesc*, size_t) { return mprotect(at, n, PROT_READ | PROT_WRITE) == 0 ? hipSuccess : hipErrorInvalidValue; }
+static inline hipError_t hipMemUnmap(void* at, size_t n) {
+    return mmap(at, n, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED, -1, 0) == at ? hipSuccess : hipErrorInvalidValue;
+}
 static inline hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) { *free_b = (size_t)1 << 40; *total_b = (size_t)1 << 40; return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <class T>

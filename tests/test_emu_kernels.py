@@ -396,14 +396,19 @@ def test_emu_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
         eng.close()
 
 
-def test_emu_arena_placement_forced(oracle, synth, monkeypatch):
-    """place_arena on small arenas (RHIP_ARENA_PLACE_MIN_MB=0) through the emulator: the candidate bookkeeping -- allocate,
-    probe, keep one, release the rest, hand the winner to the result pool -- not the timings, is what this covers."""
+@pytest.mark.parametrize("vmm", ["1", "0"])
+def test_emu_arena_placement_forced(oracle, synth, monkeypatch, vmm):
+    """place_arena on small arenas (RHIP_ARENA_PLACE_MIN_MB=0) through the emulator: the bookkeeping -- by address (the
+    shim's hipMemCreate / hipMemMap are a memfd mapped at the probed positions: the same bytes wherever they are mapped)
+    and by candidates (allocate, probe, keep one, release the rest) -- not the timings, is what this covers."""
     from emu import build_emu, emu_engine
     if not __import__("os").path.exists(build_emu.CXX):
         pytest.skip("hipemu needs the ROCm clang++ to compile the kernels for the host")
     monkeypatch.setenv("RHIP_ARENA_PLACE_MIN_MB", "0")
     monkeypatch.setenv("RHIP_ARENA_TRIES", "3")
+    monkeypatch.setenv("RHIP_ARENA_VMM", vmm)
+    monkeypatch.setenv("RHIP_ARENA_VA_WINDOW_MB", "12")
+    monkeypatch.setenv("RHIP_ARENA_VA_STEP_MB", "2")
     eng = emu_engine()
     try:
         G.arena_placement_body(eng, oracle, synth)

@@ -951,14 +951,19 @@ def test_explicit_unit_arrays(oracle, synth, monkeypatch, mode):
 
 
 @pytest.mark.gpu
-def test_arena_placement_forced(oracle, synth, monkeypatch):
-    """The measured placement of result arenas (place_arena: candidates allocated, probed with k_place_probe against the
-    operand pool, the fastest kept, the others released) forced onto SMALL arenas with RHIP_ARENA_PLACE_MIN_MB=0: results
-    byte-identical, recycled pools keep working, the probe rates are reported.  (At full size the C2 tests and bench.py
-    go through it by themselves.)"""
+@pytest.mark.parametrize("vmm", ["1", "0"])
+def test_arena_placement_forced(oracle, synth, monkeypatch, vmm):
+    """The measured placement of result arenas forced onto SMALL arenas with RHIP_ARENA_PLACE_MIN_MB=0 -- by address
+    (place_arena_va, round 6: one hipMemCreate'd allocation mapped at the positions of an address window, probed with
+    k_place_probe against the operand pool at each, left at the fastest) and by candidates (RHIP_ARENA_VMM=0, round 4:
+    several allocations probed, the fastest kept): results byte-identical, recycled pools keep working, the probe rates
+    are reported.  (At full size the C2 tests and bench.py go through it by themselves.)"""
     import croaring_amd
     monkeypatch.setenv("RHIP_ARENA_PLACE_MIN_MB", "0")
     monkeypatch.setenv("RHIP_ARENA_TRIES", "4")
+    monkeypatch.setenv("RHIP_ARENA_VMM", vmm)
+    monkeypatch.setenv("RHIP_ARENA_VA_WINDOW_MB", "12")  # six positions 2 MiB apart: every other one, then the best one's neighbours
+    monkeypatch.setenv("RHIP_ARENA_VA_STEP_MB", "2")
     eng = croaring_amd.Engine()
     try:
         arena_placement_body(eng, oracle, synth)
@@ -985,7 +990,7 @@ def arena_placement_body(eng, oracle, synth):
             for h in (oa, ob, oo):
                 oracle.free(h)
     rates = eng.last_placement()
-    assert 1 <= len(rates) <= 8 and all(r > 0 for r in rates), rates  # (RHIP_ARENA_TRIES candidates, as many again while all are slow)
+    assert 1 <= len(rates) <= 8 and all(r > 0 for r in rates), rates  # (RHIP_ARENA_TRIES candidates, as many again while all are slow; or <= 3 + 2 positions)
     b1 = eng.pairwise_begin("xor", pool, lhs, pool, rhs)  # a fresh result pool while another batch is in flight
     b2 = eng.pairwise_begin("or", pool, lhs, pool, rhs)
     r2, r1 = b2.end(), b1.end()
