@@ -776,6 +776,10 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import croaring_amd
+    if share:
+        # the dry run's batches are a few hundred container pairs: the library would MERGE their class kernels into one
+        # launch, and k_bb -- the kernel every rank reports -- would have no events of its own.  Dry run only.
+        os.environ.setdefault("RHIP_MERGE_CLASSES", "0")
     eng = croaring_amd.Engine(dev_index)
     eng.set_timing(True)
     D = Dist(rank, world, torch, dist, reps=args.reps, host_tensors=share)

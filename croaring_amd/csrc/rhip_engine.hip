@@ -2051,7 +2051,8 @@ struct rhip_batch_s {
 // addresses, not memory), and the memory is mapped at one position of the range after the other -- hipMemMap,
 // k_place_probe against the operand pool, hipMemUnmap: ~2 ms each -- until a position streams at arena_good_gbps.  When
 // the first half of the positions holds no such address, the search goes on through the second half for the first
-// position within 1.5 % of the best rate seen (the rates come in a few discrete levels) and stays there.  No candidate
+// position within 1.5 % of the best rate seen (the rates come in a few discrete levels) and stays there; where every
+// address streams just below the bar, the seventh position onwards that equals the best seen ends it.  No candidate
 // allocations, nothing released and created again (that stalled 250 ms per 8 GiB: the driver clears released memory),
 // no footprint beyond the arena itself.
 // What the driver does NOT tolerate, and this function never does (scripts/vmm_place4.hip, gpurun_out/r6j):
@@ -2148,6 +2149,9 @@ static bool place_arena_va(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_p
         c->last_placement.push_back(here);
         if (here >= (float)c->arena_good_gbps) break;                     // a fast address
         if (pos >= n_pos / 2 && here >= 0.985f * best) break;             // second half: as good as the best of the first
+        // a box whose addresses all stream within a per cent of one another, just below the bar (28 positions between 6 175
+        // and 6 260 GB/s on one): after six, a position at the level of the best seen ends the search
+        if (pos >= 6 && best >= 0.984f * (float)c->arena_good_gbps && here >= 0.995f * best) break;
         best = std::max(best, here);
     }
     if (arena.base) arena.release();  // the old, too small arena of a recycled pool
