@@ -77,6 +77,8 @@ def parse_args():
                     help="pairwise = the headline C2 line (default); ormany = C4 sharded or_many as the headline")
     ap.add_argument("--bitmaps", type=int, default=100000, help="C4: total sparse bitmaps over all ranks")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the stored PMC pass (profiles/bb_traffic.json) instead of two rocprofv3 --pmc child runs")
     ap.add_argument("--no-secondary", action="store_true", help="skip config.secondary (realdata, C4, C5)")
     ap.add_argument("--no-x10", action="store_true", help="skip the 10^6-bitmap or_many row (16 GB of images built on the host, ~20 s)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0)
@@ -166,6 +168,49 @@ def _ref_variants():
         if os.path.exists(path):
             out.append((label, type("RefVariant", (Ref,), {"PATH": path})))
     return out
+
+
+def live_bb_traffic(args):
+    """HBM bytes per k_bb launch, MEASURED NOW: two child runs of this script's headline under `rocprofv3 --pmc` -- FETCH_SIZE
+    and WRITE_SIZE each in its own pass, with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes (units of
+    KiB; FETCH_SIZE reports half of the bytes of a wide coalesced read on gfx950 and is doubled; both are calibrated in the
+    same pass on k_synth_fill / k_synth_dir, which write / read the pool exactly once).  ~25 s per pass; any failure returns
+    (None, reason) and the caller falls back to the stored figure."""
+    import csv, glob, shutil, subprocess, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    pool_bytes = args.pool * args.containers * 8192
+    res = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="rhip_pmc_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "b", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--rounds", "1", "--no-cpu", "--no-secondary",
+                   "--no-live-traffic", "--pool", str(args.pool), "--containers", str(args.containers), "--pairs", str(args.pairs)]
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+            env["TMPDIR"] = "/tmp"
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd="/tmp")
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} exited {p.returncode}: {p.stderr[-200:]!r}"
+            agg = {}
+            for r in csv.DictReader(open(files[0])):
+                if r["Counter_Name"] == counter:
+                    agg.setdefault(r["Kernel_Name"].split("(")[0].replace("void ", ""), []).append(float(r["Counter_Value"]))
+            bb = [v for k, vs in agg.items() if k.startswith("k_bb<") for v in vs]
+            cal = agg.get("k_synth_fill" if counter == "WRITE_SIZE" else "k_synth_dir", [])
+            if not bb or not cal:
+                return None, f"no k_bb / calibration rows in the {counter} pass"
+            res[counter] = (sum(bb) / len(bb) * 1024.0, cal[0] * 1024.0 / pool_bytes, len(bb))
+        except Exception as e:
+            return None, f"{counter} pass: {str(e)[:160]}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    rd, cal_r, n_r = res["FETCH_SIZE"]
+    wr, cal_w, n_w = res["WRITE_SIZE"]
+    return {"hbm_bytes_per_launch": 2.0 * rd + wr, "read_bytes": 2.0 * rd, "write_bytes": wr, "launches": [n_r, n_w],
+            "calibration": {"k_synth_dir FETCH_SIZE x1024 / pool bytes (0.5 = the gfx950 half count)": round(cal_r, 4),
+                            "k_synth_fill WRITE_SIZE x1024 / pool bytes": round(cal_w, 4)}}, None
 
 
 def cpu_baseline(args, seconds: float):
@@ -896,6 +941,18 @@ def main():
                               "(rocprofv3 --pmc passes recorded earlier; NOT re-measured in this run)")
         except Exception:
             traffic = None
+    traffic_live = None
+    if world == 1 and rank == 0 and not args.no_live_traffic:
+        traffic_live, why = live_bb_traffic(args)
+        if traffic_live is not None:
+            stored = traffic
+            traffic = traffic_live["hbm_bytes_per_launch"] * (pairs_per_launch / float(args.pairs * args.containers) if pairs_per_launch else 1.0)
+            traffic_source = ("LIVE: two `rocprofv3 --pmc` child runs of this headline made by this bench.py run (FETCH_SIZE, WRITE_SIZE; "
+                              "separate passes, --kernel-trace only; KiB units, FETCH_SIZE x 2 per the gfx950 correction; per 250-pair "
+                              f"launch x the {pairs_per_launch / float(args.pairs * args.containers):.3g} launches' worth of pairs the timed k_bb "
+                              f"launches held on average); calibration {traffic_live['calibration']}; stored pass for comparison: {stored}")
+        elif traffic_source:
+            traffic_source += f" [live measurement failed: {why}]"
     out = {
         "metric": METRIC,
         "value": total_ops / dt,
