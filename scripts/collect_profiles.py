@@ -22,7 +22,7 @@ cp(os.path.join(SRC, "pmc_l2.md"), f"{TAG}_pmc_l2.md")
 for f, d in (("c2_ops.jsonl", "c2_ops"), ("quick_c3.jsonl", "quick_c3"), ("class_throughput.jsonl", "class_throughput"),
              ("poolops.jsonl", "poolops"), ("per_kernel_c3.jsonl", "per_kernel_c3"), ("multi.txt", "multi_ops")):
     cp(os.path.join(SRC, f), f"{TAG}_{d}" + (".txt" if f.endswith(".txt") else ".jsonl"))
-for f in ("pmc_c4_sq.md",):
+for f in ("pmc_c4_sq.md", "placement_runs.txt", "timelines_many.txt"):
     cp(os.path.join(SRC, f), f"{TAG}_{f}")
 for d in sorted(glob.glob(os.path.join(SRC, "prof_*"))):
     if not os.path.isdir(d):
@@ -40,7 +40,7 @@ for d in sorted(glob.glob(os.path.join(SRC, "prof_*"))):
     if not tr:
         continue
     rows = sorted(csv.DictReader(open(tr[0])), key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if "k_count" in r["Kernel_Name"] or "k_many_gather" in r["Kernel_Name"]]
+    idx = [i for i, r in enumerate(rows) if "k_count" in r["Kernel_Name"] or "k_plan_restore" in r["Kernel_Name"] or "k_many_gather" in r["Kernel_Name"]]  # (k_plan_restore: a batch whose plan came from its pair list, round 6)
     if len(idx) < 2:
         continue
     i0, i1 = idx[-2], idx[-1]
