@@ -80,6 +80,7 @@ struct DBuf {
     const void* placed_for = nullptr;
     uint64_t placed_for_gen = 0;
     float placed_gbps = 0.f;
+    bool placed_winner = false;  // the arena a search CHOSE (a parked winner is taken back as it is; a loser kept as a spare only if it streamed at the bar)
     // A result arena placed by ADDRESS (place_arena_va): physical memory of its own (hipMemCreate) mapped at `base`, somewhere
     // inside an address range reserved for it -- the memory is released by unmapping, not by hipFree
     bool vmm = false;
@@ -105,7 +106,7 @@ struct DBuf {
         free_mem();
         p = base = nullptr;
         cap = 0;
-        placed_for = nullptr; placed_gbps = 0.f;  // (a new allocation: whatever was measured was measured on the old one)
+        placed_for = nullptr; placed_gbps = 0.f; placed_winner = false;  // (a new allocation: whatever was measured was measured on the old one)
         size_t want = n + n / 8 + 256;
         if (round_to && want + skew >= round_to) want = (want + skew + round_to - 1) / round_to * round_to - skew;
         if (exact) want = (n + 4095) & ~(size_t)4095;
@@ -467,7 +468,9 @@ static bool release_all_arena_spares() {
 static void trim_spares_when_steady(rhip_ctx_t* c, int after = 16) {
     if (c->arena_spares.size() <= 2 || ++c->batches_since_place != after) return;
     std::lock_guard<std::mutex> lk(g_ctx_mu);
-    std::sort(c->arena_spares.begin(), c->arena_spares.end(), [](const DBuf& a, const DBuf& b) { return a.placed_gbps > b.placed_gbps; });
+    std::sort(c->arena_spares.begin(), c->arena_spares.end(), [](const DBuf& a, const DBuf& b) {
+        return a.placed_winner != b.placed_winner ? a.placed_winner : a.placed_gbps > b.placed_gbps;  // (parked winners first)
+    });
     while (c->arena_spares.size() > 2) {
         c->arena_spares.back().release();
         c->arena_spares.pop_back();
@@ -917,7 +920,7 @@ static void arena_park(rhip_pool_t* P) {
     rhip_ctx_t* c = P->ctx;
     if (!g_live_ctx.count(c) || !c->arena_keep_spares) return;
     int parked = 0;
-    for (const DBuf& b : c->arena_spares) parked += b.placed_gbps >= (float)c->arena_fair_gbps ? 1 : 0;
+    for (const DBuf& b : c->arena_spares) parked += b.placed_winner ? 1 : 0;  // (the losers a search left behind do not take a winner's place)
     if (parked >= 2) return;
     c->arena_spares.push_back(P->arena);
     P->arena.base = nullptr; P->arena.p = nullptr; P->arena.cap = 0;  // (ownership moved)
@@ -2084,8 +2087,14 @@ static bool place_arena_va(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_p
     // positions: `pitch` apart -- the arena's length rounded up to the step, plus one step, so that consecutive positions
     // differ in every address bit from the step upwards (the fast zones are 3-9 GiB wide and have no period we could find)
     const size_t step = std::max<size_t>(MB2, c->arena_va_step / MB2 * MB2);
-    const size_t pitch = (len + step - 1) / step * step + step;
-    const size_t n_pos = (size_t)std::min<uint64_t>(64, std::max<uint64_t>(2, c->arena_va_window / pitch));
+    const size_t pitch = (len + step - 1) / step * step + 2 * step;
+    // ... and in the bits BELOW the step: position `pos` starts sub(pos) past its pitch mark, sub a multiple of 2 MiB below
+    // the step (a box of the round's last pass streamed at ONE rate at all 28 positions of a process -- every one of them
+    // 2 MiB past a GiB boundary -- and at another rate in the next process, while the hipMalloc'ed candidates of the fallback
+    // search, whose addresses differ below the GiB as well, found a fast one at the second try)
+    const size_t n_sub = step / MB2 > 1 ? step / MB2 - 1 : 1;  // (never a whole step: never back on a GiB boundary)
+    auto sub = [&](size_t pos) { return ((pos * 197u) % n_sub) * MB2; };
+    const size_t n_pos = (size_t)std::min<uint64_t>(24, std::max<uint64_t>(2, c->arena_va_window / pitch));
     const size_t chunk = std::min<size_t>(G1, step);
     const uint32_t n_chunks = (uint32_t)((len + chunk - 1) / chunk);
     auto chunk_len = [&](uint32_t k) { return std::min<size_t>(chunk, len - (size_t)k * chunk); };
@@ -2141,18 +2150,19 @@ static bool place_arena_va(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_p
         gbps = (float)((double)n_items * 24576.0 / (double)std::max(ms_best, 1e-6f) / 1e6);
         return true;
     };
-    c->last_placement.clear();
-    c->batches_since_place = 0;
-    float best = 0.f, here = 0.f;
+    float best = 0.f, worst = 1e30f, here = 0.f;  // (the probe rates are appended to the candidates' in last_placement)
     for (size_t pos = 0; pos < n_pos; ++pos) {
-        if (!map_at(base0 + pos * pitch) || !probe(here)) return bail();
+        if (!map_at(base0 + pos * pitch + sub(pos)) || !probe(here)) return bail();
         c->last_placement.push_back(here);
         if (here >= (float)c->arena_good_gbps) break;                     // a fast address
         if (pos >= n_pos / 2 && here >= 0.985f * best) break;             // second half: as good as the best of the first
-        // a box whose addresses all stream within a per cent of one another, just below the bar (28 positions between 6 175
-        // and 6 260 GB/s on one): after six, a position at the level of the best seen ends the search
-        if (pos >= 6 && best >= 0.984f * (float)c->arena_good_gbps && here >= 0.995f * best) break;
         best = std::max(best, here);
+        worst = std::min(worst, here);
+        // a FLAT landscape -- four positions within 1.2 % of one another, below the bar: on such a box (two of the round's
+        // six) the address does not decide, every position of a process streams alike and another process, or another
+        // allocation, streams at another rate.  The search ends; place_arena goes on with candidate ALLOCATIONS, this arena
+        // being the first of them.
+        if (pos >= 3 && best - worst < 0.012f * best) break;
     }
     if (arena.base) arena.release();  // the old, too small arena of a recycled pool
     arena.base = at;
@@ -2205,7 +2215,7 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
         for (size_t k = 0; k < c->arena_spares.size(); ++k) {
             const DBuf& sp = c->arena_spares[k];
             if (sp.base && sp.cap >= need && sp.cap <= need + need / 8 && sp.skew == arena.skew && sp.placed_for == A->arena.base &&
-                sp.placed_for_gen == A->arena.gen && sp.placed_gbps >= (float)c->arena_fair_gbps &&
+                sp.placed_for_gen == A->arena.gen && (sp.placed_winner || sp.placed_gbps >= 0.99f * (float)c->arena_good_gbps) &&  // (a lesser loser is a candidate of the search below)
                 (pick < 0 || sp.placed_gbps > c->arena_spares[(size_t)pick].placed_gbps))
                 pick = (int)k;
         }
@@ -2224,7 +2234,6 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
             return;
         }
     }
-    if (place_arena_va(c, arena, need, A)) return;  // (round 6: one allocation moved through an address window)
     size_t free_at_start = 0, tot_mem = 0;
     if (hipMemGetInfo(&free_at_start, &tot_mem) != hipSuccess) { (void)hipGetLastError(); free_at_start = 0; }
     if (free_at_start < 2 * need) return;  // (no room to choose: the caller's ordinary allocation follows)
@@ -2305,6 +2314,22 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
         if (best < 0 || cur.gbps > cands[best].gbps) best = (int)cands.size() - 1;
         if (cur.gbps >= c->arena_good_gbps) break;
     }
+    // (round 6) no candidate ALLOCATION at the bar: one more allocation, and this one is moved through an address window
+    // (place_arena_va above) -- on the boxes where the arena's virtual address decides, a fast position is usually among
+    // the first few; on a box where it does not, four positions that stream alike end the attempt.  Candidates first
+    // because they were the more dependable of the two across the boxes of round 6 (0.777-0.798 of peak in ten of ten
+    // processes; by address alone 0.785-0.801 on four boxes and 0.68-0.78 on two whose addresses all streamed alike), and
+    // the address search second because it found 6.3-6.4 TB/s where ten candidates had not (round 5's driver box).
+    if (c->arena_vmm && (best < 0 || cands[best].gbps < (float)c->arena_good_gbps)) {
+        Cand cd;
+        cd.buf.skew = arena.skew;
+        cd.buf.round_to = arena.round_to;
+        if (place_arena_va(c, cd.buf, need, A)) {
+            cd.gbps = cd.buf.placed_gbps;
+            cands.push_back(cd);
+            if (best < 0 || cd.gbps > cands[best].gbps) best = (int)cands.size() - 1;
+        }
+    }
     if (best < 0) return;
     // the losers become spares (RHIP_ARENA_SPARES=0: released instead), as long as the spares stay below half of the memory
     // that was free when the search began
@@ -2331,6 +2356,7 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
     arena.pow2_large = p2;
     arena.exact = false;
     arena.gen = g + 1;
+    arena.placed_winner = true;
 }
 
 // Everything of a pairwise call up to and including the launch of k_tail: nothing here waits for the device.

@@ -1,9 +1,9 @@
-"""Regenerate the measured-numbers block of DESIGN.md (between the NUMBERS markers) from profiles/r05_* (the files
-scripts/collect_profiles.py r05 copies out of the round-5 measurement pass, scripts/gpu_final_r5.sh).  Fails loudly on a
+"""Regenerate the measured-numbers block of DESIGN.md (between the NUMBERS markers) from profiles/r06_* (the files
+scripts/collect_profiles.py r06 copies out of the round-6 measurement pass, scripts/gpu_final_r6.sh).  Fails loudly on a
 missing or empty input."""
 import json, os, re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "r05"
+TAG = "r06"
 
 
 def P(n):
@@ -31,7 +31,7 @@ for line in open(P(f"{TAG}_quick_all.txt")):
 def row(k, label):
     v = s[k]
     cpu = v.get("cpu1_ops_per_s")
-    return (f"| {label} | {v['pairs']:,} | {v['ms_batch_median']:.3f} ({v['ms_batch_min']:.3f}) | {v['ms_adhoc_list']:.3f} | {v['ms_batch_pipelined2']:.3f} | "
+    return (f"| {label} | {v['pairs']:,} | {v['ms_batch_median']:.3f} ({v['ms_batch_min']:.3f}) | {v.get('ms_first_call', float('nan')):.3f} | {v['ms_adhoc_list']:.3f} | {v['ms_batch_pipelined2']:.3f} | "
             f"{v['ops_per_s'] / 1e6:.1f} M | {v['alg_GBps'] / 1e3:.2f} | **{v['frac']:.3f}** | {('%.2f' % v['hbm_traffic_frac']) if 'hbm_traffic_frac' in v else '--'} | {cpu / 1e3:,.0f} k | {v['ops_per_s'] / cpu:,.0f}× | {'ok' if v['checksum_ok'] else 'FAIL'} |")
 
 
@@ -41,11 +41,12 @@ t = []
 t.append(f"""**Headline (`bench.py`, C2, N = 1, driver contract).** {d['value']:,.0f} set-ops/s = {d['config']['algorithmic_GBps'] / 1e3:.2f} TB/s algorithmic over a
 {d['config']['timed_region_s']:.2f} s timed region ({d['ms_per_step']:.1f} ms per step of 3 000 ops).  Dominant kernel `k_bb`: {r['achieved'] / 1e3:.2f} TB/s = **{r['frac']:.3f} of the 8 TB/s
 HBM peak** (average launch {r['avg_launch_ms']:.2f} ms over {r['launches_timed']} launches timed with HIP events on the engine's stream; 1 024 000 container
-pairs × 24 576 B per launch); HBM traffic from the PMC passes of the same measurement pass = {traffic['hbm_bytes_per_launch'] / 1e9:.2f} GB per launch =
-**{traffic['hbm_bytes_per_launch'] / traffic['algorithmic_bytes']:.4f} × algorithmic** (`profiles/{TAG}_pmc_summary.md`: FETCH_SIZE ×2 per the gfx950 correction, calibrated on
-`k_synth_dir` / `k_synth_fill`).  `rocprofv3 --kernel-trace --stats` of the same command: `profiles/{TAG}_bench_c2_kernel_stats.csv`.
-The two result arenas were placed by the library itself (`place_arena`, §3): probe rates of the candidates, GB/s -- `and`: {pl.get('and')},
-`or`: {pl.get('or')}; no caller-side selection (`--arena-tries 0` is the default now).
+pairs × 24 576 B per launch); HBM traffic MEASURED BY THE BENCH RUN ITSELF (round 6: two `rocprofv3 --pmc` child runs, FETCH_SIZE and
+WRITE_SIZE in separate passes, `live_bb_traffic` in `bench.py`) = {r['traffic'] / 1e9:.2f} GB per launch = **{r['traffic'] / (r['pairs_per_launch'] * 24576):.4f} × algorithmic**; the
+PMC passes of `scripts/gpu_final_r6.sh` on the same box: {traffic['hbm_bytes_per_launch'] / 1e9:.2f} GB = {traffic['hbm_bytes_per_launch'] / traffic['algorithmic_bytes']:.4f} × (`profiles/{TAG}_pmc_summary.md`: FETCH_SIZE ×2 per the gfx950
+correction, calibrated on `k_synth_dir` / `k_synth_fill`).  `rocprofv3 --kernel-trace --stats` of the same command: `profiles/{TAG}_bench_c2_kernel_stats.csv`.
+The two result arenas were placed by the library itself, BY ADDRESS (`place_arena_va`, §3): probe rates of the positions visited, GB/s --
+`and`: {pl.get('and')}, `or`: {pl.get('or')}.  Fresh processes on the same box (`profiles/{TAG}_placement_runs.txt`): see below.
 CPU baseline = the real CRoaring (`oracle/_ref`, AVX-512 build) on the box's host ({cb['host_threads']} hardware threads): {cb['one_core']['ops_per_s_median']:.0f} ops/s on one core
 ({cb['one_core']['GBps_median']:.1f} GB/s); worker-process sweep {', '.join(f"{T}: {v['ops_per_s_median']:,.0f}" for T, v in cb['sweep'].items())} ops/s — best {cb['value']:,.0f} at {cb['cores']} processes,
 falling from there: CRoaring is **malloc-bound** on this workload (every op allocates, page-faults and writes a 32 MiB result; the
@@ -58,16 +59,23 @@ t.append(f"Per op on C2 (250 pairs per call, one result pool per op, each arena 
 for o in map(json.loads, open(P(f"{TAG}_c2_ops.jsonl"))):
     t.append(f"| {o['op']} | {o['ms_call']:.2f} | {o['k_bb_ms']:.3f} | {o['k_bb_GBps'] / 1e3:.2f} | {o['k_bb_GBps'] / 8000:.3f} |")
 t.append(f"""
-(`and` / `andnot` write 8 GiB arenas, `or` / `xor` 16 GiB ones -- their slot bound is the sum of both operands -- and the
-cardinality forms write nothing: 16 384 B per pair.  Which physical pages an arena gets moves `k_bb` between 3.9 and 4.7 ms;
-§3 and `profiles/r04_arena_distance.txt` say what was found out about it.  Round 5: the cardinality forms went from
-0.72 to 0.80 of peak -- a wave now adds its stretch of the queue in a register and issues one atomic per bitmap pair
-instead of one per container pair.  A call that has to ALLOCATE its result pool -- no `reuse` -- took
-{FRESH.get('and')} ms (`and`) / {FRESH.get('or')} ms (`or`) in this pass, placement search included: `c2_fresh_result_pool_ms` in the bench line.)
+(The cardinality forms write nothing: 16 384 B per pair.  WHERE IN THE ADDRESS SPACE an arena sits moves `k_bb` between 3.9 and
+4.7 ms -- §3: round 6 found that it is the virtual address, and places by it.  A call that has to ALLOCATE its result pool
+-- no `reuse` -- took {FRESH.get('and')} ms (`and`) / {FRESH.get('or')} ms (`or`) in this pass, address search included; a caller that frees its
+result and calls again gets the parked arena back: {FRESH.get('steady_and', float('nan')):.2f} / {FRESH.get('steady_or', float('nan')):.2f} ms per call (`c2_fresh_result_pool_ms` in the bench line).)
+
+Fresh processes, one after the other on the box of this pass (`profiles/{TAG}_placement_runs.txt`; value, `k_bb` ms, fraction, fresh-pool
+ms, positions probed):
+
+```
+{open(P(f"{TAG}_placement_runs.txt")).read().strip()}
+```
 
 **Realdata, ALL unordered pairs in one batched call per op** (`bench.py`, detail in `profiles/{TAG}_bench_detail.json`: wall time
-of the whole call incl. planning and the final wait over a PREPARED pair list (`rhip_pairlist_all_pairs`), median (min) of >= 10
-calls; "ad hoc" = the same call handed the two index arrays per call; "2 in flight" = per-call period of 40 calls issued with
+of the whole call incl. the final wait over a PREPARED pair list (`rhip_pairlist_all_pairs`) whose PLAN IS KEPT WITH THE LIST
+(round 6: a repeated batch starts at its class kernels), median (min) of >= 10 calls; "first call" = the same call when the
+list holds no plan yet (`rhip_pairlist_drop_plans` before it: planning kernels included -- round 5's figure); "ad hoc" = the
+same call handed the two index arrays per call (plans every time); "2 in flight" = per-call period of 40 calls issued with
 `rhip_pairwise_list_begin` / `_end`, two at a time; checksum = sum of result cardinalities against the reference fixture;
 CPU = real CRoaring, one core, same pairs; "HBM traffic" = bytes that crossed the memory side per batch in the stored PMC
 pass (`profiles/{TAG}_realdata_traffic.md`) over the batch time, as a fraction of 8 TB/s: the operands of these sets live in
@@ -75,8 +83,8 @@ the L2s, so the algorithmic fraction is NOT HBM utilisation -- the bound of ever
 with the results streaming out).  The same calls by `scripts/quick_all.py`, min of 7:
 weather {qa['prepared']['weather_sept_85']}, census1881 {qa['prepared']['census1881']}.
 
-| config | pairs | ms / batch, median (min) | ad hoc list | 2 in flight | set-ops/s | alg. TB/s | of HBM peak (algorithmic) | HBM traffic / peak | CRoaring 1 core | ratio | checksum |
-|---|---|---|---|---|---|---|---|---|---|---|---|""")
+| config | pairs | ms / batch, median (min) | first call | ad hoc list | 2 in flight | set-ops/s | alg. TB/s | of HBM peak (algorithmic) | HBM traffic / peak | CRoaring 1 core | ratio | checksum |
+|---|---|---|---|---|---|---|---|---|---|---|---|---|""")
 for k, l in (("c3_and", "C3 weather_sept_85 and"), ("c3_or", "C3 or"), ("c3_xor", "C3 xor"), ("c3_andnot", "C3 andnot"),
              ("c1_and", "C1 census1881 and"), ("c1_or", "C1 or"), ("c1_xor", "C1 xor"), ("c1_andnot", "C1 andnot"),
              ("c5_and", "C5 roaring64 wikileaks×10 and"), ("c5_or", "C5 or")):
