@@ -2045,19 +2045,19 @@ struct rhip_batch_s {
     rhip_ctx_s::SlotScratch* Q = nullptr;  // where its class queues are (class statistics)
 };
 
-// Placement of a large result arena by ADDRESS (round 6).  What decides the bitset kernel's rate on C2 beside a given
-// operand pool is where the arena sits in the VIRTUAL address space, not which physical pages it got: the same eight 1 GiB
-// chunks mapped at 89 addresses one GiB apart streamed at 6.40 TB/s at three of them and 5.89 at the others, and 17 other
-// chunk sets mapped at one address all gave that address's rate to +-0.2 % (scripts/vmm_place2.hip, gpurun_out/r6g) --
-// the translation path, not the HBM channels.  So the candidates are ADDRESSES: the arena's memory is created once
-// (hipMemCreate, chunks of <= 1 GiB), one range of address space is reserved (hipMemAddressReserve: 512 GiB by default --
-// addresses, not memory), and the memory is mapped at one position of the range after the other -- hipMemMap,
-// k_place_probe against the operand pool, hipMemUnmap: ~2 ms each -- until a position streams at arena_good_gbps.  When
-// the first half of the positions holds no such address, the search goes on through the second half for the first
-// position within 1.5 % of the best rate seen (the rates come in a few discrete levels) and stays there; where every
-// address streams just below the bar, the seventh position onwards that equals the best seen ends it.  No candidate
-// allocations, nothing released and created again (that stalled 250 ms per 8 GiB: the driver clears released memory),
-// no footprint beyond the arena itself.
+// Placement of a large result arena by ADDRESS (round 6): stage 2 of place_arena, for the boxes on which the arena's
+// VIRTUAL address decides the bitset kernel's rate beside a given operand pool.  There the same eight 1 GiB chunks mapped
+// at 89 addresses one GiB apart streamed at 6.40 TB/s at three of them and 5.89 at the others, and 17 other chunk sets
+// mapped at one address all gave that address's rate to +-0.2 % (scripts/vmm_place2.hip, profiles/r06_vmm2_*.txt) -- the
+// translation path, not the HBM channels.  (On other boxes every address of a process streams alike and other physical
+// pages do not: stage 1, the candidate allocations.)  The candidates here are ADDRESSES: the arena's memory is created
+// once (hipMemCreate, chunks of <= 1 GiB), one range of address space is reserved (hipMemAddressReserve: 512 GiB by
+// default -- addresses, not memory), and the memory is mapped at one position of the range after the other -- hipMemMap,
+// k_place_probe against the operand pool, hipMemUnmap: ~2 ms each -- until a position streams at arena_good_gbps.  Four
+// positions within 1.2 % of one another end the search (the address does not decide here); when the first half of the
+// positions holds no fast address, the second half is searched for the first position within 1.5 % of the best rate seen
+// (the rates come in a few discrete levels) and the arena stays there.  One allocation, nothing released and created
+// again (that stalled 250 ms per 8 GiB: the driver clears released memory).
 // What the driver does NOT tolerate, and this function never does (scripts/vmm_place4.hip, gpurun_out/r6j):
 //   * mapping at an ADDRESS that was mapped before (while the handle that was mapped there is alive): the address keeps
 //     translating to the old memory and the new mapping is silently ignored -- moving eight chunks one GiB at a time left
@@ -2068,8 +2068,8 @@ struct rhip_batch_s {
 //     of four processes.  Chunks of 1 GiB each went through 40 positions in every variant;
 //   * a range changing between a 1 GiB page and a table of smaller pages (both addresses and physical chunks GiB-aligned,
 //     then not): faulted twice in scripts/vmm_place3.hip.  Positions are 2 MiB past a GiB boundary, never on one.
-// Returns false (nothing changed) when the virtual-memory calls are missing or fail; the caller falls back to
-// place_arena's candidate allocations.
+// Returns false (nothing changed) when the virtual-memory calls are missing or fail; place_arena then chooses among its
+// candidate allocations alone.
 static bool place_arena_va(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool_t* A) {
     if (!c->arena_vmm) return false;
     const size_t MB2 = 2ull << 20, G1 = 1ull << 30;

@@ -45,7 +45,7 @@ pairs × 24 576 B per launch); HBM traffic MEASURED BY THE BENCH RUN ITSELF (rou
 WRITE_SIZE in separate passes, `live_bb_traffic` in `bench.py`) = {r['traffic'] / 1e9:.2f} GB per launch = **{r['traffic'] / (r['pairs_per_launch'] * 24576):.4f} × algorithmic**; the
 PMC passes of `scripts/gpu_final_r6.sh` on the same box: {traffic['hbm_bytes_per_launch'] / 1e9:.2f} GB = {traffic['hbm_bytes_per_launch'] / traffic['algorithmic_bytes']:.4f} × (`profiles/{TAG}_pmc_summary.md`: FETCH_SIZE ×2 per the gfx950
 correction, calibrated on `k_synth_dir` / `k_synth_fill`).  `rocprofv3 --kernel-trace --stats` of the same command: `profiles/{TAG}_bench_c2_kernel_stats.csv`.
-The two result arenas were placed by the library itself, BY ADDRESS (`place_arena_va`, §3): probe rates of the positions visited, GB/s --
+The two result arenas were placed by the library itself (`place_arena`, §3): probe rates of the candidate allocations and then of the address positions visited, GB/s --
 `and`: {pl.get('and')}, `or`: {pl.get('or')}.  Fresh processes on the same box (`profiles/{TAG}_placement_runs.txt`): see below.
 CPU baseline = the real CRoaring (`oracle/_ref`, AVX-512 build) on the box's host ({cb['host_threads']} hardware threads): {cb['one_core']['ops_per_s_median']:.0f} ops/s on one core
 ({cb['one_core']['GBps_median']:.1f} GB/s); worker-process sweep {', '.join(f"{T}: {v['ops_per_s_median']:,.0f}" for T, v in cb['sweep'].items())} ops/s — best {cb['value']:,.0f} at {cb['cores']} processes,
@@ -60,7 +60,7 @@ for o in map(json.loads, open(P(f"{TAG}_c2_ops.jsonl"))):
     t.append(f"| {o['op']} | {o['ms_call']:.2f} | {o['k_bb_ms']:.3f} | {o['k_bb_GBps'] / 1e3:.2f} | {o['k_bb_GBps'] / 8000:.3f} |")
 t.append(f"""
 (The cardinality forms write nothing: 16 384 B per pair.  WHERE IN THE ADDRESS SPACE an arena sits moves `k_bb` between 3.9 and
-4.7 ms -- §3: round 6 found that it is the virtual address, and places by it.  A call that has to ALLOCATE its result pool
+4.7 ms -- §3: its physical pages on some boxes, its virtual address on others; the library measures in both.  A call that has to ALLOCATE its result pool
 -- no `reuse` -- took {FRESH.get('and')} ms (`and`) / {FRESH.get('or')} ms (`or`) in this pass, address search included; a caller that frees its
 result and calls again gets the parked arena back: {FRESH.get('steady_and', float('nan')):.2f} / {FRESH.get('steady_or', float('nan')):.2f} ms per call (`c2_fresh_result_pool_ms` in the bench line).)
 
