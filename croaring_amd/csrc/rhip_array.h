@@ -200,7 +200,9 @@ template <bool GP8> struct UsmallLds {
     static constexpr uint32_t WORDS = 4 * WAVE_WORDS;
 };
 constexpr uint32_t USMALL_LDS_WORDS = UsmallLds<false>::WORDS;
-template <bool GP8>
+// OPC: the op known at compile time (a single-op batch: OP_OR drops the deleted-value arithmetic of xor from the X stream --
+// three of its twelve instructions per value), or -1: read per item (multi-op batches, the merged launch of a light batch)
+template <bool GP8, int OPC = -1>
 __device__ __forceinline__ void usmall_body(uint32_t* __restrict__ lds, uint32_t bid, uint32_t nblk, const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                                 OutView O, const FatItem* __restrict__ q,
                                                 const u64* __restrict__ qrange, int kop) {
@@ -223,7 +225,7 @@ __device__ __forceinline__ void usmall_body(uint32_t* __restrict__ lds, uint32_t
     for (; w < n; w += nwaves) {
         const FatItem t = tnext;
         if (w + nwaves < n) tnext = q[w + nwaves];
-        const int op = item_op(kop, t.types);
+        const int op = OPC >= 0 ? OPC : item_op(kop, t.types);
         const bool x_is_a = t.ca >= t.cb;
         const uint8_t* xp = x_is_a ? arenaA + t.offa : arenaB + t.offb;
         const uint8_t* yp = x_is_a ? arenaB + t.offb : arenaA + t.offa;
@@ -304,13 +306,23 @@ __device__ __forceinline__ void usmall_body(uint32_t* __restrict__ lds, uint32_t
             run_del += tot >> 16;
             const uint32_t nval = act ? (nx - 8u * g < 8u ? nx - 8u * g : 8u) : 0u;
             const uint32_t d[4] = {xq.x, xq.y, xq.z, xq.w};
+            if (8u * (g0 + 64u) <= nx) {  // every lane holds a whole group (wave-uniform): no test per value
 #pragma unroll
-            for (int h = 0; h < 8; ++h) {
-                if ((uint32_t)h < nval) {
+                for (int h = 0; h < 8; ++h) {
                     newc += ((h < 4 ? c0 : c1) >> (8 * (h & 3))) & 0xFFu;
                     const uint32_t dl = (delb >> h) & 1u;
                     if (!dl) ST[8u * g + h + newc - delc - out_base] = (uint16_t)((d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu);
                     delc += dl;
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    if ((uint32_t)h < nval) {
+                        newc += ((h < 4 ? c0 : c1) >> (8 * (h & 3))) & 0xFFu;
+                        const uint32_t dl = (delb >> h) & 1u;
+                        if (!dl) ST[8u * g + h + newc - delc - out_base] = (uint16_t)((d[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu);
+                        delc += dl;
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();  // GP of this step's groups is complete
@@ -344,12 +356,12 @@ __device__ __forceinline__ void usmall_body(uint32_t* __restrict__ lds, uint32_t
     }
     PH_FLUSH(16);
 }
-template <bool GP8>
+template <bool GP8, int OPC = -1>
 __global__ __launch_bounds__(256) void k_usmall(const uint8_t* __restrict__ arenaA, const uint8_t* __restrict__ arenaB,
                                                 OutView O, const FatItem* __restrict__ q,
                                                 const u64* __restrict__ qrange, int kop) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[UsmallLds<GP8>::WORDS];
-    usmall_body<GP8>(lds, blockIdx.x, gridDim.x, arenaA, arenaB, O, q, qrange, kop);
+    usmall_body<GP8, OPC>(lds, blockIdx.x, gridDim.x, arenaA, arenaB, O, q, qrange, kop);
 }
 
 

@@ -1888,9 +1888,16 @@ void run_kernels(rhip_ctx_t* c, const OpSet& ops, const PoolView& VA, const Pool
     }
     if (has_wave && any_union)  // or / xor of a short array with a long one, by rank: 170 us alone on weather -- a stream of
                                 // its own when the filter's is free (or / xor), else the light chain
-        hipLaunchKernelGGL(c->usmall_gp8 ? k_usmall<true> : k_usmall<false>, dim3(bounded_grid(nm)),
-                           dim3(256), 0, (fork && crit == 2) ? on_aux(1) : lst, VA.arena, VB.arena, O,
+    {
+        auto kus = k_usmall<false, -1>;  // (the op as a template argument where the batch has one: rhip_array.h)
+        if (c->usmall_gp8) kus = k_usmall<true, -1>;
+#ifndef RHIP_USMALL_NO_OPC  /* (A/B builds) */
+        else if (op == OP_OR) kus = k_usmall<false, OP_OR>;
+        else if (op == OP_XOR) kus = k_usmall<false, OP_XOR>;
+#endif
+        hipLaunchKernelGGL(kus, dim3(bounded_grid(nm)), dim3(256), 0, (fork && crit == 2) ? on_aux(1) : lst, VA.arena, VB.arena, O,
                            P.q(c, CLS_USMALL).as<FatItem>(), ranges + 2 * SEC_USMALL, op);
+    }
     if (has_filt)  // short streamed arrays: no LDS, 8 waves per SIMD -- co-resides with the LDS-bound kernels
         hipLaunchKernelGGL(k_probe, dim3(bounded_grid(nm)), dim3(256), 0, lst, VA.arena, VB.arena, O,
                            P.q(c, CLS_PROBE).as<FatItem>(), ranges + 2 * SEC_PROBE, op, cardmode, c->pair_acc.as<u64>());
