@@ -5,6 +5,7 @@ The RCCL transport itself is covered with a 1-rank nccl group (the only size one
 test_many_sharded_nccl_world1_dense."""
 import os
 import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -228,3 +229,25 @@ def test_many_sharded_c_abi_world1(engine, oracle, key_space):
     finally:
         L.ncclCommDestroy.argtypes = [C.c_void_p]
         L.ncclCommDestroy(comm)
+
+
+@pytest.mark.parametrize("world,key_space,bits", [(2, 4096, 32), (4, 0, 32), (8, 4096, 32), (8, 0, 32), (3, 0, 64), (8, 0, 64)])
+def test_many_sharded_c_abi_multi_rank(world, key_space, bits):
+    """rhip_many_sharded at world sizes 2 .. 8 on ONE GPU: the ranks are threads of a child process, each with its own
+    context and its share of the bitmaps (b mod world), and librccl is tests/fake_rccl/libfake_rccl.so (RHIP_RCCL_LIB) -- a
+    test-only stand-in whose collectives are barriers + device copies (the real RCCL refuses two ranks on one device).  What
+    this executes, and nothing else did before the 8-GPU scaling run: the owner partition, the packing and the send /
+    receive offsets of the SPARSE exchange at world > 1, the all-to-all shape of the dense one, the owners' key sets
+    (every owner holds exactly the keys = rank mod world) and their union against the reference's or_many / xor_many /
+    the 64-bit fold."""
+    import shutil
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl")
+    lib = os.path.join(here, "libfake_rccl.so")
+    src = os.path.join(here, "fake_rccl.cpp")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        subprocess.run([hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "--offload-arch=gfx950", src, "-o", lib], check=True)
+    env = dict(os.environ, RHIP_RCCL_LIB=lib)
+    p = subprocess.run([sys.executable, os.path.join(here, "child.py"), str(world), str(key_space), str(bits)], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert p.returncode == 0 and "OK" in p.stdout, (p.stdout[-500:], p.stderr[-3000:])
