@@ -378,9 +378,10 @@ rhip_pool_t *rhip_many_finalize_dense(rhip_ctx_t *ctx, rhip_op op, int is64, uin
  *   key_space   > 0: an exclusive upper bound of the container keys on EVERY rank (e.g. 4096): the dense exchange --
  *               stage 1 writes the [world x ceil(key_space / world)] chunk table, ONE ncclAllToAll on the context's
  *               stream moves it, stage 3 combines the rows; one host wait, at the very end.  A larger key anywhere
- *               fails the call (RHIP_ERR_ARG).  0: the sparse exchange, any key width (roaring64 pools): the ranks'
- *               key lists are all-gathered, the chunks each peer is owed are packed back to back and leave in one group
- *               of ncclSend / ncclRecv.
+ *               fails the call (RHIP_ERR_ARG).  0: the sparse exchange, any key width (roaring64 pools): every
+ *               rank counts and packs its chunks by owner on the device, the world x world count matrix is all-gathered
+ *               (one small collective, one host wait: send / receive counts are host arguments) and the chunks leave
+ *               in one group of ncclSend / ncclRecv.  At most 64 ranks.
  *   owned       out: this rank's share of the result, a one-bitmap pool holding the container keys with
  *               key % world == rank (the shares are disjoint: their serialized forms concatenate by key).
  * Everything is enqueued on the context's stream (rhip_ctx_stream); the call returns when the share is complete.
