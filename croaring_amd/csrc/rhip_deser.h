@@ -181,64 +181,141 @@ __global__ __launch_bounds__(256) void k_des_walk(const uint8_t* __restrict__ bl
     }
 }
 
-// One WAVE per container: the payload moves from its (arbitrarily aligned) place in the blob to its 16-byte
-// aligned slot, one dword per lane per step through registers, and is validated on the way as
-// roaring_bitmap_internal_validate would (bitset.c:1023-1044, array.c:456-493, run.c:669-716):
+// One WAVE per container: the payload moves from its (arbitrarily aligned) place in the blob to its 16-byte aligned slot,
+// SIXTEEN bytes per lane and step through registers, and is validated on the way as roaring_bitmap_internal_validate would
+// (bitset.c:1023-1044, array.c:456-493, run.c:669-716):
 //   bitset: popcount == cardinality of the descriptive header (and > 4096 by construction)
 //   array : strictly increasing
 //   run   : value + length <= 65535, runs sorted, disjoint and NOT adjacent; cardinality = sum(length + 1)
-__global__ __launch_bounds__(256) void k_des_payload(const uint8_t* __restrict__ blob, DesOut D,
+// Round 6: until then a lane moved ONE dword per step behind ~80 wave-level instructions (clamps, a 64-bit funnel shift, the
+// order test with two shuffles) -- 1.5 ms for C4's 1.64 GB, and the ablations (no stores 1.25 ms, no validation 1.20,
+// directory only 0.17; more loads in flight: nothing) said instruction issue, not memory: a wave64 instruction holds its
+// SIMD for four cycles.  Now a lane loads the two aligned 16-byte groups that cover its output group, v_alignbyte funnels
+// them by the container's (wave-uniform) misalignment, and the tests run on eight values / four runs at a time: a third of
+// the instructions per byte.  Bytes of the last group past the payload are written as ZERO (the slot is padded to 16).
+__device__ __forceinline__ uint32_t des_align(uint32_t hi, uint32_t lo, uint32_t bytes) {
+#ifdef RHIP_EMU
+    return bytes ? (lo >> (8u * bytes)) | (hi << (32u - 8u * bytes)) : lo;
+#else
+    return __builtin_amdgcn_alignbyte(hi, lo, bytes);
+#endif
+}
+// (The directory arrays come as `const __restrict__` kernel arguments of their own -- not inside DesOut -- so that the
+// compiler may read them through the scalar cache after the kernel's first store: with possibly aliasing pointers every
+// directory word was a VECTOR load followed by s_waitcnt vmcnt(0), i.e. a wait for every payload load in flight.  card_out
+// is the same array as card_in: a wave rewrites only the cardinality of the run container it has just read.)
+__global__ __launch_bounds__(256) void k_des_payload(const uint8_t* __restrict__ blob, const uint8_t* __restrict__ type_in,
+                                                     const uint32_t* __restrict__ card_in, const uint32_t* __restrict__ nruns_in,
+                                                     const u64* __restrict__ src_in, uint32_t* card_out,
                                                      const u64* __restrict__ off, uint8_t* __restrict__ arena,
                                                      u64 n_cont, const u64* __restrict__ bm_start,
-                                                     uint32_t n_bitmaps, uint32_t* status) {
+                                                     uint32_t n_bitmaps, uint32_t* __restrict__ status) {
     const uint32_t lane = lane_id();
     const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
-    for (u64 c = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; c < n_cont; c += nwaves) {
-        const uint32_t t = D.type[c], card = D.card[c], nr = D.nruns[c];
-        const uint32_t B = t == T_BITSET ? 8192u : (t == T_ARRAY ? 2u * card : 4u * nr);
-        const u64 sp = D.src[c];
-        const uint32_t d = (uint32_t)(sp & 3u);
-        const uint32_t* __restrict__ S = (const uint32_t*)(blob + (sp - d));  // aligned dwords covering the payload
-        uint32_t* __restrict__ O = (uint32_t*)(arena + off[c]);
-        const uint32_t nd = (B + 3u) >> 2;  // output dwords (the last may be half used: odd array cardinality)
+    // A wave's turn is two dependent round trips -- the container's directory words, then its payload -- and at one
+    // container per turn that chain, not bandwidth, set the pace (3.2 M containers over 8 192 waves: 390 turns of ~3 us).
+    // So the turns are pipelined two deep: while container c is validated and stored, the first step of the payload of
+    // c + nwaves is in flight and the directory words of c + 2 nwaves are on their way.
+    struct Raw { uint32_t tw, card, nr; u64 sp, offv; uint32_t sh; bool in; };  // directory words as loaded (nothing computed: no wait)
+    struct Dir { uint32_t t, card, nr, B, d16; const uint4* S; uint4* O; };
+    auto load_raw = [&](u64 c) {
+        const u64 cc = c < n_cont ? c : n_cont - 1;  // (a clamped index: the loads are unconditional)
+        Raw r;
+        // (the type byte through the SCALAR cache, as a dword: a vector byte load here would be counted with the payload
+        // loads in flight, and waiting for it would mean waiting for all of them)
+        r.tw = ((const uint32_t*)type_in)[cc >> 2];
+        r.sh = 8u * (uint32_t)(cc & 3u);
+        r.card = card_in[cc]; r.nr = nruns_in[cc];
+        r.sp = src_in[cc];
+        r.offv = off[cc];
+        r.in = c < n_cont;
+        return r;
+    };
+    auto derive = [&](const Raw& r) {
+        Dir d;
+        d.t = (r.tw >> r.sh) & 0xFFu;
+        d.card = r.card; d.nr = r.nr;
+        d.B = r.in ? (d.t == T_BITSET ? 8192u : (d.t == T_ARRAY ? 2u * d.card : 4u * d.nr)) : 0u;
+        d.d16 = (uint32_t)(r.sp & 15u);
+        d.S = (const uint4*)(blob + (r.sp - d.d16));  // aligned 16-byte groups covering the payload
+        d.O = (uint4*)(arena + r.offv);
+        return d;
+    };
+    u64 c = wave_uniform((uint32_t)(((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (c >= n_cont) return;
+    Dir cur = derive(load_raw(c)), nxt = derive(load_raw(c + nwaves));
+    uint4 a0 = cur.S[16u * lane < cur.B ? lane : 0u], b0 = cur.S[16u * lane < cur.B ? lane + 1u : 0u];
+    for (; c < n_cont; c += nwaves) {
+        const uint4 a1 = nxt.S[16u * lane < nxt.B ? lane : 0u], b1 = nxt.S[16u * lane < nxt.B ? lane + 1u : 0u];  // (nxt.B = 0 past the end)
+        const Raw nn = load_raw(c + 2 * nwaves);  // (used at the end of the turn)
+        const uint32_t t = cur.t, card = cur.card, nr = cur.nr, B = cur.B, d16 = cur.d16, dsw = d16 >> 2, dby = d16 & 3u;
+        const uint4* __restrict__ S = cur.S;
+        uint4* __restrict__ O = cur.O;
+        const uint32_t n16 = (B + 15u) >> 4;
         uint32_t acc = 0;       // bitset: popcount; run: cardinality
         uint32_t carry = 0;     // last value (array) / last run end (run) of the previous step
         bool bad = false;
-        for (uint32_t k0 = 0; k0 < nd; k0 += 64) {
+        for (uint32_t k0 = 0; k0 < n16; k0 += 64) {
             const uint32_t k = k0 + lane;
-            uint32_t w = 0;
-            if (k < nd) {
-                const u64 two = ((u64)S[k + 1] << 32) | (u64)S[k];
-                w = (uint32_t)(two >> (8u * d));
-                if (4u * k + 4u > B) w &= 0xFFFFu;  // the upper half lies beyond the payload
-                O[k] = w;
+            const bool act = k < n16;
+            uint4 a = a0, b = b0;  // (the first step arrived while the previous container was worked on)
+            if (k0) {
+                a = S[act ? k : 0u];
+                b = S[act ? k + 1u : 0u];
             }
+            const uint32_t x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            uint32_t w[4];
+            switch (dsw) {  // (wave-uniform: register indices are static in every arm)
+                case 0: for (int j = 0; j < 4; ++j) w[j] = des_align(x[j + 1], x[j], dby); break;
+                case 1: for (int j = 0; j < 4; ++j) w[j] = des_align(x[j + 2], x[j + 1], dby); break;
+                case 2: for (int j = 0; j < 4; ++j) w[j] = des_align(x[j + 3], x[j + 2], dby); break;
+                default: for (int j = 0; j < 4; ++j) w[j] = des_align(x[j + 4], x[j + 3], dby); break;
+            }
+            const uint32_t rem = act ? (B - 16u * k < 16u ? B - 16u * k : 16u) : 0u;  // payload bytes of this group
+            if (rem < 16u) {  // (the container's last group, and the idle lanes: bytes past the payload are zero)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t vb = rem > 4u * j ? rem - 4u * j : 0u;
+                    w[j] = vb >= 4u ? w[j] : (vb ? w[j] & ((1u << (8u * vb)) - 1u) : 0u);
+                }
+            }
+            if (act) O[k] = make_uint4(w[0], w[1], w[2], w[3]);
             if (t == T_BITSET) {
-                acc += __popc(w);
+                acc += __popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]);
             } else if (t == T_ARRAY) {
-                const uint32_t v0 = w & 0xFFFFu, v1 = w >> 16;
-                const bool has0 = 2u * k < card, has1 = 2u * k + 1u < card;
-                uint32_t pv = __shfl_up(v1, 1);
+                const uint32_t nv = rem >> 1;  // values of this lane: 8, less in the last group, 0 in idle lanes
+                uint32_t v[8];
+#pragma unroll
+                for (int h = 0; h < 8; ++h) v[h] = (w[h >> 1] >> ((h & 1) * 16)) & 0xFFFFu;
+#pragma unroll
+                for (int h = 1; h < 8; ++h) bad |= (uint32_t)h < nv && v[h] <= v[h - 1];
+                uint32_t pv = __shfl_up(v[7], 1);  // (the lane below an active lane is full)
                 if (lane == 0) pv = carry;
-                if (has0 && k > 0 && v0 <= pv) bad = true;
-                if (has1 && v1 <= v0) bad = true;
-                carry = __shfl(v1, 63);
+                if (nv && k > 0 && v[0] <= pv) bad = true;
+                carry = __shfl(v[7], 63);
             } else {
-                const uint32_t s = w & 0xFFFFu, l = w >> 16, e = s + l;
-                const bool has = k < nr;
-                uint32_t pe = __shfl_up(e, 1);
+                const uint32_t nq = rem >> 2;  // runs of this lane
+                uint32_t pe = __shfl_up((w[3] & 0xFFFFu) + (w[3] >> 16), 1);
                 if (lane == 0) pe = carry;
-                if (has && e > 65535u) bad = true;
-                if (has && k > 0 && s <= pe + 1u) bad = true;
-                if (has) acc += l + 1u;
-                carry = __shfl(e, 63);
+                uint32_t e3 = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t st = w[j] & 0xFFFFu, ln = w[j] >> 16, en = st + ln;
+                    const bool has = (uint32_t)j < nq;
+                    if (has && en > 65535u) bad = true;
+                    if (has && (j > 0 || k > 0) && st <= pe + 1u) bad = true;
+                    if (has) acc += ln + 1u;
+                    pe = en;
+                    e3 = en;
+                }
+                carry = __shfl(e3, 63);
             }
         }
         const uint32_t total = wave_sum(acc);
         if (t == T_BITSET && total != card) bad = true;
         const bool anybad = __ballot(bad) != 0;
         if (lane == 0) {
-            if (t == T_RUN) D.card[c] = total;
+            if (t == T_RUN) card_out[c] = total;
             if (anybad) {
                 // bitmap of container c: last i with bm_start[i] <= c
                 u64 lo = 0, hi = n_bitmaps;
@@ -250,5 +327,6 @@ __global__ __launch_bounds__(256) void k_des_payload(const uint8_t* __restrict__
                 atomicMin(status, (uint32_t)lo);
             }
         }
+        cur = nxt; nxt = derive(nn); a0 = a1; b0 = b1;
     }
 }
