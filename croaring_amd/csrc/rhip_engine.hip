@@ -266,6 +266,16 @@ struct rhip_ctx_s {
     // (bench.py's `or` arena behind its `and` arena) paid 3.2 s for ten allocations out of just-freed memory.  Released by
     // rhip_ctx_trim, rhip_ctx_destroy, and by any allocation of the library that fails (DBuf::ensure retries after it).
     std::vector<DBuf> arena_spares;
+    // physical chunks (hipMemCreate) left over by place_arena_chunks, unmapped, with the rate each streamed at beside the
+    // operand arena it was probed against: the next result arena for that operand is composed out of them first
+    struct ChunkSpare { hipMemGenericAllocationHandle_t h; size_t size; float gbps; const void* placed_for; uint64_t placed_for_gen; };
+    std::vector<ChunkSpare> chunk_spares;
+    size_t release_chunk_spares() {
+        size_t n = 0;
+        for (ChunkSpare& x : chunk_spares) { n += x.size; (void)hipMemRelease(x.h); }
+        chunk_spares.clear();
+        return n;
+    }
     int batches_since_place = 0;  // (trim_spares_when_steady)
     std::vector<float> last_placement;  // probe GB/s of the candidates of the last placement (rhip_debug_last_placement)
     bool debug_plan = false;  // RHIP_DEBUG_PLAN=1: one line per batch on stderr (bounds, fork / merge decision)
@@ -454,10 +464,11 @@ static bool release_all_arena_spares() {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     bool any = false;
     for (rhip_ctx_t* c : g_live_ctx) {
-        if (c->arena_spares.empty()) continue;
+        if (c->arena_spares.empty() && c->chunk_spares.empty()) continue;
         DeviceGuard guard(c->device);  // (the spares of a context live on ITS device)
         for (DBuf& b : c->arena_spares) { any = any || b.base != nullptr; b.release(); }
         c->arena_spares.clear();
+        any = c->release_chunk_spares() != 0 || any;
     }
     return any;
 }
@@ -466,8 +477,9 @@ static bool release_all_arena_spares() {
 // anything, all but its two best spares go back to the driver: other allocators on the device (a caching allocator,
 // another rank) cannot ask this library to let go.
 static void trim_spares_when_steady(rhip_ctx_t* c, int after = 16) {
-    if (c->arena_spares.size() <= 2 || ++c->batches_since_place != after) return;
+    if ((c->arena_spares.size() <= 2 && c->chunk_spares.empty()) || ++c->batches_since_place != after) return;
     std::lock_guard<std::mutex> lk(g_ctx_mu);
+    (void)c->release_chunk_spares();
     std::sort(c->arena_spares.begin(), c->arena_spares.end(), [](const DBuf& a, const DBuf& b) {
         return a.placed_winner != b.placed_winner ? a.placed_winner : a.placed_gbps > b.placed_gbps;  // (parked winners first)
     });
@@ -602,6 +614,7 @@ extern "C" void rhip_ctx_destroy(rhip_ctx_t* c) {
     for (auto& b : c->shard) b.release();
     for (auto& b : c->arena_spares) b.release();
     c->arena_spares.clear();
+    (void)c->release_chunk_spares();
     for (auto& b : c->sel) b.release();
     for (auto& b : c->partial_cache) { (void)hipFree(b.keys); (void)hipFree(b.words); }
     for (rhip_pool_t* R : c->many_free) { R->release(); delete R; }
@@ -2052,6 +2065,172 @@ struct rhip_batch_s {
     rhip_ctx_s::SlotScratch* Q = nullptr;  // where its class queues are (class statistics)
 };
 
+// Placement of a large result arena by its PHYSICAL CHUNKS (round 6, second half): stage 0 of place_arena.
+// scripts/vmm_place5.hip probed every one of sixteen 1 GiB chunks (hipMemCreate) at every GiB position of a C2 arena against
+// the pool region it meets there in lockstep: the rate is a property of the CHUNK -- 5.95-6.11 TB/s for chunks 0-5, 14, 15 at
+// all eight positions, 5.62-5.84 for chunks 6-13 at all eight -- not of the position or of the pair; chunks created one
+// after the other form runs of good and bad ones (the 5-6 GiB wide distance bands of round 4).  And the arena COMPOSED of the
+// eight best chunks streamed at 6.33 / 6.34 TB/s where the eight worst gave 5.42 and a plain hipMalloc arena 5.41 (a second
+// process: 6.26 / 5.39 / 5.68).  So: three times as many chunks as the arena needs are created, each is probed once ALONE
+// (mapped at an address of its own, 1 GiB of k_place_probe against the operand pool: ~0.7 ms), the best are mapped side by
+// side as the arena and the usual sampled probe checks the whole; a composition below the bar is tried at the next address
+// (the boxes on which the virtual address decides, see place_arena_va).  The chunks that were not taken stay with the
+// context, unmapped, WITH their rates: the next result arena for the same operand is composed out of them first
+// (trim_spares_when_steady / rhip_ctx_trim release them).  Transient footprint: 3 x the arena.  The driver's limits listed
+// at place_arena_va hold here too: every mapping is at an address that was never mapped before.
+// Returns 0: nothing done (the calls are missing or failed, no memory); 1: arena placed at or above arena_good_gbps;
+// 2: placed below it (arena.placed_gbps says where).
+static int place_arena_chunks(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool_t* A) {
+    if (!c->arena_vmm) return 0;
+    if (g_fail_allocs.load(std::memory_order_relaxed) > 0) return 0;  // (tests of the allocation-failure paths: through DBuf::ensure)
+    const size_t MB2 = 2ull << 20, G1 = 1ull << 30;
+    const size_t step = std::max<size_t>(MB2, c->arena_va_step / MB2 * MB2);
+    const size_t chunk = std::min<size_t>(G1, step);
+    const size_t len = (need + arena.skew + chunk - 1) / chunk * chunk;  // whole chunks: every chunk can take every place
+    const uint32_t n_need = (uint32_t)(len / chunk);
+    if (n_need > 4096) return 0;
+    size_t free_b = 0, tot_b = 0;
+    if (hipMemGetInfo(&free_b, &tot_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = c->device;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    struct Ch { hipMemGenericAllocationHandle_t h; float gbps; bool probed; };
+    std::vector<Ch> ch;
+    // the context's spare chunks that were probed against THIS operand arena come first, rates and all
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        for (size_t k = 0; k < c->chunk_spares.size();) {
+            const auto& x = c->chunk_spares[k];
+            if (x.size == chunk) {  // (one probed beside another operand, or never probed, is probed below)
+                const bool known = x.gbps > 0.f && x.placed_for == A->arena.base && x.placed_for_gen == A->arena.gen;
+                ch.push_back(Ch{x.h, known ? x.gbps : 0.f, known});
+                c->chunk_spares.erase(c->chunk_spares.begin() + (long)k);
+            } else {
+                ++k;
+            }
+        }
+    }
+    auto give_back = [&](size_t from) {  // chunks [from, ..) -> the context's spares (or the driver)
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        for (size_t k = from; k < ch.size(); ++k) {
+            if (c->arena_keep_spares) c->chunk_spares.push_back(rhip_ctx_s::ChunkSpare{ch[k].h, chunk, ch[k].probed ? ch[k].gbps : 0.f, A->arena.base, A->arena.gen});
+            else (void)hipMemRelease(ch[k].h);
+        }
+        ch.resize(from);
+    };
+    const size_t want = 3u * (size_t)n_need;
+    const size_t n_spare_in = ch.size();
+    while (ch.size() < want) {
+        if ((ch.size() + 1 - n_spare_in) * chunk + (256ull << 20) > free_b / 2 && ch.size() >= (size_t)n_need) break;  // (never more than half of what was free)
+        hipMemGenericAllocationHandle_t h{};
+        if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+        ch.push_back(Ch{h, 0.f, false});
+    }
+    if (ch.size() < (size_t)n_need) { give_back(0); return 0; }
+    // address space: a place of its own for every probe of a single chunk, then up to N_COMP places for the composed arena
+    constexpr size_t N_COMP = 6;
+    const size_t pitch = len + 2 * step;
+    const size_t va_len = ch.size() * (chunk + (step > chunk ? step - chunk : 0)) + N_COMP * pitch + 2 * G1 + 2 * MB2;
+    void* R = nullptr;
+    if (hipMemAddressReserve(&R, va_len, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); give_back(0); return 0; }
+    uint8_t* base0 = (uint8_t*)(((uintptr_t)R + G1 - 1) / G1 * G1) + MB2;  // = 2 MiB past a GiB boundary (so is every place below)
+    if (step % G1) base0 = (uint8_t*)(((uintptr_t)R + MB2 - 1) / MB2 * MB2);  // (sub-GiB steps: tests on small arenas)
+    const u64 a_items = A->arena.cap / 8192ull;
+    hipStream_t s = c->stream;
+    hipEvent_t e0 = c->ev[0], e1 = c->ev[1];
+    auto timed = [&](uint8_t* out, u64 n_slots, u64 stride, float& gbps) {
+        const u64 n_items = (n_slots + stride - 1) / stride;
+        float ms_best = 1e30f;
+        for (int r = 0; r < 3; ++r) {  // (the first pass warms the translations)
+            if (hipEventRecord(e0, s) != hipSuccess) return false;
+            hipLaunchKernelGGL(k_place_probe, dim3(8192), dim3(256), 0, s, A->arena.as<uint8_t>(), a_items, out, n_slots, stride);
+            if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return false;
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return false;
+            if (r && ms < ms_best) ms_best = ms;
+        }
+        gbps = (float)((double)n_items * 24576.0 / (double)std::max(ms_best, 1e-6f) / 1e6);
+        return true;
+    };
+    bool ok = true;
+    uint8_t* next_place = base0;
+    for (size_t k = 0; k < ch.size() && ok; ++k) {
+        if (ch[k].probed) continue;
+        uint8_t* at = next_place;
+        next_place += std::max(chunk, step);
+        ok = hipMemMap(at, chunk, 0, ch[k].h, 0) == hipSuccess;
+        if (!ok) break;
+        ok = hipMemSetAccess(at, chunk, &acc, 1) == hipSuccess && timed(at, chunk / 8192ull, 1, ch[k].gbps);
+        ok = hipMemUnmap(at, chunk) == hipSuccess && ok;
+        ch[k].probed = ok;
+        if (ok) c->last_placement.push_back(ch[k].gbps);
+        // enough good ones?  (the rates come in two levels, ~5 % apart: n_need chunks within 2.5 % of the best seen, after
+        // at least n_need + 4 probes, end the probing -- the chunks not yet probed go back unprobed)
+        if (ok && k + 1 >= (size_t)n_need + 4) {
+            float top = 0.f;
+            for (size_t i = 0; i <= k; ++i) if (ch[i].probed) top = std::max(top, ch[i].gbps);
+            size_t n_top = 0;
+            for (size_t i = 0; i <= k; ++i) n_top += ch[i].probed && ch[i].gbps >= 0.975f * top ? 1 : 0;
+            if (n_top >= (size_t)n_need) break;
+        }
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        give_back(0);
+        (void)hipMemAddressFree(R, va_len);
+        return 0;
+    }
+    std::stable_sort(ch.begin(), ch.end(), [](const Ch& a, const Ch& b) { return a.probed != b.probed ? a.probed : a.gbps > b.gbps; });
+    // the composed arena: the n_need best chunks side by side, at one place after the other until the whole streams at the bar
+    uint8_t* comp0 = (uint8_t*)(((uintptr_t)next_place + G1 - 1) / G1 * G1) + MB2;
+    if (step % G1) comp0 = next_place;
+    const u64 n_slots = need / 8192ull;
+    const u64 stride = std::max<u64>(1, n_slots / ((1ull << 30) / 8192ull));
+    uint8_t* at = nullptr;
+    float here = 0.f, best = 0.f, worst = 1e30f;
+    for (size_t pos = 0; pos < N_COMP && ok; ++pos) {
+        if (at) for (uint32_t k = 0; k < n_need; ++k) ok = hipMemUnmap(at + (size_t)k * chunk, chunk) == hipSuccess && ok;
+        at = comp0 + pos * pitch;
+        for (uint32_t k = 0; k < n_need && ok; ++k) ok = hipMemMap(at + (size_t)k * chunk, chunk, 0, ch[k].h, 0) == hipSuccess;
+        ok = ok && hipMemSetAccess(at, len, &acc, 1) == hipSuccess && timed(at + arena.skew, n_slots, stride, here);
+        if (!ok) break;
+        c->last_placement.push_back(here);
+        if (here >= 0.99f * (float)c->arena_good_gbps) break;  // (a composition of good chunks streams at 6.2-6.35 TB/s by this probe)
+        best = std::max(best, here);
+        worst = std::min(worst, here);
+        if (pos >= 2 && best - worst < 0.012f * best) break;  // the address does not decide here
+    }
+    if (!ok) {  // (a mapping may be half made: the handles are released with their mappings)
+        (void)hipGetLastError();
+        for (Ch& x : ch) (void)hipMemRelease(x.h);
+        ch.clear();
+        (void)hipMemAddressFree(R, va_len);
+        return 0;
+    }
+    hipMemGenericAllocationHandle_t* hs = new hipMemGenericAllocationHandle_t[n_need];
+    for (uint32_t k = 0; k < n_need; ++k) hs[k] = ch[k].h;
+    give_back(n_need);
+    if (arena.base) arena.release();  // the old, too small arena of a recycled pool
+    arena.base = at;
+    arena.p = at + arena.skew;
+    arena.cap = len - arena.skew;
+    arena.vmm = true;
+    arena.vmm_handles = hs;
+    arena.vmm_n = n_need;
+    arena.vmm_chunk = chunk;
+    arena.va_base = R;
+    arena.va_len = va_len;
+    arena.map_len = len;
+    arena.exact = false;
+    ++arena.gen;
+    arena.placed_for = A->arena.base; arena.placed_for_gen = A->arena.gen; arena.placed_gbps = here;
+    return here >= 0.99f * (float)c->arena_good_gbps ? 1 : 2;
+}
+
 // Placement of a large result arena by ADDRESS (round 6): stage 2 of place_arena, for the boxes on which the arena's
 // VIRTUAL address decides the bitset kernel's rate beside a given operand pool.  There the same eight 1 GiB chunks mapped
 // at 89 addresses one GiB apart streamed at 6.40 TB/s at three of them and 5.89 at the others, and 17 other chunk sets
@@ -2241,13 +2420,26 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
             return;
         }
     }
-    size_t free_at_start = 0, tot_mem = 0;
-    if (hipMemGetInfo(&free_at_start, &tot_mem) != hipSuccess) { (void)hipGetLastError(); free_at_start = 0; }
-    if (free_at_start < 2 * need) return;  // (no room to choose: the caller's ordinary allocation follows)
+    // stage 0 (round 6, second half): the arena composed of the best of three times as many physical chunks as it needs
     c->last_placement.clear();
     c->batches_since_place = 0;
+    const int by_chunks = place_arena_chunks(c, arena, need, A);
+    if (by_chunks == 1) { arena.placed_winner = true; return; }
+    size_t free_at_start = 0, tot_mem = 0;
+    if (hipMemGetInfo(&free_at_start, &tot_mem) != hipSuccess) { (void)hipGetLastError(); free_at_start = 0; }
+    if (free_at_start < 2 * need) { if (by_chunks) arena.placed_winner = true; return; }  // (no room to choose: the caller's ordinary allocation follows)
     hipEvent_t e0 = c->ev[0], e1 = c->ev[1];
     int best = -1;
+    if (by_chunks == 2) {  // below the bar: candidate 0 of the stages that follow (its configuration -- skew, rounding -- stays with `arena`)
+        Cand cd;
+        cd.buf = arena;
+        cd.gbps = arena.placed_gbps;
+        cands.push_back(cd);
+        best = 0;
+        arena.base = nullptr; arena.p = nullptr; arena.cap = 0;
+        arena.vmm = false; arena.vmm_handles = nullptr; arena.vmm_n = 0; arena.vmm_chunk = 0; arena.va_base = nullptr; arena.va_len = arena.map_len = 0;
+    }
+    const int n_placed_in = (int)cands.size();
     auto probe = [&](Cand& cur) {
         float ms_best = 1e30f;
         for (int r = 0; r < 3; ++r) {  // (the first pass touches the pages)
@@ -2279,7 +2471,7 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
             }
         }
     }
-    for (size_t k = 0; k < cands.size(); ++k) {
+    for (size_t k = (size_t)n_placed_in; k < cands.size(); ++k) {
         probe(cands[k]);
         if (best < 0 || cands[k].gbps > cands[best].gbps) best = (int)k;
     }
@@ -2776,6 +2968,7 @@ extern "C" unsigned long long rhip_ctx_trim(rhip_ctx_t* c) {
     unsigned long long n = 0;
     for (DBuf& b : c->arena_spares) { n += b.cap; b.release(); }
     c->arena_spares.clear();
+    n += c->release_chunk_spares();
     return n;
 }
 // batches of this context that a flag join gave up on and that were finished through the fallback (rhip_pairwise_end)

@@ -990,7 +990,7 @@ def arena_placement_body(eng, oracle, synth):
             for h in (oa, ob, oo):
                 oracle.free(h)
     rates = eng.last_placement()
-    assert 1 <= len(rates) <= 12 and all(r > 0 for r in rates), rates  # (positions of the address search, then RHIP_ARENA_TRIES candidates, as many again while all are slow)
+    assert 1 <= len(rates) <= 96 and all(r > 0 for r in rates), rates  # (single chunks, compositions, then RHIP_ARENA_TRIES candidates -- as many again while all are slow -- and address positions)
     b1 = eng.pairwise_begin("xor", pool, lhs, pool, rhs)  # a fresh result pool while another batch is in flight
     b2 = eng.pairwise_begin("or", pool, lhs, pool, rhs)
     r2, r1 = b2.end(), b1.end()
