@@ -195,17 +195,21 @@ rhip_pool_t *rhip_pairwise(rhip_ctx_t *ctx, rhip_op op, rhip_pool_t *A, rhip_poo
  * Placement of a NEW large result arena.  When a call has to allocate a result arena of 2 GiB or more beside an operand
  * pool of 64 MiB or more, and no batch of the context is in flight, the library does not take the first allocation: where
  * the arena lies -- its physical pages on some machines, its VIRTUAL address on others -- moves the bitset
- * kernel by up to 17 %, so it measures.  Stage 1: up to RHIP_ARENA_TRIES (10) candidate allocations, each timed with the
+ * kernel by up to 17 %, so it measures.  Stage 0: the arena is COMPOSED -- up to three times as many 1 GiB chunks as it
+ * needs are created (hipMemCreate), each timed alone with the kernel's access pattern against the operand pool (the rate is
+ * a property of the chunk: DESIGN.md 3), the best mapped side by side; transient footprint 3 x the arena, the chunks not
+ * taken stay with the context (with their rates, for the next arena beside the same operand) until it is steady.  Only
+ * when the composition stays below the bar -- stage 1: up to RHIP_ARENA_TRIES (10) candidate allocations, each timed with the
  * kernel's access pattern against the operand pool, the first that streams at 6.25 TB/s taken; they stay allocated until
  * the choice, and the search ends when they reach half of the device memory that was free when it began.  Stage 2, when no
  * candidate reaches the bar: one more allocation (hipMemCreate) is mapped at one position of a reserved address range
  * after the other (512 GiB of address space, no memory; ~2 ms a position) until one does.  This is the one place where
- * rhip_pairwise_begin WAITS for the device -- 10-60 ms, once per NEW result pool (longer while the driver is still clearing
+ * rhip_pairwise_begin WAITS for the device -- 20-60 ms, once per NEW result pool (longer while the driver is still clearing
  * memory another process has just freed).  The losers stay with the context as spares (the next search probes them first)
  * until it has run 16 batches without placing, rhip_ctx_trim, rhip_ctx_destroy, or any allocation of this library fails;
  * RHIP_ARENA_SPARES=0 releases them at once.  A pool handed back through `reuse` keeps its arena and its placement, and
  * the arena of a pool that is freed is parked with its context and taken back, as placed, by the next result pool for the
- * same operand: steady-state callers never meet the search.  RHIP_ARENA_VMM=0 leaves stage 2 out; RHIP_ARENA_TRIES=0
+ * same operand: steady-state callers never meet the search.  RHIP_ARENA_VMM=0 leaves stages 0 and 2 out; RHIP_ARENA_TRIES=0
  * (environment, read by rhip_ctx_create) turns placement off. */
 #define RHIP_MAX_BATCHES_IN_FLIGHT 4
 typedef struct rhip_batch_s rhip_batch_t;
@@ -429,8 +433,8 @@ int rhip_last_class_stats(rhip_ctx_t *ctx, rhip_class_stats_t *out, int capacity
  * (read at rhip_ctx_create) makes it block on the stream instead. */
 int rhip_debug_host_clock(rhip_ctx_t *ctx, double out_us[8], int reset);
 /* Large result arenas are placed by measurement (see rhip_pairwise_begin).  This returns the probe rates (GB/s) of the
- * context's last placement -- the candidate allocations in the order they were made, then the positions of the address
- * range in the order they were visited -- and how many there were. */
+ * context's last placement -- single chunks and compositions of stage 0, the candidate allocations in the order they were
+ * made, the positions of the address range in the order they were visited -- and how many there were. */
 int rhip_debug_last_placement(rhip_ctx_t *ctx, float *out_gbps, int capacity);
 /* Batches of this context whose flag join (the one-wave gate in front of the tail kernel of a forked batch) gave up --
  * HIP does not promise that kernels of different streams run side by side -- and that were then finished through the
