@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_des_payload(const uint8_t* __restrict__
     for (; c < n_cont; c += nwaves) {
         const uint4 a1 = nxt.S[16u * lane < nxt.B ? lane : 0u], b1 = nxt.S[16u * lane < nxt.B ? lane + 1u : 0u];  // (nxt.B = 0 past the end)
         const Raw nn = load_raw(c + 2 * nwaves);  // (used at the end of the turn)
-        const uint32_t t = cur.t, card = cur.card, nr = cur.nr, B = cur.B, d16 = cur.d16, dsw = d16 >> 2, dby = d16 & 3u;
+        const uint32_t t = cur.t, card = cur.card, B = cur.B, d16 = cur.d16, dsw = d16 >> 2, dby = d16 & 3u;
         const uint4* __restrict__ S = cur.S;
         uint4* __restrict__ O = cur.O;
         const uint32_t n16 = (B + 15u) >> 4;
