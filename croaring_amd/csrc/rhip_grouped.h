@@ -211,6 +211,9 @@ __device__ __forceinline__ void wave_extract_groups(const u32x4 (&r)[8], const u
     for (uint32_t i = lane; i < n16; i += 64) out_store16(&po[i], ((const uint4*)img)[i]);
 }
 
+#ifndef RHIP_ABL_EXTRACT
+#define RHIP_ABL_EXTRACT 0
+#endif
 template <int OP>
 __device__ __forceinline__ void union_g_body(uint32_t* __restrict__ lds, uint32_t bid, uint32_t nblk, const uint8_t* __restrict__ arenaA,
                                              const uint8_t* __restrict__ arenaB, OutView O, const FatItem* __restrict__ q,
@@ -320,7 +323,16 @@ __device__ __forceinline__ void union_g_body(uint32_t* __restrict__ lds, uint32_
             for (int i = 0; i < 8; ++i) out_store16(&po[i * 64 + lane], r[i]);
         } else if (rc) {
             __builtin_amdgcn_wave_barrier();  // every lane has read its groups of Y's image: it is the staging buffer now
+#if RHIP_ABL_EXTRACT  /* ablation builds only (WRONG results): what the bit extraction of array results costs */
+            if (rc == 0xFFFFFFFFu) wave_extract_groups(r, cnt, img, lane, rc, outp);
+            else {
+                const uint32_t n16 = (2u * rc + 15u) >> 4;
+                uint4* __restrict__ po = (uint4*)outp;
+                for (uint32_t i = lane; i < n16; i += 64) out_store16(&po[i], ((const uint4*)img)[i]);
+            }
+#else
             wave_extract_groups(r, cnt, img, lane, rc, outp);
+#endif
         }
         if (lane == 0) O.meta[t.out] = pack_meta(ty, rc, 0);
         __builtin_amdgcn_wave_barrier();  // the image is zeroed again by the next item
