@@ -96,10 +96,11 @@ class Engine:
         return bool(self.lib.rhip_debug_plan_cached(self.h))
 
     def last_placement(self) -> list:
-        """Probe rates (GB/s) of the candidate result arenas of the last measured placement (rhip_debug_last_placement)."""
-        out = (C.c_float * 32)()
-        n = self.lib.rhip_debug_last_placement(self.h, out, 32)
-        return [round(float(out[k]), 1) for k in range(min(n, 32))]
+        """Probe rates (GB/s) of the last measured placement of a result arena (rhip_debug_last_placement): single chunks and
+        compositions, candidate allocations, address positions, in the order they were probed."""
+        out = (C.c_float * 128)()
+        n = self.lib.rhip_debug_last_placement(self.h, out, 128)
+        return [round(float(out[k]), 1) for k in range(min(n, 128))]
 
     def set_timing(self, on: bool):
         self.lib.rhip_ctx_set_timing(self.h, 1 if on else 0)
