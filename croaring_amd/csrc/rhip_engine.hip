@@ -255,6 +255,7 @@ struct rhip_ctx_s {
     // search moves ONE physical allocation through an address window instead of allocating candidates: place_arena_va.
     // RHIP_ARENA_VMM=0: the candidate search of round 4; RHIP_ARENA_VA_WINDOW_MB, RHIP_ARENA_VA_STEP_MB: the window walked.
     bool arena_vmm = true;
+    int arena_chunk_runs = 2, arena_chunk_stride = 2;  // RHIP_ARENA_CHUNK_RUNS / _STRIDE: passes (the first untimed) and slot stride of a single chunk's probe -- 3 / 1, 3 / 2 and 2 / 2 placed alike on one box (0.781-0.798, twelve processes alternating; gpurun_out/r6w), 2 / 2 in 25-35 ms instead of 45
     uint64_t arena_va_window = 512ull << 30, arena_va_step = 1ull << 30;  // (address space only: 512 GiB = 56 positions of an 8 GiB arena)
     int arena_keep_spares = 1;  // RHIP_ARENA_SPARES=0: the losers of a placement search are released, not kept
     int arena_tries = 10;
@@ -555,6 +556,8 @@ extern "C" rhip_ctx_t* rhip_ctx_create(int device) {
         if (const char* e = getenv("RHIP_ARENA_TRIES")) c->arena_tries = atoi(e);
         if (const char* e = getenv("RHIP_ARENA_SPARES")) c->arena_keep_spares = atoi(e);
         if (const char* e = getenv("RHIP_ARENA_VMM")) c->arena_vmm = !(e[0] == '0');
+        if (const char* e = getenv("RHIP_ARENA_CHUNK_RUNS")) c->arena_chunk_runs = std::max(2, atoi(e));
+        if (const char* e = getenv("RHIP_ARENA_CHUNK_STRIDE")) c->arena_chunk_stride = std::max(1, atoi(e));
         if (const char* e = getenv("RHIP_ARENA_VA_WINDOW_MB")) c->arena_va_window = (uint64_t)strtoull(e, nullptr, 0) << 20;
         if (const char* e = getenv("RHIP_ARENA_VA_STEP_MB")) c->arena_va_step = std::max<uint64_t>(2, strtoull(e, nullptr, 0)) << 20;
         if (const char* e = getenv("RHIP_ARENA_PLACE_MIN_MB")) c->arena_place_min = (uint64_t)strtoull(e, nullptr, 0) << 20;
@@ -2142,10 +2145,10 @@ static int place_arena_chunks(rhip_ctx_t* c, DBuf& arena, size_t need, const rhi
     const u64 a_items = A->arena.cap / 8192ull;
     hipStream_t s = c->stream;
     hipEvent_t e0 = c->ev[0], e1 = c->ev[1];
-    auto timed = [&](uint8_t* out, u64 n_slots, u64 stride, float& gbps) {
+    auto timed = [&](uint8_t* out, u64 n_slots, u64 stride, float& gbps, int runs = 3) {
         const u64 n_items = (n_slots + stride - 1) / stride;
         float ms_best = 1e30f;
-        for (int r = 0; r < 3; ++r) {  // (the first pass warms the translations)
+        for (int r = 0; r < runs; ++r) {  // (the first pass warms the translations)
             if (hipEventRecord(e0, s) != hipSuccess) return false;
             hipLaunchKernelGGL(k_place_probe, dim3(8192), dim3(256), 0, s, A->arena.as<uint8_t>(), a_items, out, n_slots, stride);
             if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return false;
@@ -2164,7 +2167,9 @@ static int place_arena_chunks(rhip_ctx_t* c, DBuf& arena, size_t need, const rhi
         next_place += std::max(chunk, step);
         ok = hipMemMap(at, chunk, 0, ch[k].h, 0) == hipSuccess;
         if (!ok) break;
-        ok = hipMemSetAccess(at, chunk, &acc, 1) == hipSuccess && timed(at, chunk / 8192ull, 1, ch[k].gbps);
+        // (every other slot of the chunk, one warm and one timed pass: the two levels are ~5 % apart, and these probes are
+        // most of what a placement costs)
+        ok = hipMemSetAccess(at, chunk, &acc, 1) == hipSuccess && timed(at, chunk / 8192ull, chunk >= (64ull << 20) ? (u64)c->arena_chunk_stride : 1, ch[k].gbps, c->arena_chunk_runs);
         ok = hipMemUnmap(at, chunk) == hipSuccess && ok;
         ch[k].probed = ok;
         if (ok) c->last_placement.push_back(ch[k].gbps);
