@@ -2209,6 +2209,26 @@ static int place_arena_chunks(rhip_ctx_t* c, DBuf& arena, size_t need, const rhi
         worst = std::min(worst, here);
         if (pos >= 2 && best - worst < 0.012f * best) break;  // the address does not decide here
     }
+    if (ok && getenv("RHIP_ARENA_DEBUG")) {  // diagnostics: the chosen chunks' single rates, and what each streams at IN PLACE
+        fprintf(stderr, "rhip place_arena_chunks: composition %.0f GB/s at %p; chosen singles:", here, (void*)at);
+        for (uint32_t k = 0; k < n_need; ++k) fprintf(stderr, " %.0f", ch[k].gbps);
+        fprintf(stderr, "; in place (3 passes, every slot, against the pool region each meets):");
+        for (uint32_t k = 0; k < n_need; ++k) {
+            const u64 so = (u64)k * (chunk / 8192ull);
+            float ms_best = 1e30f;
+            for (int r = 0; r < 3 && so + chunk / 8192ull <= a_items; ++r) {
+                (void)hipEventRecord(e0, s);
+                hipLaunchKernelGGL(k_place_probe, dim3(8192), dim3(256), 0, s, A->arena.as<uint8_t>() + so * 8192ull, a_items - so, at + (size_t)k * chunk, chunk / 8192ull, 1ull);
+                (void)hipEventRecord(e1, s); (void)hipEventSynchronize(e1);
+                float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+                if (r && ms < ms_best) ms_best = ms;
+            }
+            fprintf(stderr, " %.0f", (double)(chunk / 8192ull) * 24576.0 / (double)ms_best / 1e6);
+        }
+        fprintf(stderr, "; all singles:");
+        for (const Ch& x : ch) fprintf(stderr, " %.0f", x.gbps);
+        fprintf(stderr, "\n");
+    }
     if (!ok) {  // (a mapping may be half made: the handles are released with their mappings)
         (void)hipGetLastError();
         for (Ch& x : ch) (void)hipMemRelease(x.h);
