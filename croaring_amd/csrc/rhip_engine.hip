@@ -271,6 +271,12 @@ struct rhip_ctx_s {
     // operand arena it was probed against: the next result arena for that operand is composed out of them first
     struct ChunkSpare { hipMemGenericAllocationHandle_t h; size_t size; float gbps; const void* placed_for; uint64_t placed_for_gen; };
     std::vector<ChunkSpare> chunk_spares;
+    // Address space in which place_arena_chunks probes single chunks, one never-used place per probe, owned by the CONTEXT and
+    // freed with it: an address keeps translating to a chunk for as long as that chunk's handle lives (place_arena_va's first
+    // limit), and the spare chunks outlive the arena whose search probed them -- in a range that was freed with that arena
+    // and handed out again, a later mapping would land on addresses that still translate to the spares
+    void* probe_va = nullptr;
+    size_t probe_va_len = 0, probe_va_used = 0;
     size_t release_chunk_spares() {
         size_t n = 0;
         for (ChunkSpare& x : chunk_spares) { n += x.size; (void)hipMemRelease(x.h); }
@@ -618,6 +624,7 @@ extern "C" void rhip_ctx_destroy(rhip_ctx_t* c) {
     for (auto& b : c->arena_spares) b.release();
     c->arena_spares.clear();
     (void)c->release_chunk_spares();
+    if (c->probe_va) { (void)hipMemAddressFree(c->probe_va, c->probe_va_len); c->probe_va = nullptr; }
     for (auto& b : c->sel) b.release();
     for (auto& b : c->partial_cache) { (void)hipFree(b.keys); (void)hipFree(b.words); }
     for (rhip_pool_t* R : c->many_free) { R->release(); delete R; }
@@ -2134,14 +2141,26 @@ static int place_arena_chunks(rhip_ctx_t* c, DBuf& arena, size_t need, const rhi
         ch.push_back(Ch{h, 0.f, false});
     }
     if (ch.size() < (size_t)n_need) { give_back(0); return 0; }
-    // address space: a place of its own for every probe of a single chunk, then up to N_COMP places for the composed arena
+    // address space: the single chunks are probed in the CONTEXT's probe range, a never-used place each (see probe_va); the
+    // composed arena gets a range of its own with up to N_COMP places -- only the arena's own chunks are ever mapped there
     constexpr size_t N_COMP = 6;
     const size_t pitch = len + 2 * step;
-    const size_t va_len = ch.size() * (chunk + (step > chunk ? step - chunk : 0)) + N_COMP * pitch + 2 * G1 + 2 * MB2;
+    const size_t slot = std::max(chunk, step);
+    size_t n_unprobed = 0;
+    for (const Ch& x : ch) n_unprobed += x.probed ? 0 : 1;
+    if (!c->probe_va) {
+        for (size_t want_va : {1ull << 40, 256ull << 30, 32ull << 30}) {
+            if (hipMemAddressReserve(&c->probe_va, want_va, 0, nullptr, 0) == hipSuccess) { c->probe_va_len = want_va; break; }
+            (void)hipGetLastError();
+            c->probe_va = nullptr;
+        }
+        c->probe_va_used = c->probe_va ? (size_t)((((uintptr_t)c->probe_va + G1 - 1) / G1 * G1 + MB2) - (uintptr_t)c->probe_va) : 0;  // 2 MiB past a GiB boundary
+    }
+    if (!c->probe_va || c->probe_va_used + n_unprobed * slot > c->probe_va_len) { give_back(0); return 0; }  // (the range is used up: the other stages)
+    const size_t va_len = N_COMP * pitch + 2 * G1 + 2 * MB2;
     void* R = nullptr;
     if (hipMemAddressReserve(&R, va_len, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); give_back(0); return 0; }
-    uint8_t* base0 = (uint8_t*)(((uintptr_t)R + G1 - 1) / G1 * G1) + MB2;  // = 2 MiB past a GiB boundary (so is every place below)
-    if (step % G1) base0 = (uint8_t*)(((uintptr_t)R + MB2 - 1) / MB2 * MB2);  // (sub-GiB steps: tests on small arenas)
+    uint8_t* base0 = (uint8_t*)c->probe_va + c->probe_va_used;
     const u64 a_items = A->arena.cap / 8192ull;
     hipStream_t s = c->stream;
     hipEvent_t e0 = c->ev[0], e1 = c->ev[1];
@@ -2164,7 +2183,8 @@ static int place_arena_chunks(rhip_ctx_t* c, DBuf& arena, size_t need, const rhi
     for (size_t k = 0; k < ch.size() && ok; ++k) {
         if (ch[k].probed) continue;
         uint8_t* at = next_place;
-        next_place += std::max(chunk, step);
+        next_place += slot;
+        c->probe_va_used += slot;  // (used, whatever happens to the probe)
         ok = hipMemMap(at, chunk, 0, ch[k].h, 0) == hipSuccess;
         if (!ok) break;
         // (every other slot of the chunk, one warm and one timed pass: the two levels are ~5 % apart, and these probes are
@@ -2191,8 +2211,8 @@ static int place_arena_chunks(rhip_ctx_t* c, DBuf& arena, size_t need, const rhi
     }
     std::stable_sort(ch.begin(), ch.end(), [](const Ch& a, const Ch& b) { return a.probed != b.probed ? a.probed : a.gbps > b.gbps; });
     // the composed arena: the n_need best chunks side by side, at one place after the other until the whole streams at the bar
-    uint8_t* comp0 = (uint8_t*)(((uintptr_t)next_place + G1 - 1) / G1 * G1) + MB2;
-    if (step % G1) comp0 = next_place;
+    uint8_t* comp0 = (uint8_t*)(((uintptr_t)R + G1 - 1) / G1 * G1) + MB2;  // = 2 MiB past a GiB boundary
+    if (step % G1) comp0 = (uint8_t*)(((uintptr_t)R + MB2 - 1) / MB2 * MB2);  // (sub-GiB steps: tests on small arenas)
     const u64 n_slots = need / 8192ull;
     const u64 stride = std::max<u64>(1, n_slots / ((1ull << 30) / 8192ull));
     uint8_t* at = nullptr;
