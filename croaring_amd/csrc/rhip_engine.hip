@@ -2090,7 +2090,7 @@ struct rhip_batch_s {
 // at place_arena_va hold here too: every mapping is at an address that was never mapped before.
 // Returns 0: nothing done (the calls are missing or failed, no memory); 1: arena placed at or above arena_good_gbps;
 // 2: placed below it (arena.placed_gbps says where).
-static int place_arena_chunks(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool_t* A) {
+static int place_arena_chunks(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool_t* A, bool fresh_only = false) {
     if (!c->arena_vmm) return 0;
     if (g_fail_allocs.load(std::memory_order_relaxed) > 0) return 0;  // (tests of the allocation-failure paths: through DBuf::ensure)
     const size_t MB2 = 2ull << 20, G1 = 1ull << 30;
@@ -2115,8 +2115,9 @@ static int place_arena_chunks(rhip_ctx_t* c, DBuf& arena, size_t need, const rhi
         std::lock_guard<std::mutex> lk(g_ctx_mu);
         for (size_t k = 0; k < c->chunk_spares.size();) {
             const auto& x = c->chunk_spares[k];
-            if (x.size == chunk) {  // (one probed beside another operand, or never probed, is probed below)
-                const bool known = x.gbps > 0.f && x.placed_for == A->arena.base && x.placed_for_gen == A->arena.gen;
+            const bool known_here = x.gbps > 0.f && x.placed_for == A->arena.base && x.placed_for_gen == A->arena.gen;
+            if (x.size == chunk && !(fresh_only && known_here)) {  // (one probed beside another operand, or never probed, is probed below)
+                const bool known = known_here;
                 ch.push_back(Ch{x.h, known ? x.gbps : 0.f, known});
                 c->chunk_spares.erase(c->chunk_spares.begin() + (long)k);
             } else {
@@ -2468,8 +2469,28 @@ static void place_arena(rhip_ctx_t* c, DBuf& arena, size_t need, const rhip_pool
     // stage 0 (round 6, second half): the arena composed of the best of three times as many physical chunks as it needs
     c->last_placement.clear();
     c->batches_since_place = 0;
-    const int by_chunks = place_arena_chunks(c, arena, need, A);
+    int by_chunks = place_arena_chunks(c, arena, need, A);
     if (by_chunks == 1) { arena.placed_winner = true; return; }
+    if (by_chunks == 2) {
+        // One process in ten draws a composition below the bar out of chunks that each stream well ("what is still
+        // open"): a SECOND composition, out of chunks the first did not see, before the stages that allocate whole candidates
+        DBuf second;
+        second.skew = arena.skew; second.round_to = arena.round_to;
+        const int again = place_arena_chunks(c, second, need, A, true);
+        if (again && second.placed_gbps > arena.placed_gbps) {
+            const bool p2 = arena.pow2_large;
+            const uint64_t g = arena.gen;
+            std::swap(arena, second);  // (the loser is kept as a spare: released memory would have to be cleared for what follows)
+            arena.pow2_large = p2; arena.gen = g + 1;
+            by_chunks = again;
+        }
+        if (again) {
+            std::lock_guard<std::mutex> lk(g_ctx_mu);
+            if (c->arena_keep_spares) c->arena_spares.push_back(second);
+            else second.release();
+        }
+        if (by_chunks == 1) { arena.placed_winner = true; return; }
+    }
     size_t free_at_start = 0, tot_mem = 0;
     if (hipMemGetInfo(&free_at_start, &tot_mem) != hipSuccess) { (void)hipGetLastError(); free_at_start = 0; }
     if (free_at_start < 2 * need) { if (by_chunks) arena.placed_winner = true; return; }  // (no room to choose: the caller's ordinary allocation follows)
